@@ -1,0 +1,186 @@
+"""Deterministic synthetic scene for the LIMO-Velo KF-update hot path.
+
+The reference ships no data, so tests/ and bench.py use this "street canyon" of planar
+patches: ground + 4 walls + random axis-aligned boxes, sampled area-uniformly so that
+`R3Math::is_plane` (reference src/Utils/Utils.cpp:59-66) accepts most matches.  The scan is drawn
+from the same surfaces with a fresh seed, restricted to 4..80 m range (mirrors `min_dist`,
+config/params.yaml:34) and expressed in the LiDAR frame through a ground-truth pose; the filter
+starts from a perturbed pose so several IKFoM passes are needed (LIMITS 1e-3, main.cpp:145).
+
+Random numbers: numpy PCG64 *raw* 64-bit outputs only, uniform = (u >> 11) * 2^-53 — bit-portable
+across platforms and numpy versions (no distribution code involved).  Noise is uniform +-sigma*sqrt(3).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+SEED_MAP = 0x4C494D4F  # "LIMO"
+SEED_SCAN = 0x56454C4F  # "VELO"
+
+# field order of state_ikfom as 26 doubles (quaternions x,y,z,w) — see include/limovelo_hip.h lv_state
+STATE_LEN = 26
+
+
+class _Rng:
+    def __init__(self, seed: int):
+        self._bg = np.random.PCG64(seed)
+
+    def uniform(self, n: int) -> np.ndarray:
+        raw = self._bg.random_raw(n).astype(np.uint64)
+        return (raw >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def quat_from_rpy(roll: float, pitch: float, yaw: float) -> np.ndarray:
+    """ZYX euler -> quaternion (x, y, z, w)."""
+    cr, sr = math.cos(roll / 2), math.sin(roll / 2)
+    cp, sp = math.cos(pitch / 2), math.sin(pitch / 2)
+    cy, sy = math.cos(yaw / 2), math.sin(yaw / 2)
+    return np.array([
+        sr * cp * cy - cr * sp * sy,
+        cr * sp * cy + sr * cp * sy,
+        cr * cp * sy - sr * sp * cy,
+        cr * cp * cy + sr * sp * sy,
+    ])
+
+
+def quat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by + ay * bw + az * bx - ax * bz,
+        aw * bz + az * bw + ax * by - ay * bx,
+        aw * bw - ax * bx - ay * by - az * bz,
+    ])
+
+
+def quat_from_rotvec(v) -> np.ndarray:
+    v = np.asarray(v, dtype=np.float64)
+    th = float(np.linalg.norm(v))
+    if th < 1e-12:
+        return np.array([0.5 * v[0], 0.5 * v[1], 0.5 * v[2], 1.0])
+    s = math.sin(th / 2) / th
+    return np.array([v[0] * s, v[1] * s, v[2] * s, math.cos(th / 2)])
+
+
+def quat_to_rot(q) -> np.ndarray:
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def make_state(pos, rot, offR=(0, 0, 0, 1), offT=(0, 0, 0), vel=(0, 0, 0), bg=(0, 0, 0), ba=(0, 0, 0),
+               grav=(0, 0, -9.809)) -> np.ndarray:
+    """Pack a state_ikfom as 26 float64: pos3 rot4 offset_R_L_I4 offset_T_L_I3 vel3 bg3 ba3 grav3."""
+    s = np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in (pos, rot, offR, offT, vel, bg, ba, grav)])
+    assert s.shape == (STATE_LEN,)
+    return s
+
+
+def default_P0() -> np.ndarray:
+    """Initial covariance of Localizator::init_IKFoM_state (reference Localizator.cpp:144-150)."""
+    P = np.eye(23)
+    for i in (6, 7, 8, 9, 10, 11):
+        P[i, i] = 0.00001
+    for i in (15, 16, 17):
+        P[i, i] = 0.0001
+    for i in (18, 19, 20):
+        P[i, i] = 0.001
+    for i in (21, 22):
+        P[i, i] = 0.00001
+    return P
+
+
+def _surfaces(rng: _Rng, m_points: int, density: float = 25.0, wall_h: float = 8.0):
+    """Rectangles (origin, edge u, edge v) of the scene; total area ~ m_points / density."""
+    n_boxes = int(max(4, min(64, m_points // 15625)))
+    u = rng.uniform(n_boxes * 5)
+    side_x = 2.0 + 4.0 * u[0::5]
+    side_y = 2.0 + 4.0 * u[1::5]
+    height = 2.0 + 4.0 * u[2::5]
+    box_area = float(np.sum(side_x * side_y + 2 * height * (side_x + side_y)))
+    target = m_points / density
+    # (2L)^2 + 4 * (2L) * wall_h + box_area = target
+    rem = max(target - box_area, 0.25 * target)
+    L = (-8 * wall_h + math.sqrt((8 * wall_h) ** 2 + 16 * rem)) / 8.0
+    rects = []
+    rects.append(((-L, -L, 0.0), (2 * L, 0, 0), (0, 2 * L, 0)))  # ground
+    rects.append(((-L, -L, 0.0), (2 * L, 0, 0), (0, 0, wall_h)))  # y = -L
+    rects.append(((-L, L, 0.0), (2 * L, 0, 0), (0, 0, wall_h)))  # y = +L
+    rects.append(((-L, -L, 0.0), (0, 2 * L, 0), (0, 0, wall_h)))  # x = -L
+    rects.append(((L, -L, 0.0), (0, 2 * L, 0), (0, 0, wall_h)))  # x = +L
+    cx = (2 * u[3::5] - 1) * (L - 8.0)
+    cy = (2 * u[4::5] - 1) * (L - 8.0)
+    for b in range(n_boxes):
+        x0, y0 = cx[b] - side_x[b] / 2, cy[b] - side_y[b] / 2
+        sx, sy, h = side_x[b], side_y[b], height[b]
+        rects.append(((x0, y0, h), (sx, 0, 0), (0, sy, 0)))  # top
+        rects.append(((x0, y0, 0), (sx, 0, 0), (0, 0, h)))
+        rects.append(((x0, y0 + sy, 0), (sx, 0, 0), (0, 0, h)))
+        rects.append(((x0, y0, 0), (0, sy, 0), (0, 0, h)))
+        rects.append(((x0 + sx, y0, 0), (0, sy, 0), (0, 0, h)))
+    o = np.array([r[0] for r in rects], dtype=np.float64)
+    eu = np.array([r[1] for r in rects], dtype=np.float64)
+    ev = np.array([r[2] for r in rects], dtype=np.float64)
+    area = np.linalg.norm(np.cross(eu, ev), axis=1)
+    return o, eu, ev, area, L
+
+
+def _sample(rng: _Rng, surf, n: int, sigma: float) -> np.ndarray:
+    o, eu, ev, area, _ = surf
+    cdf = np.cumsum(area) / np.sum(area)
+    u = rng.uniform(n * 6).reshape(n, 6)
+    which = np.minimum(np.searchsorted(cdf, u[:, 0], side="right"), len(area) - 1)
+    p = o[which] + u[:, 1:2] * eu[which] + u[:, 2:3] * ev[which]
+    p += (2.0 * u[:, 3:6] - 1.0) * (sigma * math.sqrt(3.0))
+    return p
+
+
+XALOC_EXTRINSICS = dict(  # config/xaloc.yaml:16-21 (LiDAR -> IMU)
+    t=(-0.17, 0.0, -0.04),
+)
+
+
+def make_scene(m_points: int, n_points: int, *, sigma: float = 0.01, extrinsics: str = "identity",
+               seed_map: int = SEED_MAP, seed_scan: int = SEED_SCAN, rmin: float = 4.0, rmax: float = 80.0):
+    """Returns dict(map_xyz [M,3] f32 world frame, scan_xyz [N,3] f32 LiDAR frame, x_true, x_init
+    (26 f64 each), P0 [23,23] f64, L)."""
+    rng_m = _Rng(seed_map)
+    surf = _surfaces(rng_m, m_points)
+    map_xyz = _sample(rng_m, surf, m_points, sigma).astype(np.float32)
+
+    pos_true = np.array([3.0, -2.0, 1.5])
+    q_true = quat_from_rpy(math.radians(2.0), math.radians(-1.0), math.radians(30.0))
+    if extrinsics == "identity":
+        offR, offT = np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3)
+    elif extrinsics == "xaloc":
+        offR = quat_from_rpy(0.0, 0.0, math.radians(1.5))
+        offT = np.array(XALOC_EXTRINSICS["t"])
+    else:
+        raise ValueError(extrinsics)
+    R = quat_to_rot(q_true)
+    RLI = quat_to_rot(offR)
+    sensor = R @ offT + pos_true
+
+    rng_s = _Rng(seed_scan)
+    chunks, have = [], 0
+    while have < n_points:
+        c = _sample(rng_s, surf, max(4096, 2 * (n_points - have)), sigma)
+        r = np.linalg.norm(c - sensor, axis=1)
+        c = c[(r >= rmin) & (r <= rmax)]
+        chunks.append(c)
+        have += len(c)
+    pw = np.concatenate(chunks)[:n_points]
+    # p_w = R (RLI p_l + tLI) + pos   =>   p_l = RLI^T (R^T (p_w - pos) - tLI)
+    pl = ((pw - pos_true) @ R - offT) @ RLI
+    scan_xyz = pl.astype(np.float32)
+
+    x_true = make_state(pos_true, q_true, offR, offT)
+    dq = quat_from_rotvec(np.radians([0.5, -0.4, 0.8]))
+    x_init = make_state(pos_true + np.array([0.10, -0.07, 0.05]), quat_mul(q_true, dq), offR, offT)
+    return dict(map_xyz=map_xyz, scan_xyz=scan_xyz, x_true=x_true, x_init=x_init, P0=default_P0(), L=surf[4])

@@ -1,0 +1,135 @@
+/*
+ * lv_oracle.h — C interface of the CPU ORACLE for the LIMO-Velo iterated-KF-update hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library, and there only as the checker / the timed
+ * CPU baseline.  The product path (limo-velo_amd/) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference (Huguet57/LIMO-Velo) ships no tests, no golden vectors and cannot
+ * be built in this container (ROS/PCL/Eigen absent, the ikd-Tree and IKFoM submodules are empty —
+ * SURVEY.md F1-F4).  This oracle is a restatement of the in-tree reference files (cited per
+ * function in lv_oracle.cpp) plus the published algorithms of the two absent dependencies
+ * (hku-mars/ikd-Tree, hku-mars/IKFoM as vendored by FAST-LIO2; every such piece is tagged
+ * [UPSTREAM-RECALL]).  It is cross-checked against scipy/numpy (tests/test_oracle_*.py), not
+ * against reference outputs.
+ */
+#ifndef LV_ORACLE_H
+#define LV_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Hot-path keys of struct Params (reference include/Headers/Common.hpp:56-107; defaults
+ * config/params.yaml:32,46-53). */
+typedef struct lvo_params {
+    int    max_num_iters;        /* MAX_NUM_ITERS (3) -> maximum_iter; passes = max_num_iters+1 */
+    int    num_match_points;     /* NUM_MATCH_POINTS (5); this oracle supports 1..8 */
+    double max_dist_plane;       /* MAX_DIST_PLANE (2.0) */
+    float  planes_threshold;     /* PLANES_THRESHOLD (0.05) */
+    int    estimate_extrinsics;  /* estimate_extrinsics (false) */
+    double lidar_noise;          /* LiDAR_noise (1e-3) -> R */
+    double limits[23];           /* LIMITS (23 x 1e-3) */
+} lvo_params;
+
+/* state_ikfom (IKFoM fork; field order confirmed by reference src/Objects/State.cpp:53-61 and
+ * Localizator.cpp:137-150).  Quaternions are stored in Eigen coefficient order x,y,z,w. */
+typedef struct lvo_state {
+    double pos[3];
+    double rot[4];
+    double offset_R_L_I[4];
+    double offset_T_L_I[3];
+    double vel[3];
+    double bg[3];
+    double ba[3];
+    double grav[3];
+} lvo_state;
+
+/* f32 mirror built by State(const state_ikfom&, double) (State.cpp:51-62): row-major 3x3. */
+typedef struct lvo_pose_f32 {
+    float R[9];
+    float pos[3];
+    float RLI[9];
+    float tLI[3];
+} lvo_pose_f32;
+
+typedef struct lvo_iter_out {
+    double HTH[144];   /* row-major 12x12 */
+    double HTh[12];
+    double sum_h2;     /* sum of h(i)^2 over matches */
+    int64_t n_valid;   /* number of chosen matches */
+} lvo_iter_out;
+
+void lvo_default_params(lvo_params* p);
+void lvo_state_to_pose(const lvo_state* s, lvo_pose_f32* out);
+
+/* World transform of Mapper.cpp:51:  p_w = X * X.I_Rt_L() * p  (f32, op order of
+ * State.cpp:83-85, RotTransl.cpp:36-48).  xyz arrays are N x 3 packed floats. */
+void lvo_transform_scan(const lvo_pose_f32* pose, const float* scan_xyz, size_t n, float* out_xyz);
+
+/* Exact k-NN, brute force, distance (ax-bx)^2+(ay-by)^2+(az-bz)^2 in f32 unfused
+ * [UPSTREAM-RECALL ikd-Tree calc_dist]; ties -> lowest map index.  idx/d2 are N x k, ascending;
+ * entries past found[i] are 0xFFFFFFFF / +inf.  n_ties (may be NULL) counts queries whose k-th
+ * and (k+1)-th distances are bit-equal. */
+void lvo_knn_brute(const float* map_xyz, size_t m, const float* q_xyz, size_t n, int k,
+                   uint32_t* idx, float* d2, int32_t* found, int64_t* n_ties, int nthreads);
+
+/* Pointer kd-tree, one point per node, box-pruned descent, size-k max-heap
+ * [UPSTREAM-RECALL ikd-Tree Build/Search].  Same result contract as lvo_knn_brute. */
+void* lvo_kdtree_build(const float* map_xyz, size_t m);
+void  lvo_kdtree_free(void* tree);
+size_t lvo_kdtree_size(const void* tree);
+void  lvo_kdtree_knn(const void* tree, const float* q_xyz, size_t n, int k,
+                     uint32_t* idx, float* d2, int32_t* found, int nthreads);
+
+/* Plane(near, sq_dists) (Plane.cpp:19-55) + R3Math::estimate_plane / is_plane (Utils.cpp:32-66).
+ * near_xyz: found x 3 neighbours in ascending distance order.  Returns is_plane (0/1). */
+int lvo_plane_fit(const float* near_xyz, const float* sq_dists, int found, const lvo_params* prm,
+                  float abcd[4]);
+
+/* f64 exact least-squares solution of the same 5x3 system (noise-floor reference for the f32 QR). */
+void lvo_plane_fit_f64(const float* near_xyz, int npts, double abcd[4]);
+
+/* One Jacobian row of Localizator::calculate_H (Localizator.cpp:29-57) for a world point p_w
+ * matched to plane abcd with signed distance dist. */
+void lvo_calculate_H_row(const lvo_state* s, const float p_w[3], const float abcd[4], float dist,
+                         int estimate_extrinsics, double Hrow[12], double* h);
+
+/* One measurement-model evaluation = IKFoM::h_share_model [UPSTREAM-RECALL glue] =
+ * Mapper::match (Mapper.cpp:40-56) + Localizator::calculate_H + the H^T H / H^T h products of
+ * esekf (a-8).  tree == NULL -> brute-force kNN over map_xyz.  Optional per-point outputs (any
+ * may be NULL): knn_idx N x k, knn_d2 N x k, valid N, abcd N x 4, dist N, Hrows N x 12, h N. */
+void lvo_iterate(const lvo_state* s, const lvo_params* prm, const void* tree,
+                 const float* map_xyz, size_t m, const float* scan_xyz, size_t n,
+                 lvo_iter_out* out, uint32_t* knn_idx, float* knn_d2, uint8_t* valid,
+                 float* abcd, float* dist, double* Hrows, double* h, int nthreads);
+
+/* esekf::update_iterated_dyn_share_modified [UPSTREAM-RECALL, degeneracy stage off].
+ * x, P (row-major 23x23) updated in place.  trace (may be NULL): per pass 23 doubles dx_ followed
+ * by the 26 state doubles after boxplus (49 per pass, up to max_num_iters+1 passes).
+ * Returns number of measurement passes executed. */
+int lvo_update(lvo_state* x, double* P, const lvo_params* prm, const void* tree,
+               const float* map_xyz, size_t m, const float* scan_xyz, size_t n,
+               double* trace, lvo_iter_out* per_pass_out, int nthreads);
+
+/* The algebra of one esekf pass given the reduced sums (used to check the device solve alone):
+ * consumes HTH/HTh/n_valid, x (current), x_prop, P_prop; produces dx_ and updates x; when
+ * `finalize` it also writes the posterior P.  Returns 1 if |dx_| <= limits for all 23 dof. */
+int lvo_kf_step(lvo_state* x, const lvo_state* x_prop, const double* P_prop, const lvo_params* prm,
+                const lvo_iter_out* sums, double dx_out[23], int finalize, double* P_out);
+
+/* Manifold helpers exposed for tests. */
+void lvo_boxplus(lvo_state* x, const double dx[23]);
+void lvo_boxminus(const lvo_state* x, const lvo_state* other, double dx[23]);
+
+/* IMU predict  esekf::predict(dt, Q, in) with LIMO-Velo's process model [UPSTREAM-RECALL
+ * use-ikfom get_f/df_dx/df_dw]; Q is row-major 12x12.  Used to produce realistic P for tests. */
+void lvo_predict(lvo_state* x, double* P, double dt, const double* Q, const double acc[3],
+                 const double gyro[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
