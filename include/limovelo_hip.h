@@ -1,0 +1,178 @@
+/*
+ * limovelo_hip.h — C-ABI of the MI355X-native LIMO-Velo iterated-KF-update hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each
+ * entry point names the reference interface it replaces (paths relative to the reference repo
+ * Huguet57/LIMO-Velo).  The C++ shim classes `Mapper` / `Localizator` in
+ * limo-velo_amd/host/ keep the reference's method names on top of these calls; INTEGRATION.md shows
+ * the binding a maintainer adds to the ROS node.
+ *
+ * Conventions
+ *   - every function returns an int status: LV_OK (0) or a negative LV_E* code; lv_last_error()
+ *     returns a thread-local message for the last failure.  "No map yet" and "fewer than k map
+ *     points" are NOT errors: they yield n_valid = 0, mirroring Mapper::match returning an empty
+ *     vector (src/Modules/Mapper.cpp:42) and Localizator::correct returning early
+ *     (src/Modules/Localizator.cpp:24).
+ *   - point arrays are passed as (base pointer, stride in bytes, count); x,y,z are three consecutive
+ *     floats at the start of each record.  stride = 32 accepts the reference's `Point` records
+ *     (include/Headers/Objects.hpp:20-28: float x,y,z; double time; float intensity, range) as they
+ *     lie in a PointVector; stride = 12 accepts packed xyz.
+ *   - a context is single-caller and non-reentrant (the reference modules are singletons driven from
+ *     one thread: src/main.cpp:52,128).  All device work of a context is issued on one HIP stream.
+ *   - the HIP extension is mandatory: there is no CPU fallback behind this ABI.
+ */
+#ifndef LIMOVELO_HIP_H
+#define LIMOVELO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LV_OK 0
+#define LV_EINVAL (-1)   /* bad argument */
+#define LV_EHIP (-2)     /* HIP runtime error (message in lv_last_error) */
+#define LV_ENODEV (-3)   /* no usable GPU */
+#define LV_ESTATE (-4)   /* call out of order (e.g. iterate before scan_set) */
+#define LV_ERANGE (-5)   /* coordinates outside the supported voxel range */
+
+#define LV_STATE_DOF 23
+#define LV_SUMS_LEN 96   /* doubles in the per-pass reduction record (see lv_sums_layout below) */
+
+typedef struct lv_ctx lv_ctx;
+
+/* Hot-path keys of `struct Params` (include/Headers/Common.hpp:56-107; defaults from
+ * config/params.yaml:32,46-53 and src/main.cpp:145), same names. */
+typedef struct lv_params {
+    int    MAX_NUM_ITERS;        /* 3  -> esekf maximum_iter; up to MAX_NUM_ITERS+1 measurement passes */
+    int    NUM_MATCH_POINTS;     /* 5  (this build supports 5 only) */
+    double MAX_DIST_PLANE;       /* 2.0 */
+    float  PLANES_THRESHOLD;     /* 0.05 */
+    int    estimate_extrinsics;  /* 0 */
+    double LiDAR_noise;          /* 0.001 */
+    double LIMITS[LV_STATE_DOF]; /* 23 x 0.001 */
+    double degeneracy_threshold; /* parsed, NOT applied: the fork-only degeneracy stage is unknown */
+    /* ---- structure tuning (no reference counterpart) ---- */
+    float  voxel_size;           /* level-0 cell edge of the voxel hash in metres (default 0.5) */
+    int    lanes_per_query;      /* 1,2,4,8,16: lanes of a wavefront cooperating on one scan point (default 8) */
+} lv_params;
+
+/* state_ikfom of the IKFoM fork (field order evidenced by src/Objects/State.cpp:53-61 and
+ * src/Modules/Localizator.cpp:137-150).  Quaternions in Eigen coefficient order x,y,z,w.
+ * 26 doubles, no padding. */
+typedef struct lv_state {
+    double pos[3];
+    double rot[4];
+    double offset_R_L_I[4];
+    double offset_T_L_I[3];
+    double vel[3];
+    double bg[3];
+    double ba[3];
+    double grav[3];
+} lv_state;
+
+/* Result of one measurement-model evaluation: what esekf needs from the N-sized data
+ * (SURVEY §8 a-8): H^T H (12x12 row-major), H^T h, sum h^2, number of chosen matches. */
+typedef struct lv_sums {
+    double  HTH[144];
+    double  HTh[12];
+    double  sum_h2;
+    int64_t n_valid;
+} lv_sums;
+
+/* Device-side record layout of the LV_SUMS_LEN doubles that lv_pass_reduce() produces and that is
+ * all-reduced (sum) across GPUs: [0..77] upper triangle of H^T H row by row, [78..89] H^T h,
+ * [90] n_valid (as double), [91] sum h^2, [92..95] zero padding. */
+
+void        lv_default_params(lv_params* p);
+const char* lv_last_error(void);
+const char* lv_version(void);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* device = HIP device ordinal.  Replaces the construction of the Mapper / Localizator singletons
+ * (include/Headers/Mapper.hpp:35-38, src/Modules/Localizator.cpp:100-117 init_IKFoM). */
+int  lv_create(const lv_params* params, int device, lv_ctx** out);
+void lv_destroy(lv_ctx* ctx);
+/* Issue all work on an existing hipStream_t (e.g. torch's current stream); NULL = context's own. */
+int  lv_set_stream(lv_ctx* ctx, void* hip_stream);
+void* lv_get_stream(lv_ctx* ctx);
+int  lv_synchronize(lv_ctx* ctx);
+
+/* ---- Mapper side ---------------------------------------------------------------------------- */
+/* KD_TREE<Point>::Build(PointVector)              — call site src/Modules/Mapper.cpp:68-71 */
+int    lv_map_build(lv_ctx* ctx, const void* points, size_t stride, size_t n);
+/* KD_TREE<Point>::Add_Points(PointVector&, bool)  — call site src/Modules/Mapper.cpp:73-76.
+ * downsample != 0 applies ikd-Tree's box rule with box_length 0.2 m (Mapper.cpp:65): per 0.2 m box
+ * touched by new points only the point nearest to the box centre survives. */
+int    lv_map_add(lv_ctx* ctx, const void* points, size_t stride, size_t n, int downsample);
+/* KD_TREE<Point>::size()                          — src/Modules/Mapper.cpp:33,79 */
+size_t lv_map_size(lv_ctx* ctx);
+/* Copy the current map points (xyz packed, insertion order = the index space of lv_fetch_knn). */
+int    lv_map_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
+
+/* ---- Localizator side ----------------------------------------------------------------------- */
+/* `this->points2match = points`                   — src/Modules/Localizator.cpp:131.
+ * Uploads the scan (LiDAR frame) once per correct(); it is invariant across IKFoM passes. */
+int lv_scan_set(lv_ctx* ctx, const void* points, size_t stride, size_t n);
+
+/* One IKFoM::h_share_model evaluation (registered at src/Modules/Localizator.cpp:112) =
+ * Mapper::match (Mapper.cpp:40-56) + Localizator::calculate_H (Localizator.cpp:29-57), reduced to
+ * H^T H / H^T h on the GPU.  Synchronous. */
+int lv_iterate(lv_ctx* ctx, const lv_state* x, lv_sums* out);
+
+/* esekf::update_iterated_dyn_share_modified(R, degeneracy_threshold, solve_time, print)
+ *                                                 — call site src/Modules/Localizator.cpp:132.
+ * Runs the whole iterated update on the device.  x and P (23x23 row-major) are updated in place.
+ * passes (may be NULL) receives the number of measurement passes executed; per_pass (may be NULL)
+ * receives the sums of each pass (capacity MAX_NUM_ITERS+1); trace (may be NULL) receives per pass
+ * 23 doubles dx_ followed by the 26 state doubles after boxplus (49 x (MAX_NUM_ITERS+1)). */
+int lv_update(lv_ctx* ctx, lv_state* x, double* P, int* passes, lv_sums* per_pass, double* trace);
+
+/* Split form of lv_update for multi-GPU runs (scan points sharded across ranks, map replicated):
+ *   lv_update_begin(x, P)
+ *   repeat MAX_NUM_ITERS+1 times:
+ *       lv_pass_reduce()                      -> fills the device record lv_sums_device_ptr()
+ *       <all-reduce(sum) LV_SUMS_LEN doubles at lv_sums_device_ptr() across ranks, same stream>
+ *       lv_pass_solve()                       -> 23-dof solve, boxplus, convergence bookkeeping
+ *   lv_update_end(x, P, passes)
+ * All calls are asynchronous on the context stream except lv_update_end. */
+int   lv_update_begin(lv_ctx* ctx, const lv_state* x, const double* P);
+int   lv_pass_reduce(lv_ctx* ctx);
+void* lv_sums_device_ptr(lv_ctx* ctx);
+/* Use caller-owned device memory (>= LV_SUMS_LEN doubles, e.g. a torch tensor handed to RCCL) as
+ * the sums record; NULL restores the context's own buffer. */
+int   lv_set_sums_buffer(lv_ctx* ctx, void* device_ptr);
+int   lv_pass_solve(lv_ctx* ctx);
+int   lv_update_end(lv_ctx* ctx, lv_state* x, double* P, int* passes);
+
+/* ---- API-parity / debug fetches (results of the most recent CAPTURED pass; original scan order) --
+ * lv_iterate always captures; lv_update captures only after lv_set_capture(ctx, 1) (the last pass
+ * executed wins).  Capturing writes ~200 B per scan point and is off on the fast path. */
+int lv_set_capture(lv_ctx* ctx, int enabled);
+/* Nearest_Search outputs: idx N x k (index into the map in insertion order, 0xFFFFFFFF = none),
+ * d2 N x k squared distances ascending (+inf = none). */
+int lv_fetch_knn(lv_ctx* ctx, uint32_t* idx, float* d2);
+/* Mapper::match outputs: valid N (Match::is_chosen), p_world N x 3, abcd N x 4 (Normal A,B,C,D),
+ * dist N (Match::distance).  Any pointer may be NULL. */
+int lv_fetch_matches(lv_ctx* ctx, uint8_t* valid, float* p_world, float* abcd, float* dist);
+/* calculate_H outputs as N x 12 rows / N residuals with zero rows for rejected points. */
+int lv_fetch_rows(lv_ctx* ctx, double* H, double* h);
+
+/* ---- instrumentation ------------------------------------------------------------------------- */
+typedef struct lv_timing {
+    float last_update_ms;      /* device time of the last lv_update (HIP events on the ctx stream) */
+    float last_reduce_ms;      /* average device time of the match+reduce kernel in the last lv_update */
+    float last_solve_ms;       /* average device time of the solve kernel in the last lv_update */
+    int   last_passes;
+    int   fallback_queries;    /* scan points that left the level-0 voxel search in the last pass */
+} lv_timing;
+int lv_get_timing(lv_ctx* ctx, lv_timing* out);
+/* enable per-kernel HIP-event timing inside lv_update (adds event records to the stream) */
+int lv_set_profiling(lv_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIMOVELO_HIP_H */

@@ -1,0 +1,247 @@
+"""ctypes binding of the C-ABI (include/limovelo_hip.h) for tests, smoke() and bench.py.
+
+This is plumbing, not the product: the product is liblimovelo_hip.so (HIP, gfx950) and the C++
+Mapper / Localizator shim in limo-velo_amd/host/.  There is NO CPU fallback: loading fails loudly if
+the HIP library has not been built, and Context() fails if no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblimovelo_hip.so")
+
+LV_OK = 0
+SUMS_LEN = 96
+NS = 23
+
+# every symbol include/limovelo_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
+    "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_iterate",
+    "lv_update", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_get_timing", "lv_set_profiling",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("MAX_NUM_ITERS", C.c_int),
+        ("NUM_MATCH_POINTS", C.c_int),
+        ("MAX_DIST_PLANE", C.c_double),
+        ("PLANES_THRESHOLD", C.c_float),
+        ("estimate_extrinsics", C.c_int),
+        ("LiDAR_noise", C.c_double),
+        ("LIMITS", C.c_double * NS),
+        ("degeneracy_threshold", C.c_double),
+        ("voxel_size", C.c_float),
+        ("lanes_per_query", C.c_int),
+    ]
+
+
+class Sums(C.Structure):
+    _fields_ = [("HTH", C.c_double * 144), ("HTh", C.c_double * 12), ("sum_h2", C.c_double), ("n_valid", C.c_int64)]
+
+    def as_dict(self):
+        return dict(HTH=np.array(self.HTH).reshape(12, 12), HTh=np.array(self.HTh), sum_h2=float(self.sum_h2),
+                    n_valid=int(self.n_valid))
+
+
+class Timing(C.Structure):
+    _fields_ = [("last_update_ms", C.c_float), ("last_reduce_ms", C.c_float), ("last_solve_ms", C.c_float),
+                ("last_passes", C.c_int), ("fallback_queries", C.c_int)]
+
+
+class LvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen liblimovelo_hip.so.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LvError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.lv_last_error.restype = C.c_char_p
+        lib.lv_version.restype = C.c_char_p
+        lib.lv_map_size.restype = C.c_size_t
+        lib.lv_map_size.argtypes = [C.c_void_p]
+        lib.lv_get_stream.restype = C.c_void_p
+        lib.lv_get_stream.argtypes = [C.c_void_p]
+        lib.lv_sums_device_ptr.restype = C.c_void_p
+        lib.lv_sums_device_ptr.argtypes = [C.c_void_p]
+        lib.lv_destroy.restype = None
+        lib.lv_destroy.argtypes = [C.c_void_p]
+        lib.lv_default_params.restype = None
+        _lib = lib
+    return _lib
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load_library().lv_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k == "LIMITS":
+            for i in range(NS):
+                p.LIMITS[i] = float(v[i])
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _points(a):
+    """Accepts [N,3] float32 (stride 12) or a structured/2-D array with a custom byte stride."""
+    a = np.asarray(a)
+    if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] < 3 or not a.flags["C_CONTIGUOUS"]:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.strides[0], a.shape[0]
+
+
+class Context:
+    def __init__(self, params: Params | None = None, device: int = 0):
+        self.lib = load_library()
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        self._check(self.lib.lv_create(C.byref(self.params), int(device), C.byref(self.h)))
+
+    def _check(self, rc):
+        if rc != LV_OK:
+            raise LvError(f"limovelo_hip error {rc}: {self.lib.lv_last_error().decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.lv_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- Mapper side
+    def map_build(self, pts):
+        a, stride, n = _points(pts)
+        self._check(self.lib.lv_map_build(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(stride), C.c_size_t(n)))
+
+    def map_add(self, pts, downsample=False):
+        a, stride, n = _points(pts)
+        self._check(self.lib.lv_map_add(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(stride), C.c_size_t(n),
+                                        int(bool(downsample))))
+
+    def map_size(self) -> int:
+        return int(self.lib.lv_map_size(self.h))
+
+    def map_fetch(self) -> np.ndarray:
+        n = self.map_size()
+        out = np.empty((n, 3), np.float32)
+        self._check(self.lib.lv_map_fetch(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        return out
+
+    # --- Localizator side
+    def scan_set(self, pts):
+        a, stride, n = _points(pts)
+        self._n = n
+        self._check(self.lib.lv_scan_set(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(stride), C.c_size_t(n)))
+
+    def iterate(self, state) -> dict:
+        s = np.ascontiguousarray(state, np.float64)
+        out = Sums()
+        self._check(self.lib.lv_iterate(self.h, s.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return out.as_dict()
+
+    def update(self, state, P, want_trace=True):
+        x = np.ascontiguousarray(state, np.float64).copy()
+        Pm = np.ascontiguousarray(P, np.float64).copy().reshape(NS, NS)
+        npass = self.params.MAX_NUM_ITERS + 1
+        passes = C.c_int(0)
+        sums = (Sums * npass)()
+        trace = np.zeros((npass, 49))
+        self._check(self.lib.lv_update(self.h, x.ctypes.data_as(C.c_void_p), Pm.ctypes.data_as(C.c_void_p), C.byref(passes),
+                                       sums if want_trace else None,
+                                       trace.ctypes.data_as(C.c_void_p) if want_trace else None))
+        n = passes.value
+        return x, Pm, n, trace[:n], [sums[i].as_dict() for i in range(n)] if want_trace else []
+
+    def update_begin(self, state, P):
+        x = np.ascontiguousarray(state, np.float64)
+        Pm = np.ascontiguousarray(P, np.float64)
+        self._check(self.lib.lv_update_begin(self.h, x.ctypes.data_as(C.c_void_p), Pm.ctypes.data_as(C.c_void_p)))
+
+    def pass_reduce(self):
+        self._check(self.lib.lv_pass_reduce(self.h))
+
+    def pass_solve(self):
+        self._check(self.lib.lv_pass_solve(self.h))
+
+    def sums_device_ptr(self) -> int:
+        return int(self.lib.lv_sums_device_ptr(self.h))
+
+    def set_sums_buffer(self, device_ptr: int | None):
+        self._check(self.lib.lv_set_sums_buffer(self.h, C.c_void_p(device_ptr or 0)))
+
+    def update_end(self):
+        x = np.zeros(26)
+        Pm = np.zeros((NS, NS))
+        passes = C.c_int(0)
+        self._check(self.lib.lv_update_end(self.h, x.ctypes.data_as(C.c_void_p), Pm.ctypes.data_as(C.c_void_p), C.byref(passes)))
+        return x, Pm, passes.value
+
+    def set_stream(self, stream_handle: int | None):
+        self._check(self.lib.lv_set_stream(self.h, C.c_void_p(stream_handle or 0)))
+
+    def get_stream(self) -> int:
+        return int(self.lib.lv_get_stream(self.h) or 0)
+
+    def synchronize(self):
+        self._check(self.lib.lv_synchronize(self.h))
+
+    def set_capture(self, on: bool):
+        self._check(self.lib.lv_set_capture(self.h, int(on)))
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.lv_set_profiling(self.h, int(on)))
+
+    def timing(self) -> dict:
+        t = Timing()
+        self._check(self.lib.lv_get_timing(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    # --- fetches
+    def fetch_knn(self):
+        n = self._n
+        idx = np.empty((n, 5), np.uint32)
+        d2 = np.empty((n, 5), np.float32)
+        self._check(self.lib.lv_fetch_knn(self.h, idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p)))
+        return idx, d2
+
+    def fetch_matches(self):
+        n = self._n
+        valid = np.empty(n, np.uint8)
+        pw = np.empty((n, 3), np.float32)
+        abcd = np.empty((n, 4), np.float32)
+        dist = np.empty(n, np.float32)
+        self._check(self.lib.lv_fetch_matches(self.h, valid.ctypes.data_as(C.c_void_p), pw.ctypes.data_as(C.c_void_p),
+                                              abcd.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
+        return valid, pw, abcd, dist
+
+    def fetch_rows(self):
+        n = self._n
+        H = np.empty((n, 12), np.float64)
+        h = np.empty(n, np.float64)
+        self._check(self.lib.lv_fetch_rows(self.h, H.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
+        return H, h

@@ -1,0 +1,531 @@
+// lv_api.hip — the C-ABI of include/limovelo_hip.h on top of the HIP kernels.
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "lv_host.hpp"
+
+namespace lv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace lv
+
+using namespace lv;
+
+struct lv_ctx {
+    lv_params prm;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    MapStore map;
+    std::vector<float4> h_map;  // host mirror (insertion order) for add() / fetch
+    float map_bbox_min[3], map_bbox_max[3];
+
+    ScanStore scan;
+    float4* h_stage = nullptr;  // pinned upload staging
+    size_t h_stage_cap = 0;
+
+    KfDev* d_kf = nullptr;
+    KfDev* h_kf = nullptr;  // pinned mirror
+    double* d_partials = nullptr;
+    double* d_sums = nullptr;      // record in use (own or caller-provided)
+    double* d_sums_own = nullptr;
+    double* h_sums = nullptr;  // pinned
+    int* d_fallback = nullptr;
+    int max_blocks = 1024;
+    int grid = 1;
+
+    // capture (debug / API-parity) buffers, sized for the current scan
+    bool capture = false;
+    size_t cap_n = 0;
+    DebugOut dbg{};
+    bool dbg_valid = false;
+
+    bool in_update = false;
+    int passes_issued = 0;
+
+    bool profiling = false;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pass;  // 3 per pass: before match kernel, after it, after reduce_partials + solve
+    hipEvent_t ev_mid = nullptr;      // set while a profiled pass is in flight: recorded right after the match kernel
+    lv_timing timing{};
+};
+
+namespace {
+
+#define LV_CHECK_CTX(ctx)                        \
+    do {                                         \
+        if (!(ctx)) {                            \
+            set_error("null context");           \
+            return LV_EINVAL;                    \
+        }                                        \
+        hipError_t _e = hipSetDevice((ctx)->device); \
+        if (_e != hipSuccess) {                  \
+            set_error("hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(_e)); \
+            return LV_EHIP;                      \
+        }                                        \
+    } while (0)
+
+int ensure_stage(lv_ctx* c, size_t n) {
+    if (n <= c->h_stage_cap) return LV_OK;
+    size_t cap = c->h_stage_cap ? c->h_stage_cap : 4096;
+    while (cap < n) cap *= 2;
+    if (c->h_stage) hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->h_stage_cap = 0;
+    LV_HIP(hipHostMalloc((void**)&c->h_stage, cap * sizeof(float4), hipHostMallocDefault));
+    c->h_stage_cap = cap;
+    return LV_OK;
+}
+
+inline void read_xyz(const void* base, size_t stride, size_t i, float& x, float& y, float& z) {
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * stride);
+    x = p[0]; y = p[1]; z = p[2];
+}
+
+void free_capture(lv_ctx* c) {
+    hipFree(c->dbg.knn_idx); hipFree(c->dbg.knn_d2); hipFree(c->dbg.valid); hipFree(c->dbg.p_world);
+    hipFree(c->dbg.abcd); hipFree(c->dbg.dist); hipFree(c->dbg.rows); hipFree(c->dbg.h);
+    c->dbg = DebugOut{};
+    c->cap_n = 0;
+    c->dbg_valid = false;
+}
+
+int ensure_capture(lv_ctx* c, size_t n) {
+    if (n <= c->cap_n && c->dbg.knn_idx) return LV_OK;
+    free_capture(c);
+    size_t cap = n ? n : 1;
+    LV_HIP(hipMalloc(&c->dbg.knn_idx, cap * KNN * sizeof(uint32_t)));
+    LV_HIP(hipMalloc(&c->dbg.knn_d2, cap * KNN * sizeof(float)));
+    LV_HIP(hipMalloc(&c->dbg.valid, cap));
+    LV_HIP(hipMalloc(&c->dbg.p_world, cap * 3 * sizeof(float)));
+    LV_HIP(hipMalloc(&c->dbg.abcd, cap * 4 * sizeof(float)));
+    LV_HIP(hipMalloc(&c->dbg.dist, cap * sizeof(float)));
+    LV_HIP(hipMalloc(&c->dbg.rows, cap * 12 * sizeof(double)));
+    LV_HIP(hipMalloc(&c->dbg.h, cap * sizeof(double)));
+    c->cap_n = cap;
+    return LV_OK;
+}
+
+void unpack_sums(const double* rec, lv_sums* out) {
+    int idx = 0;
+    for (int i = 0; i < 12; ++i)
+        for (int j = i; j < 12; ++j) {
+            out->HTH[i * 12 + j] = rec[idx];
+            out->HTH[j * 12 + i] = rec[idx];
+            ++idx;
+        }
+    for (int i = 0; i < 12; ++i) out->HTh[i] = rec[78 + i];
+    out->n_valid = (int64_t)rec[90];
+    out->sum_h2 = rec[91];
+}
+
+int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
+    KfDev* h = c->h_kf;
+    std::memcpy(h->x, x, sizeof(double) * NX);
+    std::memcpy(h->x_prop, x, sizeof(double) * NX);
+    if (P) {
+        std::memcpy(h->P_prop, P, sizeof(double) * NS * NS);
+        std::memcpy(h->P_post, P, sizeof(double) * NS * NS);
+    } else {
+        for (int i = 0; i < NS * NS; ++i) h->P_prop[i] = h->P_post[i] = (i / NS == i % NS) ? 1.0 : 0.0;
+    }
+    const size_t head = offsetof(KfDev, trace);
+    LV_HIP(hipMemcpyAsync(c->d_kf, h, head, hipMemcpyHostToDevice, c->stream));
+    int rc = launch_kf_begin(c->stream, c->d_kf);
+    if (rc) return rc;
+    LV_HIP(hipMemsetAsync(c->d_fallback, 0, sizeof(int), c->stream));
+    c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks);
+    return LV_OK;
+}
+
+int pass_reduce(lv_ctx* c) {
+    MatchParams mp;
+    mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
+    mp.planes_threshold = c->prm.PLANES_THRESHOLD;
+    mp.estimate_extrinsics = c->prm.estimate_extrinsics;
+    DebugOut dbg{};
+    if (c->capture) {
+        int rc = ensure_capture(c, c->scan.n);
+        if (rc) return rc;
+        dbg = c->dbg;
+        c->dbg_valid = true;
+    }
+    LV_HIP(hipMemsetAsync(c->d_fallback, 0, sizeof(int), c->stream));
+    int rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
+                                 c->d_partials, c->grid, dbg, c->d_fallback);
+    if (rc) return rc;
+    if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));
+    return launch_reduce_partials(c->stream, c->d_partials, c->grid, c->d_sums, c->d_kf);
+}
+
+int pass_solve(lv_ctx* c) {
+    SolveParams sp;
+    sp.R = c->prm.LiDAR_noise;
+    for (int i = 0; i < NS; ++i) sp.limits[i] = c->prm.LIMITS[i];
+    sp.maximum_iter = c->prm.MAX_NUM_ITERS;
+    return launch_solve(c->stream, c->d_kf, c->d_sums, sp);
+}
+
+}  // namespace
+
+extern "C" {
+
+void lv_default_params(lv_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->MAX_NUM_ITERS = 3;           // config/params.yaml:46
+    p->NUM_MATCH_POINTS = 5;        // :48
+    p->MAX_DIST_PLANE = 2.0;        // :49
+    p->PLANES_THRESHOLD = 5.e-2f;   // :50
+    p->estimate_extrinsics = 0;     // :13
+    p->LiDAR_noise = 0.001;         // :32
+    for (int i = 0; i < LV_STATE_DOF; ++i) p->LIMITS[i] = 0.001;  // src/main.cpp:145
+    p->degeneracy_threshold = 5.0;  // :52 (not applied)
+    p->voxel_size = 0.5f;
+    p->lanes_per_query = 8;
+}
+
+const char* lv_last_error(void) { return lv::g_err; }
+const char* lv_version(void) { return "limovelo_hip 0.1 (gfx950)"; }
+
+int lv_create(const lv_params* params, int device, lv_ctx** out) {
+    if (!params || !out) { set_error("null argument"); return LV_EINVAL; }
+    *out = nullptr;
+    if (params->NUM_MATCH_POINTS != KNN) { set_error("NUM_MATCH_POINTS=%d unsupported (this build: %d)", params->NUM_MATCH_POINTS, KNN); return LV_EINVAL; }
+    if (params->MAX_NUM_ITERS < 0 || params->MAX_NUM_ITERS + 1 > MAX_PASSES) { set_error("MAX_NUM_ITERS out of range"); return LV_EINVAL; }
+    if (!(params->voxel_size > 0.f)) { set_error("voxel_size must be > 0"); return LV_EINVAL; }
+    const int S = params->lanes_per_query;
+    if (!(S == 1 || S == 2 || S == 4 || S == 8 || S == 16)) { set_error("lanes_per_query must be 1,2,4,8,16"); return LV_EINVAL; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { set_error("no HIP device available (%s)", hipGetErrorString(e)); return LV_ENODEV; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return LV_EINVAL; }
+    LV_HIP(hipSetDevice(device));
+    lv_ctx* c = new (std::nothrow) lv_ctx();
+    if (!c) { set_error("out of host memory"); return LV_EINVAL; }
+    c->prm = *params;
+    c->device = device;
+    for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
+    hipDeviceProp_t prop;
+    LV_HIP(hipGetDeviceProperties(&prop, device));
+    c->max_blocks = prop.multiProcessorCount * 4;
+    if (c->max_blocks < 64) c->max_blocks = 64;
+    LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    LV_HIP(hipMalloc(&c->d_kf, sizeof(KfDev)));
+    LV_HIP(hipMemset(c->d_kf, 0, sizeof(KfDev)));
+    LV_HIP(hipHostMalloc((void**)&c->h_kf, sizeof(KfDev), hipHostMallocDefault));
+    std::memset(c->h_kf, 0, sizeof(KfDev));
+    LV_HIP(hipMalloc(&c->d_partials, (size_t)c->max_blocks * SUMS_LEN * sizeof(double)));
+    LV_HIP(hipMalloc(&c->d_sums_own, SUMS_LEN * sizeof(double)));
+    LV_HIP(hipMemset(c->d_sums_own, 0, SUMS_LEN * sizeof(double)));
+    c->d_sums = c->d_sums_own;
+    LV_HIP(hipHostMalloc((void**)&c->h_sums, SUMS_LEN * sizeof(double), hipHostMallocDefault));
+    LV_HIP(hipMalloc(&c->d_fallback, sizeof(int)));
+    LV_HIP(hipEventCreate(&c->ev_begin));
+    LV_HIP(hipEventCreate(&c->ev_end));
+    c->ev_pass.resize((size_t)(params->MAX_NUM_ITERS + 1) * 3);
+    for (auto& ev : c->ev_pass) LV_HIP(hipEventCreate(&ev));
+    *out = c;
+    return LV_OK;
+}
+
+void lv_destroy(lv_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    c->map.release();
+    c->scan.release();
+    free_capture(c);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_kf) hipHostFree(c->h_kf);
+    if (c->h_sums) hipHostFree(c->h_sums);
+    hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_sums_own); hipFree(c->d_fallback);
+    if (c->ev_begin) hipEventDestroy(c->ev_begin);
+    if (c->ev_end) hipEventDestroy(c->ev_end);
+    for (auto ev : c->ev_pass) hipEventDestroy(ev);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int lv_set_stream(lv_ctx* c, void* hip_stream) {
+    LV_CHECK_CTX(c);
+    LV_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return LV_OK;
+}
+void* lv_get_stream(lv_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int lv_synchronize(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    LV_HIP(hipStreamSynchronize(c->stream));
+    return LV_OK;
+}
+
+static int upload_and_rebuild(lv_ctx* c) {
+    const size_t m = c->h_map.size();
+    if (m > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
+    int rc = c->map.reserve(m);
+    if (rc) return rc;
+    c->map.m = (uint32_t)m;
+    if (m) LV_HIP(hipMemcpyAsync(c->map.d_orig, c->h_map.data(), m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    rc = c->map.rebuild(c->stream, c->prm.voxel_size, c->map_bbox_min, c->map_bbox_max);
+    if (rc) return rc;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    return LV_OK;
+}
+
+static int append_points(lv_ctx* c, const void* points, size_t stride, size_t n) {
+    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
+    c->h_map.reserve(c->h_map.size() + n);
+    for (size_t i = 0; i < n; ++i) {
+        float x, y, z;
+        read_xyz(points, stride, i, x, y, z);
+        if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) { set_error("non-finite map point at %zu", i); return LV_EINVAL; }
+        c->h_map.push_back(make_float4(x, y, z, 0.f));
+        c->map_bbox_min[0] = fminf(c->map_bbox_min[0], x); c->map_bbox_max[0] = fmaxf(c->map_bbox_max[0], x);
+        c->map_bbox_min[1] = fminf(c->map_bbox_min[1], y); c->map_bbox_max[1] = fmaxf(c->map_bbox_max[1], y);
+        c->map_bbox_min[2] = fminf(c->map_bbox_min[2], z); c->map_bbox_max[2] = fmaxf(c->map_bbox_max[2], z);
+    }
+    return LV_OK;
+}
+
+int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
+    LV_CHECK_CTX(c);
+    c->h_map.clear();
+    for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
+    c->map.origin_set = false;
+    int rc = append_points(c, points, stride, n);
+    if (rc) { c->h_map.clear(); return rc; }
+    return upload_and_rebuild(c);
+}
+
+int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downsample) {
+    LV_CHECK_CTX(c);
+    if (downsample) { set_error("lv_map_add(downsample=1): ikd-Tree box downsample not built yet"); return LV_ESTATE; }
+    if (n == 0) return LV_OK;
+    const size_t before = c->h_map.size();
+    int rc = append_points(c, points, stride, n);
+    if (rc) { c->h_map.resize(before); return rc; }
+    return upload_and_rebuild(c);
+}
+
+size_t lv_map_size(lv_ctx* c) { return c ? c->h_map.size() : 0; }
+
+int lv_map_fetch(lv_ctx* c, float* xyz_out, size_t capacity) {
+    LV_CHECK_CTX(c);
+    if (capacity < c->h_map.size() || (!xyz_out && capacity)) { set_error("capacity too small"); return LV_EINVAL; }
+    for (size_t i = 0; i < c->h_map.size(); ++i) {
+        xyz_out[3 * i] = c->h_map[i].x; xyz_out[3 * i + 1] = c->h_map[i].y; xyz_out[3 * i + 2] = c->h_map[i].z;
+    }
+    return LV_OK;
+}
+
+int lv_scan_set(lv_ctx* c, const void* points, size_t stride, size_t n) {
+    LV_CHECK_CTX(c);
+    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
+    if (n > 0xFFFFFFF0ull) { set_error("scan too large"); return LV_EINVAL; }
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    rc = c->scan.reserve(n);
+    if (rc) return rc;
+    LV_HIP(hipStreamSynchronize(c->stream));  // staging buffer reuse
+    float bmin[3] = {INFINITY, INFINITY, INFINITY};
+    for (size_t i = 0; i < n; ++i) {
+        float x, y, z;
+        read_xyz(points, stride, i, x, y, z);
+        uint32_t ui = (uint32_t)i;
+        float w;
+        std::memcpy(&w, &ui, 4);
+        c->h_stage[i] = make_float4(x, y, z, w);
+        if (x < bmin[0]) bmin[0] = x;
+        if (y < bmin[1]) bmin[1] = y;
+        if (z < bmin[2]) bmin[2] = z;
+    }
+    c->scan.n = (uint32_t)n;
+    c->dbg_valid = false;
+    if (n == 0) return LV_OK;
+    LV_HIP(hipMemcpyAsync(c->scan.d_raw, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return c->scan.sort(c->stream, bmin, c->prm.voxel_size);
+}
+
+int lv_set_capture(lv_ctx* c, int enabled) {
+    LV_CHECK_CTX(c);
+    c->capture = enabled != 0;
+    return LV_OK;
+}
+
+int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
+    LV_CHECK_CTX(c);
+    if (!x || !out) { set_error("null argument"); return LV_EINVAL; }
+    std::memset(out, 0, sizeof(*out));
+    if (c->map.m == 0 || c->scan.n == 0) { c->dbg_valid = false; return LV_OK; }  // Mapper.cpp:42 — empty Matches
+    int rc = begin_common(c, x, nullptr);
+    if (rc) return rc;
+    const bool cap = c->capture;
+    c->capture = true;  // lv_iterate is the API-parity path: always captures per-point outputs
+    rc = pass_reduce(c);
+    c->capture = cap;
+    if (rc) return rc;
+    LV_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, SUMS_LEN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LV_HIP(hipMemcpyAsync(&c->h_kf->fallback_queries, c->d_fallback, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LV_HIP(hipStreamSynchronize(c->stream));
+    unpack_sums(c->h_sums, out);
+    c->timing.fallback_queries = c->h_kf->fallback_queries;
+    return LV_OK;
+}
+
+int lv_update_begin(lv_ctx* c, const lv_state* x, const double* P) {
+    LV_CHECK_CTX(c);
+    if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
+    c->in_update = true;
+    c->passes_issued = 0;
+    return begin_common(c, x, P);
+}
+
+int lv_pass_reduce(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    if (!c->in_update) { set_error("lv_pass_reduce outside lv_update_begin/end"); return LV_ESTATE; }
+    if (c->map.m == 0 || c->scan.n == 0) {
+        LV_HIP(hipMemsetAsync(c->d_sums, 0, SUMS_LEN * sizeof(double), c->stream));
+        return LV_OK;
+    }
+    return pass_reduce(c);
+}
+
+void* lv_sums_device_ptr(lv_ctx* c) { return c ? (void*)c->d_sums : nullptr; }
+
+int lv_set_sums_buffer(lv_ctx* c, void* device_ptr) {
+    LV_CHECK_CTX(c);
+    if (c->in_update) { set_error("lv_set_sums_buffer inside an update"); return LV_ESTATE; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    c->d_sums = device_ptr ? static_cast<double*>(device_ptr) : c->d_sums_own;
+    return LV_OK;
+}
+
+int lv_pass_solve(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    if (!c->in_update) { set_error("lv_pass_solve outside lv_update_begin/end"); return LV_ESTATE; }
+    c->passes_issued++;
+    return pass_solve(c);
+}
+
+int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
+    LV_CHECK_CTX(c);
+    if (!c->in_update) { set_error("lv_update_end without lv_update_begin"); return LV_ESTATE; }
+    c->in_update = false;
+    LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, sizeof(KfDev), hipMemcpyDeviceToHost, c->stream));
+    LV_HIP(hipStreamSynchronize(c->stream));
+    if (x) std::memcpy(x, c->h_kf->x, sizeof(double) * NX);
+    if (P) std::memcpy(P, c->h_kf->P_post, sizeof(double) * NS * NS);
+    if (passes) *passes = c->h_kf->passes;
+    c->timing.last_passes = c->h_kf->passes;
+    return LV_OK;
+}
+
+int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass, double* trace) {
+    LV_CHECK_CTX(c);
+    if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
+    if (passes) *passes = 0;
+    if (c->map.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
+    const int npass = c->prm.MAX_NUM_ITERS + 1;
+    int rc = lv_update_begin(c, x, P);
+    if (rc) return rc;
+    if (c->profiling) LV_HIP(hipEventRecord(c->ev_begin, c->stream));
+    for (int i = 0; i < npass; ++i) {
+        if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
+        c->ev_mid = c->profiling ? c->ev_pass[3 * i + 1] : nullptr;
+        rc = lv_pass_reduce(c);
+        c->ev_mid = nullptr;
+        if (rc) { c->in_update = false; return rc; }
+        rc = lv_pass_solve(c);
+        if (rc) { c->in_update = false; return rc; }
+        if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
+    }
+    if (c->profiling) LV_HIP(hipEventRecord(c->ev_end, c->stream));
+    int np = 0;
+    rc = lv_update_end(c, x, P, &np);
+    if (rc) return rc;
+    if (passes) *passes = np;
+    if (per_pass)
+        for (int i = 0; i < np && i < MAX_PASSES; ++i) unpack_sums(c->h_kf->sums_log + (size_t)i * SUMS_LEN, &per_pass[i]);
+    if (trace) std::memcpy(trace, c->h_kf->trace, sizeof(double) * 49 * (size_t)(np < MAX_PASSES ? np : MAX_PASSES));
+    if (c->profiling) {
+        float ms = 0.f, r = 0.f, s = 0.f;
+        hipEventElapsedTime(&ms, c->ev_begin, c->ev_end);
+        c->timing.last_update_ms = ms;
+        int cnt = np > 0 ? np : 1;
+        for (int i = 0; i < np && i < npass; ++i) {
+            float a = 0.f, b = 0.f;
+            hipEventElapsedTime(&a, c->ev_pass[3 * i + 0], c->ev_pass[3 * i + 1]);
+            hipEventElapsedTime(&b, c->ev_pass[3 * i + 1], c->ev_pass[3 * i + 2]);
+            r += a;
+            s += b;
+        }
+        c->timing.last_reduce_ms = r / cnt;
+        c->timing.last_solve_ms = s / cnt;
+    }
+    return LV_OK;
+}
+
+static int fetch_check(lv_ctx* c) {
+    if (!c->dbg_valid || !c->dbg.knn_idx) { set_error("no captured pass: call lv_iterate (or lv_set_capture(1) before lv_update)"); return LV_ESTATE; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    return LV_OK;
+}
+
+int lv_fetch_knn(lv_ctx* c, uint32_t* idx, float* d2) {
+    LV_CHECK_CTX(c);
+    int rc = fetch_check(c);
+    if (rc) return rc;
+    const size_t n = c->scan.n;
+    if (idx) LV_HIP(hipMemcpy(idx, c->dbg.knn_idx, n * KNN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (d2) LV_HIP(hipMemcpy(d2, c->dbg.knn_d2, n * KNN * sizeof(float), hipMemcpyDeviceToHost));
+    return LV_OK;
+}
+
+int lv_fetch_matches(lv_ctx* c, uint8_t* valid, float* p_world, float* abcd, float* dist) {
+    LV_CHECK_CTX(c);
+    int rc = fetch_check(c);
+    if (rc) return rc;
+    const size_t n = c->scan.n;
+    if (valid) LV_HIP(hipMemcpy(valid, c->dbg.valid, n, hipMemcpyDeviceToHost));
+    if (p_world) LV_HIP(hipMemcpy(p_world, c->dbg.p_world, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (abcd) LV_HIP(hipMemcpy(abcd, c->dbg.abcd, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (dist) LV_HIP(hipMemcpy(dist, c->dbg.dist, n * sizeof(float), hipMemcpyDeviceToHost));
+    return LV_OK;
+}
+
+int lv_fetch_rows(lv_ctx* c, double* H, double* h) {
+    LV_CHECK_CTX(c);
+    int rc = fetch_check(c);
+    if (rc) return rc;
+    const size_t n = c->scan.n;
+    if (H) LV_HIP(hipMemcpy(H, c->dbg.rows, n * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    if (h) LV_HIP(hipMemcpy(h, c->dbg.h, n * sizeof(double), hipMemcpyDeviceToHost));
+    return LV_OK;
+}
+
+int lv_get_timing(lv_ctx* c, lv_timing* out) {
+    if (!c || !out) { set_error("null argument"); return LV_EINVAL; }
+    *out = c->timing;
+    return LV_OK;
+}
+
+int lv_set_profiling(lv_ctx* c, int enabled) {
+    if (!c) { set_error("null context"); return LV_EINVAL; }
+    c->profiling = enabled != 0;
+    return LV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// lv_device.hpp — shared device-side types and arithmetic of the MI355X KF-update hot path.
+//
+// Everything numeric here must produce the same bits as the reference's x86-64 -O3 build without
+// FMA (reference CMakeLists.txt:8,16): this translation unit family is compiled with
+// -ffp-contract=off, f32 sqrt/div are correctly rounded (hipcc default), and every sum is written
+// in the evaluation order of the reference expression it mirrors (cited per function).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lv {
+
+constexpr int KNN = 5;              // NUM_MATCH_POINTS (config/params.yaml:48)
+constexpr int NS = 23;              // state dof
+constexpr int NX = 26;              // state doubles (lv_state)
+constexpr int SUMS_LEN = 96;        // per-pass reduction record (include/limovelo_hip.h)
+constexpr int N_OUT = 92;           // used entries of the record
+constexpr int CELL_OFFSET = 1 << 20;
+constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-force path
+constexpr int MAX_LEVELS = 16;
+constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr int MAX_PASSES = 16;
+
+struct RT32 {  // RotTransl (reference include/Headers/Objects.hpp:139-151), row-major R
+    float R[9];
+    float t[3];
+};
+
+// Constants of one measurement pass, derived on the device from the f64 state.
+struct PoseConsts {
+    RT32 Tc;              // X * X.I_Rt_L()                       (Mapper.cpp:51)
+    RT32 back;            // S.I_Rt_L().inv() * S.inv()            (Localizator.cpp:38)
+    RT32 LI;              // S.I_Rt_L()                            (Localizator.cpp:39)
+    double R_inv[9];      // s.rot.conjugate().toRotationMatrix()  (Localizator.cpp:43)
+    double I_R_L_inv[9];  // s.offset_R_L_I.conjugate()...         (Localizator.cpp:44)
+};
+
+// Device-resident filter state of one lv_update (esekf x_, P_, loop bookkeeping).
+struct KfDev {
+    double x[NX];
+    double x_prop[NX];
+    double P_prop[NS * NS];
+    double P_post[NS * NS];
+    double trace[MAX_PASSES * 49];
+    double sums_log[MAX_PASSES * SUMS_LEN];
+    int t;        // converge counter
+    int iter;     // upstream loop index i (starts at -1)
+    int done;
+    int passes;
+    int fallback_queries;
+    int pad_[3];
+    PoseConsts pose;
+};
+
+struct GridLevel {
+    const uint4* table;  // {key lo, key hi, start, count}
+    uint32_t mask;
+    uint32_t shift;      // 64 - log2(size)
+};
+
+struct MapView {
+    const float4* sorted;   // xyz + original index (bits) in Morton order of level-0 cells
+    const float4* orig;     // xyz in insertion order
+    uint32_t m;
+    int n_levels;
+    float origin[3];
+    float cell;             // level-0 cell edge
+    float inv_cell;
+    GridLevel lv[MAX_LEVELS];
+};
+
+struct MatchParams {
+    double max_dist_plane_sq;  // MAX_DIST_PLANE * MAX_DIST_PLANE (f64, Plane.cpp:42)
+    float planes_threshold;
+    int estimate_extrinsics;
+};
+
+struct DebugOut {  // all optional (nullptr = skip); indexed by ORIGINAL scan index
+    uint32_t* knn_idx;  // N x 5
+    float* knn_d2;      // N x 5
+    uint8_t* valid;     // N
+    float* p_world;     // N x 3
+    float* abcd;        // N x 4
+    float* dist;        // N
+    double* rows;       // N x 12
+    double* h;          // N
+};
+
+// ---------------------------------------------------------------------------------------------
+// f32 / f64 3-vector algebra in Eigen 3.3 fixed-size evaluation order: x0 + (x1 + x2).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3f(float a0, float b0, float a1, float b1, float a2, float b2) {
+    float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+    float t = p1 + p2;
+    return p0 + t;
+}
+__device__ __forceinline__ double dot3d(double a0, double b0, double a1, double b1, double a2, double b2) {
+    double p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+    double t = p1 + p2;
+    return p0 + t;
+}
+
+// RotTransl operator*(RT1, RT2) — reference src/Objects/RotTransl.cpp:36-41
+__device__ inline RT32 rt_compose(const RT32& a, const RT32& b) {
+    RT32 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.R[i * 3 + j] = dot3f(a.R[i * 3 + 0], b.R[0 * 3 + j], a.R[i * 3 + 1], b.R[1 * 3 + j], a.R[i * 3 + 2], b.R[2 * 3 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o.t[i] = dot3f(a.R[i * 3 + 0], b.t[0], a.R[i * 3 + 1], b.t[1], a.R[i * 3 + 2], b.t[2]) + a.t[i];
+    return o;
+}
+// Point operator*(RT, p) — reference src/Objects/RotTransl.cpp:43-48
+__device__ __forceinline__ void rt_apply(const RT32& a, float px, float py, float pz, float& ox, float& oy, float& oz) {
+    ox = dot3f(a.R[0], px, a.R[1], py, a.R[2], pz) + a.t[0];
+    oy = dot3f(a.R[3], px, a.R[4], py, a.R[5], pz) + a.t[1];
+    oz = dot3f(a.R[6], px, a.R[7], py, a.R[8], pz) + a.t[2];
+}
+// RotTransl::inv() — reference src/Objects/RotTransl.cpp:29-34
+__device__ inline RT32 rt_inv(const RT32& a) {
+    RT32 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = a.R[j * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o.t[i] = dot3f(-o.R[i * 3 + 0], a.t[0], -o.R[i * 3 + 1], a.t[1], -o.R[i * 3 + 2], a.t[2]);
+    return o;
+}
+
+// [UPSTREAM-RECALL Eigen Quaternion::toRotationMatrix]; q = (x,y,z,w)
+__device__ inline void quat_to_rot(const double q[4], double R[9]) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// State(const state_ikfom&, double) (reference src/Objects/State.cpp:51-62) followed by the
+// per-pass transforms.  x = lv_state as 26 doubles.
+__device__ inline void compute_pose_consts(const double* x, PoseConsts* out) {
+    double R[9], RLI[9];
+    quat_to_rot(x + 3, R);
+    quat_to_rot(x + 7, RLI);
+    RT32 X, LI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { X.R[i] = (float)R[i]; LI.R[i] = (float)RLI[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { X.t[i] = (float)x[i]; LI.t[i] = (float)x[11 + i]; }
+    out->Tc = rt_compose(X, LI);
+    out->back = rt_compose(rt_inv(LI), rt_inv(X));
+    out->LI = LI;
+    double qc[4];
+    qc[0] = -x[3]; qc[1] = -x[4]; qc[2] = -x[5]; qc[3] = x[6];
+    quat_to_rot(qc, out->R_inv);
+    qc[0] = -x[7]; qc[1] = -x[8]; qc[2] = -x[9]; qc[3] = x[10];
+    quat_to_rot(qc, out->I_R_L_inv);
+}
+
+// voxel coordinates -----------------------------------------------------------------------------
+__device__ __forceinline__ int cell_coord(float p, float origin, float inv_cell) {
+    float f = floorf((p - origin) * inv_cell);
+    // clamp in float first: out-of-range / NaN map to the clamp limits (NaN -> lower limit)
+    f = fminf(fmaxf(f, -1048000.0f), 1048000.0f);
+    return (int)f + CELL_OFFSET;
+}
+__device__ __forceinline__ uint64_t pack_cell(uint32_t ix, uint32_t iy, uint32_t iz) {
+    return (uint64_t)ix | ((uint64_t)iy << 21) | ((uint64_t)iz << 42);
+}
+__device__ __forceinline__ uint32_t hash_cell(uint64_t key, uint32_t shift) {
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift);
+}
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit
+    uint64_t x = v & 0x1fffff;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__device__ __forceinline__ uint32_t compact21(uint64_t x) {
+    x &= 0x1249249249249249ull;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ull;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00full;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffull;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffull;
+    x = (x ^ (x >> 32)) & 0x1fffff;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint64_t morton3(uint32_t ix, uint32_t iy, uint32_t iz) {
+    return spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+}
+
+}  // namespace lv
+
+// host-side launch declarations (defined in the .hip files) ----------------------------------------
+namespace lv {
+struct MapBuffers;  // lv_map.hip
+}

@@ -1,0 +1,79 @@
+// lv_host.hpp — host-side state behind the C-ABI (include/limovelo_hip.h).
+#pragma once
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/limovelo_hip.h"
+#include "lv_device.hpp"
+
+namespace lv {
+
+void set_error(const char* fmt, ...);
+
+#define LV_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ::lv::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return LV_EHIP;                                                                       \
+        }                                                                                         \
+    } while (0)
+
+struct MapStore {
+    float4* d_orig = nullptr;
+    float4* d_sorted = nullptr;
+    uint64_t* d_keys = nullptr;
+    uint64_t* d_keys_sorted = nullptr;
+    uint32_t* d_idx = nullptr;
+    uint32_t* d_idx_sorted = nullptr;
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t* d_counts = nullptr;
+    uint4* d_tables[MAX_LEVELS] = {};
+    uint32_t table_size[MAX_LEVELS] = {};
+    uint32_t n_cells[MAX_LEVELS] = {};
+    size_t capacity = 0;
+    uint32_t m = 0;
+    bool origin_set = false;
+    float origin[3] = {0, 0, 0};
+    MapView view{};
+
+    int reserve(size_t cap);
+    int rebuild(hipStream_t stream, float cell, const float bbox_min[3], const float bbox_max[3]);
+    void release();
+};
+
+// lv_match.hip
+int launch_match_reduce(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n,
+                        const KfDev* kf, const MatchParams& prm, double* partials, int grid, const DebugOut& dbg,
+                        int* fallback_counter);
+int match_grid_size(int lanes_per_query, uint32_t n, int max_blocks);
+// lv_solve.hip
+int launch_kf_begin(hipStream_t stream, KfDev* kf);
+int launch_reduce_partials(hipStream_t stream, const double* partials, int nblocks, double* sums, KfDev* kf);
+struct SolveParams {
+    double R;
+    double limits[NS];
+    int maximum_iter;
+};
+int launch_solve(hipStream_t stream, KfDev* kf, const double* sums, const SolveParams& prm);
+// lv_scan.hip
+struct ScanStore {
+    float4* d_raw = nullptr;     // upload order; w = original index
+    float4* d_sorted = nullptr;  // Morton order (LiDAR frame)
+    uint32_t* d_keys = nullptr;
+    uint32_t* d_keys_sorted = nullptr;
+    uint32_t* d_idx = nullptr;
+    uint32_t* d_idx_sorted = nullptr;
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    size_t capacity = 0;
+    uint32_t n = 0;
+    int reserve(size_t cap);
+    int sort(hipStream_t stream, const float bbox_min[3], float cell);
+    void release();
+};
+
+}  // namespace lv

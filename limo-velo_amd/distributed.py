@@ -1,0 +1,82 @@
+"""Multi-GPU form of the iterated update: scan points sharded across ranks, map replicated, one
+all-reduce(sum) of the 96-double record per IKFoM pass, everything else local.
+
+The sharding / collective / loop logic is engine-agnostic so that it is exercised on CPU with the
+`gloo` backend (tests/test_distributed_cpu.py plugs a CPU engine built on the oracle — test
+infrastructure); the product engine is `HipEngine` over the C-ABI, and it is the only engine this
+package ships.  One process per GPU; `dist` is torch.distributed (backend "nccl" == RCCL on ROCm).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SUMS_LEN = 96
+
+
+def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced split of n scan points: ranks < n % world get one extra point."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HipEngine:
+    """Per-rank engine over the C-ABI split form (lv_update_begin / lv_pass_reduce / lv_pass_solve /
+    lv_update_end).  The sums record lives in a torch tensor so RCCL can reduce it in place."""
+
+    def __init__(self, ctx, torch, multi: bool):
+        self.ctx, self.torch, self.multi = ctx, torch, multi
+        self.max_passes = ctx.params.MAX_NUM_ITERS + 1
+        self.sums = None
+        if multi:
+            self.sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
+            ctx.set_sums_buffer(self.sums.data_ptr())
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def scan_set(self, pts):
+        self.ctx.scan_set(pts)
+
+    def update_fused(self, x, P):
+        xo, Po, passes, _, _ = self.ctx.update(x, P, want_trace=False)
+        return xo, Po, passes
+
+    def begin(self, x, P):
+        self.ctx.update_begin(x, P)
+
+    def reduce(self):
+        self.ctx.pass_reduce()
+        return self.sums
+
+    def solve(self):
+        self.ctx.pass_solve()
+
+    def end(self):
+        return self.ctx.update_end()
+
+
+class ShardedUpdater:
+    def __init__(self, ctx_or_engine, rank: int, world: int, dist, torch):
+        self.rank, self.world, self.dist = rank, world, dist
+        if hasattr(ctx_or_engine, "begin"):
+            self.engine = ctx_or_engine
+        else:
+            self.engine = HipEngine(ctx_or_engine, torch, multi=world > 1)
+        self.n_local = 0
+
+    def scan_set(self, scan_xyz):
+        scan_xyz = np.ascontiguousarray(scan_xyz, dtype=np.float32)
+        lo, hi = shard_bounds(len(scan_xyz), self.rank, self.world)
+        self.n_local = hi - lo
+        self.engine.scan_set(scan_xyz[lo:hi])
+
+    def update(self, x, P):
+        """Returns (x_post, P_post, passes).  Every rank computes the identical posterior: the solve
+        consumes only the all-reduced record, which is bitwise identical on all ranks."""
+        if self.world == 1:
+            return self.engine.update_fused(x, P)
+        self.engine.begin(x, P)
+        for _ in range(self.engine.max_passes):
+            rec = self.engine.reduce()
+            self.dist.all_reduce(rec, op=self.dist.ReduceOp.SUM)
+            self.engine.solve()
+        return self.engine.end()

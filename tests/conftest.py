@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lv():
+    import lvamd
+
+    return lvamd.load()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import lvoracle
+
+    lvoracle.build()
+    return lvoracle
+
+
+@pytest.fixture(scope="session")
+def scene_small(lv):
+    """configs[0]: 2k-pt scan vs 50k-pt map."""
+    from limo_velo_amd import synth
+
+    return synth.make_scene(50_000, 2_000)

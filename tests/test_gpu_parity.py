@@ -1,0 +1,243 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): kNN indices and f32 distances bit-exact; every f32-origin per-point
+quantity (world point, plane ABCD, point-to-plane distance) bit-exact because the device code executes
+the same IEEE operation sequence (-ffp-contract=off, correctly rounded sqrt/div); f64 rows bit-exact;
+reduced sums within 1e-10 relative (different but fixed summation order); state after each IKFoM pass
+within 1e-9 (abs, metres / radians) — the device solve uses unpivoted Gauss-Jordan where the oracle
+uses pivoted LU.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_SUMS_REL = 1e-10
+TOL_STATE = 1e-9
+
+
+@pytest.fixture(scope="module")
+def capi(lv):
+    from limo_velo_amd import capi as c
+
+    return c
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _compare_pass(ctx, oracle, state, map_xyz, scan_xyz, tree=None, params=None):
+    g = ctx.iterate(state)
+    o = oracle.iterate(state, map_xyz, scan_xyz, tree=tree, params=params)
+    idx, d2 = ctx.fetch_knn()
+    assert np.array_equal(idx, o["knn_idx"]), f"kNN index mismatches: {(idx != o['knn_idx']).any(axis=1).sum()}"
+    assert np.array_equal(_bits(d2), _bits(o["knn_d2"]))
+    valid, pw, abcd, dist = ctx.fetch_matches()
+    assert np.array_equal(valid, o["valid"]), f"valid-mask flips: {(valid != o['valid']).sum()}"
+    assert np.array_equal(_bits(pw), _bits(oracle.transform_scan(state, scan_xyz)))
+    assert np.array_equal(_bits(abcd), _bits(o["abcd"]))
+    assert np.array_equal(_bits(dist), _bits(o["dist"]))
+    H, h = ctx.fetch_rows()
+    assert np.array_equal(H, o["Hrows"])
+    assert np.array_equal(h, o["h"])
+    assert g["n_valid"] == o["n_valid"]
+    scale = max(np.abs(o["HTH"]).max(), 1e-300)
+    assert np.abs(g["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * scale
+    assert np.abs(g["HTh"] - o["HTh"]).max() <= TOL_SUMS_REL * max(np.abs(o["HTh"]).max(), 1.0)
+    assert abs(g["sum_h2"] - o["sum_h2"]) <= TOL_SUMS_REL * max(o["sum_h2"], 1.0)
+    return g, o
+
+
+def test_single_pass_cfg0(capi, oracle, scene_small):
+    sc = scene_small
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        g, o = _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
+        assert g["n_valid"] > 1500
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
+def test_lanes_per_query_all_identical(capi, oracle, scene_small, lanes):
+    sc = scene_small
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context(capi.default_params(lanes_per_query=lanes)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"][:777])  # ragged: not a multiple of any tile
+        _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"][:777], tree)
+
+
+def test_estimate_extrinsics_rows(capi, oracle, lv):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 1500, extrinsics="xaloc")
+    prm_o = oracle.default_params(estimate_extrinsics=1)
+    with capi.Context(capi.default_params(estimate_extrinsics=1)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        g, o = _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], None, prm_o)
+        assert np.abs(o["HTH"][6:, 6:]).max() > 0
+
+
+def test_update_cfg0(capi, oracle, scene_small):
+    sc = scene_small
+    tree = oracle.KdTree(sc["map_xyz"])
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+    assert passes == po
+    for i in range(passes):
+        assert sums[i]["n_valid"] == so[i]["n_valid"], f"pass {i}"
+        assert np.abs(tr[i] - tro[i]).max() < TOL_STATE, f"pass {i}: {np.abs(tr[i] - tro[i]).max()}"
+    assert np.abs(x - xo).max() < TOL_STATE
+    assert np.abs(P - Po).max() < 1e-10
+    assert np.linalg.norm(x[:3] - sc["x_true"][:3]) < 5e-3  # converged to the ground truth pose
+
+
+def test_update_with_correlated_P(capi, oracle, scene_small):
+    """P after IMU predicts has cross terms: exercises grav (S2) and velocity/bias columns."""
+    sc = scene_small
+    x, P = sc["x_init"].copy(), sc["P0"].copy()
+    Q = np.diag([1e-4] * 3 + [1e-2] * 3 + [1e-5] * 3 + [1e-4] * 3)
+    for _ in range(20):
+        x, P = oracle.predict(x, P, 0.005, Q, [0.1, -0.05, 9.81], [0.01, 0.02, -0.01])
+    tree = oracle.KdTree(sc["map_xyz"])
+    xo, Po, po, tro, _ = oracle.update(x, P, sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        xg, Pg, pg, trg, _ = ctx.update(x, P)
+    assert pg == po
+    assert np.abs(trg - tro).max() < TOL_STATE
+    assert np.abs(xg - xo).max() < TOL_STATE
+    assert np.abs(Pg - Po).max() < 1e-9 * max(1.0, np.abs(Po).max())
+
+
+def test_no_map_and_tiny_maps(capi, oracle, scene_small):
+    sc = scene_small
+    scan = sc["scan_xyz"][:300]
+    with capi.Context() as ctx:
+        ctx.scan_set(scan)
+        g = ctx.iterate(sc["x_init"])  # no map: Mapper::match returns empty (Mapper.cpp:42)
+        assert g["n_valid"] == 0 and not g["HTH"].any()
+        x, P, passes, _, _ = ctx.update(sc["x_init"], sc["P0"])
+        assert passes == 0 and np.array_equal(x, sc["x_init"])  # Localizator::correct no-ops (Localizator.cpp:24)
+        for m in (1, 4, 5, 7):  # fewer than / exactly k points
+            ctx.map_build(sc["map_xyz"][:m])
+            assert ctx.map_size() == m
+            g = ctx.iterate(sc["x_init"])
+            idx, d2 = ctx.fetch_knn()
+            oi, od, found, _ = oracle.knn_brute(sc["map_xyz"][:m], oracle.transform_scan(sc["x_init"], scan))
+            assert np.array_equal(idx, oi) and np.array_equal(_bits(d2), _bits(od))
+            if m < 5:
+                assert g["n_valid"] == 0
+        ctx.map_build(sc["map_xyz"][:0])
+        assert ctx.map_size() == 0
+        assert ctx.iterate(sc["x_init"])["n_valid"] == 0
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(scan[:0])  # empty scan
+        assert ctx.iterate(sc["x_init"])["n_valid"] == 0
+
+
+def test_duplicates_and_ties(capi, oracle, scene_small):
+    """Exact duplicate map points and lattice maps create equal distances: ties resolve to the lowest
+    map index, like the oracle."""
+    sc = scene_small
+    rng = np.random.default_rng(5)
+    base = sc["map_xyz"][:20000]
+    dup = np.concatenate([base, base[rng.integers(0, len(base), 5000)]])
+    lattice = np.stack(np.meshgrid(np.arange(-8, 8, 0.25), np.arange(-8, 8, 0.25), [0.0, 0.25]), -1).reshape(-1, 3)
+    lattice = lattice.astype(np.float32)
+    q_lat = (rng.integers(-28, 28, (400, 3)) * 0.125).astype(np.float32)  # queries on half-lattice sites
+    ident = sc["x_true"].copy()
+    ident[:3] = 0
+    ident[3:7] = [0, 0, 0, 1]
+    with capi.Context() as ctx:
+        ctx.map_build(dup)
+        ctx.scan_set(sc["scan_xyz"][:500])
+        _compare_pass(ctx, oracle, sc["x_init"], dup, sc["scan_xyz"][:500], None)
+        ctx.map_build(lattice)
+        ctx.scan_set(q_lat)
+        ctx.iterate(ident)
+        idx, d2 = ctx.fetch_knn()
+        oi, od, _, ties = oracle.knn_brute(lattice, q_lat)
+        assert ties > 0
+        assert np.array_equal(idx, oi) and np.array_equal(_bits(d2), _bits(od))
+
+
+def test_far_and_sparse_queries_fall_back_exactly(capi, oracle, scene_small):
+    """Queries far outside the map / in empty space must leave the level-0 search and still be exact."""
+    sc = scene_small
+    rng = np.random.default_rng(9)
+    far = (rng.uniform(-1, 1, (256, 3)) * [400, 400, 50]).astype(np.float32)
+    far[:8] *= 1000.0  # beyond the voxel range -> brute force
+    near = sc["scan_xyz"][:256]
+    scan = np.concatenate([far, near])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(scan)
+        _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], scan, None)
+        assert ctx.timing()["fallback_queries"] >= 200
+
+
+def test_point_stride_32(capi, oracle, scene_small):
+    """The reference's 32-byte Point records (Objects.hpp:20-28) are accepted in place."""
+    sc = scene_small
+    rec = np.zeros(len(sc["map_xyz"]), dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("pad", "f4"), ("time", "f8"),
+                                               ("intensity", "f4"), ("range", "f4")])
+    assert rec.dtype.itemsize == 32
+    rec["x"], rec["y"], rec["z"] = sc["map_xyz"].T
+    rec["time"] = 1.5
+    import ctypes as C
+
+    with capi.Context() as ctx:
+        ctx._check(ctx.lib.lv_map_build(ctx.h, rec.ctypes.data_as(C.c_void_p), C.c_size_t(32), C.c_size_t(len(rec))))
+        assert np.array_equal(ctx.map_fetch(), sc["map_xyz"])
+
+
+def test_medium_cfg1_like(capi, oracle, lv):
+    """30k-pt scan vs 500k-pt map, single pass (BASELINE configs[1] sizes)."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(500_000, 30_000)
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
+
+
+def test_headline_size_update(capi, oracle, lv):
+    """64k-pt scan vs 1M-pt map, full iterated update (the BASELINE metric's configuration)."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(1_048_576, 65_536)
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    assert passes == po
+    assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+    assert np.abs(tr - tro).max() < TOL_STATE
+    assert np.abs(x - xo).max() < TOL_STATE
+
+
+def test_update_split_form_matches_fused(capi, scene_small):
+    sc = scene_small
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x1, P1, p1, _, _ = ctx.update(sc["x_init"], sc["P0"])
+        ctx.update_begin(sc["x_init"], sc["P0"])
+        for _ in range(ctx.params.MAX_NUM_ITERS + 1):
+            ctx.pass_reduce()
+            ctx.pass_solve()
+        x2, P2, p2 = ctx.update_end()
+    assert p1 == p2 and np.array_equal(x1, x2) and np.array_equal(P1, P2)
