@@ -166,7 +166,9 @@ typedef struct lv_timing {
     float last_reduce_ms;      /* average device time of the match+reduce kernel in the last lv_update */
     float last_solve_ms;       /* average device time of the solve kernel in the last lv_update */
     int   last_passes;
-    int   fallback_queries;    /* scan points that left the level-0 voxel search in the last pass */
+    int   fallback_queries;    /* scan points that left the bucketed voxel levels (generic search) in the last update */
+    float pass_match_ms[8];    /* device time of the match+reduce kernel per pass of the last profiled lv_update */
+    float pass_solve_ms[8];    /* device time of reduce_groups + solve per pass */
 } lv_timing;
 int lv_get_timing(lv_ctx* ctx, lv_timing* out);
 /* enable per-kernel HIP-event timing inside lv_update (adds event records to the stream) */

@@ -52,7 +52,8 @@ class Sums(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("last_update_ms", C.c_float), ("last_reduce_ms", C.c_float), ("last_solve_ms", C.c_float),
-                ("last_passes", C.c_int), ("fallback_queries", C.c_int)]
+                ("last_passes", C.c_int), ("fallback_queries", C.c_int), ("pass_match_ms", C.c_float * 8),
+                ("pass_solve_ms", C.c_float * 8)]
 
 
 class LvError(RuntimeError):
@@ -219,7 +220,10 @@ class Context:
     def timing(self) -> dict:
         t = Timing()
         self._check(self.lib.lv_get_timing(self.h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in Timing._fields_}
+        out = {k: getattr(t, k) for k, _ in Timing._fields_}
+        out["pass_match_ms"] = list(t.pass_match_ms)
+        out["pass_solve_ms"] = list(t.pass_solve_ms)
+        return out
 
     # --- fetches
     def fetch_knn(self):

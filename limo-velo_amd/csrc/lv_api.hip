@@ -38,10 +38,11 @@ struct lv_ctx {
     KfDev* d_kf = nullptr;
     KfDev* h_kf = nullptr;  // pinned mirror
     double* d_partials = nullptr;
+    double* d_groups = nullptr;    // group records (reduce stage 1)
+    int ngroups = 0;
     double* d_sums = nullptr;      // record in use (own or caller-provided)
     double* d_sums_own = nullptr;
     double* h_sums = nullptr;  // pinned
-    int* d_fallback = nullptr;
     int max_blocks = 1024;
     int grid = 1;
 
@@ -52,6 +53,7 @@ struct lv_ctx {
     bool dbg_valid = false;
 
     bool in_update = false;
+    bool want_log = false;         // download trace / per-pass sums at lv_update_end
     int passes_issued = 0;
 
     bool profiling = false;
@@ -133,23 +135,20 @@ void unpack_sums(const double* rec, lv_sums* out) {
 int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
     KfDev* h = c->h_kf;
     std::memcpy(h->x, x, sizeof(double) * NX);
-    std::memcpy(h->x_prop, x, sizeof(double) * NX);
     if (P) {
         std::memcpy(h->P_prop, P, sizeof(double) * NS * NS);
-        std::memcpy(h->P_post, P, sizeof(double) * NS * NS);
     } else {
-        for (int i = 0; i < NS * NS; ++i) h->P_prop[i] = h->P_post[i] = (i / NS == i % NS) ? 1.0 : 0.0;
+        for (int i = 0; i < NS * NS; ++i) h->P_prop[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
-    const size_t head = offsetof(KfDev, trace);
+    const size_t head = offsetof(KfDev, P_post);  // upload region: x, P_prop
     LV_HIP(hipMemcpyAsync(c->d_kf, h, head, hipMemcpyHostToDevice, c->stream));
     int rc = launch_kf_begin(c->stream, c->d_kf);
     if (rc) return rc;
-    LV_HIP(hipMemsetAsync(c->d_fallback, 0, sizeof(int), c->stream));
     c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks);
     return LV_OK;
 }
 
-int pass_reduce(lv_ctx* c) {
+int pass_reduce(lv_ctx* c, bool finalize) {
     MatchParams mp;
     mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
     mp.planes_threshold = c->prm.PLANES_THRESHOLD;
@@ -161,20 +160,23 @@ int pass_reduce(lv_ctx* c) {
         dbg = c->dbg;
         c->dbg_valid = true;
     }
-    LV_HIP(hipMemsetAsync(c->d_fallback, 0, sizeof(int), c->stream));
     int rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
-                                 c->d_partials, c->grid, dbg, c->d_fallback);
+                                 c->d_partials, c->grid, dbg);
     if (rc) return rc;
     if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));
-    return launch_reduce_partials(c->stream, c->d_partials, c->grid, c->d_sums, c->d_kf);
+    rc = launch_reduce_groups(c->stream, c->d_partials, c->grid, c->d_groups, &c->ngroups, c->d_kf);
+    if (rc) return rc;
+    if (finalize) return launch_reduce_final(c->stream, c->d_groups, c->ngroups, c->d_sums, c->d_kf);
+    return LV_OK;
 }
 
-int pass_solve(lv_ctx* c) {
+int pass_solve(lv_ctx* c, bool from_groups) {
     SolveParams sp;
     sp.R = c->prm.LiDAR_noise;
     for (int i = 0; i < NS; ++i) sp.limits[i] = c->prm.LIMITS[i];
     sp.maximum_iter = c->prm.MAX_NUM_ITERS;
-    return launch_solve(c->stream, c->d_kf, c->d_sums, sp);
+    if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_groups, c->ngroups, c->d_sums, sp);
+    return launch_solve(c->stream, c->d_kf, c->d_sums, 1, nullptr, sp);
 }
 
 }  // namespace
@@ -227,12 +229,12 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipMemset(c->d_kf, 0, sizeof(KfDev)));
     LV_HIP(hipHostMalloc((void**)&c->h_kf, sizeof(KfDev), hipHostMallocDefault));
     std::memset(c->h_kf, 0, sizeof(KfDev));
-    LV_HIP(hipMalloc(&c->d_partials, (size_t)c->max_blocks * SUMS_LEN * sizeof(double)));
+    LV_HIP(hipMalloc(&c->d_partials, (size_t)(c->max_blocks + 8) * SUMS_LEN * sizeof(double)));
+    LV_HIP(hipMalloc(&c->d_groups, (size_t)(c->max_blocks / 32 + 2) * SUMS_LEN * sizeof(double)));
     LV_HIP(hipMalloc(&c->d_sums_own, SUMS_LEN * sizeof(double)));
     LV_HIP(hipMemset(c->d_sums_own, 0, SUMS_LEN * sizeof(double)));
     c->d_sums = c->d_sums_own;
     LV_HIP(hipHostMalloc((void**)&c->h_sums, SUMS_LEN * sizeof(double), hipHostMallocDefault));
-    LV_HIP(hipMalloc(&c->d_fallback, sizeof(int)));
     LV_HIP(hipEventCreate(&c->ev_begin));
     LV_HIP(hipEventCreate(&c->ev_end));
     c->ev_pass.resize((size_t)(params->MAX_NUM_ITERS + 1) * 3);
@@ -251,7 +253,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_kf) hipHostFree(c->h_kf);
     if (c->h_sums) hipHostFree(c->h_sums);
-    hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_sums_own); hipFree(c->d_fallback);
+    hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (auto ev : c->ev_pass) hipEventDestroy(ev);
@@ -374,11 +376,11 @@ int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
     if (rc) return rc;
     const bool cap = c->capture;
     c->capture = true;  // lv_iterate is the API-parity path: always captures per-point outputs
-    rc = pass_reduce(c);
+    rc = pass_reduce(c, true);
     c->capture = cap;
     if (rc) return rc;
     LV_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, SUMS_LEN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    LV_HIP(hipMemcpyAsync(&c->h_kf->fallback_queries, c->d_fallback, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LV_HIP(hipMemcpyAsync(&c->h_kf->fallback_queries, &c->d_kf->fallback_queries, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
     unpack_sums(c->h_sums, out);
     c->timing.fallback_queries = c->h_kf->fallback_queries;
@@ -400,7 +402,7 @@ int lv_pass_reduce(lv_ctx* c) {
         LV_HIP(hipMemsetAsync(c->d_sums, 0, SUMS_LEN * sizeof(double), c->stream));
         return LV_OK;
     }
-    return pass_reduce(c);
+    return pass_reduce(c, true);
 }
 
 void* lv_sums_device_ptr(lv_ctx* c) { return c ? (void*)c->d_sums : nullptr; }
@@ -417,15 +419,17 @@ int lv_pass_solve(lv_ctx* c) {
     LV_CHECK_CTX(c);
     if (!c->in_update) { set_error("lv_pass_solve outside lv_update_begin/end"); return LV_ESTATE; }
     c->passes_issued++;
-    return pass_solve(c);
+    return pass_solve(c, false);
 }
 
 int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
     LV_CHECK_CTX(c);
     if (!c->in_update) { set_error("lv_update_end without lv_update_begin"); return LV_ESTATE; }
     c->in_update = false;
-    LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, sizeof(KfDev), hipMemcpyDeviceToHost, c->stream));
+    const size_t bytes = c->want_log ? offsetof(KfDev, pose) : offsetof(KfDev, x_prop);
+    LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, bytes, hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
+    c->timing.fallback_queries = c->h_kf->fallback_queries;
     if (x) std::memcpy(x, c->h_kf->x, sizeof(double) * NX);
     if (P) std::memcpy(P, c->h_kf->P_post, sizeof(double) * NS * NS);
     if (passes) *passes = c->h_kf->passes;
@@ -445,16 +449,24 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     for (int i = 0; i < npass; ++i) {
         if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
         c->ev_mid = c->profiling ? c->ev_pass[3 * i + 1] : nullptr;
-        rc = lv_pass_reduce(c);
+        if (c->scan.n == 0) {
+            LV_HIP(hipMemsetAsync(c->d_groups, 0, SUMS_LEN * sizeof(double), c->stream));
+            c->ngroups = 1;
+            rc = LV_OK;
+        } else {
+            rc = pass_reduce(c, false);
+        }
         c->ev_mid = nullptr;
         if (rc) { c->in_update = false; return rc; }
-        rc = lv_pass_solve(c);
+        rc = pass_solve(c, true);
         if (rc) { c->in_update = false; return rc; }
         if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
     }
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_end, c->stream));
     int np = 0;
+    c->want_log = (per_pass != nullptr) || (trace != nullptr);
     rc = lv_update_end(c, x, P, &np);
+    c->want_log = false;
     if (rc) return rc;
     if (passes) *passes = np;
     if (per_pass)
@@ -471,6 +483,7 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
             hipEventElapsedTime(&b, c->ev_pass[3 * i + 1], c->ev_pass[3 * i + 2]);
             r += a;
             s += b;
+            if (i < 8) { c->timing.pass_match_ms[i] = a; c->timing.pass_solve_ms[i] = b; }
         }
         c->timing.last_reduce_ms = r / cnt;
         c->timing.last_solve_ms = s / cnt;

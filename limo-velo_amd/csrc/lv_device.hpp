@@ -19,6 +19,7 @@ constexpr int N_OUT = 92;           // used entries of the record
 constexpr int CELL_OFFSET = 1 << 20;
 constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-force path
 constexpr int MAX_LEVELS = 16;
+constexpr int MAX_BUCKET_LEVELS = 3;
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr int MAX_PASSES = 16;
 
@@ -37,19 +38,20 @@ struct PoseConsts {
 };
 
 // Device-resident filter state of one lv_update (esekf x_, P_, loop bookkeeping).
+// Layout: [x, P_prop] is the upload region, [x .. fallback_queries] the download region.
 struct KfDev {
     double x[NX];
-    double x_prop[NX];
     double P_prop[NS * NS];
     double P_post[NS * NS];
-    double trace[MAX_PASSES * 49];
-    double sums_log[MAX_PASSES * SUMS_LEN];
     int t;        // converge counter
     int iter;     // upstream loop index i (starts at -1)
     int done;
     int passes;
     int fallback_queries;
     int pad_[3];
+    double x_prop[NX];
+    double trace[MAX_PASSES * 49];
+    double sums_log[MAX_PASSES * SUMS_LEN];
     PoseConsts pose;
 };
 
@@ -68,6 +70,12 @@ struct MapView {
     float cell;             // level-0 cell edge
     float inv_cell;
     GridLevel lv[MAX_LEVELS];
+    // neighbourhood buckets for levels 0..n_bucket_levels-1: for every voxel whose 3x3x3 block holds at
+    // least one point, the points of that block copied into one contiguous run.  bt[l].table entries are
+    // {key lo, key hi, bucket start, bucket count}.
+    int n_bucket_levels;
+    GridLevel bt[MAX_BUCKET_LEVELS];
+    const float4* bucket[MAX_BUCKET_LEVELS];
 };
 
 struct MatchParams {

@@ -34,6 +34,21 @@ struct MapStore {
     uint4* d_tables[MAX_LEVELS] = {};
     uint32_t table_size[MAX_LEVELS] = {};
     uint32_t n_cells[MAX_LEVELS] = {};
+    // neighbourhood buckets (levels 0..MAX_BUCKET_LEVELS-1)
+    uint4* d_btable[MAX_BUCKET_LEVELS] = {};
+    uint32_t btable_size[MAX_BUCKET_LEVELS] = {};
+    float4* d_bucket[MAX_BUCKET_LEVELS] = {};
+    size_t bucket_cap[MAX_BUCKET_LEVELS] = {};
+    size_t bucket_points[MAX_BUCKET_LEVELS] = {};
+    uint32_t n_bcells[MAX_BUCKET_LEVELS] = {};
+    uint32_t* d_cell_slots = nullptr;  // scratch: table slots of the bucket voxels of the level being built
+    uint32_t* d_bcount = nullptr;
+    uint32_t* d_boff = nullptr;
+    size_t cells_cap = 0;
+    uint32_t* d_flags = nullptr;       // [0] = append cursor, [1] = overflow flag
+    void* d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    int build_buckets(hipStream_t stream, int level, uint32_t n_occupied);
     size_t capacity = 0;
     uint32_t m = 0;
     bool origin_set = false;
@@ -47,18 +62,18 @@ struct MapStore {
 
 // lv_match.hip
 int launch_match_reduce(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n,
-                        const KfDev* kf, const MatchParams& prm, double* partials, int grid, const DebugOut& dbg,
-                        int* fallback_counter);
+                        KfDev* kf, const MatchParams& prm, double* partials, int grid, const DebugOut& dbg);
 int match_grid_size(int lanes_per_query, uint32_t n, int max_blocks);
 // lv_solve.hip
 int launch_kf_begin(hipStream_t stream, KfDev* kf);
-int launch_reduce_partials(hipStream_t stream, const double* partials, int nblocks, double* sums, KfDev* kf);
+int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf);
+int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf);
 struct SolveParams {
     double R;
     double limits[NS];
     int maximum_iter;
 };
-int launch_solve(hipStream_t stream, KfDev* kf, const double* sums, const SolveParams& prm);
+int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
 // lv_scan.hip
 struct ScanStore {
     float4* d_raw = nullptr;     // upload order; w = original index

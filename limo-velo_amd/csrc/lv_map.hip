@@ -61,6 +61,12 @@ __global__ void map_count_heads_kernel(const uint64_t* __restrict__ keys, uint32
     if (threadIdx.x < n_levels && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+struct GridLevelW {
+    uint4* table;
+    uint32_t mask;
+    uint32_t shift;
+};
+
 struct TablePtrs {
     uint4* table[MAX_LEVELS];
     uint32_t mask[MAX_LEVELS];
@@ -95,6 +101,128 @@ __global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m,
             }
             slot = (slot + 1) & tp.mask[l];
         }
+    }
+}
+
+
+// ---- neighbourhood buckets -----------------------------------------------------------------------
+// For every level-l voxel c whose 3x3x3 block holds at least one point (the occupied voxels dilated by
+// one), the points of that block are copied into one contiguous run ("bucket").  A query then needs ONE
+// hash probe and ONE coalesced stream per level instead of 27 probes + 27 short dependent gathers; the
+// search region, and therefore the exactness argument of lv_match.hip, is unchanged.  Every point lands
+// in 27 buckets per level: HBM capacity (288 GB) is traded for latency.
+__device__ __forceinline__ bool probe_cell(const GridLevelW& g, uint64_t key, uint32_t& start, uint32_t& count) {
+    uint32_t slot = hash_cell(key, g.shift) & g.mask;
+    for (;;) {
+        const uint4 e = g.table[slot];
+        const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+        if (ek == key) { start = e.z; count = e.w; return true; }
+        if (ek == EMPTY_KEY) { start = 0; count = 0; return false; }
+        slot = (slot + 1) & g.mask;
+    }
+}
+
+// pass 1: every occupied voxel registers its 27 neighbours (incl. itself) in the bucket table
+__global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridLevelW bt, uint32_t* __restrict__ cell_slots,
+                                       uint32_t cell_cap, uint32_t* __restrict__ flags) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = t / 27, nb = t % 27;
+    if (slot >= occ_slots) return;
+    const uint4 e = occ.table[slot];
+    const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    if (key == EMPTY_KEY) return;
+    const uint32_t cx = (uint32_t)(key & 0x1fffff), cy = (uint32_t)((key >> 21) & 0x1fffff), cz = (uint32_t)((key >> 42) & 0x1fffff);
+    const int dz = (int)nb / 9 - 1, dy = ((int)nb / 3) % 3 - 1, dx = (int)nb % 3 - 1;
+    const uint32_t nx = cx + dx, ny = cy + dy, nz = cz + dz;
+    if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) return;
+    const uint64_t nkey = pack_cell(nx, ny, nz);
+    uint32_t bs = hash_cell(nkey, bt.shift) & bt.mask;
+    for (uint32_t probes = 0; probes <= bt.mask; ++probes) {
+        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&bt.table[bs]);
+        const unsigned long long old = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)nkey);
+        if (old == (unsigned long long)EMPTY_KEY) {
+            const uint32_t idx = atomicAdd(&flags[0], 1u);
+            if (idx < cell_cap) cell_slots[idx] = bs;
+            else flags[1] = 1;
+            return;
+        }
+        if (old == (unsigned long long)nkey) return;
+        bs = (bs + 1) & bt.mask;
+    }
+    flags[1] = 1;
+}
+
+// pass 2 (count) / pass 3 (fill): one 64-lane workgroup per bucket voxel; lane c < 27 owns neighbour c
+template <bool FILL>
+__global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLevelW bt, const uint32_t* __restrict__ cell_slots,
+                                                        uint32_t n_cells, const float4* __restrict__ sorted,
+                                                        uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
+                                                        float4* __restrict__ bucket) {
+    const uint32_t cell = blockIdx.x;
+    if (cell >= n_cells) return;
+    const int lane = threadIdx.x;
+    const uint32_t slot = cell_slots[cell];
+    const uint4 e = bt.table[slot];
+    const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    const uint32_t cx = (uint32_t)(key & 0x1fffff), cy = (uint32_t)((key >> 21) & 0x1fffff), cz = (uint32_t)((key >> 42) & 0x1fffff);
+    uint32_t start = 0, count = 0;
+    if (lane < 27) {
+        const int dz = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dx = lane % 3 - 1;
+        const uint32_t nx = cx + dx, ny = cy + dy, nz = cz + dz;
+        if (nx < (1u << 21) && ny < (1u << 21) && nz < (1u << 21)) probe_cell(occ, pack_cell(nx, ny, nz), start, count);
+    }
+    uint32_t incl = count;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    if (!FILL) {
+        if (lane == 0) bcount[cell] = total;
+    } else {
+        const uint32_t base = boff[cell] + (incl - count);
+        for (uint32_t j = 0; j < count; ++j) bucket[(size_t)base + j] = sorted[start + j];
+        if (lane == 0) { bt.table[slot].z = boff[cell]; bt.table[slot].w = total; }
+    }
+}
+
+// Sort every bucket by ORIGINAL index (ascending).  The match kernel orders candidates by
+// (distance, position-in-bucket); with this layout that equals the reference's (distance, index)
+// order, ties included.  Bitonic network in the "flip" form (always-ascending compare-exchange,
+// partners beyond n skipped == padding with +inf), valid for any n.  One workgroup per bucket.
+constexpr int BSORT_THREADS = 256;
+constexpr uint32_t BSORT_LDS = 2048;
+__global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ bcount,
+                                                                    const uint32_t* __restrict__ boff, uint32_t n_cells,
+                                                                    float4* __restrict__ bucket) {
+    __shared__ float4 s_pts[BSORT_LDS];
+    const uint32_t cell = blockIdx.x;
+    if (cell >= n_cells) return;
+    const uint32_t n = bcount[cell];
+    if (n < 2) return;
+    float4* g = bucket + boff[cell];
+    const bool in_lds = n <= BSORT_LDS;
+    float4* a = in_lds ? s_pts : g;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) s_pts[i] = g[i];
+    }
+    __syncthreads();
+    for (uint32_t k = 2; (k >> 1) < n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const bool flip = (j == (k >> 1));
+            for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+                const uint32_t l = flip ? (i ^ (k - 1)) : (i ^ j);
+                if (l > i && l < n) {
+                    const float4 x = a[i], y = a[l];
+                    if (__float_as_uint(x.w) > __float_as_uint(y.w)) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) g[i] = s_pts[i];
     }
 }
 
@@ -137,6 +265,8 @@ int MapStore::reserve(size_t cap) {
 void MapStore::release() {
     hipFree(d_orig); hipFree(d_sorted); hipFree(d_keys); hipFree(d_keys_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
     hipFree(d_sort_tmp); hipFree(d_counts);
+    hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
+    for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bucket[l]); }
     for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
     *this = MapStore();
 }
@@ -205,7 +335,85 @@ int MapStore::rebuild(hipStream_t stream, float cell, const float bbox_min[3], c
     LV_HIP(hipGetLastError());
     view.sorted = d_sorted;
     view.orig = d_orig;
+    view.n_bucket_levels = n_levels < MAX_BUCKET_LEVELS ? n_levels : MAX_BUCKET_LEVELS;
+    for (int l = 0; l < view.n_bucket_levels; ++l) {
+        int rc = build_buckets(stream, l, counts[l]);
+        if (rc) return rc;
+    }
     return LV_OK;
+}
+
+int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) {
+    if (!d_flags) LV_HIP(hipMalloc(&d_flags, 2 * sizeof(uint32_t)));
+    GridLevelW occ{d_tables[level], view.lv[level].mask, view.lv[level].shift};
+    const uint32_t occ_slots = view.lv[level].mask + 1;
+    uint32_t size = next_pow2((uint64_t)n_occupied * 16);  // dilation factor <= 8 keeps the load <= 0.5
+    if (size < btable_size[level]) size = btable_size[level];
+    for (;;) {
+        if (size > btable_size[level]) {
+            hipFree(d_btable[level]);
+            d_btable[level] = nullptr;
+            LV_HIP(hipMalloc(&d_btable[level], (size_t)size * sizeof(uint4)));
+            btable_size[level] = size;
+        }
+        const size_t need_cells = (size_t)size / 2;
+        if (need_cells > cells_cap) {
+            hipFree(d_cell_slots); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
+            d_cell_slots = d_bcount = d_boff = nullptr;
+            d_scan_tmp = nullptr;
+            LV_HIP(hipMalloc(&d_cell_slots, need_cells * sizeof(uint32_t)));
+            LV_HIP(hipMalloc(&d_bcount, need_cells * sizeof(uint32_t)));
+            LV_HIP(hipMalloc(&d_boff, need_cells * sizeof(uint32_t)));
+            scan_tmp_bytes = 0;
+            LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_bcount, d_boff, (int)need_cells, (hipStream_t)0));
+            LV_HIP(hipMalloc(&d_scan_tmp, scan_tmp_bytes));
+            cells_cap = need_cells;
+        }
+        LV_HIP(hipMemsetAsync(d_btable[level], 0xFF, (size_t)size * sizeof(uint4), stream));
+        LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
+        int lg = 0;
+        while ((1u << lg) < size) ++lg;
+        GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - lg)};
+        const uint64_t threads = (uint64_t)occ_slots * 27;
+        hipLaunchKernelGGL(bucket_register_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, occ, occ_slots, bt,
+                           d_cell_slots, (uint32_t)(size / 2), d_flags);
+        uint32_t flags[2];
+        LV_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        if (flags[1] || flags[0] > size / 2) {  // table too small for this map's dilation factor: double and retry
+            size *= 2;
+            continue;
+        }
+        const uint32_t nb = flags[0];
+        n_bcells[level] = nb;
+        hipLaunchKernelGGL((map_bucket_kernel<false>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
+                           d_boff, (float4*)nullptr);
+        size_t stmp = scan_tmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcount, d_boff, (int)nb, stream));
+        uint32_t last_off = 0, last_cnt = 0;
+        LV_HIP(hipMemcpyAsync(&last_off, d_boff + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipMemcpyAsync(&last_cnt, d_bcount + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        const uint64_t total = (uint64_t)last_off + last_cnt;
+        if (total > 0xFFFFFFF0ull) { set_error("bucket array exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
+        bucket_points[level] = (size_t)total;
+        if (bucket_points[level] > bucket_cap[level]) {
+            hipFree(d_bucket[level]);
+            d_bucket[level] = nullptr;
+            size_t cap = bucket_points[level] + bucket_points[level] / 8;
+            LV_HIP(hipMalloc(&d_bucket[level], cap * sizeof(float4)));
+            bucket_cap[level] = cap;
+        }
+        hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
+                           d_boff, d_bucket[level]);
+        hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket[level]);
+        LV_HIP(hipGetLastError());
+        view.bt[level].table = d_btable[level];
+        view.bt[level].mask = size - 1;
+        view.bt[level].shift = (uint32_t)(64 - lg);
+        view.bucket[level] = d_bucket[level];
+        return LV_OK;
+    }
 }
 
 }  // namespace lv

@@ -27,14 +27,75 @@
 
 namespace lv {
 
-constexpr uint64_t NONE_KEY = ~0ull;
-constexpr int ROW_W = 14;  // r[0..11], h, valid
+// Candidate keys.  A key packs (f32 distance bits << 32 | position) and is handled as an IEEE f64:
+// for non-negative distances the f64 order of the bit pattern equals the unsigned order, so ONE
+// v_min_f64 / v_max_f64 pair is a compare-exchange on the (distance, position) pair.  Inside a bucket
+// the points are stored in ascending ORIGINAL index, so (distance, position) order == the reference's
+// (distance, index) order, ties included; the generic path uses (distance, index) directly.
+// NONE = largest finite f64 (its high word 0x7FEFFFFF is an f32 NaN pattern no distance produces;
+// no key is ever an f64 NaN/inf because valid distance bits are <= 0x7F800000).
+typedef double kkey;
+__device__ __forceinline__ kkey make_key(float d, uint32_t low) {
+    return __longlong_as_double((long long)(((uint64_t)__float_as_uint(d) << 32) | (uint64_t)low));
+}
+__device__ __forceinline__ uint32_t key_lo(kkey k) { return (uint32_t)(uint64_t)__double_as_longlong(k); }
+__device__ __forceinline__ uint32_t key_hi(kkey k) { return (uint32_t)((uint64_t)__double_as_longlong(k) >> 32); }
+#define LV_NONE_BITS 0x7FEFFFFFFFFFFFFFll
+__device__ __forceinline__ kkey none_key() { return __longlong_as_double(LV_NONE_BITS); }
+__device__ __forceinline__ bool is_none(kkey k) { return __double_as_longlong(k) == LV_NONE_BITS; }
 
-__device__ __forceinline__ void top5_insert(uint64_t (&k)[KNN], uint64_t x) {
+
+__device__ __forceinline__ kkey kmin(kkey a, kkey b) {
+    kkey r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ kkey kmax(kkey a, kkey b) {
+    kkey r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void cswap(kkey& a, kkey& b) {
+    const kkey lo = kmin(a, b), hi = kmax(a, b);
+    a = lo;
+    b = hi;
+}
+// Batcher odd-even merge sort, 8 keys, 19 comparators (verified exhaustively with the 0-1 principle)
+__device__ __forceinline__ void sort8(kkey (&c)[8]) {
+    cswap(c[0], c[1]); cswap(c[2], c[3]); cswap(c[4], c[5]); cswap(c[6], c[7]);
+    cswap(c[0], c[2]); cswap(c[1], c[3]); cswap(c[4], c[6]); cswap(c[5], c[7]);
+    cswap(c[1], c[2]); cswap(c[5], c[6]);
+    cswap(c[0], c[4]); cswap(c[1], c[5]); cswap(c[2], c[6]); cswap(c[3], c[7]);
+    cswap(c[2], c[4]); cswap(c[3], c[5]);
+    cswap(c[1], c[2]); cswap(c[3], c[4]); cswap(c[5], c[6]);
+}
+// optimal 5-key sorter, 9 comparators
+__device__ __forceinline__ void sort5(kkey (&c)[KNN]) {
+    cswap(c[0], c[1]); cswap(c[3], c[4]); cswap(c[2], c[4]); cswap(c[2], c[3]); cswap(c[1], c[4]);
+    cswap(c[0], c[3]); cswap(c[0], c[2]); cswap(c[1], c[3]); cswap(c[1], c[2]);
+}
+// k, o sorted ascending (o: at least 5 entries) -> k = the 5 smallest of the union, sorted:
+// min(k[i], o[4-i]) selects exactly the 5 smallest (bitonic halving), sort5 orders them.
+template <typename T>
+__device__ __forceinline__ void merge5(kkey (&k)[KNN], const T& o) {
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) k[i] = kmin(o[KNN - 1 - i], k[i]);
+    sort5(k);
+}
+template <int S>
+__device__ __forceinline__ void merge_group(kkey (&k)[KNN]) {
+#pragma unroll
+    for (int off = S / 2; off >= 1; off >>= 1) {
+        kkey o[KNN];
+#pragma unroll
+        for (int j = 0; j < KNN; ++j) o[j] = __shfl_xor(k[j], off);
+        merge5(k, o);
+    }
+}
+__device__ __forceinline__ void insert1(kkey (&k)[KNN], kkey x) {  // generic path: one candidate
 #pragma unroll
     for (int j = 0; j < KNN; ++j) {
-        uint64_t lo = k[j] < x ? k[j] : x;
-        uint64_t hi = k[j] < x ? x : k[j];
+        const kkey lo = kmin(k[j], x), hi = kmax(k[j], x);
         k[j] = lo;
         x = hi;
     }
@@ -48,26 +109,12 @@ __device__ __forceinline__ float calc_dist(float qx, float qy, float qz, float4 
     return s + sz;
 }
 
+// generic path: scan a range of the Morton-sorted array with (distance, original index) keys
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, uint32_t start, uint32_t count, float qx,
-                                           float qy, float qz, uint64_t (&k)[KNN]) {
+                                           float qy, float qz, kkey (&k)[KNN]) {
     for (uint32_t j = 0; j < count; ++j) {
-        float4 m = sorted[start + j];
-        float d = calc_dist(qx, qy, qz, m);
-        uint64_t key = ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)__float_as_uint(m.w);
-        if (key < k[KNN - 1]) top5_insert(k, key);
-    }
-}
-
-template <int S>
-__device__ __forceinline__ void merge_group(uint64_t (&k)[KNN]) {
-#pragma unroll
-    for (int off = S / 2; off >= 1; off >>= 1) {
-        uint64_t o[KNN];
-#pragma unroll
-        for (int j = 0; j < KNN; ++j) o[j] = __shfl_xor(k[j], off);
-#pragma unroll
-        for (int j = 0; j < KNN; ++j)
-            if (o[j] < k[KNN - 1]) top5_insert(k, o[j]);
+        const float4 m = sorted[start + j];
+        insert1(k, make_key(calc_dist(qx, qy, qz, m), __float_as_uint(m.w)));
     }
 }
 
@@ -209,135 +256,249 @@ __device__ inline void plane_qr_solve(float (&A)[KNN][3], float (&x)[3]) {
     }
 }
 
-__device__ __forceinline__ void out_pair(int t, int& a, int& b) {
-    if (t < 78) {
+// reduction outputs: thread t owns the product column pair (a, b) of the staged row and its slot
+// `rec` in the 96-double record ([0..77] upper triangle of the 12x12 H^T H, [78..89] H^T h, 90 n_valid,
+// 91 sum h^2).  W = number of Jacobian columns that can be non-zero (6 without extrinsics, else 12).
+template <int W>
+__device__ __forceinline__ void out_pair(int t, int& a, int& b, int& rec) {
+    constexpr int NTRI = W * (W + 1) / 2;
+    if (t < NTRI) {
         int i = 0, rem = t;
-        while (rem >= 12 - i) { rem -= 12 - i; ++i; }
+        while (rem >= W - i) { rem -= W - i; ++i; }
         a = i;
         b = i + rem;
-    } else if (t < 90) {
-        a = t - 78;
-        b = 12;
-    } else if (t == 90) {
-        a = 13;
-        b = 13;
+        rec = a * 12 - a * (a - 1) / 2 + (b - a);
+    } else if (t < NTRI + W) {
+        a = t - NTRI;
+        b = W;          // h
+        rec = 78 + a;
+    } else if (t == NTRI + W) {
+        a = W + 1;      // valid * valid
+        b = W + 1;
+        rec = 90;
     } else {
-        a = 12;
-        b = 12;
+        a = W;          // h * h
+        b = W;
+        rec = 91;
     }
 }
 
-template <int S, bool DBG>
+struct QueryStage {     // kNN result of one scan point, handed from the search lanes to the fit lane
+    float qx, qy, qz;
+    uint32_t oq;        // original scan index
+    uint32_t pos[KNN];  // bucket positions (src >= 0) or original map indices (src < 0)
+    uint32_t dbits[KNN];
+    uint32_t bstart;
+    int src;            // bucket level the winners came from, -1 = generic path (pos = map index)
+    int found;
+};
+
+template <int S, bool EXT, bool DBG>
 __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
-                                                           const KfDev* __restrict__ kf, MatchParams prm,
-                                                           double* __restrict__ partials, DebugOut dbg,
-                                                           int* __restrict__ fallback_counter) {
-    constexpr int G = 256 / S;  // scan points per block iteration
+                                                           KfDev* __restrict__ kf, MatchParams prm,
+                                                           double* __restrict__ partials, DebugOut dbg) {
+    constexpr int G = 256 / S;             // scan points per block iteration
+    constexpr int W = EXT ? 12 : 6;        // live Jacobian columns
+    constexpr int ROW_W = W + 2;           // + h, valid
+    constexpr int NOUT = W * (W + 1) / 2 + W + 2;
+    __shared__ QueryStage s_q[G];
     __shared__ double s_rows[G][ROW_W];
+    __shared__ double s_out[SUMS_LEN];
     if (kf->done) return;
     const int tid = threadIdx.x;
     const int gq = tid / S, gl = tid % S;
     const PoseConsts& pc = kf->pose;
 
-    int oa = 0, ob = 0;
-    if (tid < N_OUT) out_pair(tid, oa, ob);
+    int oa = 0, ob = 0, orec = 0;
+    if (tid < NOUT) out_pair<W>(tid, oa, ob, orec);
     double acc = 0.0;
+    if (tid < SUMS_LEN) s_out[tid] = 0.0;
 
+    // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed placement, used for L2
+    // affinity only); every XCD gets a contiguous run of Morton-ordered query tiles.  gridDim.x % 8 == 0.
+    const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
     const uint32_t per_iter = (uint32_t)G * gridDim.x;
     const uint32_t iters = (n + per_iter - 1) / per_iter;
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t q = (it * gridDim.x + blockIdx.x) * (uint32_t)G + (uint32_t)gq;
-        double row[12];
+        const uint32_t qbase = (it * gridDim.x + vb) * (uint32_t)G;
+        // ================= phase 1: S lanes per scan point — exact 5-NN =========================
+        {
+            const uint32_t q = qbase + (uint32_t)gq;
+            kkey k[KNN];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) row[i] = 0.0;
-        double hres = 0.0;
-        bool chosen = false;
-        if (q < n) {
-            const float4 sp = scan[q];
-            const uint32_t oq = __float_as_uint(sp.w);
-            float qx, qy, qz;
-            rt_apply(pc.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
-
-            // ---- exact 5-NN ------------------------------------------------------------------
-            uint64_t k[KNN];
-#pragma unroll
-            for (int j = 0; j < KNN; ++j) k[j] = NONE_KEY;
-            int found = 0;
-            if (map.m > 0) {
-                const int c0x = cell_coord(qx, map.origin[0], map.inv_cell);
-                const int c0y = cell_coord(qy, map.origin[1], map.inv_cell);
-                const int c0z = cell_coord(qz, map.origin[2], map.inv_cell);
-                const int ax = abs(c0x - CELL_OFFSET), ay = abs(c0y - CELL_OFFSET), az = abs(c0z - CELL_OFFSET);
-                const int amax = max(ax, max(ay, az));
-                const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
-                bool decided = false;
-                int level = (finite && amax < CELL_FAR) ? 0 : map.n_levels;
-                while (!decided) {
-                    if (level < map.n_levels) {
-                        const GridLevel gl_ = map.lv[level];
-                        const int clx = c0x >> level, cly = c0y >> level, clz = c0z >> level;
-                        for (int c = gl; c < 27; c += S) {
-                            const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
-                            const uint32_t nx = (uint32_t)(clx + dx), ny = (uint32_t)(cly + dy), nz = (uint32_t)(clz + dz);
-                            if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) continue;
-                            const uint64_t key = pack_cell(nx, ny, nz);
-                            uint32_t slot = hash_cell(key, gl_.shift) & gl_.mask;
-                            uint32_t start = 0, count = 0;
+            for (int j = 0; j < KNN; ++j) k[j] = none_key();
+            float qx = 0.f, qy = 0.f, qz = 0.f;
+            uint32_t oq = 0, bstart = 0;
+            int src = -1;
+            if (q < n) {
+                const float4 sp = scan[q];
+                oq = __float_as_uint(sp.w);
+                rt_apply(pc.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
+                if (map.m > 0) {
+                    const float tx = (qx - map.origin[0]) * map.inv_cell, ty = (qy - map.origin[1]) * map.inv_cell,
+                                tz = (qz - map.origin[2]) * map.inv_cell;
+                    const int c0x = cell_coord(qx, map.origin[0], map.inv_cell);
+                    const int c0y = cell_coord(qy, map.origin[1], map.inv_cell);
+                    const int c0z = cell_coord(qz, map.origin[2], map.inv_cell);
+                    const int amax = max(abs(c0x - CELL_OFFSET), max(abs(c0y - CELL_OFFSET), abs(c0z - CELL_OFFSET)));
+                    const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
+                    const bool in_range = finite && amax < CELL_FAR;
+                    bool decided = false;
+                    int level = in_range ? 0 : map.n_levels;
+                    // guaranteed search radius of the 27-voxel block at `lvl` for THIS query: one voxel edge
+                    // plus the distance to the nearest wall of its own voxel, shrunk by 1e-3 relative and by
+                    // the f32 rounding bound of the voxel coordinates (see file header).
+                    auto radius = [&](int lvl) -> float {
+                        const float scale = (float)(1 << lvl);
+                        const float bx = (float)((((c0x >> lvl) << lvl)) - CELL_OFFSET), by = (float)((((c0y >> lvl) << lvl)) - CELL_OFFSET),
+                                    bz = (float)((((c0z >> lvl) << lvl)) - CELL_OFFSET);
+                        const float mx = fminf(tx - bx, scale - (tx - bx)), my = fminf(ty - by, scale - (ty - by)),
+                                    mz = fminf(tz - bz, scale - (tz - bz));
+                        const float marg = fmaxf(fminf(mx, fminf(my, mz)), 0.f);
+                        return map.cell * ((scale + marg) * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)amax + 2.f * scale));
+                    };
+                    // fast path: per level ONE probe of the bucket table and ONE coalesced stream over the
+                    // neighbourhood bucket.  A miss means the whole 27-voxel block is empty.
+                    if (in_range) {
+                        for (int bl = 0; bl < map.n_bucket_levels && !decided; ++bl) {
+                            const GridLevel g = map.bt[bl];
+                            const uint64_t key = pack_cell((uint32_t)(c0x >> bl), (uint32_t)(c0y >> bl), (uint32_t)(c0z >> bl));
+                            uint32_t slot = hash_cell(key, g.shift) & g.mask;
+                            uint32_t bcount = 0;
                             for (;;) {
-                                const uint4 e = gl_.table[slot];
+                                const uint4 e = g.table[slot];
                                 const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                                if (ek == key) { start = e.z; count = e.w; break; }
+                                if (ek == key) { bstart = e.z; bcount = e.w; break; }
                                 if (ek == EMPTY_KEY) break;
-                                slot = (slot + 1) & gl_.mask;
+                                slot = (slot + 1) & g.mask;
                             }
-                            scan_range(map.sorted, start, count, qx, qy, qz, k);
-                        }
-                        merge_group<S>(k);
-                        const float scale = (float)(1 << level);
-                        const float r = map.cell * (scale * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)amax + 2.f * scale));
-                        const float d5 = __uint_as_float((uint32_t)(k[KNN - 1] >> 32));
-                        if (k[KNN - 1] != NONE_KEY && r > 0.f && d5 < r * r) {
-                            decided = true;
-                        } else {
+                            level = bl + 1;
+                            if (bcount >= KNN) {
+                                constexpr int U = 8;
+                                const float4* __restrict__ bp = map.bucket[bl] + bstart;
+                                for (uint32_t base = 0; base < bcount; base += S * U) {
+                                    float4 mpt[U];
 #pragma unroll
-                            for (int j = 0; j < KNN; ++j) k[j] = NONE_KEY;
-                            ++level;
+                                    for (int u = 0; u < U; ++u) {
+                                        const uint32_t j = base + (uint32_t)(u * S + gl);
+                                        mpt[u] = bp[j < bcount ? j : 0];
+                                    }
+                                    kkey ck[U];
+#pragma unroll
+                                    for (int u = 0; u < U; ++u) {
+                                        const uint32_t j = base + (uint32_t)(u * S + gl);
+                                        ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
+                                    }
+                                    sort8(ck);
+                                    merge5(k, ck);
+                                }
+                                merge_group<S>(k);
+                                const float r = radius(bl);
+                                const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+                                if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
+                                    decided = true;
+                                    src = bl;
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+                                }
+                            }
                         }
-                    } else {
-                        for (uint32_t j = gl; j < map.m; j += S) scan_range(map.sorted, j, 1, qx, qy, qz, k);
-                        merge_group<S>(k);
-                        decided = true;
-                        level = map.n_levels + 1;
                     }
-                }
-                if (level > 0 && gl == 0 && fallback_counter) atomicAdd(fallback_counter, 1);
+                    const bool fell_back = !decided;
+                    while (!decided) {  // generic path: 27 probes per level over the Morton-sorted array, then brute force
+                        if (level < map.n_levels) {
+                            const GridLevel gl_ = map.lv[level];
+                            const int clx = c0x >> level, cly = c0y >> level, clz = c0z >> level;
+                            for (int c = gl; c < 27; c += S) {
+                                const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+                                const uint32_t nx = (uint32_t)(clx + dx), ny = (uint32_t)(cly + dy), nz = (uint32_t)(clz + dz);
+                                if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) continue;
+                                const uint64_t key = pack_cell(nx, ny, nz);
+                                uint32_t slot = hash_cell(key, gl_.shift) & gl_.mask;
+                                uint32_t start = 0, count = 0;
+                                for (;;) {
+                                    const uint4 e = gl_.table[slot];
+                                    const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                                    if (ek == key) { start = e.z; count = e.w; break; }
+                                    if (ek == EMPTY_KEY) break;
+                                    slot = (slot + 1) & gl_.mask;
+                                }
+                                scan_range(map.sorted, start, count, qx, qy, qz, k);
+                            }
+                            merge_group<S>(k);
+                            const float r = radius(level);
+                            const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+                            if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
+                                decided = true;
+                            } else {
 #pragma unroll
-                for (int j = 0; j < KNN; ++j) found += (k[j] != NONE_KEY) ? 1 : 0;
+                                for (int j = 0; j < KNN; ++j) k[j] = none_key();
+                                ++level;
+                            }
+                        } else {
+                            for (uint32_t j = gl; j < map.m; j += S) scan_range(map.sorted, j, 1, qx, qy, qz, k);
+                            merge_group<S>(k);
+                            decided = true;
+                        }
+                    }
+                    if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
+                }
             }
-
-            // ---- Plane(near, sq_dists): gates, fit, is_plane ---------------------------------
+            if (gl == 0) {
+                QueryStage& st = s_q[gq];
+                st.qx = qx; st.qy = qy; st.qz = qz;
+                st.oq = oq;
+                st.bstart = bstart;
+                st.src = src;
+                int found = 0;
+#pragma unroll
+                for (int j = 0; j < KNN; ++j) {
+                    st.pos[j] = key_lo(k[j]);
+                    st.dbits[j] = key_hi(k[j]);
+                    found += is_none(k[j]) ? 0 : 1;
+                }
+                st.found = (q < n) ? found : -1;
+            }
+        }
+        __syncthreads();
+        // ================= phase 2: one lane per scan point — plane fit, gates, Jacobian row ==========
+        if (tid < G) {
+            const QueryStage st = s_q[tid];
+            double row[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) row[i] = 0.0;
+            double hres = 0.0;
+            bool chosen = false;
             float abcd[4] = {0.f, 0.f, 0.f, 0.f};
             float dist = 0.f;
-            if (found >= KNN) {                                                   // Plane.cpp:36-38
-                const float d5 = __uint_as_float((uint32_t)(k[KNN - 1] >> 32));
-                if ((double)d5 < prm.max_dist_plane_sq) {                         // Plane.cpp:40-43
-                    float A[KNN][3], P[KNN][3];
+            const float qx = st.qx, qy = st.qy, qz = st.qz;
+            uint32_t nidx[KNN];
 #pragma unroll
-                    for (int j = 0; j < KNN; ++j) {
-                        const float4 nb = map.orig[(uint32_t)k[j]];
-                        A[j][0] = P[j][0] = nb.x;
-                        A[j][1] = P[j][1] = nb.y;
-                        A[j][2] = P[j][2] = nb.z;
-                    }
+            for (int j = 0; j < KNN; ++j) nidx[j] = 0xFFFFFFFFu;
+            if (st.found >= KNN) {                                                // Plane.cpp:36-38
+                float P[KNN][3];
+#pragma unroll
+                for (int j = 0; j < KNN; ++j) {
+                    float4 nb;
+                    if (st.src >= 0) { nb = map.bucket[st.src][(size_t)st.bstart + st.pos[j]]; nidx[j] = __float_as_uint(nb.w); }
+                    else { nb = map.orig[st.pos[j]]; nidx[j] = st.pos[j]; }
+                    P[j][0] = nb.x; P[j][1] = nb.y; P[j][2] = nb.z;
+                }
+                const float d5 = __uint_as_float(st.dbits[KNN - 1]);
+                if ((double)d5 < prm.max_dist_plane_sq) {                         // Plane.cpp:40-43
+                    float A[KNN][3];
+#pragma unroll
+                    for (int j = 0; j < KNN; ++j) { A[j][0] = P[j][0]; A[j][1] = P[j][1]; A[j][2] = P[j][2]; }
                     float nv[3];
                     plane_qr_solve(A, nv);                                        // Utils.cpp:47
                     const float nrm = sqrtf(dot3f(nv[0], nv[0], nv[1], nv[1], nv[2], nv[2]));  // Utils.cpp:50
-                    float e0 = nv[0] / nrm, e1 = nv[1] / nrm, e2 = nv[2] / nrm;
-                    float e3 = (float)(1.0 / (double)nrm);                        // Utils.cpp:54
+                    const float e0 = nv[0] / nrm, e1 = nv[1] / nrm, e2 = nv[2] / nrm;
+                    const float e3 = (float)(1.0 / (double)nrm);                  // Utils.cpp:54
                     bool ok = true;                                               // Utils.cpp:59-66
 #pragma unroll
                     for (int j = 0; j < KNN; ++j) {
-                        float res = e0 * P[j][0] + e1 * P[j][1] + e2 * P[j][2] + e3;
+                        const float res = e0 * P[j][0] + e1 * P[j][1] + e2 * P[j][2] + e3;
                         if (fabsf(res) > prm.planes_threshold) ok = false;
                     }
                     if (ok) {
@@ -346,44 +507,51 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
                         dist = e0 * qx + e1 * qy + e2 * qz + e3;                  // Plane.cpp:27-29, Match.cpp:21
                     }
                 }
+            } else if (DBG && st.found > 0) {
+#pragma unroll
+                for (int j = 0; j < KNN; ++j)
+                    if (j < st.found) nidx[j] = st.src >= 0 ? __float_as_uint(map.bucket[st.src][(size_t)st.bstart + st.pos[j]].w) : st.pos[j];
             }
-
-            // ---- Localizator::calculate_H row (Localizator.cpp:36-56) --------------------------
+            // ---- Localizator::calculate_H row (Localizator.cpp:36-56) ------------------------------
             if (chosen) {
                 float plx, ply, plz, pix, piy, piz;
                 rt_apply(pc.back, qx, qy, qz, plx, ply, plz);                     // :38
                 rt_apply(pc.LI, plx, ply, plz, pix, piy, piz);                    // :39
                 const double n0 = (double)abcd[0], n1 = (double)abcd[1], n2 = (double)abcd[2];
                 const double* Ri = pc.R_inv;
-                const double* Li = pc.I_R_L_inv;
                 const double C0 = dot3d(Ri[0], n0, Ri[1], n1, Ri[2], n2);         // :47
                 const double C1 = dot3d(Ri[3], n0, Ri[4], n1, Ri[5], n2);
                 const double C2 = dot3d(Ri[6], n0, Ri[7], n1, Ri[8], n2);
-                const double t0 = dot3d(Li[0], C0, Li[1], C1, Li[2], C2);
-                const double t1 = dot3d(Li[3], C0, Li[4], C1, Li[5], C2);
-                const double t2 = dot3d(Li[6], C0, Li[7], C1, Li[8], C2);
-                const double lx = (double)plx, ly = (double)ply, lz = (double)plz;
                 const double ix = (double)pix, iy = (double)piy, iz = (double)piz;
                 row[0] = n0; row[1] = n1; row[2] = n2;                            // :51
                 row[3] = iy * C2 - iz * C1;                                       // A = p_imu x C  :49
                 row[4] = iz * C0 - ix * C2;
                 row[5] = ix * C1 - iy * C0;
-                if (prm.estimate_extrinsics) {                                    // :52
-                    row[6] = ly * t2 - lz * t1;                                   // B = p_lidar x (I_R_L_inv C)  :48
-                    row[7] = lz * t0 - lx * t2;
-                    row[8] = lx * t1 - ly * t0;
-                    row[9] = C0; row[10] = C1; row[11] = C2;
+                if (EXT) {                                                        // :52
+                    const double* Li = pc.I_R_L_inv;
+                    const double t0 = dot3d(Li[0], C0, Li[1], C1, Li[2], C2);
+                    const double t1 = dot3d(Li[3], C0, Li[4], C1, Li[5], C2);
+                    const double t2 = dot3d(Li[6], C0, Li[7], C1, Li[8], C2);
+                    const double lx = (double)plx, ly = (double)ply, lz = (double)plz;
+                    row[W - 6] = ly * t2 - lz * t1;                               // B = p_lidar x (I_R_L_inv C)  :48
+                    row[W - 5] = lz * t0 - lx * t2;
+                    row[W - 4] = lx * t1 - ly * t0;
+                    row[W - 3] = C0; row[W - 2] = C1; row[W - 1] = C2;
                 }
                 hres = -(double)dist;                                             // :55
             }
-
-            if (DBG && gl == 0) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) s_rows[tid][j] = row[j];
+            s_rows[tid][W] = hres;
+            s_rows[tid][W + 1] = chosen ? 1.0 : 0.0;
+            if (DBG && st.found >= 0) {
+                const uint32_t oq = st.oq;
                 if (dbg.knn_idx) {
 #pragma unroll
                     for (int j = 0; j < KNN; ++j) {
-                        dbg.knn_idx[(size_t)oq * KNN + j] = (uint32_t)k[j];
-                        dbg.knn_d2[(size_t)oq * KNN + j] = k[j] == NONE_KEY ? __uint_as_float(0x7f800000u)
-                                                                           : __uint_as_float((uint32_t)(k[j] >> 32));
+                        const bool have = j < st.found;
+                        dbg.knn_idx[(size_t)oq * KNN + j] = have ? nidx[j] : 0xFFFFFFFFu;
+                        dbg.knn_d2[(size_t)oq * KNN + j] = have ? __uint_as_float(st.dbits[j]) : __uint_as_float(0x7f800000u);
                     }
                 }
                 if (dbg.valid) dbg.valid[oq] = chosen ? 1 : 0;
@@ -395,52 +563,53 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
                 if (dbg.dist) dbg.dist[oq] = dist;
                 if (dbg.rows) {
 #pragma unroll
-                    for (int j = 0; j < 12; ++j) dbg.rows[(size_t)oq * 12 + j] = row[j];
+                    for (int j = 0; j < 12; ++j) dbg.rows[(size_t)oq * 12 + j] = (j < W) ? row[j < W ? j : 0] : 0.0;
                     dbg.h[oq] = hres;
                 }
             }
         }
-        if (gl == 0) {
-#pragma unroll
-            for (int j = 0; j < 12; ++j) s_rows[gq][j] = row[j];
-            s_rows[gq][12] = hres;
-            s_rows[gq][13] = chosen ? 1.0 : 0.0;
-        }
         __syncthreads();
-        if (tid < N_OUT) {
+        // ================= phase 3: contract the staged rows into the block partial =====================
+        if (tid < NOUT) {
 #pragma unroll 8
             for (int p = 0; p < G; ++p) acc += s_rows[p][oa] * s_rows[p][ob];
         }
         __syncthreads();
     }
-    if (tid < SUMS_LEN) partials[(size_t)blockIdx.x * SUMS_LEN + tid] = tid < N_OUT ? acc : 0.0;
+    if (tid < NOUT) s_out[orec] = acc;
+    __syncthreads();
+    if (tid < SUMS_LEN) partials[(size_t)blockIdx.x * SUMS_LEN + tid] = s_out[tid];
 }
 
 int match_grid_size(int S, uint32_t n, int max_blocks) {
     const uint32_t G = 256 / S;
     uint32_t need = (n + G - 1) / G;
     if (need < 1) need = 1;
-    return (int)(need < (uint32_t)max_blocks ? need : (uint32_t)max_blocks);
+    uint32_t grid = need < (uint32_t)max_blocks ? need : (uint32_t)max_blocks;
+    grid = (grid + 7u) & ~7u;  // multiple of 8 (XCD-aware tile order)
+    return (int)grid;
 }
 
 template <int S>
-static void launch_s(hipStream_t stream, bool dbg_on, int grid, const MapView& map, const float4* scan, uint32_t n,
-                     const KfDev* kf, const MatchParams& prm, double* partials, const DebugOut& dbg, int* fb) {
-    if (dbg_on)
-        hipLaunchKernelGGL((match_reduce_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, prm, partials, dbg, fb);
-    else
-        hipLaunchKernelGGL((match_reduce_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, prm, partials, dbg, fb);
+static void launch_s(hipStream_t stream, bool dbg_on, bool ext, int grid, const MapView& map, const float4* scan, uint32_t n,
+                     KfDev* kf, const MatchParams& prm, double* partials, const DebugOut& dbg) {
+#define LV_LAUNCH(EXT_, DBG_) \
+    hipLaunchKernelGGL((match_reduce_kernel<S, EXT_, DBG_>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, prm, partials, dbg)
+    if (ext) { if (dbg_on) LV_LAUNCH(true, true); else LV_LAUNCH(true, false); }
+    else { if (dbg_on) LV_LAUNCH(false, true); else LV_LAUNCH(false, false); }
+#undef LV_LAUNCH
 }
 
-int launch_match_reduce(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, const KfDev* kf,
-                        const MatchParams& prm, double* partials, int grid, const DebugOut& dbg, int* fallback_counter) {
+int launch_match_reduce(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
+                        const MatchParams& prm, double* partials, int grid, const DebugOut& dbg) {
     const bool dbg_on = dbg.knn_idx || dbg.valid || dbg.p_world || dbg.abcd || dbg.dist || dbg.rows;
+    const bool ext = prm.estimate_extrinsics != 0;
     switch (S) {
-        case 1: launch_s<1>(stream, dbg_on, grid, map, scan_sorted, n, kf, prm, partials, dbg, fallback_counter); break;
-        case 2: launch_s<2>(stream, dbg_on, grid, map, scan_sorted, n, kf, prm, partials, dbg, fallback_counter); break;
-        case 4: launch_s<4>(stream, dbg_on, grid, map, scan_sorted, n, kf, prm, partials, dbg, fallback_counter); break;
-        case 8: launch_s<8>(stream, dbg_on, grid, map, scan_sorted, n, kf, prm, partials, dbg, fallback_counter); break;
-        case 16: launch_s<16>(stream, dbg_on, grid, map, scan_sorted, n, kf, prm, partials, dbg, fallback_counter); break;
+        case 1: launch_s<1>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
+        case 2: launch_s<2>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
+        case 4: launch_s<4>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
+        case 8: launch_s<8>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
+        case 16: launch_s<16>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
         default: set_error("lanes_per_query must be 1,2,4,8 or 16 (got %d)", S); return LV_EINVAL;
     }
     LV_HIP(hipGetLastError());

@@ -1,21 +1,34 @@
 // lv_solve.hip — the N-independent tail of each IKFoM pass, kept on the device so that the
 // iterated update never leaves the GPU:
-//   reduce_partials_kernel : block partials -> the 96-double record (fixed summation order)
-//   solve_kernel           : esekf::update_iterated_dyn_share_modified's per-pass algebra
-//                            [IKFoM absent from the reference mount; UPSTREAM-RECALL of
-//                            hku-mars/IKFoM esekfom.hpp; call site reference
-//                            src/Modules/Localizator.cpp:132] — manifold projections, the two
-//                            23x23 inverses, K_h / K_x, boxplus, LIMITS test (src/main.cpp:145),
-//                            posterior covariance on the terminal pass — and the f32 pose constants
-//                            of the next pass (State(const state_ikfom&, double),
-//                            reference src/Objects/State.cpp:51-62).
+//   reduce_groups_kernel : 1024 block partials -> 32 group records   (fixed summation order;
+//                          a single CU only pulls ~25-60 GB/s, so the 786 KB of partials are first
+//                          folded by 32 workgroups in parallel)
+//   reduce_final_kernel  : group records -> the one 96-double record (multi-GPU path: this is what
+//                          RCCL all-reduces)
+//   solve_kernel         : esekf::update_iterated_dyn_share_modified's per-pass algebra
+//                          [IKFoM absent from the reference mount; UPSTREAM-RECALL of hku-mars/IKFoM
+//                          esekfom.hpp; call site reference src/Modules/Localizator.cpp:132] —
+//                          manifold projections, gain, boxplus, LIMITS test (src/main.cpp:145),
+//                          posterior covariance on the terminal pass — and the f32 pose constants of
+//                          the next pass (State(const state_ikfom&, double), src/Objects/State.cpp:51-62).
+//
+// Gain algebra.  Upstream computes  P_inv = ((P_/R)^-1 + E HTH E^T)^-1  (two 23x23 inverses) and uses
+// only X = P_inv[:, 0:12].  Multiplying the defining equation by Pr = P_/R gives the block system
+//     (I + Pr11 HTH) X_top = Pr11,   X_bot = Pr21 (I - HTH X_top)
+// whose numerically safe form is  X_top = (Pr11^-1 + HTH)^-1,  X_bot = Pr21 Pr11^-1 X_top :
+// two 12x12 SPD inversions (unpivoted Gauss-Jordan) instead of two 23x23 ones, no cancellation
+// (the naive S = I + Pr11 HTH solve loses ~6 digits in the posterior covariance; measured in
+// tests/test_oracle_numerics.py).  Algebraically identical to upstream, rounding-level different.
 #include "lv_host.hpp"
 #include "lv_manifold.hpp"
 
 namespace lv {
 
-__global__ void kf_begin_kernel(KfDev* kf) {
-    if (threadIdx.x == 0) {
+__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf) {
+    const int tid = threadIdx.x;
+    if (tid < NS * NS) kf->P_post[tid] = kf->P_prop[tid];
+    if (tid < NX) kf->x_prop[tid] = kf->x[tid];
+    if (tid == 0) {
         kf->t = 0;
         kf->iter = -1;  // upstream loop starts at i = -1
         kf->done = 0;
@@ -25,56 +38,36 @@ __global__ void kf_begin_kernel(KfDev* kf) {
     }
 }
 
-constexpr int RED_SEGS = 8;
-__global__ __launch_bounds__(SUMS_LEN* RED_SEGS) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
-                                                                              double* __restrict__ sums, const KfDev* kf) {
-    __shared__ double s_seg[RED_SEGS][SUMS_LEN];
+// ---- staged, order-fixed reduction of the block partials ------------------------------------------
+constexpr int RG_THREADS = 384;  // 96 outputs x 4 segments
+__global__ __launch_bounds__(RG_THREADS) void reduce_groups_kernel(const double* __restrict__ partials, int nblocks, int group,
+                                                                    double* __restrict__ groups, const KfDev* kf) {
+    __shared__ double s_seg[4][SUMS_LEN];
     if (kf->done) return;
     const int o = threadIdx.x % SUMS_LEN, seg = threadIdx.x / SUMS_LEN;
+    const int b0 = blockIdx.x * group;
+    int b1 = b0 + group;
+    if (b1 > nblocks) b1 = nblocks;
     double s = 0.0;
-    for (int b = seg; b < nblocks; b += RED_SEGS) s += partials[(size_t)b * SUMS_LEN + o];
+    for (int b = b0 + seg; b < b1; b += 4) s += partials[(size_t)b * SUMS_LEN + o];
     s_seg[seg][o] = s;
     __syncthreads();
-    if (seg == 0) {
-        double r = s_seg[0][o];
-#pragma unroll
-        for (int g = 1; g < RED_SEGS; ++g) r += s_seg[g][o];
-        sums[o] = r;
-    }
+    if (seg == 0) groups[(size_t)blockIdx.x * SUMS_LEN + o] = ((s_seg[0][o] + s_seg[1][o]) + s_seg[2][o]) + s_seg[3][o];
 }
 
+__global__ __launch_bounds__(SUMS_LEN) void reduce_final_kernel(const double* __restrict__ groups, int ngroups,
+                                                                 double* __restrict__ sums, const KfDev* kf) {
+    if (kf->done) return;
+    const int o = threadIdx.x;
+    double s = 0.0;
+    for (int g = 0; g < ngroups; ++g) s += groups[(size_t)g * SUMS_LEN + o];
+    sums[o] = s;
+}
+
+// ---- solve ------------------------------------------------------------------------------------------
 constexpr int LD = NS + 1;  // padded leading dimension in LDS
+constexpr int SOLVE_THREADS = 576;
 
-// in-place Gauss-Jordan inverse of an SPD 23x23 matrix held in LDS, ping-pong between M and W;
-// the result ends in M.  All 576 threads must call it; tid < 529 own element (i, j).
-__device__ inline void gj_inverse(double (*M)[LD], double (*W)[LD], int tid) {
-    const int i = tid / NS, j = tid % NS;
-    const bool act = tid < NS * NS;
-    double (*src)[LD] = M;
-    double (*dst)[LD] = W;
-    for (int k = 0; k < NS; ++k) {
-        if (act) {
-            const double p = src[k][k];
-            double v;
-            if (i == k) {
-                v = (j == k) ? 1.0 / p : src[k][j] / p;
-            } else {
-                const double f = src[i][k];
-                v = (j == k) ? -f / p : src[i][j] - f * (src[k][j] / p);
-            }
-            dst[i][j] = v;
-        }
-        __syncthreads();
-        double (*t)[LD] = src;
-        src = dst;
-        dst = t;
-    }
-    // NS is odd: after 23 swaps the result lives in W; copy back to M
-    if (act) M[i][j] = src[i][j];
-    __syncthreads();
-}
-
-// out = J * in * J^T with J = identity except the SO3 blocks (3,6) and the S2 block (21)
 __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double (*b)[LD], bool b_transposed, int tid) {
     if (tid < NS * NS) {
         const int i = tid / NS, j = tid % NS;
@@ -83,42 +76,108 @@ __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double
         out[i][j] = s;
     }
 }
+// in-place (ping-pong) Gauss-Jordan inverse of an SPD 12x12 matrix; all threads call, tid < 144 work
+__device__ inline void gj12(double (*W)[12][13], int& cur, int tid) {
+    for (int k = 0; k < 12; ++k) {
+        if (tid < 144) {
+            const int i = tid / 12, j = tid % 12;
+            const double p = W[cur][k][k];
+            double v;
+            if (i == k) {
+                v = (j == k) ? 1.0 / p : W[cur][k][j] / p;
+            } else {
+                const double f = W[cur][i][k];
+                v = (j == k) ? -f / p : W[cur][i][j] - f * (W[cur][k][j] / p);
+            }
+            W[cur ^ 1][i][j] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
 
 __device__ inline void set_identity(double (*J)[LD], int tid) {
     if (tid < NS * NS) J[tid / NS][tid % NS] = (tid / NS == tid % NS) ? 1.0 : 0.0;
 }
 
-// thread 0: J blocks from a tangent vector `seg` (23): A(seg[3:6])^T, A(seg[6:9])^T, Nx(x.grav) Mx(xprop.grav, seg[21:23])
-__device__ inline void fill_projection(double (*J)[LD], const double* seg, const double* x, const double* xprop) {
-    for (int b = 0; b < 2; ++b) {
-        const int idx = b == 0 ? 3 : 6;
+// The three manifold blocks are independent: wave 0 / 1 / 2 (lane 0 of each) compute them concurrently
+// on different SIMDs.  part 0: rot (dof 3), 1: offset_R_L_I (dof 6), 2: grav (dof 21).
+// mode 0: seg = x [-] x_prop for this block (written to dx), then the projection block from seg
+// mode 1: projection block from the given tangent `seg_in`
+__device__ inline void manifold_block(int part, int mode, const double* x, const double* xp, const double* seg_in, double* dx,
+                                      double (*J)[LD]) {
+    if (part < 2) {
+        const int idx = part == 0 ? 3 : 6, q = part == 0 ? 3 : 7;
+        double seg[3];
+        if (mode == 0) {
+            double c[4] = {-xp[q], -xp[q + 1], -xp[q + 2], xp[q + 3]}, qq[4];
+            d_quat_mul(c, x + q, qq);
+            d_so3_log(qq, seg);
+            dx[idx] = seg[0]; dx[idx + 1] = seg[1]; dx[idx + 2] = seg[2];
+        } else {
+            seg[0] = seg_in[idx]; seg[1] = seg_in[idx + 1]; seg[2] = seg_in[idx + 2];
+        }
         double A[9];
-        d_A_matrix(seg + idx, A);
+        d_A_matrix(seg, A);
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) J[idx + r][idx + c] = A[c * 3 + r];  // transpose
+            for (int c = 0; c < 3; ++c) J[idx + r][idx + c] = A[c * 3 + r];  // res_temp_SO3 = A^T
+    } else {
+        double seg[2];
+        if (mode == 0) {
+            d_s2_boxminus(x + 23, xp + 23, seg);
+            dx[21] = seg[0]; dx[22] = seg[1];
+        } else {
+            seg[0] = seg_in[21]; seg[1] = seg_in[22];
+        }
+        double T[4];
+        d_s2_proj(x + 23, xp + 23, seg, T);
+        J[21][21] = T[0]; J[21][22] = T[1]; J[22][21] = T[2]; J[22][22] = T[3];
     }
-    double T[4];
-    d_s2_proj(x + 23, xprop + 23, seg + 21, T);
-    J[21][21] = T[0]; J[21][22] = T[1]; J[22][21] = T[2]; J[22][22] = T[3];
 }
 
-__global__ __launch_bounds__(576) void solve_kernel(KfDev* kf, const double* __restrict__ sums, SolveParams prm) {
+__device__ inline void boxplus_block(int part, double* x, const double* d) {
+    if (part == 0) { double e[4], o[4]; d_so3_exp(d + 3, 1.0, e); d_quat_mul(x + 3, e, o); for (int i = 0; i < 4; ++i) x[3 + i] = o[i]; }
+    else if (part == 1) { double e[4], o[4]; d_so3_exp(d + 6, 1.0, e); d_quat_mul(x + 7, e, o); for (int i = 0; i < 4; ++i) x[7 + i] = o[i]; }
+    else d_s2_boxplus(x + 23, d + 21);
+}
+
+// dof index -> offset in the 26-double state for the vect components
+__device__ __forceinline__ int vect_state_index(int dof) {  // dof in {0..2, 9..20}
+    return dof < 3 ? dof : dof + 2;                         // 9..11 -> 11..13, 12..14 -> 14..16, ...
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const double* __restrict__ recs, int nrec,
+                                                              double* __restrict__ sums_out, SolveParams prm) {
     __shared__ double sP[NS][LD], sA[NS][LD], sB[NS][LD], sJ[NS][LD];
-    __shared__ double sKx[NS][12], sHTH[12][12], sHTh[12], sdx[NS], sdxnew[NS], sdxo[NS], sKh[NS];
-    __shared__ int s_last;
+    __shared__ double sW[2][12][13], sT[12][12];
+    __shared__ double sX[NS][12], sG[NS][12], sKx[NS][12], sHTH[12][12], sHTh[12];
+    __shared__ double sdx[NS], sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
+    __shared__ int s_last, s_conv;
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     if (kf->done) return;
     const int pass = kf->passes;
 
+    // fold the group records (fixed order) — nrec == 1 when the record was already finalised / all-reduced
+    if (tid < SUMS_LEN) {
+        double s = 0.0;
+        for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid];
+        srec[tid] = s;
+        if (sums_out) sums_out[tid] = s;
+        if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = s;
+    }
+    if (tid >= 128 && tid < 128 + NX) { sx[tid - 128] = kf->x[tid - 128]; sxp[tid - 128] = kf->x_prop[tid - 128]; }
+    if (tid == 200) s_conv = 1;
+    set_identity(sJ, tid);
+    if (tid < NS * NS) sB[tid / NS][tid % NS] = kf->P_prop[tid];
+    __syncthreads();
     if (tid < 144) {
         const int a = tid / 12, b = tid % 12;
         const int lo = a < b ? a : b, hi = a < b ? b : a;
-        const int idx = lo * 12 - lo * (lo - 1) / 2 + (hi - lo);
-        sHTH[a][b] = sums[idx];
+        sHTH[a][b] = srec[lo * 12 - lo * (lo - 1) / 2 + (hi - lo)];
     }
-    if (tid < 12) sHTh[tid] = sums[78 + tid];
-    if (tid < SUMS_LEN && pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = sums[tid];
-    const double n_valid = sums[90];
+    if (tid >= 192 && tid < 204) sHTh[tid - 192] = srec[78 + tid - 192];
+    const double n_valid = srec[90];
     if (n_valid == 0.0) {  // h_share_model: dyn_share.valid = false -> `continue`
         if (tid == 0) {
             if (pass < MAX_PASSES) {
@@ -132,124 +191,162 @@ __global__ __launch_bounds__(576) void solve_kernel(KfDev* kf, const double* __r
         return;
     }
 
-    set_identity(sJ, tid);
-    if (tid < NS * NS) sB[tid / NS][tid % NS] = kf->P_prop[tid];
-    __syncthreads();
-    if (tid == 0) {
-        double dx[NS];
-        d_state_boxminus(kf->x, kf->x_prop, dx);
-        fill_projection(sJ, dx, kf->x, kf->x_prop);
-        for (int i = 0; i < NS; ++i) { sdx[i] = dx[i]; sdxnew[i] = dx[i]; }
+    // dx = x [-] x_prop and the projection J(dx): three manifold blocks on three waves, vect parts on wave 3
+    if (wave < 3 && lane == 0) manifold_block(wave, 0, sx, sxp, nullptr, sdx, sJ);
+    if (wave == 3 && lane < 15) {
+        const int dof = lane < 3 ? lane : lane + 6;  // 0..2, 9..20
+        const int si = vect_state_index(dof);
+        sdx[dof] = sx[si] - sxp[si];
     }
     __syncthreads();
-    if (tid == 0) {  // dx_new blocks projected
-        for (int b = 0; b < 3; ++b) {
-            const int idx = b == 0 ? 3 : (b == 1 ? 6 : 21), r = b == 2 ? 2 : 3;
-            double t[3];
-            for (int i = 0; i < r; ++i) {
-                double s = 0;
-                if (r == 3) s = dot3d(sJ[idx + i][idx], sdx[idx], sJ[idx + i][idx + 1], sdx[idx + 1], sJ[idx + i][idx + 2], sdx[idx + 2]);
-                else s = sJ[idx + i][idx] * sdx[idx] + sJ[idx + i][idx + 1] * sdx[idx + 1];
-                t[i] = s;
-            }
-            for (int i = 0; i < r; ++i) sdxnew[idx + i] = t[i];
-        }
+    if (tid < NS) {  // dx_new = J dx (identity outside the blocks)
+        double s = 0.0;
+        const int b = (tid >= 3 && tid < 6) ? 3 : (tid >= 6 && tid < 9) ? 6 : (tid >= 21) ? 21 : -1;
+        if (b < 0) s = sdx[tid];
+        else if (b == 21) s = sJ[tid][21] * sdx[21] + sJ[tid][22] * sdx[22];
+        else s = dot3d(sJ[tid][b], sdx[b], sJ[tid][b + 1], sdx[b + 1], sJ[tid][b + 2], sdx[b + 2]);
+        sdxnew[tid] = s;
     }
     // P_ = J P_prop J^T
     mm(sA, sJ, sB, false, tid);
     __syncthreads();
     mm(sP, sA, sJ, true, tid);
     __syncthreads();
-    // P_temp = (P_/R)^-1 ; += HTH ; P_inv = P_temp^-1
+    // Pr = P_/R -> sA ; G = Pr[:, :12] HTH -> sG
     if (tid < NS * NS) sA[tid / NS][tid % NS] = sP[tid / NS][tid % NS] / prm.R;
     __syncthreads();
-    gj_inverse(sA, sB, tid);
-    if (tid < 144) sA[tid / 12][tid % 12] += sHTH[tid / 12][tid % 12];
+    // X_top = (Pr11^-1 + HTH)^-1 : two unpivoted Gauss-Jordan inversions of SPD 12x12 matrices
+    if (tid < 144) sW[0][tid / 12][tid % 12] = sA[tid / 12][tid % 12];
     __syncthreads();
-    gj_inverse(sA, sB, tid);  // sA = P_inv
-    if (tid < NS) {
-        double s = 0;
-        for (int j = 0; j < 12; ++j) s += sA[tid][j] * sHTh[j];
-        sKh[tid] = s;
+    int cur = 0;
+    gj12(sW, cur, tid);
+    if (tid < 144) {
+        const int i = tid / 12, j = tid % 12;
+        const double a1 = sW[cur][i][j];
+        sG[i][j] = a1;                      // keep A1 = Pr11^-1
+        sW[cur][i][j] = a1 + sHTH[i][j];
     }
-    if (tid >= 64 && tid < 64 + NS * 12) {
-        const int e = tid - 64, i = e / 12, c = e % 12;
-        double t = 0;
-        for (int j = 0; j < 12; ++j) t += sA[i][j] * sHTH[j][c];
+    __syncthreads();
+    gj12(sW, cur, tid);                     // sW[cur] = X_top
+    if (tid < 144) {                        // T = A1 X_top
+        const int i = tid / 12, c = tid % 12;
+        double s = 0.0;
+        for (int j = 0; j < 12; ++j) s += sG[i][j] * sW[cur][j][c];
+        sT[i][c] = s;
+    }
+    __syncthreads();
+    if (tid < NS * 12) {                    // X = [X_top ; Pr21 T]
+        const int i = tid / 12, c = tid % 12;
+        double v;
+        if (i < 12) {
+            v = sW[cur][i][c];
+        } else {
+            double s = 0.0;
+            for (int j = 0; j < 12; ++j) s += sA[i][j] * sT[j][c];
+            v = s;
+        }
+        sX[i][c] = v;
+    }
+    __syncthreads();
+    // K_h = X HTh ; K_x[:, :12] = X HTH
+    if (tid < NS * 12) {
+        const int i = tid / 12, c = tid % 12;
+        double t = 0.0;
+        for (int j = 0; j < 12; ++j) t += sX[i][j] * sHTH[j][c];
         sKx[i][c] = t;
     }
+    if (tid >= 320 && tid < 320 + NS) {
+        const int i = tid - 320;
+        double s = 0.0;
+        for (int j = 0; j < 12; ++j) s += sX[i][j] * sHTh[j];
+        sKh[i] = s;
+    }
     __syncthreads();
-    if (tid < NS) {
-        double s = 0;
+    if (tid < NS) {  // dx_ = K_h + (K_x - I) dx_new
+        double s = 0.0;
         for (int j = 0; j < NS; ++j) {
             const double kx = j < 12 ? sKx[tid][j] : 0.0;
             s += (kx - (tid == j ? 1.0 : 0.0)) * sdxnew[j];
         }
-        sdxo[tid] = sKh[tid] + s;
+        const double d = sKh[tid] + s;
+        sdxo[tid] = d;
+        if (fabs(d) > prm.limits[tid]) s_conv = 0;  // dyn_share.converge
     }
     __syncthreads();
-    if (tid == 0) {
-        double d[NS];
-        for (int i = 0; i < NS; ++i) d[i] = sdxo[i];
-        d_state_boxplus(kf->x, d);
-        int converge = 1;
-        for (int i = 0; i < NS; ++i)
-            if (fabs(d[i]) > prm.limits[i]) { converge = 0; break; }
+    // x_.boxplus(dx_)
+    if (wave < 3 && lane == 0) boxplus_block(wave, sx, sdxo);
+    if (wave == 3 && lane < 15) {
+        const int dof = lane < 3 ? lane : lane + 6;
+        sx[vect_state_index(dof)] += sdxo[dof];
+    }
+    if (tid == 256) {
         int t = kf->t;
-        if (converge) t++;
+        if (s_conv) t++;
         kf->t = t;
-        const int last = (t > 1 || kf->iter == prm.maximum_iter - 1) ? 1 : 0;
-        s_last = last;
-        if (pass < MAX_PASSES) {
-            for (int i = 0; i < NS; ++i) kf->trace[pass * 49 + i] = d[i];
-            for (int i = 0; i < NX; ++i) kf->trace[pass * 49 + NS + i] = kf->x[i];
-        }
+        s_last = (t > 1 || kf->iter == prm.maximum_iter - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < NX) kf->x[tid] = sx[tid];
+    if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
+        const int e = tid - 64;
+        kf->trace[pass * 49 + e] = e < NS ? sdxo[e] : sx[e - NS];
+    }
+    const int last = s_last;
+    if (tid == 0) {
         kf->passes = pass + 1;
         kf->iter += 1;
         if (last) kf->done = 1;
-        else compute_pose_consts(kf->x, &kf->pose);
+        else compute_pose_consts(sx, &kf->pose);
     }
-    __syncthreads();
-    if (!s_last) return;
+    if (!last) return;
 
     // terminal pass: L_ = J2 P_ J2^T, K_x rows projected, P_ <- P_ J2^T, P = L_ - K_x[:, :12] P_[0:12, :]
+    __syncthreads();
     set_identity(sJ, tid);
     __syncthreads();
-    if (tid == 0) fill_projection(sJ, sdxo, kf->x, kf->x_prop);
+    if (wave < 3 && lane == 0) manifold_block(wave, 1, sx, sxp, sdxo, nullptr, sJ);
     __syncthreads();
-    mm(sA, sJ, sP, false, tid);          // sA = J2 P_
+    mm(sA, sJ, sP, false, tid);  // sA = J2 P_
     __syncthreads();
-    mm(sB, sA, sJ, true, tid);           // sB = L_ = J2 P_ J2^T
+    mm(sB, sA, sJ, true, tid);   // sB = L_ = J2 P_ J2^T
     __syncthreads();
-    mm(sA, sP, sJ, true, tid);           // sA = P_ J2^T
+    mm(sA, sP, sJ, true, tid);   // sA = P_ J2^T
     __syncthreads();
-    if (tid < NS * 12) {                 // K_x <- J2 K_x (rows)
+    if (tid < NS * 12) {         // K_x <- J2 K_x (rows)
         const int i = tid / 12, c = tid % 12;
         double s = 0;
         for (int r = 0; r < NS; ++r) s += sJ[i][r] * sKx[r][c];
-        sP[i][c] = s;                    // stage projected K_x in sP (P_ no longer needed)
+        sX[i][c] = s;
     }
     __syncthreads();
     if (tid < NS * NS) {
         const int i = tid / NS, j = tid % NS;
         double s = 0;
-        for (int c = 0; c < 12; ++c) s += sP[i][c] * sA[c][j];
+        for (int c = 0; c < 12; ++c) s += sX[i][c] * sA[c][j];
         kf->P_post[tid] = sB[i][j] - s;
     }
 }
 
 int launch_kf_begin(hipStream_t stream, KfDev* kf) {
-    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(64), 0, stream, kf);
+    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
-int launch_reduce_partials(hipStream_t stream, const double* partials, int nblocks, double* sums, KfDev* kf) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(SUMS_LEN * RED_SEGS), 0, stream, partials, nblocks, sums, kf);
+int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf) {
+    const int group = 32;
+    const int ngroups = (nblocks + group - 1) / group;
+    hipLaunchKernelGGL(reduce_groups_kernel, dim3(ngroups), dim3(RG_THREADS), 0, stream, partials, nblocks, group, groups, kf);
+    LV_HIP(hipGetLastError());
+    *ngroups_out = ngroups;
+    return LV_OK;
+}
+int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf) {
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(SUMS_LEN), 0, stream, groups, ngroups, sums, kf);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
-int launch_solve(hipStream_t stream, KfDev* kf, const double* sums, const SolveParams& prm) {
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(576), 0, stream, kf, sums, prm);
+int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm) {
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, recs, nrec, sums_out, prm);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
