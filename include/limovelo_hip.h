@@ -171,8 +171,11 @@ typedef struct lv_timing {
     float pass_solve_ms[8];    /* device time of reduce_groups + solve per pass */
 } lv_timing;
 int lv_get_timing(lv_ctx* ctx, lv_timing* out);
-/* enable per-kernel HIP-event timing inside lv_update (adds event records to the stream) */
+/* 0 = off; 1 = per-kernel HIP-event timing inside lv_update (adds event records to the stream);
+ * 2 = the match kernel stamps 8 shader-clock values per workgroup (phase boundaries) */
 int lv_set_profiling(lv_ctx* ctx, int enabled);
+/* after a pass run with lv_set_profiling(ctx, 2): out receives n_blocks x 8 clock64() stamps */
+int lv_get_phase_clocks(lv_ctx* ctx, long long* out, int capacity_blocks, int* n_blocks);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_iterate",
     "lv_update", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
-    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_get_timing", "lv_set_profiling",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks",
 ]
 
 
@@ -214,8 +214,14 @@ class Context:
     def set_capture(self, on: bool):
         self._check(self.lib.lv_set_capture(self.h, int(on)))
 
-    def set_profiling(self, on: bool):
-        self._check(self.lib.lv_set_profiling(self.h, int(on)))
+    def set_profiling(self, mode):
+        self._check(self.lib.lv_set_profiling(self.h, int(mode)))
+
+    def phase_clocks(self, capacity=4096) -> np.ndarray:
+        out = np.zeros((capacity, 8), np.int64)
+        nb = C.c_int(0)
+        self._check(self.lib.lv_get_phase_clocks(self.h, out.ctypes.data_as(C.c_void_p), capacity, C.byref(nb)))
+        return out[:nb.value]
 
     def timing(self) -> dict:
         t = Timing()

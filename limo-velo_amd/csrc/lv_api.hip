@@ -57,6 +57,8 @@ struct lv_ctx {
     int passes_issued = 0;
 
     bool profiling = false;
+    bool phase_clocks = false;     // lv_set_profiling(ctx, 2): per-workgroup phase stamps of the match kernel
+    long long* d_clk = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pass;  // 3 per pass: before match kernel, after it, after reduce_partials + solve
     hipEvent_t ev_mid = nullptr;      // set while a profiled pass is in flight: recorded right after the match kernel
@@ -160,6 +162,10 @@ int pass_reduce(lv_ctx* c, bool finalize) {
         dbg = c->dbg;
         c->dbg_valid = true;
     }
+    if (c->phase_clocks) {
+        if (!c->d_clk) LV_HIP(hipMalloc(&c->d_clk, (size_t)(c->max_blocks + 8) * 8 * sizeof(long long)));
+        dbg.clk = c->d_clk;
+    }
     int rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
                                  c->d_partials, c->grid, dbg);
     if (rc) return rc;
@@ -253,7 +259,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_kf) hipHostFree(c->h_kf);
     if (c->h_sums) hipHostFree(c->h_sums);
-    hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
+    hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (auto ev : c->ev_pass) hipEventDestroy(ev);
@@ -537,7 +543,18 @@ int lv_get_timing(lv_ctx* c, lv_timing* out) {
 
 int lv_set_profiling(lv_ctx* c, int enabled) {
     if (!c) { set_error("null context"); return LV_EINVAL; }
-    c->profiling = enabled != 0;
+    c->profiling = enabled == 1;
+    c->phase_clocks = enabled == 2;
+    return LV_OK;
+}
+
+int lv_get_phase_clocks(lv_ctx* c, long long* out, int capacity_blocks, int* n_blocks) {
+    LV_CHECK_CTX(c);
+    if (!c->d_clk) { set_error("no phase clocks captured: lv_set_profiling(ctx, 2) first"); return LV_ESTATE; }
+    const int nb = c->grid < capacity_blocks ? c->grid : capacity_blocks;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(out, c->d_clk, (size_t)nb * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (n_blocks) *n_blocks = nb;
     return LV_OK;
 }
 

@@ -93,6 +93,7 @@ struct DebugOut {  // all optional (nullptr = skip); indexed by ORIGINAL scan in
     float* dist;        // N
     double* rows;       // N x 12
     double* h;          // N
+    long long* clk;     // instrumentation: 8 shader-clock stamps per workgroup (first block iteration)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -319,8 +319,10 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
     const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
     const uint32_t per_iter = (uint32_t)G * gridDim.x;
     const uint32_t iters = (n + per_iter - 1) / per_iter;
+#define LV_STAMP(i) do { if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t qbase = (it * gridDim.x + vb) * (uint32_t)G;
+        LV_STAMP(0);
         // ================= phase 1: S lanes per scan point — exact 5-NN =========================
         {
             const uint32_t q = qbase + (uint32_t)gq;
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
                 const float4 sp = scan[q];
                 oq = __float_as_uint(sp.w);
                 rt_apply(pc.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
+                if (DBG && dbg.clk) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); LV_STAMP(1); }
                 if (map.m > 0) {
                     const float tx = (qx - map.origin[0]) * map.inv_cell, ty = (qy - map.origin[1]) * map.inv_cell,
                                 tz = (qz - map.origin[2]) * map.inv_cell;
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
                                 slot = (slot + 1) & g.mask;
                             }
                             level = bl + 1;
+                            if (DBG && dbg.clk && bl == 0) { asm volatile("" :: "v"(bcount)); LV_STAMP(2); }
                             if (bcount >= KNN) {
                                 constexpr int U = 8;
                                 const float4* __restrict__ bp = map.bucket[bl] + bstart;
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
                     if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
                 }
             }
+            if (DBG && dbg.clk) { asm volatile("" :: "v"(k[0]), "v"(k[4])); LV_STAMP(3); }
             if (gl == 0) {
                 QueryStage& st = s_q[gq];
                 st.qx = qx; st.qy = qy; st.qz = qz;
@@ -461,7 +466,9 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
                 st.found = (q < n) ? found : -1;
             }
         }
+        LV_STAMP(4);
         __syncthreads();
+        LV_STAMP(5);
         // ================= phase 2: one lane per scan point — plane fit, gates, Jacobian row ==========
         if (tid < G) {
             const QueryStage st = s_q[tid];
@@ -569,13 +576,16 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
             }
         }
         __syncthreads();
+        LV_STAMP(6);
         // ================= phase 3: contract the staged rows into the block partial =====================
         if (tid < NOUT) {
 #pragma unroll 8
             for (int p = 0; p < G; ++p) acc += s_rows[p][oa] * s_rows[p][ob];
         }
         __syncthreads();
+        LV_STAMP(7);
     }
+#undef LV_STAMP
     if (tid < NOUT) s_out[orec] = acc;
     __syncthreads();
     if (tid < SUMS_LEN) partials[(size_t)blockIdx.x * SUMS_LEN + tid] = s_out[tid];
@@ -602,7 +612,7 @@ static void launch_s(hipStream_t stream, bool dbg_on, bool ext, int grid, const 
 
 int launch_match_reduce(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
                         const MatchParams& prm, double* partials, int grid, const DebugOut& dbg) {
-    const bool dbg_on = dbg.knn_idx || dbg.valid || dbg.p_world || dbg.abcd || dbg.dist || dbg.rows;
+    const bool dbg_on = dbg.knn_idx || dbg.valid || dbg.p_world || dbg.abcd || dbg.dist || dbg.rows || dbg.clk;
     const bool ext = prm.estimate_extrinsics != 0;
     switch (S) {
         case 1: launch_s<1>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;

@@ -1,0 +1,32 @@
+"""Per-phase shader-clock breakdown of the match kernel (instrumentation, GPU only)."""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import lvamd
+
+lvamd.load()
+from limo_velo_amd import capi, synth
+
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+sc = synth.make_scene(1_048_576, 65_536)
+ctx = capi.Context(capi.default_params(lanes_per_query=lanes))
+ctx.map_build(sc["map_xyz"])
+ctx.scan_set(sc["scan_xyz"])
+for _ in range(3):
+    ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+ctx.set_profiling(2)
+names = ["scan+pose", "probe", "stream+sel", "stage", "barrier1", "fit", "reduce"]
+for state, label in ((sc["x_true"], "converged pose"), (sc["x_init"], "perturbed pose")):
+    ctx.update_begin(state, sc["P0"])
+    ctx.pass_reduce()
+    clk = ctx.phase_clocks()
+    ctx.update_end()
+    d = np.diff(clk, axis=1).astype(np.float64)
+    tot = clk[:, 7] - clk[:, 0]
+    span = clk[:, 7].max() - clk[:, 0].min()
+    print(label, "blocks", len(clk), "| per-block total cycles mean %.0f max %.0f | first start -> last end %.0f" % (tot.mean(), tot.max(), span))
+    print("   start spread (cycles):", clk[:, 0].max() - clk[:, 0].min())
+    for i, nm in enumerate(names):
+        print("   %-11s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
