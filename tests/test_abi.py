@@ -1,0 +1,89 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports exactly what
+include/limovelo_hip.h declares; struct layouts seen by the ctypes binding match the C side; and the
+product path fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "limovelo_hip.h")
+
+
+@pytest.fixture(scope="module")
+def capi(lv):
+    from limo_velo_amd import capi as c
+
+    if not os.path.exists(c.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return c
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lv_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(capi):
+    declared = _declared_functions()
+    assert declared == sorted(capi.ABI_SYMBOLS), set(declared) ^ set(capi.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.load_library()
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in limovelo_hip.h but not exported"
+    assert b"gfx950" in lib.lv_version()
+
+
+def test_struct_layouts_match_c(capi, tmp_path):
+    """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "limovelo_hip.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(lv_params), offsetof(lv_params, LIMITS),"
+        " offsetof(lv_params, voxel_size), offsetof(lv_params, lanes_per_query), sizeof(lv_state), sizeof(lv_sums),"
+        " offsetof(lv_sums, n_valid), sizeof(lv_timing));return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(capi.Params), capi.Params.LIMITS.offset, capi.Params.voxel_size.offset,
+            capi.Params.lanes_per_query.offset, 26 * 8, C.sizeof(capi.Sums), capi.Sums.n_valid.offset,
+            C.sizeof(capi.Timing)]
+    assert got == want
+
+
+def test_default_params_mirror_reference_yaml(capi):
+    p = capi.default_params()  # config/params.yaml:32,46-53; src/main.cpp:145
+    assert (p.MAX_NUM_ITERS, p.NUM_MATCH_POINTS, p.MAX_DIST_PLANE, p.estimate_extrinsics) == (3, 5, 2.0, 0)
+    assert abs(p.PLANES_THRESHOLD - 0.05) < 1e-9 and p.LiDAR_noise == 0.001
+    assert list(p.LIMITS) == [0.001] * 23
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capi):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.LvError) as e:
+        capi.Context()
+    assert "HIP device" in str(e.value) or "-3" in str(e.value)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under limo-velo_amd/ (or the ABI header) may import,
+    link or call it."""
+    pkg = os.path.join(ROOT, "limo-velo_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"lvoracle|lv_oracle|liblvoracle|lvo_", text):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders

@@ -1,0 +1,158 @@
+"""The N>1 path on CPU: world_size-2 `gloo` run of limo_velo_amd.distributed.ShardedUpdater.
+
+The per-rank engine used here is built on the CPU oracle (test infrastructure) so that the sharding,
+the per-pass all-reduce of the 96-double record and the pass loop are exercised without a GPU; on a
+GPU node the same ShardedUpdater drives HipEngine over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def pack_record(s):
+    """lv_sums -> the 96-double device record layout of include/limovelo_hip.h."""
+    rec = np.zeros(96)
+    k = 0
+    for i in range(12):
+        for j in range(i, 12):
+            rec[k] = s["HTH"][i, j]
+            k += 1
+    rec[78:90] = s["HTh"]
+    rec[90] = s["n_valid"]
+    rec[91] = s["sum_h2"]
+    return rec
+
+
+def unpack_record(rec):
+    HTH = np.zeros((12, 12))
+    k = 0
+    for i in range(12):
+        for j in range(i, 12):
+            HTH[i, j] = HTH[j, i] = rec[k]
+            k += 1
+    return dict(HTH=HTH, HTh=rec[78:90].copy(), n_valid=int(round(rec[90])), sum_h2=float(rec[91]))
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine with the same begin/reduce/solve/end protocol and the device-side pass
+    bookkeeping of lv_solve.hip (t, iter from -1, done)."""
+
+    def __init__(self, lo, torch, map_xyz, max_iters=3):
+        self.lo, self.torch, self.map_xyz = lo, torch, map_xyz
+        self.tree = lo.KdTree(map_xyz)
+        self.max_passes = max_iters + 1
+        self.maximum_iter = max_iters
+
+    def scan_set(self, pts):
+        self.scan = pts
+
+    def update_fused(self, x, P):
+        xo, Po, passes, _, _ = self.lo.update(x, P, self.map_xyz, self.scan, tree=self.tree)
+        return xo, Po, passes
+
+    def begin(self, x, P):
+        self.x, self.x_prop, self.P_prop, self.P_post = x.copy(), x.copy(), P.copy(), P.copy()
+        self.t, self.iter, self.done, self.passes = 0, -1, False, 0
+
+    def reduce(self):
+        if self.done:
+            self.rec = self.torch.zeros(96, dtype=self.torch.float64)
+        elif len(self.scan) == 0:
+            self.rec = self.torch.zeros(96, dtype=self.torch.float64)
+        else:
+            s = self.lo.iterate(self.x, self.map_xyz, self.scan, tree=self.tree, details=False)
+            self.rec = self.torch.from_numpy(pack_record(s))
+        return self.rec
+
+    def solve(self):
+        if self.done:
+            return
+        s = unpack_record(self.rec.numpy())
+        self.passes += 1
+        if s["n_valid"] == 0:
+            self.iter += 1
+            self.done = self.iter >= self.maximum_iter
+            return
+        xn, dx, conv, Pn = self.lo.kf_step(self.x, self.x_prop, self.P_prop, s)
+        self.x = xn
+        self.t += int(conv)
+        last = self.t > 1 or self.iter == self.maximum_iter - 1
+        self.iter += 1
+        if last:
+            self.P_post, self.done = Pn, True
+
+    def end(self):
+        return self.x, self.P_post, self.passes
+
+
+def _worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import lvamd
+
+    lvamd.load()
+    from limo_velo_amd import synth
+    from limo_velo_amd.distributed import ShardedUpdater
+
+    import lvoracle as lo
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = synth.make_scene(50_000, 2_001)  # odd size: uneven shards
+    upd = ShardedUpdater(OracleEngine(lo, torch, sc["map_xyz"]), rank, world, dist, torch)
+    upd.scan_set(sc["scan_xyz"])
+    x, P, passes = upd.update(sc["x_init"], sc["P0"])
+    out_q.put((rank, upd.n_local, x, P, passes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds(lv):
+    from limo_velo_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 2001, 65536):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def test_two_rank_gloo_update_equals_single_process(oracle, lv):
+    import torch.multiprocessing as mp
+
+    from limo_velo_amd import synth
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = synth.make_scene(50_000, 2_001)
+    tree = oracle.KdTree(sc["map_xyz"])
+    xo, Po, po, _, _ = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    assert res[0][1] + res[1][1] == 2001 and abs(res[0][1] - res[1][1]) <= 1
+    for rank, n_local, x, P, passes in res:
+        assert passes == po
+        assert np.abs(x - xo).max() < 1e-10 and np.abs(P - Po).max() < 1e-12
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])  # ranks agree bitwise
