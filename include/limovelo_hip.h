@@ -160,6 +160,13 @@ int lv_fetch_matches(lv_ctx* ctx, uint8_t* valid, float* p_world, float* abcd, f
 /* calculate_H outputs as N x 12 rows / N residuals with zero rows for rejected points. */
 int lv_fetch_rows(lv_ctx* ctx, double* H, double* h);
 
+/* Localizator::calculate_H(const state_ikfom&, const Matches&, MatrixXd& H, VectorXd& h)
+ *                                                 — src/Modules/Localizator.cpp:29-57
+ * for caller-supplied matches: p_world n x 3 (Match::point), abcd n x 4 (Match::plane.n), dist n
+ * (Match::distance).  H receives n x 12 row-major rows, h receives n residuals.  Synchronous. */
+int lv_calculate_H(lv_ctx* ctx, const lv_state* x, const float* p_world, const float* abcd, const float* dist, size_t n,
+                   double* H, double* h);
+
 /* ---- instrumentation ------------------------------------------------------------------------- */
 typedef struct lv_timing {
     float last_update_ms;      /* device time of the last lv_update (HIP events on the ctx stream) */

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_iterate",
     "lv_update", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
-    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks",
 ]
 
 
@@ -248,6 +248,19 @@ class Context:
         self._check(self.lib.lv_fetch_matches(self.h, valid.ctypes.data_as(C.c_void_p), pw.ctypes.data_as(C.c_void_p),
                                               abcd.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
         return valid, pw, abcd, dist
+
+    def calculate_H(self, state, p_world, abcd, dist):
+        s = np.ascontiguousarray(state, np.float64)
+        pw = np.ascontiguousarray(p_world, np.float32)
+        ab = np.ascontiguousarray(abcd, np.float32)
+        di = np.ascontiguousarray(dist, np.float32)
+        n = len(di)
+        H = np.zeros((n, 12))
+        h = np.zeros(n)
+        self._check(self.lib.lv_calculate_H(self.h, s.ctypes.data_as(C.c_void_p), pw.ctypes.data_as(C.c_void_p),
+                                            ab.ctypes.data_as(C.c_void_p), di.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                            H.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
+        return H, h
 
     def fetch_rows(self):
         n = self._n

@@ -535,6 +535,35 @@ int lv_fetch_rows(lv_ctx* c, double* H, double* h) {
     return LV_OK;
 }
 
+int lv_calculate_H(lv_ctx* c, const lv_state* x, const float* p_world, const float* abcd, const float* dist, size_t n,
+                   double* H, double* h) {
+    LV_CHECK_CTX(c);
+    if (!x || (n && (!p_world || !abcd || !dist || !H || !h))) { set_error("null argument"); return LV_EINVAL; }
+    if (n == 0) return LV_OK;
+    if (c->in_update) { set_error("lv_calculate_H inside an update"); return LV_ESTATE; }
+    int rc = begin_common(c, x, nullptr);  // derives the pass constants from x on the device
+    if (rc) return rc;
+    float *d_in = nullptr;
+    double* d_out = nullptr;
+    LV_HIP(hipMalloc(&d_in, n * 8 * sizeof(float)));
+    LV_HIP(hipMalloc(&d_out, n * 13 * sizeof(double)));
+    float* d_pw = d_in;
+    float* d_abcd = d_in + 3 * n;
+    float* d_dist = d_in + 7 * n;
+    hipError_t e1 = hipMemcpyAsync(d_pw, p_world, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    hipError_t e2 = hipMemcpyAsync(d_abcd, abcd, n * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    hipError_t e3 = hipMemcpyAsync(d_dist, dist, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    rc = (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) ? LV_EHIP : LV_OK;
+    if (!rc) rc = launch_rows_from_matches(c->stream, c->d_kf, d_pw, d_abcd, d_dist, (uint32_t)n, c->prm.estimate_extrinsics, d_out, d_out + n * 12);
+    if (!rc && hipMemcpyAsync(H, d_out, n * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = LV_EHIP;
+    if (!rc && hipMemcpyAsync(h, d_out + n * 12, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = LV_EHIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = LV_EHIP;
+    hipFree(d_in);
+    hipFree(d_out);
+    if (rc == LV_EHIP) set_error("lv_calculate_H: HIP error");
+    return rc;
+}
+
 int lv_get_timing(lv_ctx* c, lv_timing* out) {
     if (!c || !out) { set_error("null argument"); return LV_EINVAL; }
     *out = c->timing;

@@ -74,6 +74,9 @@ struct SolveParams {
     int maximum_iter;
 };
 int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
+// lv_rows.hip
+int launch_rows_from_matches(hipStream_t stream, const KfDev* kf, const float* p_world, const float* abcd, const float* dist,
+                             uint32_t n, int estimate_extrinsics, double* H, double* h);
 // lv_scan.hip
 struct ScanStore {
     float4* d_raw = nullptr;     // upload order; w = original index

@@ -1,0 +1,172 @@
+// limovelo_shim.hpp — C++ host side above the C-ABI: the reference's `Mapper` / `Localizator`
+// interface for the iterated-KF-update path, ROS/PCL/Eigen-free.
+//
+// Same class names, method names, argument meaning and "no map yet => silently do nothing" behaviour
+// as the reference (Huguet57/LIMO-Velo):
+//   Mapper        include/Headers/Mapper.hpp:8-48,       src/Modules/Mapper.cpp:18-90
+//   Localizator   include/Headers/Localizator.hpp:8-54,  src/Modules/Localizator.cpp:18-179
+//   Point / Normal / Plane / Match / State   include/Headers/Objects.hpp:20-190
+//   Params (hot keys)                         include/Headers/Common.hpp:56-107
+// so that src/main.cpp:76-102 (`loc.correct(...)`, `loc.latest_state()`, `map.add(...)`) compiles
+// against it unchanged.  Differences forced by the environment (documented in INTEGRATION.md):
+//   * Eigen is not available here: the two Eigen-typed signatures use the tiny row-major `MatrixXd` /
+//     `VectorXd` stand-ins below (operator()(i,j), rows(), cols()); with Eigen present they are
+//     drop-in replaceable by Eigen::Map views.
+//   * state_ikfom is the plain lv_state record (26 doubles, quaternions x,y,z,w) instead of the MTK
+//     compound manifold; IKFoM's esekf lives on the GPU (lv_update).
+//   * State(const state_ikfom&, double) no longer reaches into the Accumulator singleton
+//     (reference src/Objects/State.cpp:41-51): IMU-derived members are not on this path.
+// All arithmetic of the path runs in liblimovelo_hip.so; this file only moves data.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/limovelo_hip.h"
+
+typedef double TimeType;
+
+struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107), same names
+    bool estimate_extrinsics = false;
+    double degeneracy_threshold = 5.0;
+    int MAX_NUM_ITERS = 3;
+    int MAX_POINTS2MATCH = 10;
+    std::vector<double> LIMITS = std::vector<double>(23, 0.001);
+    int NUM_MATCH_POINTS = 5;
+    double MAX_DIST_PLANE = 2.0;
+    float PLANES_THRESHOLD = 5.e-2f;
+    double LiDAR_noise = 0.001;
+    double full_rotation_time = 0.1;
+    std::vector<float> initial_gravity = {0.f, 0.f, -9.807f};
+    std::vector<float> I_Rotation_L = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::vector<float> I_Translation_L = {0, 0, 0};
+};
+extern struct Params Config;  // the reference's global (src/main.cpp:14)
+
+class Point {  // reference Objects.hpp:20-28 — 32 bytes, xyz at offset 0
+  public:
+    float x, y, z;
+    TimeType time;
+    float intensity;
+    float range;
+    Point() : x(0), y(0), z(0), time(0), intensity(0), range(0) {}
+    Point(float x_, float y_, float z_, TimeType t = 0) : x(x_), y(y_), z(z_), time(t), intensity(0), range(0) {}
+};
+static_assert(sizeof(Point) == 32, "Point must keep the reference's 32-byte layout");
+
+typedef std::deque<Point> Points;
+typedef std::vector<Point> PointVector;
+typedef lv_state state_ikfom;
+
+struct MatrixXd {  // minimal row-major stand-in for Eigen::MatrixXd on the calculate_H signature
+    int r = 0, c = 0;
+    std::vector<double> d;
+    void resize(int rows_, int cols_) { r = rows_; c = cols_; d.assign((size_t)rows_ * cols_, 0.0); }
+    int rows() const { return r; }
+    int cols() const { return c; }
+    double& operator()(int i, int j) { return d[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+};
+struct VectorXd {
+    std::vector<double> d;
+    void resize(int n) { d.assign((size_t)n, 0.0); }
+    int size() const { return (int)d.size(); }
+    double& operator()(int i) { return d[(size_t)i]; }
+    double operator()(int i) const { return d[(size_t)i]; }
+};
+
+class Normal {  // reference Objects.hpp:153-162
+  public:
+    float A = 0, B = 0, C = 0, D = 0;
+};
+class Plane {  // reference Objects.hpp:164-179
+  public:
+    bool is_plane = false;
+    Point centroid;  // visualisation only in the reference (buggy accumulator): left at 0
+    Normal n;
+    float dist_to_plane(const Point& p) const { return n.A * p.x + n.B * p.y + n.C * p.z + n.D; }
+};
+class Match {  // reference Objects.hpp:181-190
+  public:
+    Point point;  // world frame
+    Plane plane;
+    float distance = 0;
+    bool is_chosen() { return plane.is_plane; }
+};
+typedef std::vector<Match> Matches;
+
+class State {  // f32 mirror of the filter state (reference Objects.hpp:97-137); only the pose members
+  public:
+    float R[9], pos[3], RLI[9], tLI[3];
+    TimeType time = 0;
+    state_ikfom x;  // the f64 source it was built from
+    State() { std::memset(this, 0, sizeof(*this)); }
+    State(const state_ikfom& s, double t);
+};
+
+// One GPU context shared by the two singletons (the reference's singletons share the process).
+class HipRuntime {
+  public:
+    static lv_ctx* ctx();
+    static void configure(int device, float voxel_size = 0.5f, int lanes_per_query = 8);  // before first use
+    static void shutdown();
+};
+
+class Mapper {
+  public:
+    double last_map_time = -1;
+
+    bool exists();
+    int size();
+    void add(Points&, double time, bool downsample = false);
+    Matches match(const State&, const Points&);
+    bool hasToMap(double t);
+
+    static Mapper& getInstance() {
+        static Mapper* mapper = new Mapper();
+        return *mapper;
+    }
+
+  private:
+    Mapper() = default;
+    Mapper(const Mapper&) = delete;
+    Mapper& operator=(const Mapper&) = delete;
+};
+
+class Localizator {
+  public:
+    Points points2match;
+    double last_time_integrated = -1;
+    double last_time_updated = -1;
+    bool initialized = false;
+
+    // filter state: x_ and P_ of esekf<state_ikfom, 12, input_ikfom> (reference Localizator.hpp:19)
+    void init_state(const state_ikfom& x0);  // init_IKFoM_state's x0 / P0 (Localizator.cpp:135-153)
+    const state_ikfom& get_x() const { return x_; }
+    const double* get_P() const { return P_; }
+    void change_x(const state_ikfom& x) { x_ = x; }
+    void change_P(const double* P) { std::memcpy(P_, P, sizeof(P_)); }
+
+    void correct(const Points&, double time);
+    void calculate_H(const state_ikfom&, const Matches&, MatrixXd& H, VectorXd& h);
+    State latest_state();
+    int last_passes = 0;  // measurement passes of the last correct()
+
+    static Localizator& getInstance() {
+        static Localizator* localizator = new Localizator();
+        return *localizator;
+    }
+
+  private:
+    Localizator();
+    Localizator(const Localizator&) = delete;
+    Localizator& operator=(const Localizator&) = delete;
+    void IKFoM_update(const Points&);
+    state_ikfom x_;
+    double P_[23 * 23];
+};

@@ -1,0 +1,71 @@
+// shim_demo.cpp — drives the reference-style C++ API exactly like src/main.cpp:84-102 does
+// (map.add -> loc.correct -> loc.latest_state), plus Mapper::match / Localizator::calculate_H.
+// Input/Output are raw little-endian files so tests/test_gpu_shim.py can compare with the oracle.
+//   shim_demo <map.f32> <scan.f32> <state26.f64> <P529.f64> <out.bin>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "limovelo_shim.hpp"
+
+template <typename T>
+static std::vector<T> slurp(const char* path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    f.seekg(0, std::ios::end);
+    size_t n = (size_t)f.tellg() / sizeof(T);
+    f.seekg(0);
+    std::vector<T> v(n);
+    f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(T)));
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 6) { std::cerr << "usage: shim_demo map.f32 scan.f32 state.f64 P.f64 out.bin\n"; return 2; }
+    try {
+        auto mapv = slurp<float>(argv[1]);
+        auto scanv = slurp<float>(argv[2]);
+        auto xs = slurp<double>(argv[3]);
+        auto Pv = slurp<double>(argv[4]);
+        Points map_pts, scan_pts;
+        for (size_t i = 0; i + 2 < mapv.size(); i += 3) map_pts.push_back(Point(mapv[i], mapv[i + 1], mapv[i + 2], 0.0));
+        for (size_t i = 0; i + 2 < scanv.size(); i += 3) scan_pts.push_back(Point(scanv[i], scanv[i + 1], scanv[i + 2], 0.1));
+        state_ikfom x0;
+        std::memcpy(&x0, xs.data(), sizeof(x0));
+
+        Mapper& map = Mapper::getInstance();
+        Localizator& loc = Localizator::getInstance();
+        loc.correct(scan_pts, 0.05);  // no map yet: must be a silent no-op (Localizator.cpp:24)
+        if (loc.last_time_updated >= 0) { std::cerr << "correct() without a map must not update\n"; return 1; }
+        map.add(map_pts, 0.0, false);
+        loc.init_state(x0);
+        loc.change_P(Pv.data());
+
+        Matches matches = map.match(State(loc.get_x(), 0.1), scan_pts);
+        MatrixXd H;
+        VectorXd h;
+        loc.calculate_H(loc.get_x(), matches, H, h);
+
+        loc.correct(scan_pts, 0.1);
+        State Xt2 = loc.latest_state();
+
+        std::ofstream out(argv[5], std::ios::binary);
+        double header[4] = {(double)map.size(), (double)matches.size(), (double)loc.last_passes, Xt2.time};
+        out.write(reinterpret_cast<const char*>(header), sizeof(header));
+        out.write(reinterpret_cast<const char*>(&loc.get_x()), sizeof(state_ikfom));
+        out.write(reinterpret_cast<const char*>(loc.get_P()), sizeof(double) * 529);
+        out.write(reinterpret_cast<const char*>(H.d.data()), (std::streamsize)(sizeof(double) * H.d.size()));
+        out.write(reinterpret_cast<const char*>(h.d.data()), (std::streamsize)(sizeof(double) * h.d.size()));
+        for (auto& m : matches) {
+            float rec[8] = {m.point.x, m.point.y, m.point.z, m.plane.n.A, m.plane.n.B, m.plane.n.C, m.plane.n.D, m.distance};
+            out.write(reinterpret_cast<const char*>(rec), sizeof(rec));
+        }
+        std::printf("shim_demo: map %d pts, %zu matches, %d passes, pos %.6f %.6f %.6f\n", map.size(), matches.size(),
+                    loc.last_passes, loc.get_x().pos[0], loc.get_x().pos[1], loc.get_x().pos[2]);
+        HipRuntime::shutdown();
+    } catch (const std::exception& e) {
+        std::cerr << "shim_demo failed: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

@@ -26,7 +26,7 @@ def capi(lv):
 def _declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(lv_[a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(lv_[A-Za-z_0-9]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree(capi):
@@ -87,3 +87,14 @@ def test_product_package_never_touches_the_oracle():
                 if re.search(r"lvoracle|lv_oracle|liblvoracle|lvo_", text):
                     offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_cpp_shim_builds_with_reference_method_names(capi):
+    """g++ compiles and links the Mapper / Localizator shim (no GPU needed) and it exports the reference's
+    method names (Mapper.hpp:9-38, Localizator.hpp:12-45)."""
+    host = os.path.join(ROOT, "limo-velo_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host])
+    syms = subprocess.check_output(["nm", "-DC", os.path.join(ROOT, "limo-velo_amd", "liblimovelo_shim.so")], text=True)
+    for name in ("Mapper::add(", "Mapper::match(", "Mapper::exists()", "Mapper::size()", "Mapper::hasToMap(",
+                 "Localizator::correct(", "Localizator::calculate_H(", "Localizator::latest_state()"):
+        assert name in syms, name
