@@ -961,17 +961,32 @@ void lvo_iterate(const lvo_state* s, const lvo_params* prm, const void* tree, co
         if (abcd_out) std::memcpy(abcd_out + 4 * i, abcd, sizeof(abcd));
         if (dist_out) dist_out[i] = d;
     }
-    // H^T H and H^T h in scan-index order (esekf a-8; f64)
+    // H^T H and H^T h (esekf a-8; f64).  Fixed chunks of 1024 points are contracted independently (in
+    // parallel) and the chunk partials are added in chunk order: deterministic for any thread count.
     std::memset(out, 0, sizeof(*out));
-    for (size_t i = 0; i < n; ++i) {
-        if (!ok[i]) continue;
-        const double* r = &rows[i * 12];
-        for (int a = 0; a < 12; ++a) {
-            for (int b = 0; b < 12; ++b) out->HTH[a * 12 + b] += r[a] * r[b];
-            out->HTh[a] += r[a] * hv[i];
+    const size_t CH = 1024, nch = (n + CH - 1) / CH;
+    std::vector<lvo_iter_out> part(nch);
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t c = 0; c < (int64_t)nch; ++c) {
+        lvo_iter_out& o = part[c];
+        std::memset(&o, 0, sizeof(o));
+        const size_t i1 = std::min(n, (size_t)(c + 1) * CH);
+        for (size_t i = (size_t)c * CH; i < i1; ++i) {
+            if (!ok[i]) continue;
+            const double* r = &rows[i * 12];
+            for (int a = 0; a < 12; ++a) {
+                for (int b = 0; b < 12; ++b) o.HTH[a * 12 + b] += r[a] * r[b];
+                o.HTh[a] += r[a] * hv[i];
+            }
+            o.sum_h2 += hv[i] * hv[i];
+            o.n_valid += 1;
         }
-        out->sum_h2 += hv[i] * hv[i];
-        out->n_valid += 1;
+    }
+    for (size_t c = 0; c < nch; ++c) {
+        for (int a = 0; a < 144; ++a) out->HTH[a] += part[c].HTH[a];
+        for (int a = 0; a < 12; ++a) out->HTh[a] += part[c].HTh[a];
+        out->sum_h2 += part[c].sum_h2;
+        out->n_valid += part[c].n_valid;
     }
     if (valid) std::memcpy(valid, ok.data(), n);
     if (Hrows) std::memcpy(Hrows, rows.data(), n * 12 * sizeof(double));
