@@ -179,8 +179,10 @@ int pass_reduce(lv_ctx* c, bool finalize) {
 int pass_solve(lv_ctx* c, bool from_groups) {
     SolveParams sp;
     sp.R = c->prm.LiDAR_noise;
+    sp.R_inv = 1.0 / c->prm.LiDAR_noise;
     for (int i = 0; i < NS; ++i) sp.limits[i] = c->prm.LIMITS[i];
     sp.maximum_iter = c->prm.MAX_NUM_ITERS;
+    sp.estimate_extrinsics = c->prm.estimate_extrinsics;
     if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_groups, c->ngroups, c->d_sums, sp);
     return launch_solve(c->stream, c->d_kf, c->d_sums, 1, nullptr, sp);
 }
@@ -562,6 +564,14 @@ int lv_calculate_H(lv_ctx* c, const lv_state* x, const float* p_world, const flo
     hipFree(d_out);
     if (rc == LV_EHIP) set_error("lv_calculate_H: HIP error");
     return rc;
+}
+
+int lv_get_solve_clocks(lv_ctx* c, long long* out, int capacity) {
+    LV_CHECK_CTX(c);
+    if (!out || capacity < MAX_PASSES * 16) { set_error("capacity must be >= %d", MAX_PASSES * 16); return LV_EINVAL; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(out, c->d_kf->solve_clk, sizeof(long long) * MAX_PASSES * 16, hipMemcpyDeviceToHost));
+    return LV_OK;
 }
 
 int lv_get_timing(lv_ctx* c, lv_timing* out) {

@@ -53,6 +53,7 @@ struct KfDev {
     double trace[MAX_PASSES * 49];
     double sums_log[MAX_PASSES * SUMS_LEN];
     PoseConsts pose;
+    long long solve_clk[MAX_PASSES * 16];  // instrumentation: shader-clock stamps of solve_kernel phases
 };
 
 struct GridLevel {

@@ -70,8 +70,10 @@ int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks
 int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf);
 struct SolveParams {
     double R;
+    double R_inv;
     double limits[NS];
     int maximum_iter;
+    int estimate_extrinsics;
 };
 int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
 // lv_rows.hip

@@ -7,7 +7,79 @@
 #pragma once
 #include "lv_device.hpp"
 
+// From here on (this header and the rest of lv_solve.hip) FMA contraction is allowed: the 23-dof algebra
+// is compared with the oracle at 1e-9, not bitwise, and fused code is ~35 % smaller — solve_kernel's
+// time is instruction fetch of cold code.  The pose constants that feed the bit-exact f32 path
+// (quat_to_rot, rt_compose, rt_inv in lv_device.hpp; finish_pose_consts) keep contraction OFF.
+#pragma clang fp contract(fast)
+
 namespace lv {
+
+// ---- lean f64 elementary functions -----------------------------------------------------------------
+// solve_kernel is one workgroup running cold code once per pass: its time is dominated by instruction
+// fetch, so the ~40 KB of inlined libm range-reduction / correctly-rounded division code is replaced by
+// compact versions accurate to a few ulp (the filter state is compared at 1e-9, see tests).
+__device__ __forceinline__ double ddiv(double a, double b) {  // a / b, <= 2 ulp
+    double r = __builtin_amdgcn_rcp(b);
+    r = r * (2.0 - b * r);
+    r = r * (2.0 - b * r);
+    double q = a * r;
+    return q + r * (a - b * q);
+}
+// sin and cos of x for |x| < ~1e5: Cody-Waite reduction to |r| <= pi/4, Taylor kernels
+__device__ inline void dsincos(double x, double& sn, double& cs) {
+    const double k = rint(x * 0.63661977236758134308);  // 2/pi
+    double r = x - k * 1.57079632673412561417e+00;      // pi/2 split in three parts
+    r = r - k * 6.07710050650619224932e-11;
+    r = r - k * 2.02226624879595063154e-21;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;             // 1/13!
+    ps = ps * z - 2.50507602534068634195e-08;           // -1/11!
+    ps = ps * z + 2.75573137070700676789e-06;           // 1/9!
+    ps = ps * z - 1.98412698298579493134e-04;           // -1/7!
+    ps = ps * z + 8.33333333332248946124e-03;           // 1/5!
+    ps = ps * z - 1.66666666666666324348e-01;           // -1/3!
+    const double s0 = r + r * z * ps;
+    double pc = -1.13596475577881948265e-11;            // -1/14!
+    pc = pc * z + 2.08757232129817482790e-09;           // 1/12!
+    pc = pc * z - 2.75573143513906633035e-07;           // -1/10!
+    pc = pc * z + 2.48015872894767294178e-05;           // 1/8!
+    pc = pc * z - 1.38888888888741095749e-03;           // -1/6!
+    pc = pc * z + 4.16666666666666019037e-02;           // 1/4!
+    const double c0 = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)k & 3;
+    sn = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
+    cs = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
+}
+// atan(t): two half-angle reductions t -> t / (1 + sqrt(1 + t^2)) bring |t| below tan(pi/16), then Taylor
+__device__ inline double datan(double t) {
+    const bool inv = fabs(t) > 1.0;
+    double u = inv ? ddiv(1.0, t) : t;
+    u = ddiv(u, 1.0 + sqrt(1.0 + u * u));
+    u = ddiv(u, 1.0 + sqrt(1.0 + u * u));
+    const double z = u * u;
+    double p = 1.0 / 25.0;
+    p = p * -z + 1.0 / 23.0;
+    p = p * -z + 1.0 / 21.0;
+    p = p * -z + 1.0 / 19.0;
+    p = p * -z + 1.0 / 17.0;
+    p = p * -z + 1.0 / 15.0;
+    p = p * -z + 1.0 / 13.0;
+    p = p * -z + 1.0 / 11.0;
+    p = p * -z + 1.0 / 9.0;
+    p = p * -z + 1.0 / 7.0;
+    p = p * -z + 1.0 / 5.0;
+    p = p * -z + 1.0 / 3.0;
+    p = p * -z + 1.0;
+    double a = 4.0 * (u * p);
+    if (inv) a = (t > 0 ? 1.57079632679489661923 : -1.57079632679489661923) - a;
+    return a;
+}
+__device__ inline double datan2(double y, double x) {
+    if (x > 0) return datan(ddiv(y, x));
+    if (x < 0) return datan(ddiv(y, x)) + (y >= 0 ? 3.14159265358979323846 : -3.14159265358979323846);
+    return y > 0 ? 1.57079632679489661923 : (y < 0 ? -1.57079632679489661923 : 0.0);
+}
 
 constexpr double MTK_TOL = 1e-11;             // [UPSTREAM-RECALL MTK::tolerance<double>()]
 constexpr double S2_LEN = 98090.0 / 10000.0;  // [UPSTREAM-RECALL typedef MTK::S2<double, 98090, 10000, 1> S2]
@@ -47,9 +119,9 @@ __device__ inline void d_hat3(const double v[3], double H[9]) {
 __device__ inline void d_cos_sinc_sqrt(double x2, double& c, double& s) {
     const double taylor_n_bound = 1.220703125e-04;  // sqrt(sqrt(DBL_EPSILON)) = 2^-13
     if (x2 >= taylor_n_bound) {
-        double x = sqrt(x2);
-        c = cos(x);
-        s = sin(x) / x;
+        double x = sqrt(x2), sn;
+        dsincos(x, sn, c);
+        s = ddiv(sn, x);
         return;
     }
     const double inv[7] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
@@ -78,7 +150,7 @@ __device__ inline void d_so3_exp(const double v[3], double scale, double q[4]) {
 __device__ inline void d_so3_log(const double q[4], double out[3]) {
     double nv = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
     if (nv < MTK_TOL) nv = MTK_TOL;
-    double s = 2.0 / nv * atan(nv / q[3]);
+    double s = ddiv(2.0, nv) * datan(ddiv(nv, q[3]));
     out[0] = s * q[0]; out[1] = s * q[1]; out[2] = s * q[2];
 }
 // [UPSTREAM-RECALL MTK::A_matrix]
@@ -90,16 +162,19 @@ __device__ inline void d_A_matrix(const double v[3], double A[9]) {
     double H[9], HH[9];
     d_hat3(v, H);
     d_mat3_mul(H, H, HH);
-    double c1 = (1 - cos(norm)) / squaredNorm;
-    double c2 = (1 - sin(norm) / norm) / squaredNorm;
+    double sn, cn;
+    dsincos(norm, sn, cn);
+    double c1 = ddiv(1 - cn, squaredNorm);
+    double c2 = ddiv(1 - ddiv(sn, norm), squaredNorm);
     for (int i = 0; i < 9; ++i) A[i] = A[i] + c1 * H[i] + c2 * HH[i];
 }
 __device__ inline void d_s2_Bx(const double vec[3], double Bx[6]) {
     if (vec[0] + S2_LEN > MTK_TOL) {
-        Bx[0] = -vec[1];                                       Bx[1] = -vec[2];
-        Bx[2] = S2_LEN - vec[1] * vec[1] / (S2_LEN + vec[0]);  Bx[3] = -vec[2] * vec[1] / (S2_LEN + vec[0]);
-        Bx[4] = -vec[2] * vec[1] / (S2_LEN + vec[0]);          Bx[5] = S2_LEN - vec[2] * vec[2] / (S2_LEN + vec[0]);
-        for (int i = 0; i < 6; ++i) Bx[i] /= S2_LEN;
+        const double rd = ddiv(1.0, S2_LEN + vec[0]);
+        Bx[0] = -vec[1];                           Bx[1] = -vec[2];
+        Bx[2] = S2_LEN - vec[1] * vec[1] * rd;     Bx[3] = -vec[2] * vec[1] * rd;
+        Bx[4] = -vec[2] * vec[1] * rd;             Bx[5] = S2_LEN - vec[2] * vec[2] * rd;
+        for (int i = 0; i < 6; ++i) Bx[i] *= (1.0 / S2_LEN);
     } else {
         for (int i = 0; i < 6; ++i) Bx[i] = 0;
         Bx[3] = -1;
@@ -122,7 +197,7 @@ __device__ inline void d_s2_boxminus(const double vec[3], const double other[3],
     d_mat3_vec(H, other, hv);
     double v_sin = sqrt(hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2]);
     double v_cos = vec[0] * other[0] + vec[1] * other[1] + vec[2] * other[2];
-    double theta = atan2(v_sin, v_cos);
+    double theta = datan2(v_sin, v_cos);
     if (v_sin < MTK_TOL) {
         if (fabs(theta) > MTK_TOL) { res[0] = 3.1415926; res[1] = 0; }
         else { res[0] = 0; res[1] = 0; }
@@ -131,7 +206,7 @@ __device__ inline void d_s2_boxminus(const double vec[3], const double other[3],
         d_s2_Bx(other, Bx);
         d_hat3(other, Ho);
         d_mat3_vec(Ho, vec, t);
-        double f = theta / v_sin;
+        double f = ddiv(theta, v_sin);
         res[0] = f * (Bx[0] * t[0] + Bx[2] * t[1] + Bx[4] * t[2]);
         res[1] = f * (Bx[1] * t[0] + Bx[3] * t[1] + Bx[5] * t[2]);
     }

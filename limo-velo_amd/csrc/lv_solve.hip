@@ -72,22 +72,25 @@ __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double
     if (tid < NS * NS) {
         const int i = tid / NS, j = tid % NS;
         double s = 0.0;
+#pragma unroll 1
         for (int c = 0; c < NS; ++c) s += a[i][c] * (b_transposed ? b[j][c] : b[c][j]);
         out[i][j] = s;
     }
 }
-// in-place (ping-pong) Gauss-Jordan inverse of an SPD 12x12 matrix; all threads call, tid < 144 work
-__device__ inline void gj12(double (*W)[12][13], int& cur, int tid) {
-    for (int k = 0; k < 12; ++k) {
-        if (tid < 144) {
-            const int i = tid / 12, j = tid % 12;
-            const double p = W[cur][k][k];
+// in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix (NW = 6 or 12); all threads call,
+// tid < NW*NW work; one reciprocal per step
+template <int NW>
+__device__ inline void gj_spd(double (*W)[12][13], int& cur, int tid) {
+    for (int k = 0; k < NW; ++k) {
+        if (tid < NW * NW) {
+            const int i = tid / NW, j = tid % NW;
+            const double rp = ddiv(1.0, W[cur][k][k]);
             double v;
             if (i == k) {
-                v = (j == k) ? 1.0 / p : W[cur][k][j] / p;
+                v = (j == k) ? rp : W[cur][k][j] * rp;
             } else {
                 const double f = W[cur][i][k];
-                v = (j == k) ? -f / p : W[cur][i][j] - f * (W[cur][k][j] / p);
+                v = (j == k) ? -(f * rp) : W[cur][i][j] - f * (W[cur][k][j] * rp);
             }
             W[cur ^ 1][i][j] = v;
         }
@@ -98,6 +101,21 @@ __device__ inline void gj12(double (*W)[12][13], int& cur, int tid) {
 
 __device__ inline void set_identity(double (*J)[LD], int tid) {
     if (tid < NS * NS) J[tid / NS][tid % NS] = (tid / NS == tid % NS) ? 1.0 : 0.0;
+}
+
+// compute_pose_consts (lv_device.hpp) with the four quaternion -> matrix conversions already done
+__device__ inline void finish_pose_consts(const double* x, const double (*rot)[9], PoseConsts* out) {
+#pragma clang fp contract(off)
+    RT32 X, LI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { X.R[i] = (float)rot[0][i]; LI.R[i] = (float)rot[1][i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { X.t[i] = (float)x[i]; LI.t[i] = (float)x[11 + i]; }
+    out->Tc = rt_compose(X, LI);
+    out->back = rt_compose(rt_inv(LI), rt_inv(X));
+    out->LI = LI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { out->R_inv[i] = rot[2][i]; out->I_R_L_inv[i] = rot[3][i]; }
 }
 
 // The three manifold blocks are independent: wave 0 / 1 / 2 (lane 0 of each) compute them concurrently
@@ -146,22 +164,40 @@ __device__ __forceinline__ int vect_state_index(int dof) {  // dof in {0..2, 9..
     return dof < 3 ? dof : dof + 2;                         // 9..11 -> 11..13, 12..14 -> 14..16, ...
 }
 
+// NW = number of Jacobian columns that can be non-zero: 6 without extrinsic estimation (H^T H lives in
+// the leading 6x6 block, only P_inv[:, 0:6] is needed), 12 with it.
+template <int NW>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const double* __restrict__ recs, int nrec,
                                                               double* __restrict__ sums_out, SolveParams prm) {
     __shared__ double sP[NS][LD], sA[NS][LD], sB[NS][LD], sJ[NS][LD];
     __shared__ double sW[2][12][13], sT[12][12];
     __shared__ double sX[NS][12], sG[NS][12], sKx[NS][12], sHTH[12][12], sHTh[12];
     __shared__ double sdx[NS], sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
+    __shared__ double s_part[32][SUMS_LEN];
+    __shared__ double sRot[4][9];
     __shared__ int s_last, s_conv;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     if (kf->done) return;
     const int pass = kf->passes;
+#define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
+    SV_STAMP(0);
 
-    // fold the group records (fixed order) — nrec == 1 when the record was already finalised / all-reduced
+    // fold the group records in fixed order.  All loads are issued at once (6 per thread), the ordered
+    // sum runs out of LDS — a serial `s += recs[g]` loop costs one HBM round trip per record.
+    if (nrec <= 32) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int e = tid + r * SOLVE_THREADS;
+            const int g = e / SUMS_LEN, o = e % SUMS_LEN;
+            if (g < nrec) s_part[g][o] = recs[(size_t)g * SUMS_LEN + o];
+        }
+    }
+    __syncthreads();
     if (tid < SUMS_LEN) {
         double s = 0.0;
-        for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid];
+        if (nrec <= 32) { for (int g = 0; g < nrec; ++g) s += s_part[g][tid]; }
+        else { for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid]; }
         srec[tid] = s;
         if (sums_out) sums_out[tid] = s;
         if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = s;
@@ -191,6 +227,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         return;
     }
 
+    SV_STAMP(1);
     // dx = x [-] x_prop and the projection J(dx): three manifold blocks on three waves, vect parts on wave 3
     if (wave < 3 && lane == 0) manifold_block(wave, 0, sx, sxp, nullptr, sdx, sJ);
     if (wave == 3 && lane < 15) {
@@ -207,65 +244,70 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         else s = dot3d(sJ[tid][b], sdx[b], sJ[tid][b + 1], sdx[b + 1], sJ[tid][b + 2], sdx[b + 2]);
         sdxnew[tid] = s;
     }
+    SV_STAMP(2);
     // P_ = J P_prop J^T
     mm(sA, sJ, sB, false, tid);
     __syncthreads();
     mm(sP, sA, sJ, true, tid);
     __syncthreads();
     // Pr = P_/R -> sA ; G = Pr[:, :12] HTH -> sG
-    if (tid < NS * NS) sA[tid / NS][tid % NS] = sP[tid / NS][tid % NS] / prm.R;
+    if (tid < NS * NS) sA[tid / NS][tid % NS] = sP[tid / NS][tid % NS] * prm.R_inv;
     __syncthreads();
-    // X_top = (Pr11^-1 + HTH)^-1 : two unpivoted Gauss-Jordan inversions of SPD 12x12 matrices
-    if (tid < 144) sW[0][tid / 12][tid % 12] = sA[tid / 12][tid % 12];
+    SV_STAMP(3);
+    // X = P_inv[:, 0:NW]:  X_top = (Pr_ww^-1 + HTH_ww)^-1 (two unpivoted Gauss-Jordan inversions of SPD
+    // NW x NW matrices),  X_bot = Pr[NW:, 0:NW] Pr_ww^-1 X_top
+    if (tid < NW * NW) sW[0][tid / NW][tid % NW] = sA[tid / NW][tid % NW];
     __syncthreads();
     int cur = 0;
-    gj12(sW, cur, tid);
-    if (tid < 144) {
-        const int i = tid / 12, j = tid % 12;
+    gj_spd<NW>(sW, cur, tid);
+    SV_STAMP(4);
+    if (tid < NW * NW) {
+        const int i = tid / NW, j = tid % NW;
         const double a1 = sW[cur][i][j];
-        sG[i][j] = a1;                      // keep A1 = Pr11^-1
+        sG[i][j] = a1;                      // keep A1 = Pr_ww^-1
         sW[cur][i][j] = a1 + sHTH[i][j];
     }
     __syncthreads();
-    gj12(sW, cur, tid);                     // sW[cur] = X_top
-    if (tid < 144) {                        // T = A1 X_top
-        const int i = tid / 12, c = tid % 12;
+    gj_spd<NW>(sW, cur, tid);               // sW[cur] = X_top
+    SV_STAMP(5);
+    if (tid < NW * NW) {                    // T = A1 X_top
+        const int i = tid / NW, c = tid % NW;
         double s = 0.0;
-        for (int j = 0; j < 12; ++j) s += sG[i][j] * sW[cur][j][c];
+        for (int j = 0; j < NW; ++j) s += sG[i][j] * sW[cur][j][c];
         sT[i][c] = s;
     }
     __syncthreads();
-    if (tid < NS * 12) {                    // X = [X_top ; Pr21 T]
-        const int i = tid / 12, c = tid % 12;
+    if (tid < NS * NW) {                    // X = [X_top ; Pr[NW:, :NW] T]
+        const int i = tid / NW, c = tid % NW;
         double v;
-        if (i < 12) {
+        if (i < NW) {
             v = sW[cur][i][c];
         } else {
             double s = 0.0;
-            for (int j = 0; j < 12; ++j) s += sA[i][j] * sT[j][c];
+            for (int j = 0; j < NW; ++j) s += sA[i][j] * sT[j][c];
             v = s;
         }
         sX[i][c] = v;
     }
     __syncthreads();
-    // K_h = X HTh ; K_x[:, :12] = X HTH
-    if (tid < NS * 12) {
-        const int i = tid / 12, c = tid % 12;
+    // K_h = X HTh ; K_x[:, :NW] = X HTH  (columns >= NW of K_x are zero)
+    if (tid < NS * NW) {
+        const int i = tid / NW, c = tid % NW;
         double t = 0.0;
-        for (int j = 0; j < 12; ++j) t += sX[i][j] * sHTH[j][c];
+        for (int j = 0; j < NW; ++j) t += sX[i][j] * sHTH[j][c];
         sKx[i][c] = t;
     }
     if (tid >= 320 && tid < 320 + NS) {
         const int i = tid - 320;
         double s = 0.0;
-        for (int j = 0; j < 12; ++j) s += sX[i][j] * sHTh[j];
+        for (int j = 0; j < NW; ++j) s += sX[i][j] * sHTh[j];
         sKh[i] = s;
     }
     __syncthreads();
     if (tid < NS) {  // dx_ = K_h + (K_x - I) dx_new
         double s = 0.0;
         for (int j = 0; j < NS; ++j) {
-            const double kx = j < 12 ? sKx[tid][j] : 0.0;
+            const double kx = j < NW ? sKx[tid][j] : 0.0;
             s += (kx - (tid == j ? 1.0 : 0.0)) * sdxnew[j];
         }
         const double d = sKh[tid] + s;
@@ -273,6 +315,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         if (fabs(d) > prm.limits[tid]) s_conv = 0;  // dyn_share.converge
     }
     __syncthreads();
+    SV_STAMP(6);
     // x_.boxplus(dx_)
     if (wave < 3 && lane == 0) boxplus_block(wave, sx, sdxo);
     if (wave == 3 && lane < 15) {
@@ -286,18 +329,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         s_last = (t > 1 || kf->iter == prm.maximum_iter - 1) ? 1 : 0;
     }
     __syncthreads();
+    SV_STAMP(7);
     if (tid < NX) kf->x[tid] = sx[tid];
     if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
         const int e = tid - 64;
         kf->trace[pass * 49 + e] = e < NS ? sdxo[e] : sx[e - NS];
     }
     const int last = s_last;
+    if (!last && tid >= 320 && tid < 324) {  // the four rotation matrices of the next pass, one lane each
+        const int w = tid - 320;               // 0: rot, 1: offset_R_L_I, 2: conj(rot), 3: conj(offset_R_L_I)
+        const int q = (w & 1) ? 7 : 3;
+        const double sg = (w & 2) ? -1.0 : 1.0;
+        const double qq[4] = {sg * sx[q], sg * sx[q + 1], sg * sx[q + 2], sx[q + 3]};
+        quat_to_rot(qq, &sRot[w][0]);
+    }
+    __syncthreads();
     if (tid == 0) {
         kf->passes = pass + 1;
         kf->iter += 1;
         if (last) kf->done = 1;
-        else compute_pose_consts(sx, &kf->pose);
+        else finish_pose_consts(sx, sRot, &kf->pose);
     }
+    SV_STAMP(8);
     if (!last) return;
 
     // terminal pass: L_ = J2 P_ J2^T, K_x rows projected, P_ <- P_ J2^T, P = L_ - K_x[:, :12] P_[0:12, :]
@@ -312,8 +365,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     __syncthreads();
     mm(sA, sP, sJ, true, tid);   // sA = P_ J2^T
     __syncthreads();
-    if (tid < NS * 12) {         // K_x <- J2 K_x (rows)
-        const int i = tid / 12, c = tid % 12;
+    if (tid < NS * NW) {         // K_x <- J2 K_x (rows)
+        const int i = tid / NW, c = tid % NW;
         double s = 0;
         for (int r = 0; r < NS; ++r) s += sJ[i][r] * sKx[r][c];
         sX[i][c] = s;
@@ -322,9 +375,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     if (tid < NS * NS) {
         const int i = tid / NS, j = tid % NS;
         double s = 0;
-        for (int c = 0; c < 12; ++c) s += sX[i][c] * sA[c][j];
+        for (int c = 0; c < NW; ++c) s += sX[i][c] * sA[c][j];
         kf->P_post[tid] = sB[i][j] - s;
     }
+    SV_STAMP(9);
+#undef SV_STAMP
 }
 
 int launch_kf_begin(hipStream_t stream, KfDev* kf) {
@@ -346,7 +401,10 @@ int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, d
     return LV_OK;
 }
 int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm) {
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, recs, nrec, sums_out, prm);
+    if (prm.estimate_extrinsics)
+        hipLaunchKernelGGL((solve_kernel<12>), dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, recs, nrec, sums_out, prm);
+    else
+        hipLaunchKernelGGL((solve_kernel<6>), dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, recs, nrec, sums_out, prm);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }

@@ -30,3 +30,11 @@ for state, label in ((sc["x_true"], "converged pose"), (sc["x_init"], "perturbed
     print("   start spread (cycles):", clk[:, 0].max() - clk[:, 0].min())
     for i, nm in enumerate(names):
         print("   %-11s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
+
+ctx.set_profiling(0)
+ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+sclk = ctx.solve_clocks()
+snames = ["fold+load", "manifold", "dxnew", "mm x2+Pr", "gj#1", "gj#2", "X,Kx,Kh,dx", "boxplus", "store+pose", "terminal"]
+for p in range(4):
+    d = np.diff(sclk[p, :10])
+    print("solve pass", p, "total", sclk[p, 9 if sclk[p, 9] else 8] - sclk[p, 0], dict(zip(snames[1:], d.tolist())))
