@@ -112,6 +112,13 @@ class Context:
         self.params = params or default_params()
         self.h = C.c_void_p()
         self._check(self.lib.lv_create(C.byref(self.params), int(device), C.byref(self.h)))
+        # pre-bound buffers for the hot call (keeps the Python overhead of update() at a few microseconds)
+        self._xb = np.zeros(26)
+        self._Pb = np.zeros((NS, NS))
+        self._passes = C.c_int(0)
+        self._xp = self._xb.ctypes.data_as(C.c_void_p)
+        self._Pp = self._Pb.ctypes.data_as(C.c_void_p)
+        self._passes_ref = C.byref(self._passes)
 
     def _check(self, rc):
         if rc != LV_OK:
@@ -166,6 +173,13 @@ class Context:
         return out.as_dict()
 
     def update(self, state, P, want_trace=True):
+        if not want_trace:
+            self._xb[:] = state
+            self._Pb[:] = np.asarray(P).reshape(NS, NS)
+            rc = self.lib.lv_update(self.h, self._xp, self._Pp, self._passes_ref, None, None)
+            if rc != LV_OK:
+                self._check(rc)
+            return self._xb.copy(), self._Pb.copy(), self._passes.value, None, []
         x = np.ascontiguousarray(state, np.float64).copy()
         Pm = np.ascontiguousarray(P, np.float64).copy().reshape(NS, NS)
         npass = self.params.MAX_NUM_ITERS + 1

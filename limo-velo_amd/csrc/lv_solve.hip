@@ -99,6 +99,30 @@ __device__ inline void gj_spd(double (*W)[12][13], int& cur, int tid) {
     }
 }
 
+// out = J in J^T for J = identity except the 3x3 blocks at 3 and 6 and the 2x2 block at 21: every output
+// element touches at most 3 x 3 inputs, so the congruence is one pass (no intermediate product)
+__device__ __forceinline__ void blk_range(int i, int& lo, int& n) {
+    if (i >= 3 && i < 6) { lo = 3; n = 3; }
+    else if (i >= 6 && i < 9) { lo = 6; n = 3; }
+    else if (i >= 21) { lo = 21; n = 2; }
+    else { lo = i; n = 1; }
+}
+__device__ inline void congruence(double (*out)[LD], const double (*J)[LD], const double (*in)[LD], int tid) {
+    if (tid < NS * NS) {
+        const int i = tid / NS, j = tid % NS;
+        int ia, na, jb, nb;
+        blk_range(i, ia, na);
+        blk_range(j, jb, nb);
+        double s = 0.0;
+        for (int a = 0; a < na; ++a) {
+            double t = 0.0;
+            for (int b = 0; b < nb; ++b) t += in[ia + a][jb + b] * J[j][jb + b];
+            s += J[i][ia + a] * t;
+        }
+        out[i][j] = s;
+    }
+}
+
 __device__ inline void set_identity(double (*J)[LD], int tid) {
     if (tid < NS * NS) J[tid / NS][tid % NS] = (tid / NS == tid % NS) ? 1.0 : 0.0;
 }
@@ -196,8 +220,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     __syncthreads();
     if (tid < SUMS_LEN) {
         double s = 0.0;
-        if (nrec <= 32) { for (int g = 0; g < nrec; ++g) s += s_part[g][tid]; }
-        else { for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid]; }
+        if (nrec <= 32) {  // four interleaved accumulators, combined in a fixed order (deterministic)
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int g = 0; g + 3 < nrec; g += 4) {
+                a0 += s_part[g][tid]; a1 += s_part[g + 1][tid]; a2 += s_part[g + 2][tid]; a3 += s_part[g + 3][tid];
+            }
+            for (int g = nrec & ~3; g < nrec; ++g) a0 += s_part[g][tid];
+            s = (a0 + a1) + (a2 + a3);
+        } else {
+            for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid];
+        }
         srec[tid] = s;
         if (sums_out) sums_out[tid] = s;
         if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = s;
@@ -246,9 +278,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     }
     SV_STAMP(2);
     // P_ = J P_prop J^T
-    mm(sA, sJ, sB, false, tid);
-    __syncthreads();
-    mm(sP, sA, sJ, true, tid);
+    congruence(sP, sJ, sB, tid);
     __syncthreads();
     // Pr = P_/R -> sA ; G = Pr[:, :12] HTH -> sG
     if (tid < NS * NS) sA[tid / NS][tid % NS] = sP[tid / NS][tid % NS] * prm.R_inv;
