@@ -144,7 +144,7 @@ def main() -> None:
         ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         ctx.synchronize()
         torch.cuda.synchronize()
 

@@ -28,10 +28,22 @@ class HipEngine:
         self.ctx, self.torch, self.multi = ctx, torch, multi
         self.max_passes = ctx.params.MAX_NUM_ITERS + 1
         self.sums = None
+        self.stream = None
         if multi:
-            self.sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
+            # One explicit (non-default) torch stream carries BOTH the library's kernels and the point RCCL
+            # orders its collective against: lv_set_stream(NULL) would mean "the context's own stream", which
+            # torch knows nothing about.
+            self.stream = torch.cuda.Stream()
+            with torch.cuda.stream(self.stream):
+                self.sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
+            self.stream.synchronize()
             ctx.set_sums_buffer(self.sums.data_ptr())
-            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.set_stream(self.stream.cuda_stream)
+
+    def stream_ctx(self):
+        import contextlib
+
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def scan_set(self, pts):
         self.ctx.scan_set(pts)
@@ -74,9 +86,15 @@ class ShardedUpdater:
         consumes only the all-reduced record, which is bitwise identical on all ranks."""
         if self.world == 1:
             return self.engine.update_fused(x, P)
-        self.engine.begin(x, P)
-        for _ in range(self.engine.max_passes):
-            rec = self.engine.reduce()
-            self.dist.all_reduce(rec, op=self.dist.ReduceOp.SUM)
-            self.engine.solve()
-        return self.engine.end()
+        ctx = self.engine.stream_ctx() if hasattr(self.engine, "stream_ctx") else None
+        if ctx is None:
+            import contextlib
+
+            ctx = contextlib.nullcontext()
+        with ctx:
+            self.engine.begin(x, P)
+            for _ in range(self.engine.max_passes):
+                rec = self.engine.reduce()
+                self.dist.all_reduce(rec, op=self.dist.ReduceOp.SUM)
+                self.engine.solve()
+            return self.engine.end()

@@ -1,0 +1,53 @@
+"""The multi-GPU engine (HipEngine, split-form C-ABI, RCCL all-reduce on the torch tensor that backs the sums
+record) exercised on ONE GPU: a world-size-1 `nccl` group drives exactly the code path bench.py uses for
+--gpus N, and must reproduce the fused single-GPU update bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_split_path_with_rccl_world1(lv, scene_small):
+    import torch
+    import torch.distributed as dist
+
+    from limo_velo_amd import capi
+    from limo_velo_amd.distributed import HipEngine, ShardedUpdater
+
+    sc = scene_small
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        with capi.Context() as ref:
+            ref.map_build(sc["map_xyz"])
+            ref.scan_set(sc["scan_xyz"])
+            x1, P1, p1, _, _ = ref.update(sc["x_init"], sc["P0"])
+        with capi.Context() as ctx:
+            ctx.map_build(sc["map_xyz"])
+            eng = HipEngine(ctx, torch, multi=True)  # torch tensor as sums record, torch's stream
+            upd = ShardedUpdater(eng, 0, 2, dist, torch)  # world=2 logic: takes the all-reduce branch ...
+            upd.world = 1  # ... but shard as one rank
+            upd.scan_set(sc["scan_xyz"])
+            upd.world = 2
+            for _ in range(3):
+                x2, P2, p2 = upd.update(sc["x_init"], sc["P0"])
+            torch.cuda.synchronize()
+            rec = eng.sums.cpu().numpy()
+        assert p1 == p2
+        assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
+        assert rec[90] > 1500  # n_valid of the last pass sits in the all-reduced record
+    finally:
+        dist.destroy_process_group()
