@@ -82,15 +82,30 @@ __device__ __forceinline__ void merge5(kkey (&k)[KNN], const T& o) {
     for (int i = 0; i < KNN; ++i) k[i] = kmin(o[KNN - 1 - i], k[i]);
     sort5(k);
 }
+// cross-lane exchange of a key through DPP (VALU data path, no LDS round trip):
+//   0xB1 quad_perm(1,0,3,2) = lane ^ 1, 0x4E quad_perm(2,3,0,1) = lane ^ 2,
+//   0x141 row_half_mirror = lane <-> 7 - lane (8-lane halves), 0x140 row_mirror = lane <-> 15 - lane.
+// After the two quad rounds all four lanes of a quad hold the same list, so a mirror is as good as xor 4 / 8.
+template <int CTRL>
+__device__ __forceinline__ kkey dpp_key(kkey v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ void merge_round(kkey (&k)[KNN]) {
+    kkey o[KNN];
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) o[j] = dpp_key<CTRL>(k[j]);
+    merge5(k, o);
+}
 template <int S>
 __device__ __forceinline__ void merge_group(kkey (&k)[KNN]) {
-#pragma unroll
-    for (int off = S / 2; off >= 1; off >>= 1) {
-        kkey o[KNN];
-#pragma unroll
-        for (int j = 0; j < KNN; ++j) o[j] = __shfl_xor(k[j], off);
-        merge5(k, o);
-    }
+    if (S >= 2) merge_round<0xB1>(k);
+    if (S >= 4) merge_round<0x4E>(k);
+    if (S >= 8) merge_round<0x141>(k);
+    if (S >= 16) merge_round<0x140>(k);
 }
 __device__ __forceinline__ void insert1(kkey (&k)[KNN], kkey x) {  // generic path: one candidate
 #pragma unroll
@@ -297,7 +312,12 @@ template <int S, bool EXT, bool DBG>
 __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
                                                            KfDev* __restrict__ kf, MatchParams prm,
                                                            double* __restrict__ partials, DebugOut dbg) {
-    constexpr int G = 256 / S;             // scan points per block iteration
+    // A workgroup searches SUB sub-tiles of 256/S points back to back and then fits all G of them at once:
+    // the plane-fit phase is a ~10k-cycle dependent chain executed by G lanes, so it should always see a
+    // full wavefront (G = 64) instead of being paid once per 32 or 16 points.
+    constexpr int SUB = S > 4 ? S / 4 : 1;
+    constexpr int GS = 256 / S;            // scan points searched concurrently
+    constexpr int G = SUB * GS;            // scan points per block iteration (64 for S >= 4)
     constexpr int W = EXT ? 12 : 6;        // live Jacobian columns
     constexpr int ROW_W = W + 2;           // + h, valid
     constexpr int NOUT = W * (W + 1) / 2 + W + 2;
@@ -324,8 +344,10 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
         const uint32_t qbase = (it * gridDim.x + vb) * (uint32_t)G;
         LV_STAMP(0);
         // ================= phase 1: S lanes per scan point — exact 5-NN =========================
-        {
-            const uint32_t q = qbase + (uint32_t)gq;
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int sq = sub * GS + gq;   // staging slot of this lane group's point
+            const uint32_t q = qbase + (uint32_t)sq;
             kkey k[KNN];
 #pragma unroll
             for (int j = 0; j < KNN; ++j) k[j] = none_key();
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
             }
             if (DBG && dbg.clk) { asm volatile("" :: "v"(k[0]), "v"(k[4])); LV_STAMP(3); }
             if (gl == 0) {
-                QueryStage& st = s_q[gq];
+                QueryStage& st = s_q[sq];
                 st.qx = qx; st.qy = qy; st.qz = qz;
                 st.oq = oq;
                 st.bstart = bstart;
