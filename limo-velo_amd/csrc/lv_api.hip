@@ -1,5 +1,6 @@
 // lv_api.hip — the C-ABI of include/limovelo_hip.h on top of the HIP kernels.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -163,7 +164,7 @@ int pass_reduce(lv_ctx* c, bool finalize) {
         c->dbg_valid = true;
     }
     if (c->phase_clocks) {
-        if (!c->d_clk) LV_HIP(hipMalloc(&c->d_clk, (size_t)(c->max_blocks + 8) * 8 * sizeof(long long)));
+        if (!c->d_clk) LV_HIP(hipMalloc(&c->d_clk, (size_t)(c->max_blocks + 8) * 16 * sizeof(long long)));
         dbg.clk = c->d_clk;
     }
     int rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
@@ -229,7 +230,9 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
     hipDeviceProp_t prop;
     LV_HIP(hipGetDeviceProperties(&prop, device));
-    c->max_blocks = prop.multiProcessorCount * 4;
+    int per_cu = 4;
+    if (const char* e = getenv("LV_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;  // tuning knob
+    c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -590,7 +593,9 @@ int lv_set_profiling(lv_ctx* c, int enabled) {
 int lv_get_phase_clocks(lv_ctx* c, long long* out, int capacity_blocks, int* n_blocks) {
     LV_CHECK_CTX(c);
     if (!c->d_clk) { set_error("no phase clocks captured: lv_set_profiling(ctx, 2) first"); return LV_ESTATE; }
-    const int nb = c->grid < capacity_blocks ? c->grid : capacity_blocks;
+    // layout: grid x 8 shader-clock stamps, then grid x 8 records whose first two entries are wall_clock64()
+    // (100 MHz, chip-global) at workgroup start / end
+    const int nb = 2 * c->grid < capacity_blocks ? 2 * c->grid : capacity_blocks;
     LV_HIP(hipStreamSynchronize(c->stream));
     LV_HIP(hipMemcpy(out, c->d_clk, (size_t)nb * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (n_blocks) *n_blocks = nb;

@@ -308,14 +308,20 @@ struct QueryStage {     // kNN result of one scan point, handed from the search 
     int found;
 };
 
+#ifndef LV_MATCH_BOUNDS
+#define LV_MATCH_BOUNDS __launch_bounds__(256)
+#endif
+#ifndef LV_FIT_POINTS
+#define LV_FIT_POINTS 64   // scan points fitted together per workgroup iteration
+#endif
 template <int S, bool EXT, bool DBG>
-__global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
+__global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
                                                            KfDev* __restrict__ kf, MatchParams prm,
                                                            double* __restrict__ partials, DebugOut dbg) {
     // A workgroup searches SUB sub-tiles of 256/S points back to back and then fits all G of them at once:
     // the plane-fit phase is a ~10k-cycle dependent chain executed by G lanes, so it should always see a
     // full wavefront (G = 64) instead of being paid once per 32 or 16 points.
-    constexpr int SUB = S > 4 ? S / 4 : 1;
+    constexpr int SUB = (LV_FIT_POINTS * S) / 256 > 1 ? (LV_FIT_POINTS * S) / 256 : 1;
     constexpr int GS = 256 / S;            // scan points searched concurrently
     constexpr int G = SUB * GS;            // scan points per block iteration (64 for S >= 4)
     constexpr int W = EXT ? 12 : 6;        // live Jacobian columns
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
 #define LV_STAMP(i) do { if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t qbase = (it * gridDim.x + vb) * (uint32_t)G;
+        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(gridDim.x + blockIdx.x) * 8 + 0] = wall_clock64();
         LV_STAMP(0);
         // ================= phase 1: S lanes per scan point — exact 5-NN =========================
 #pragma unroll 1
@@ -606,6 +613,7 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
         }
         __syncthreads();
         LV_STAMP(7);
+        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(gridDim.x + blockIdx.x) * 8 + 1] = wall_clock64();
     }
 #undef LV_STAMP
     if (tid < NOUT) s_out[orec] = acc;
@@ -614,7 +622,8 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MapView map, const fl
 }
 
 int match_grid_size(int S, uint32_t n, int max_blocks) {
-    const uint32_t G = 256 / S;
+    const uint32_t sub = (LV_FIT_POINTS * S) / 256 > 1 ? (LV_FIT_POINTS * S) / 256 : 1;
+    const uint32_t G = sub * (256 / S);
     uint32_t need = (n + G - 1) / G;
     if (need < 1) need = 1;
     uint32_t grid = need < (uint32_t)max_blocks ? need : (uint32_t)max_blocks;

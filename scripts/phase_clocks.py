@@ -21,8 +21,13 @@ names = ["scan+pose", "probe", "stream+sel", "stage", "barrier1", "fit", "reduce
 for state, label in ((sc["x_true"], "converged pose"), (sc["x_init"], "perturbed pose")):
     ctx.update_begin(state, sc["P0"])
     ctx.pass_reduce()
-    clk = ctx.phase_clocks()
+    clk2 = ctx.phase_clocks()
     ctx.update_end()
+    nb = len(clk2) // 2
+    clk, wall = clk2[:nb], clk2[nb:]
+    w0, w1 = wall[:, 0], wall[:, 1]
+    print(label, "WALL(100MHz ticks): first start 0, last start %d, first end %d, last end %d  (=%.1f us span)" % (
+        w0.max() - w0.min(), w1.min() - w0.min(), w1.max() - w0.min(), (w1.max() - w0.min()) / 100.0))
     d = np.diff(clk, axis=1).astype(np.float64)
     tot = clk[:, 7] - clk[:, 0]
     span = clk[:, 7].max() - clk[:, 0].min()
