@@ -104,8 +104,10 @@ int  lv_synchronize(lv_ctx* ctx);
 /* KD_TREE<Point>::Build(PointVector)              — call site src/Modules/Mapper.cpp:68-71 */
 int    lv_map_build(lv_ctx* ctx, const void* points, size_t stride, size_t n);
 /* KD_TREE<Point>::Add_Points(PointVector&, bool)  — call site src/Modules/Mapper.cpp:73-76.
- * downsample != 0 applies ikd-Tree's box rule with box_length 0.2 m (Mapper.cpp:65): per 0.2 m box
- * touched by new points only the point nearest to the box centre survives. */
+ * downsample != 0 applies ikd-Tree's box rule with box_length 0.2 m (Mapper.cpp:65), evaluated exactly as
+ * upstream's sequential loop would: in every 0.2 m box touched by new points only the point nearest to the
+ * box centre survives (occupants must be strictly closer to beat a new point).  The map afterwards is
+ * [surviving old points, old order] + [surviving new points, input order] — the index space of lv_fetch_knn. */
 int    lv_map_add(lv_ctx* ctx, const void* points, size_t stride, size_t n, int downsample);
 /* KD_TREE<Point>::size()                          — src/Modules/Mapper.cpp:33,79 */
 size_t lv_map_size(lv_ctx* ctx);

@@ -29,7 +29,6 @@ struct lv_ctx {
     hipStream_t stream = nullptr;
 
     MapStore map;
-    std::vector<float4> h_map;  // host mirror (insertion order) for add() / fetch
     float map_bbox_min[3], map_bbox_max[3];
 
     ScanStore scan;
@@ -285,62 +284,79 @@ int lv_synchronize(lv_ctx* c) {
     return LV_OK;
 }
 
-static int upload_and_rebuild(lv_ctx* c) {
-    const size_t m = c->h_map.size();
-    if (m > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
-    int rc = c->map.reserve(m);
+// repack caller points into the pinned staging buffer (float4), grow the map bounding box, upload to
+// d_orig[offset ..)
+static int stage_map_points(lv_ctx* c, const void* points, size_t stride, size_t n, size_t offset) {
+    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
+    if (offset + n > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
+    int rc = ensure_stage(c, n);
     if (rc) return rc;
-    c->map.m = (uint32_t)m;
-    if (m) LV_HIP(hipMemcpyAsync(c->map.d_orig, c->h_map.data(), m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    rc = c->map.rebuild(c->stream, c->prm.voxel_size, c->map_bbox_min, c->map_bbox_max);
+    LV_HIP(hipStreamSynchronize(c->stream));  // staging buffer reuse
+    float bmin[3] = {c->map_bbox_min[0], c->map_bbox_min[1], c->map_bbox_min[2]};
+    float bmax[3] = {c->map_bbox_max[0], c->map_bbox_max[1], c->map_bbox_max[2]};
+    for (size_t i = 0; i < n; ++i) {
+        float x, y, z;
+        read_xyz(points, stride, i, x, y, z);
+        if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) { set_error("non-finite map point at %zu", i); return LV_EINVAL; }
+        c->h_stage[i] = make_float4(x, y, z, 0.f);
+        bmin[0] = fminf(bmin[0], x); bmax[0] = fmaxf(bmax[0], x);
+        bmin[1] = fminf(bmin[1], y); bmax[1] = fmaxf(bmax[1], y);
+        bmin[2] = fminf(bmin[2], z); bmax[2] = fmaxf(bmax[2], z);
+    }
+    rc = c->map.reserve(offset + n);
+    if (rc) return rc;
+    if (n) LV_HIP(hipMemcpyAsync(c->map.d_orig + offset, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = bmin[a]; c->map_bbox_max[a] = bmax[a]; }
+    return LV_OK;
+}
+
+static int rebuild_map(lv_ctx* c) {
+    int rc = c->map.rebuild(c->stream, c->prm.voxel_size, c->map_bbox_min, c->map_bbox_max);
     if (rc) return rc;
     LV_HIP(hipStreamSynchronize(c->stream));
     return LV_OK;
 }
 
-static int append_points(lv_ctx* c, const void* points, size_t stride, size_t n) {
-    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
-    c->h_map.reserve(c->h_map.size() + n);
-    for (size_t i = 0; i < n; ++i) {
-        float x, y, z;
-        read_xyz(points, stride, i, x, y, z);
-        if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) { set_error("non-finite map point at %zu", i); return LV_EINVAL; }
-        c->h_map.push_back(make_float4(x, y, z, 0.f));
-        c->map_bbox_min[0] = fminf(c->map_bbox_min[0], x); c->map_bbox_max[0] = fmaxf(c->map_bbox_max[0], x);
-        c->map_bbox_min[1] = fminf(c->map_bbox_min[1], y); c->map_bbox_max[1] = fmaxf(c->map_bbox_max[1], y);
-        c->map_bbox_min[2] = fminf(c->map_bbox_min[2], z); c->map_bbox_max[2] = fmaxf(c->map_bbox_max[2], z);
-    }
-    return LV_OK;
-}
-
 int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
     LV_CHECK_CTX(c);
-    c->h_map.clear();
+    const float old_min[3] = {c->map_bbox_min[0], c->map_bbox_min[1], c->map_bbox_min[2]};
+    const float old_max[3] = {c->map_bbox_max[0], c->map_bbox_max[1], c->map_bbox_max[2]};
     for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
+    int rc = stage_map_points(c, points, stride, n, 0);
+    if (rc) {  // leave the previous map untouched on bad input
+        for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = old_min[a]; c->map_bbox_max[a] = old_max[a]; }
+        return rc;
+    }
     c->map.origin_set = false;
-    int rc = append_points(c, points, stride, n);
-    if (rc) { c->h_map.clear(); return rc; }
-    return upload_and_rebuild(c);
+    c->map.m = (uint32_t)n;
+    return rebuild_map(c);
 }
 
 int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downsample) {
     LV_CHECK_CTX(c);
-    if (downsample) { set_error("lv_map_add(downsample=1): ikd-Tree box downsample not built yet"); return LV_ESTATE; }
     if (n == 0) return LV_OK;
-    const size_t before = c->h_map.size();
-    int rc = append_points(c, points, stride, n);
-    if (rc) { c->h_map.resize(before); return rc; }
-    return upload_and_rebuild(c);
+    int rc = stage_map_points(c, points, stride, n, c->map.m);
+    if (rc) return rc;
+    if (downsample) {
+        rc = c->map.add_downsample(c->stream, (uint32_t)n, 0.2f);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
+        if (rc) return rc;
+    } else {
+        c->map.m += (uint32_t)n;
+    }
+    return rebuild_map(c);
 }
 
-size_t lv_map_size(lv_ctx* c) { return c ? c->h_map.size() : 0; }
+size_t lv_map_size(lv_ctx* c) { return c ? c->map.m : 0; }
 
 int lv_map_fetch(lv_ctx* c, float* xyz_out, size_t capacity) {
     LV_CHECK_CTX(c);
-    if (capacity < c->h_map.size() || (!xyz_out && capacity)) { set_error("capacity too small"); return LV_EINVAL; }
-    for (size_t i = 0; i < c->h_map.size(); ++i) {
-        xyz_out[3 * i] = c->h_map[i].x; xyz_out[3 * i + 1] = c->h_map[i].y; xyz_out[3 * i + 2] = c->h_map[i].z;
-    }
+    const size_t m = c->map.m;
+    if (capacity < m || (!xyz_out && capacity)) { set_error("capacity too small"); return LV_EINVAL; }
+    if (m == 0) return LV_OK;
+    std::vector<float4> tmp(m);
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(tmp.data(), c->map.d_orig, m * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; ++i) { xyz_out[3 * i] = tmp[i].x; xyz_out[3 * i + 1] = tmp[i].y; xyz_out[3 * i + 2] = tmp[i].z; }
     return LV_OK;
 }
 

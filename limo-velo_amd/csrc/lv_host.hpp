@@ -55,8 +55,18 @@ struct MapStore {
     float origin[3] = {0, 0, 0};
     MapView view{};
 
+    // ikd-Tree style box down-sampling on insert (lv_map.hip: add_downsample)
+    float4* d_orig2 = nullptr;     // compaction target (swapped with d_orig)
+    uint32_t* d_alive = nullptr;
+    uint32_t* d_apos = nullptr;
+    void* d_ascan_tmp = nullptr;
+    size_t ascan_tmp_bytes = 0;
+
     int reserve(size_t cap);
     int rebuild(hipStream_t stream, float cell, const float bbox_min[3], const float bbox_max[3]);
+    // d_orig[0..m) = current map, d_orig[m..m+k) = freshly uploaded points; applies the box rule and leaves the
+    // surviving points compacted in d_orig, updating m
+    int add_downsample(hipStream_t stream, uint32_t k, float box_length);
     void release();
 };
 

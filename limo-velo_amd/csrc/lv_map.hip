@@ -226,6 +226,116 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
     }
 }
 
+// ---- KD_TREE::Add_Points(points, downsample = true) ------------------------------------------------
+// [UPSTREAM-RECALL ikd-Tree; call site reference src/Modules/Mapper.cpp:73-76, box_length 0.2 m :65].
+// Upstream processes the new points one by one: the point nearest to the centre of p's 0.2 m box among
+// {p} U (current occupants) survives if the box held more than one point or p is that nearest point
+// (occupants must be STRICTLY closer to beat p), otherwise the box is left alone.  The batch form below
+// reproduces exactly that sequence: all points are keyed by their box, a stable radix sort groups each box
+// with its old occupants first (old order) and the new points after (input order), and one lane replays
+// the sequential rule inside its box.  Boxes are independent, so the result equals the sequential one.
+__device__ __forceinline__ int box_coord(float v, float len) {
+    float f = floorf(v / len);
+    f = fminf(fmaxf(f, -1048000.0f), 1048000.0f);
+    return (int)f + CELL_OFFSET;
+}
+__device__ __forceinline__ float box_center_dist(float4 p, float len) {
+    const float c[3] = {p.x, p.y, p.z};
+    float mid[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float vmin = floorf(c[a] / len) * len;
+        const float vmax = vmin + len;
+        mid[a] = (float)((double)vmin + (double)(vmax - vmin) / 2.0);
+    }
+    const float dx = p.x - mid[0], dy = p.y - mid[1], dz = p.z - mid[2];  // calc_dist(point, mid_point)
+    const float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    const float s = sx + sy;
+    return s + sz;
+}
+
+__global__ void box_keys_kernel(const float4* __restrict__ pts, uint32_t total, float len, uint64_t* __restrict__ keys,
+                                uint32_t* __restrict__ idx, uint32_t* __restrict__ alive, uint32_t m_old) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float4 p = pts[i];
+    keys[i] = pack_cell((uint32_t)box_coord(p.x, len), (uint32_t)box_coord(p.y, len), (uint32_t)box_coord(p.z, len));
+    idx[i] = i;
+    alive[i] = i < m_old ? 1u : 0u;
+}
+
+__global__ void box_rule_kernel(const float4* __restrict__ pts, const uint64_t* __restrict__ keys_sorted,
+                                const uint32_t* __restrict__ idx_sorted, uint32_t total, uint32_t m_old, float len,
+                                uint32_t* __restrict__ alive) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t key = keys_sorted[i];
+    if (i > 0 && keys_sorted[i - 1] == key) return;  // not the head of its box
+    uint32_t end = i + 1;
+    while (end < total && keys_sorted[end] == key) ++end;
+    // old occupants come first (ascending index), new points after
+    uint32_t nE = 0;
+    while (i + nE < end && idx_sorted[i + nE] < m_old) ++nE;
+    if (i + nE == end) return;  // box untouched by new points
+    bool multi = nE > 1;
+    uint32_t cur = nE == 1 ? idx_sorted[i] : 0xFFFFFFFFu;
+    float dcur = nE == 1 ? box_center_dist(pts[cur], len) : 0.f;
+    for (uint32_t j = i + nE; j < end; ++j) {
+        const uint32_t p = idx_sorted[j];
+        uint32_t best = p;
+        float md = box_center_dist(pts[p], len);
+        if (multi) {
+            for (uint32_t e = i; e < i + nE; ++e) {
+                const uint32_t ei = idx_sorted[e];
+                const float d = box_center_dist(pts[ei], len);
+                if (d < md) { md = d; best = ei; }
+            }
+        } else if (cur != 0xFFFFFFFFu) {
+            if (dcur < md) { md = dcur; best = cur; }
+        }
+        if (multi || best == p) {
+            if (multi) { for (uint32_t e = i; e < i + nE; ++e) alive[idx_sorted[e]] = 0u; }
+            else if (cur != 0xFFFFFFFFu) alive[cur] = 0u;
+            alive[best] = 1u;
+            cur = best;
+            dcur = md;
+            multi = false;
+        }
+    }
+}
+
+__global__ void box_compact_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ alive,
+                                   const uint32_t* __restrict__ apos, uint32_t total, float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (alive[i]) out[apos[i]] = pts[i];
+}
+
+int MapStore::add_downsample(hipStream_t stream, uint32_t k, float box_length) {
+    const uint32_t total = m + k;
+    if (k == 0) return LV_OK;
+    const int B = 256;
+    const uint32_t grid = (total + B - 1) / B;
+    hipLaunchKernelGGL(box_keys_kernel, dim3(grid), dim3(B), 0, stream, d_orig, total, box_length, d_keys, d_idx, d_alive, m);
+    size_t tmp = sort_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tmp, d_keys, d_keys_sorted, d_idx, d_idx_sorted, (int)total,
+                                                           0, 63, stream));
+    hipLaunchKernelGGL(box_rule_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_keys_sorted, d_idx_sorted, total, m, box_length,
+                       d_alive);
+    size_t stmp = ascan_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ascan_tmp, stmp, d_alive, d_apos, (int)total, stream));
+    hipLaunchKernelGGL(box_compact_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_alive, d_apos, total, d_orig2);
+    uint32_t last_pos = 0, last_alive = 0;
+    LV_HIP(hipMemcpyAsync(&last_pos, d_apos + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipMemcpyAsync(&last_alive, d_alive + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    float4* t = d_orig;
+    d_orig = d_orig2;
+    d_orig2 = t;
+    m = last_pos + last_alive;
+    return LV_OK;
+}
+
 static inline uint32_t next_pow2(uint64_t v) {
     uint32_t p = 64;
     while (p < v) p <<= 1;
@@ -247,6 +357,17 @@ int MapStore::reserve(size_t cap) {
     if (d_keys_sorted) hipFree(d_keys_sorted);
     if (d_idx) hipFree(d_idx);
     if (d_idx_sorted) hipFree(d_idx_sorted);
+    if (d_orig2) hipFree(d_orig2);
+    if (d_alive) hipFree(d_alive);
+    if (d_apos) hipFree(d_apos);
+    if (d_ascan_tmp) hipFree(d_ascan_tmp);
+    d_ascan_tmp = nullptr;
+    LV_HIP(hipMalloc(&d_orig2, ncap * sizeof(float4)));
+    LV_HIP(hipMalloc(&d_alive, ncap * sizeof(uint32_t)));
+    LV_HIP(hipMalloc(&d_apos, ncap * sizeof(uint32_t)));
+    ascan_tmp_bytes = 0;
+    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, ascan_tmp_bytes, d_alive, d_apos, (int)ncap, (hipStream_t)0));
+    LV_HIP(hipMalloc(&d_ascan_tmp, ascan_tmp_bytes));
     LV_HIP(hipMalloc(&d_sorted, ncap * sizeof(float4)));
     LV_HIP(hipMalloc(&d_keys, ncap * sizeof(uint64_t)));
     LV_HIP(hipMalloc(&d_keys_sorted, ncap * sizeof(uint64_t)));
@@ -265,6 +386,7 @@ int MapStore::reserve(size_t cap) {
 void MapStore::release() {
     hipFree(d_orig); hipFree(d_sorted); hipFree(d_keys); hipFree(d_keys_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
     hipFree(d_sort_tmp); hipFree(d_counts);
+    hipFree(d_orig2); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
     for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bucket[l]); }
     for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <unordered_map>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -1157,6 +1158,58 @@ void lvo_predict(lvo_state* x, double* P, double dt, const double* Q, const doub
             Pn[i * NS + j] = s + q;
         }
     std::memcpy(P, Pn.data(), NS * NS * sizeof(double));
+}
+
+// KD_TREE::Add_Points with downsampling [UPSTREAM-RECALL ikd-Tree], sequential restatement.
+size_t lvo_map_add(const float* map_xyz, size_t m, const float* new_xyz, size_t k, int downsample, float box_length,
+                   float* out_xyz) {
+    struct P { float x, y, z; };
+    std::vector<P> pts(m + k);
+    std::vector<uint8_t> alive(m + k, 0);
+    for (size_t i = 0; i < m; ++i) { pts[i] = {map_xyz[3 * i], map_xyz[3 * i + 1], map_xyz[3 * i + 2]}; alive[i] = 1; }
+    for (size_t j = 0; j < k; ++j) pts[m + j] = {new_xyz[3 * j], new_xyz[3 * j + 1], new_xyz[3 * j + 2]};
+    if (!downsample) {
+        for (size_t j = 0; j < k; ++j) alive[m + j] = 1;
+    } else {
+        auto cell = [&](float v) { return (int64_t)std::floor(v / box_length); };
+        auto key = [&](const P& p) {
+            return (uint64_t)((cell(p.x) + (1 << 20)) & 0x1fffff) | ((uint64_t)((cell(p.y) + (1 << 20)) & 0x1fffff) << 21) |
+                   ((uint64_t)((cell(p.z) + (1 << 20)) & 0x1fffff) << 42);
+        };
+        std::unordered_map<uint64_t, std::vector<uint32_t>> boxes;  // current occupants, in insertion order
+        boxes.reserve(m + k);
+        for (size_t i = 0; i < m; ++i) boxes[key(pts[i])].push_back((uint32_t)i);
+        for (size_t j = 0; j < k; ++j) {
+            const P& p = pts[m + j];
+            // Box_of_Point / mid_point exactly as upstream: min = floor(x/len)*len, max = min+len, mid = min+(max-min)/2
+            float mid[3];
+            const float c[3] = {p.x, p.y, p.z};
+            for (int a = 0; a < 3; ++a) {
+                float vmin = std::floor(c[a] / box_length) * box_length;
+                float vmax = vmin + box_length;
+                mid[a] = (float)(vmin + (vmax - vmin) / 2.0);
+            }
+            std::vector<uint32_t>& occ = boxes[key(p)];
+            const float pf[3] = {p.x, p.y, p.z};
+            float min_dist = calc_dist(pf, mid);
+            uint32_t best = (uint32_t)(m + j);
+            for (uint32_t e : occ) {
+                const float ef[3] = {pts[e].x, pts[e].y, pts[e].z};
+                float d = calc_dist(ef, mid);
+                if (d < min_dist) { min_dist = d; best = e; }
+            }
+            if (occ.size() > 1 || best == (uint32_t)(m + j)) {
+                for (uint32_t e : occ) alive[e] = 0;  // Delete_by_range(Box_of_Point)
+                occ.clear();
+                occ.push_back(best);                  // Add_by_point(downsample_result)
+                alive[best] = 1;
+            }
+        }
+    }
+    size_t n = 0;
+    for (size_t i = 0; i < m + k; ++i)
+        if (alive[i]) { out_xyz[3 * n] = pts[i].x; out_xyz[3 * n + 1] = pts[i].y; out_xyz[3 * n + 2] = pts[i].z; ++n; }
+    return n;
 }
 
 }  // extern "C"

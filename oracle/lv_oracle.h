@@ -129,6 +129,17 @@ void lvo_boxminus(const lvo_state* x, const lvo_state* other, double dx[23]);
 void lvo_predict(lvo_state* x, double* P, double dt, const double* Q, const double acc[3],
                  const double gyro[3]);
 
+/* KD_TREE::Add_Points(PointToAdd, downsample_on) [UPSTREAM-RECALL ikd-Tree], call site reference
+ * src/Modules/Mapper.cpp:73-76 with box_length = 0.2 m (Mapper.cpp:65), processed SEQUENTIALLY in input order:
+ * for every new point p the 0.2 m box holding it is searched; the point nearest to the box centre among
+ * {p} U (points currently in the box) is kept when the box held more than one point or p itself is that
+ * nearest point (ties: p wins against the current occupants, which must be STRICTLY closer); otherwise the
+ * box is left untouched.  downsample == 0 appends.  The resulting map is written to out_xyz as
+ * [surviving old points in their old order] + [surviving new points in input order]; returns its size
+ * (capacity needed <= m + k). */
+size_t lvo_map_add(const float* map_xyz, size_t m, const float* new_xyz, size_t k, int downsample, float box_length,
+                   float* out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ def lib():
         _lib.lvo_plane_fit.restype = C.c_int
         _lib.lvo_update.restype = C.c_int
         _lib.lvo_kf_step.restype = C.c_int
+        _lib.lvo_map_add.restype = C.c_size_t
     return _lib
 
 
@@ -248,3 +249,11 @@ def predict(x, P, dt, Q, acc, gyro):
     lib().lvo_predict(_p(xs, C.c_double), _p(Pm, C.c_double), C.c_double(dt), _p(Qm, C.c_double), _p(a, C.c_double),
                       _p(g, C.c_double))
     return xs, Pm
+
+
+def map_add(map_xyz, new_xyz, downsample=True, box_length=0.2):
+    m, k = _f32(map_xyz).reshape(-1, 3), _f32(new_xyz).reshape(-1, 3)
+    out = np.empty((len(m) + len(k), 3), np.float32)
+    n = lib().lvo_map_add(_p(m, C.c_float), C.c_size_t(len(m)), _p(k, C.c_float), C.c_size_t(len(k)), int(downsample),
+                          C.c_float(box_length), _p(out, C.c_float))
+    return out[:n].copy()

@@ -218,3 +218,26 @@ def test_gain_form_numerics():
     e_naive = np.abs(X_naive - X_ref).max() / np.abs(X_ref).max()
     assert e_info < 1e-9
     assert e_naive > 10 * e_info
+
+
+def test_map_add_box_rule(oracle):
+    """ikd-Tree Add_Points(downsample) restatement: hand-checkable cases of the 0.2 m box rule."""
+    f = np.float32
+    box0 = np.array([[0.02, 0.02, 0.02], [0.18, 0.18, 0.18]], f)  # two occupants of box (0,0,0), centre 0.1
+    # a new point closer to the centre replaces both
+    out = oracle.map_add(box0, np.array([[0.09, 0.1, 0.1]], f))
+    assert out.tolist() == np.array([[0.09, 0.1, 0.1]], f).tolist()
+    # a new point farther than an occupant still collapses a multi-point box onto the best occupant
+    out = oracle.map_add(np.array([[0.02, 0.02, 0.02], [0.11, 0.1, 0.1]], f), np.array([[0.19, 0.19, 0.19]], f))
+    assert out.tolist() == np.array([[0.11, 0.1, 0.1]], f).tolist()
+    # single occupant that is strictly closer: nothing changes; equal distance: the new point wins
+    one = np.array([[0.12, 0.1, 0.1]], f)
+    assert oracle.map_add(one, np.array([[0.15, 0.1, 0.1]], f)).tolist() == one.tolist()
+    # exact tie (box 0.25 is representable: centre 0.125, both points 0.0625 away): the new point wins
+    tie_old, tie_new = np.array([[0.1875, 0.125, 0.125]], f), np.array([[0.0625, 0.125, 0.125]], f)
+    assert oracle.map_add(tie_old, tie_new, box_length=0.25).tolist() == tie_new.tolist()
+    # untouched boxes keep all their points; order = surviving old points, then surviving new points
+    old = np.array([[1.01, 0, 0], [1.02, 0, 0], [0.05, 0.05, 0.05]], f)
+    out = oracle.map_add(old, np.array([[0.1, 0.1, 0.1], [2.0, 2.0, 2.0]], f))
+    assert out.tolist() == np.array([[1.01, 0, 0], [1.02, 0, 0], [0.1, 0.1, 0.1], [2.0, 2.0, 2.0]], f).tolist()
+    assert len(oracle.map_add(old, old, downsample=False)) == 6
