@@ -191,6 +191,32 @@ __global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLeve
 // (distance, position-in-bucket); with this layout that equals the reference's (distance, index)
 // order, ties included.  Bitonic network in the "flip" form (always-ascending compare-exchange,
 // partners beyond n skipped == padding with +inf), valid for any n.  One workgroup per bucket.
+// small buckets (<= 64 points, the bulk at level 0): one wavefront per bucket, bitonic network through
+// cross-lane shuffles, no LDS, no barriers
+__global__ __launch_bounds__(256) void bucket_sort_wave_kernel(const uint32_t* __restrict__ bcount,
+                                                               const uint32_t* __restrict__ boff, uint32_t n_cells,
+                                                               float4* __restrict__ bucket) {
+    const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (cell >= n_cells) return;
+    const uint32_t n = bcount[cell];
+    if (n < 2 || n > 64) return;
+    float4* g = bucket + boff[cell];
+    float4 v = (uint32_t)lane < n ? g[lane] : make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+    for (int k = 2; k <= 64; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int partner = lane ^ j;
+            float4 o;
+            o.x = __shfl(v.x, partner); o.y = __shfl(v.y, partner); o.z = __shfl(v.z, partner); o.w = __shfl(v.w, partner);
+            const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+            const uint32_t a = __float_as_uint(v.w), b = __float_as_uint(o.w);
+            const bool use_other = take_min ? (b < a) : (b > a);
+            if (use_other) v = o;
+        }
+    }
+    if ((uint32_t)lane < n) g[lane] = v;
+}
+
 constexpr int BSORT_THREADS = 256;
 constexpr uint32_t BSORT_LDS = 2048;
 __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ bcount,
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
     const uint32_t cell = blockIdx.x;
     if (cell >= n_cells) return;
     const uint32_t n = bcount[cell];
-    if (n < 2) return;
+    if (n <= 64) return;  // handled by bucket_sort_wave_kernel
     float4* g = bucket + boff[cell];
     const bool in_lds = n <= BSORT_LDS;
     float4* a = in_lds ? s_pts : g;
@@ -528,6 +554,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         }
         hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
                            d_boff, d_bucket[level]);
+        hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket[level]);
         hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket[level]);
         LV_HIP(hipGetLastError());
         view.bt[level].table = d_btable[level];

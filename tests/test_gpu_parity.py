@@ -241,3 +241,16 @@ def test_update_split_form_matches_fused(capi, scene_small):
             ctx.pass_solve()
         x2, P2, p2 = ctx.update_end()
     assert p1 == p2 and np.array_equal(x1, x2) and np.array_equal(P1, P2)
+
+
+def test_large_cfg3_like(capi, oracle, lv):
+    """260k-pt scan vs 5M-pt map (BASELINE configs[3] sizes, one GPU's worth): single pass, full per-point parity."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(5_000_000, 260_000)
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        g, o = _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
+        assert g["n_valid"] > 200_000
