@@ -185,6 +185,9 @@ int lv_get_timing(lv_ctx* ctx, lv_timing* out);
 int lv_set_profiling(lv_ctx* ctx, int enabled);
 /* after a pass run with lv_set_profiling(ctx, 2): out receives n_blocks x 8 clock64() stamps */
 int lv_get_phase_clocks(lv_ctx* ctx, long long* out, int capacity_blocks, int* n_blocks);
+/* captured passes (lv_iterate / lv_set_capture): how many scan points were decided at voxel-bucket level
+ * 0, 1, 2 ([0..2]), by the generic multi-level search ([3]) or by brute force ([4]) since the last begin */
+int lv_get_level_histogram(lv_ctx* ctx, int out[8]);
 /* shader-clock stamps of the solve kernel's phases of the last update: 16 passes x 16 stamps (capacity >= 256) */
 int lv_get_solve_clocks(lv_ctx* ctx, long long* out, int capacity);
 

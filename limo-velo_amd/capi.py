@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_iterate",
     "lv_update", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
-    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
 ]
 
 
@@ -230,6 +230,11 @@ class Context:
 
     def set_profiling(self, mode):
         self._check(self.lib.lv_set_profiling(self.h, int(mode)))
+
+    def level_histogram(self) -> list:
+        out = (C.c_int * 8)()
+        self._check(self.lib.lv_get_level_histogram(self.h, out))
+        return list(out)
 
     def solve_clocks(self) -> np.ndarray:
         out = np.zeros((16, 16), np.int64)

@@ -585,6 +585,14 @@ int lv_calculate_H(lv_ctx* c, const lv_state* x, const float* p_world, const flo
     return rc;
 }
 
+int lv_get_level_histogram(lv_ctx* c, int out[8]) {
+    LV_CHECK_CTX(c);
+    if (!out) { set_error("null argument"); return LV_EINVAL; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(out, c->d_kf->level_hist, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    return LV_OK;
+}
+
 int lv_get_solve_clocks(lv_ctx* c, long long* out, int capacity) {
     LV_CHECK_CTX(c);
     if (!out || capacity < MAX_PASSES * 16) { set_error("capacity must be >= %d", MAX_PASSES * 16); return LV_EINVAL; }

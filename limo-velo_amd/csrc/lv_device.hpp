@@ -54,6 +54,7 @@ struct KfDev {
     double sums_log[MAX_PASSES * SUMS_LEN];
     PoseConsts pose;
     long long solve_clk[MAX_PASSES * 16];  // instrumentation: shader-clock stamps of solve_kernel phases
+    int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / generic levels / brute force
 };
 
 struct GridLevel {

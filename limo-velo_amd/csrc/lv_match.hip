@@ -476,6 +476,7 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
                         }
                     }
                     if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
+                    if (DBG && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
                 }
             }
             if (DBG && dbg.clk) { asm volatile("" :: "v"(k[0]), "v"(k[4])); LV_STAMP(3); }

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf) {
         kf->done = 0;
         kf->passes = 0;
         kf->fallback_queries = 0;
+        for (int i = 0; i < 8; ++i) kf->level_hist[i] = 0;
         compute_pose_consts(kf->x, &kf->pose);
     }
 }
@@ -199,16 +200,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     __shared__ double sdx[NS], sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
     __shared__ double s_part[32][SUMS_LEN];
     __shared__ double sRot[4][9];
+    __shared__ PoseConsts s_pose;
     __shared__ int s_last, s_conv;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    if (kf->done) return;
-    const int pass = kf->passes;
-#define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
-    SV_STAMP(0);
-
-    // fold the group records in fixed order.  All loads are issued at once (6 per thread), the ordered
-    // sum runs out of LDS — a serial `s += recs[g]` loop costs one HBM round trip per record.
+    // every global read of this kernel is issued up front (one memory round trip): the group records, x,
+    // x_prop, P_prop — independent of the done / passes words read next
     if (nrec <= 32) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -217,6 +214,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
             if (g < nrec) s_part[g][o] = recs[(size_t)g * SUMS_LEN + o];
         }
     }
+    if (tid >= 128 && tid < 128 + NX) { sx[tid - 128] = kf->x[tid - 128]; sxp[tid - 128] = kf->x_prop[tid - 128]; }
+    if (tid < NS * NS) sB[tid / NS][tid % NS] = kf->P_prop[tid];
+    if (kf->done) return;
+    const int pass = kf->passes;
+#define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
+    SV_STAMP(0);
     __syncthreads();
     if (tid < SUMS_LEN) {
         double s = 0.0;
@@ -234,10 +237,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         if (sums_out) sums_out[tid] = s;
         if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = s;
     }
-    if (tid >= 128 && tid < 128 + NX) { sx[tid - 128] = kf->x[tid - 128]; sxp[tid - 128] = kf->x_prop[tid - 128]; }
     if (tid == 200) s_conv = 1;
     set_identity(sJ, tid);
-    if (tid < NS * NS) sB[tid / NS][tid % NS] = kf->P_prop[tid];
     __syncthreads();
     if (tid < 144) {
         const int a = tid / 12, b = tid % 12;
@@ -378,7 +379,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         kf->passes = pass + 1;
         kf->iter += 1;
         if (last) kf->done = 1;
-        else finish_pose_consts(sx, sRot, &kf->pose);
+        else finish_pose_consts(sx, sRot, &s_pose);
+    }
+    if (!last) {  // publish the next pass' constants with coalesced stores
+        __syncthreads();
+        constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_pose);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&kf->pose);
+        if (tid < NW32) dst[tid] = src[tid];
     }
     SV_STAMP(8);
     if (!last) return;
@@ -389,11 +397,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     __syncthreads();
     if (wave < 3 && lane == 0) manifold_block(wave, 1, sx, sxp, sdxo, nullptr, sJ);
     __syncthreads();
-    mm(sA, sJ, sP, false, tid);  // sA = J2 P_
-    __syncthreads();
-    mm(sB, sA, sJ, true, tid);   // sB = L_ = J2 P_ J2^T
-    __syncthreads();
-    mm(sA, sP, sJ, true, tid);   // sA = P_ J2^T
+    congruence(sB, sJ, sP, tid);  // sB = L_ = J2 P_ J2^T
+    mm(sA, sP, sJ, true, tid);    // sA = P_ J2^T
     __syncthreads();
     if (tid < NS * NW) {         // K_x <- J2 K_x (rows)
         const int i = tid / NW, c = tid % NW;
