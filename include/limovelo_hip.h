@@ -132,6 +132,16 @@ int lv_iterate(lv_ctx* ctx, const lv_state* x, lv_sums* out);
  * 23 doubles dx_ followed by the 26 state doubles after boxplus (49 x (MAX_NUM_ITERS+1)). */
 int lv_update(lv_ctx* ctx, lv_state* x, double* P, int* passes, lv_sums* per_pass, double* trace);
 
+/* ---- resident filter (row f-3): x and P stay on the device between prediction and correction -----------
+ * lv_filter_set / lv_filter_get     = esekf::change_x + change_P / get_x + get_P (src/Modules/Localizator.cpp:136-152)
+ * lv_predict(dt, Q, acc, gyro)      = esekf::predict(dt, Q, in) as called by Localizator::propagate
+ *                                     (Localizator.cpp:159-173; Q row-major 12x12, acc = imu.a, gyro = imu.w)
+ * lv_correct(passes)                = lv_update on the resident state; asynchronous when passes == NULL. */
+int lv_filter_set(lv_ctx* ctx, const lv_state* x, const double* P);
+int lv_filter_get(lv_ctx* ctx, lv_state* x, double* P);
+int lv_predict(lv_ctx* ctx, double dt, const double* Q, const double acc[3], const double gyro[3]);
+int lv_correct(lv_ctx* ctx, int* passes);
+
 /* Split form of lv_update for multi-GPU runs (scan points sharded across ranks, map replicated):
  *   lv_update_begin(x, P)
  *   repeat MAX_NUM_ITERS+1 times:

@@ -22,7 +22,7 @@ NS = 23
 ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_iterate",
-    "lv_update", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
+    "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
 ]
 
@@ -191,6 +191,30 @@ class Context:
                                        trace.ctypes.data_as(C.c_void_p) if want_trace else None))
         n = passes.value
         return x, Pm, n, trace[:n], [sums[i].as_dict() for i in range(n)] if want_trace else []
+
+    # --- resident filter (row f-3)
+    def filter_set(self, state, P):
+        x = np.ascontiguousarray(state, np.float64)
+        Pm = np.ascontiguousarray(P, np.float64)
+        self._check(self.lib.lv_filter_set(self.h, x.ctypes.data_as(C.c_void_p), Pm.ctypes.data_as(C.c_void_p)))
+
+    def filter_get(self):
+        x = np.zeros(26)
+        Pm = np.zeros((NS, NS))
+        self._check(self.lib.lv_filter_get(self.h, x.ctypes.data_as(C.c_void_p), Pm.ctypes.data_as(C.c_void_p)))
+        return x, Pm
+
+    def predict(self, dt, Q, acc, gyro):
+        Qm = np.ascontiguousarray(Q, np.float64)
+        a = np.ascontiguousarray(acc, np.float64)
+        g = np.ascontiguousarray(gyro, np.float64)
+        self._check(self.lib.lv_predict(self.h, C.c_double(dt), Qm.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                                        g.ctypes.data_as(C.c_void_p)))
+
+    def correct(self, want_passes=True) -> int:
+        p = C.c_int(0)
+        self._check(self.lib.lv_correct(self.h, C.byref(p) if want_passes else None))
+        return p.value
 
     def update_begin(self, state, P):
         x = np.ascontiguousarray(state, np.float64)

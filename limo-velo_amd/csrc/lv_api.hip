@@ -36,6 +36,9 @@ struct lv_ctx {
     size_t h_stage_cap = 0;
 
     KfDev* d_kf = nullptr;
+    FilterDev* d_filter = nullptr;  // x, P resident between lv_predict / lv_correct (row f-3)
+    FilterDev* h_filter = nullptr;  // pinned staging
+    bool filter_set = false;
     KfDev* h_kf = nullptr;  // pinned mirror
     double* d_partials = nullptr;
     double* d_groups = nullptr;    // group records (reduce stage 1)
@@ -134,6 +137,14 @@ void unpack_sums(const double* rec, lv_sums* out) {
     out->sum_h2 = rec[91];
 }
 
+// x / P_prop of d_kf are in place (uploaded or copied from the resident filter): derive the pass constants
+int begin_device(lv_ctx* c) {
+    int rc = launch_kf_begin(c->stream, c->d_kf);
+    if (rc) return rc;
+    c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks);
+    return LV_OK;
+}
+
 int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
     KfDev* h = c->h_kf;
     std::memcpy(h->x, x, sizeof(double) * NX);
@@ -144,10 +155,7 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
     }
     const size_t head = offsetof(KfDev, P_post);  // upload region: x, P_prop
     LV_HIP(hipMemcpyAsync(c->d_kf, h, head, hipMemcpyHostToDevice, c->stream));
-    int rc = launch_kf_begin(c->stream, c->d_kf);
-    if (rc) return rc;
-    c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks);
-    return LV_OK;
+    return begin_device(c);
 }
 
 int pass_reduce(lv_ctx* c, bool finalize) {
@@ -237,6 +245,9 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     c->stream = c->own_stream;
     LV_HIP(hipMalloc(&c->d_kf, sizeof(KfDev)));
     LV_HIP(hipMemset(c->d_kf, 0, sizeof(KfDev)));
+    LV_HIP(hipMalloc(&c->d_filter, sizeof(FilterDev)));
+    LV_HIP(hipMemset(c->d_filter, 0, sizeof(FilterDev)));
+    LV_HIP(hipHostMalloc((void**)&c->h_filter, sizeof(FilterDev), hipHostMallocDefault));
     LV_HIP(hipHostMalloc((void**)&c->h_kf, sizeof(KfDev), hipHostMallocDefault));
     std::memset(c->h_kf, 0, sizeof(KfDev));
     LV_HIP(hipMalloc(&c->d_partials, (size_t)(c->max_blocks + 8) * SUMS_LEN * sizeof(double)));
@@ -262,6 +273,8 @@ void lv_destroy(lv_ctx* c) {
     free_capture(c);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_kf) hipHostFree(c->h_kf);
+    if (c->h_filter) hipHostFree(c->h_filter);
+    hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
     hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
@@ -514,6 +527,69 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
         }
         c->timing.last_reduce_ms = r / cnt;
         c->timing.last_solve_ms = s / cnt;
+    }
+    return LV_OK;
+}
+
+// ---- resident filter (row f-3) ---------------------------------------------------------------------
+int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
+    LV_CHECK_CTX(c);
+    if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
+    LV_HIP(hipStreamSynchronize(c->stream));  // staging reuse
+    std::memcpy(c->h_filter->x, x, sizeof(double) * NX);
+    std::memcpy(c->h_filter->P, P, sizeof(double) * NS * NS);
+    LV_HIP(hipMemcpyAsync(c->d_filter, c->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, c->stream));
+    c->filter_set = true;
+    return LV_OK;
+}
+
+int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
+    LV_CHECK_CTX(c);
+    if (!c->filter_set) { set_error("lv_filter_get before lv_filter_set"); return LV_ESTATE; }
+    LV_HIP(hipMemcpyAsync(c->h_filter, c->d_filter, sizeof(FilterDev), hipMemcpyDeviceToHost, c->stream));
+    LV_HIP(hipStreamSynchronize(c->stream));
+    if (x) std::memcpy(x, c->h_filter->x, sizeof(double) * NX);
+    if (P) std::memcpy(P, c->h_filter->P, sizeof(double) * NS * NS);
+    return LV_OK;
+}
+
+int lv_predict(lv_ctx* c, double dt, const double* Q, const double acc[3], const double gyro[3]) {
+    LV_CHECK_CTX(c);
+    if (!Q || !acc || !gyro) { set_error("null argument"); return LV_EINVAL; }
+    if (!c->filter_set) { set_error("lv_predict before lv_filter_set"); return LV_ESTATE; }
+    return launch_predict(c->stream, c->d_filter, dt, Q, acc, gyro);
+}
+
+int lv_correct(lv_ctx* c, int* passes) {
+    LV_CHECK_CTX(c);
+    if (!c->filter_set) { set_error("lv_correct before lv_filter_set"); return LV_ESTATE; }
+    if (passes) *passes = 0;
+    if (c->map.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
+    int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
+    if (rc) return rc;
+    rc = begin_device(c);
+    if (rc) return rc;
+    c->in_update = true;
+    const int npass = c->prm.MAX_NUM_ITERS + 1;
+    for (int i = 0; i < npass; ++i) {
+        if (c->scan.n == 0) {
+            LV_HIP(hipMemsetAsync(c->d_groups, 0, SUMS_LEN * sizeof(double), c->stream));
+            c->ngroups = 1;
+            rc = LV_OK;
+        } else {
+            rc = pass_reduce(c, false);
+        }
+        if (rc) { c->in_update = false; return rc; }
+        rc = pass_solve(c, true);
+        if (rc) { c->in_update = false; return rc; }
+    }
+    c->in_update = false;
+    rc = launch_kf_to_filter(c->stream, c->d_kf, c->d_filter);
+    if (rc) return rc;
+    if (passes) {  // optional: the only synchronisation point
+        LV_HIP(hipMemcpyAsync(&c->h_kf->passes, &c->d_kf->passes, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        LV_HIP(hipStreamSynchronize(c->stream));
+        *passes = c->h_kf->passes;
     }
     return LV_OK;
 }

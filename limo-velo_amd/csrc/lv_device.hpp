@@ -57,6 +57,12 @@ struct KfDev {
     int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / generic levels / brute force
 };
 
+// Filter state resident on the device between lv_predict / lv_correct calls (row f-3).
+struct FilterDev {
+    double x[NX];
+    double P[NS * NS];
+};
+
 struct GridLevel {
     const uint4* table;  // {key lo, key hi, start, count}
     uint32_t mask;

@@ -86,6 +86,10 @@ struct SolveParams {
     int estimate_extrinsics;
 };
 int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
+// lv_predict.hip
+int launch_predict(hipStream_t stream, FilterDev* f, double dt, const double* Q, const double* acc, const double* gyro);
+int launch_filter_to_kf(hipStream_t stream, const FilterDev* f, KfDev* kf);
+int launch_kf_to_filter(hipStream_t stream, const KfDev* kf, FilterDev* f);
 // lv_rows.hip
 int launch_rows_from_matches(hipStream_t stream, const KfDev* kf, const float* p_world, const float* abcd, const float* dist,
                              uint32_t n, int estimate_extrinsics, double* H, double* h);

@@ -119,6 +119,44 @@ Localizator::Localizator() {
     for (int i = 0; i < 23 * 23; ++i) P_[i] = (i / 23 == i % 23) ? 1.0 : 0.0;
 }
 
+void Localizator::pull() {
+    if (!host_stale_) return;
+    check(lv_filter_get(HipRuntime::ctx(), &x_, P_), "lv_filter_get");
+    host_stale_ = false;
+}
+void Localizator::push() { check(lv_filter_set(HipRuntime::ctx(), &x_, P_), "lv_filter_set"); host_stale_ = false; }
+const state_ikfom& Localizator::get_x() { pull(); return x_; }
+const double* Localizator::get_P() { pull(); return P_; }
+void Localizator::change_x(const state_ikfom& x) { pull(); x_ = x; push(); }
+void Localizator::change_P(const double* P) { pull(); std::memcpy(P_, P, sizeof(P_)); push(); }
+
+void Localizator::propagate(const IMU& imu) {                            // :159-173
+    double Q[144] = {0};
+    for (int i = 0; i < 3; ++i) {
+        Q[(0 + i) * 12 + 0 + i] = Config.cov_gyro;
+        Q[(3 + i) * 12 + 3 + i] = Config.cov_acc;
+        Q[(6 + i) * 12 + 6 + i] = Config.cov_bias_gyro;
+        Q[(9 + i) * 12 + 9 + i] = Config.cov_bias_acc;
+    }
+    const double acc[3] = {imu.a[0], imu.a[1], imu.a[2]}, gyro[3] = {imu.w[0], imu.w[1], imu.w[2]};
+    const double dt = imu.time - last_time_integrated;
+    check(lv_predict(HipRuntime::ctx(), dt, Q, acc, gyro), "lv_predict");
+    host_stale_ = true;
+}
+
+void Localizator::propagate_to(const IMUs& imus, double t) {             // :59-75
+    if (last_time_integrated < 0) last_time_integrated = t;
+    for (const IMU& imu : imus) {
+        propagate(imu);
+        last_time_integrated = imu.time;
+    }
+    if (!imus.empty()) {
+        IMU last(imus.back().a, imus.back().w, t);
+        propagate(last);
+        last_time_integrated = t;
+    }
+}
+
 void Localizator::init_state(const state_ikfom& x0) {                    // :135-153
     x_ = x0;
     for (int i = 0; i < 23 * 23; ++i) P_[i] = (i / 23 == i % 23) ? 1.0 : 0.0;
@@ -126,11 +164,13 @@ void Localizator::init_state(const state_ikfom& x0) {                    // :135
     for (int i : {15, 16, 17}) P_[i * 23 + i] = 0.0001;
     for (int i : {18, 19, 20}) P_[i * 23 + i] = 0.001;
     for (int i : {21, 22}) P_[i * 23 + i] = 0.00001;
+    push();
     initialized = true;
 }
 
 void Localizator::correct(const Points& points, double time) {           // :23-27
     if (!Mapper::getInstance().exists()) return;
+    if (!initialized) { push(); initialized = true; }
     IKFoM_update(points);
     last_time_updated = time;
 }
@@ -140,7 +180,8 @@ void Localizator::IKFoM_update(const Points& points) {                   // :129
     lv_ctx* c = HipRuntime::ctx();
     PointVector v = as_vector(points);
     check(lv_scan_set(c, v.data(), sizeof(Point), v.size()), "lv_scan_set");
-    check(lv_update(c, &x_, P_, &last_passes, nullptr, nullptr), "lv_update");  // update_iterated_dyn_share_modified :132
+    check(lv_correct(c, &last_passes), "lv_correct");  // update_iterated_dyn_share_modified :132, on the resident state
+    host_stale_ = true;
 }
 
 void Localizator::calculate_H(const state_ikfom& s, const Matches& matches, MatrixXd& H, VectorXd& h) {  // :29-57
@@ -159,6 +200,7 @@ void Localizator::calculate_H(const state_ikfom& s, const Matches& matches, Matr
 }
 
 State Localizator::latest_state() {                                      // :77-97
+    pull();
     if (last_time_updated < 0) return State(x_, last_time_integrated);
     return State(x_, last_time_updated);
 }

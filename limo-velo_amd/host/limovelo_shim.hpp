@@ -41,6 +41,7 @@ struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107)
     double MAX_DIST_PLANE = 2.0;
     float PLANES_THRESHOLD = 5.e-2f;
     double LiDAR_noise = 0.001;
+    double cov_acc = 1.e-2, cov_gyro = 1.e-4, cov_bias_acc = 1.e-4, cov_bias_gyro = 1.e-5;  // config/params.yaml:39-42
     double full_rotation_time = 0.1;
     std::vector<float> initial_gravity = {0.f, 0.f, -9.807f};
     std::vector<float> I_Rotation_L = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -58,6 +59,16 @@ class Point {  // reference Objects.hpp:20-28 — 32 bytes, xyz at offset 0
     Point(float x_, float y_, float z_, TimeType t = 0) : x(x_), y(y_), z(z_), time(t), intensity(0), range(0) {}
 };
 static_assert(sizeof(Point) == 32, "Point must keep the reference's 32-byte layout");
+
+class IMU {  // reference Objects.hpp IMU (a, w, time); the ROS constructors are ingest-only
+  public:
+    float a[3] = {0, 0, 0};
+    float w[3] = {0, 0, 0};
+    TimeType time = 0;
+    IMU() = default;
+    IMU(const float a_[3], const float w_[3], TimeType t) : time(t) { for (int i = 0; i < 3; ++i) { a[i] = a_[i]; w[i] = w_[i]; } }
+};
+typedef std::deque<IMU> IMUs;
 
 typedef std::deque<Point> Points;
 typedef std::vector<Point> PointVector;
@@ -145,14 +156,19 @@ class Localizator {
     double last_time_updated = -1;
     bool initialized = false;
 
-    // filter state: x_ and P_ of esekf<state_ikfom, 12, input_ikfom> (reference Localizator.hpp:19)
+    // filter state: x_ and P_ of esekf<state_ikfom, 12, input_ikfom> (reference Localizator.hpp:19) live on
+    // the GPU (lv_filter_set / lv_predict / lv_correct); the host copies below are refreshed on demand
     void init_state(const state_ikfom& x0);  // init_IKFoM_state's x0 / P0 (Localizator.cpp:135-153)
-    const state_ikfom& get_x() const { return x_; }
-    const double* get_P() const { return P_; }
-    void change_x(const state_ikfom& x) { x_ = x; }
-    void change_P(const double* P) { std::memcpy(P_, P, sizeof(P_)); }
+    const state_ikfom& get_x();
+    const double* get_P();
+    void change_x(const state_ikfom& x);
+    void change_P(const double* P);
 
     void correct(const Points&, double time);
+    // Localizator::propagate_to(t) (Localizator.cpp:59-75) with the IMU interval handed in by the caller (the
+    // reference pulls it from the Accumulator singleton): integrates every sample, then the last one up to t
+    void propagate_to(const IMUs& imus, double t);
+    void propagate(const IMU& imu);          // Localizator.cpp:159-173
     void calculate_H(const state_ikfom&, const Matches&, MatrixXd& H, VectorXd& h);
     State latest_state();
     int last_passes = 0;  // measurement passes of the last correct()
@@ -167,6 +183,9 @@ class Localizator {
     Localizator(const Localizator&) = delete;
     Localizator& operator=(const Localizator&) = delete;
     void IKFoM_update(const Points&);
+    void pull();   // device -> host copies if stale
+    void push();   // host copies -> device
     state_ikfom x_;
     double P_[23 * 23];
+    bool host_stale_ = false;
 };

@@ -46,6 +46,12 @@ int main(int argc, char** argv) {
         VectorXd h;
         loc.calculate_H(loc.get_x(), matches, H, h);
 
+        // two zero-length IMU steps exercise propagate_to (Localizator.cpp:59-75) without moving the state
+        IMUs imus;
+        const float a0[3] = {0.f, 0.f, 9.809f}, w0[3] = {0.f, 0.f, 0.f};
+        loc.last_time_integrated = 0.1;
+        imus.push_back(IMU(a0, w0, 0.1));
+        loc.propagate_to(imus, 0.1);
         loc.correct(scan_pts, 0.1);
         State Xt2 = loc.latest_state();
 

@@ -1,0 +1,60 @@
+"""Row f-3: device-resident filter — esekf::predict on the GPU (lv_predict) and correction of the resident state
+(lv_correct) against the oracle's restatement of IKFoM predict + iterated update, over several
+propagate -> correct cycles as src/main.cpp:76-85 runs them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _Q():  # Localizator::propagate (Localizator.cpp:164-168) with config/params.yaml:39-42
+    return np.diag([1e-4] * 3 + [1e-2] * 3 + [1e-5] * 3 + [1e-4] * 3)
+
+
+def test_predict_matches_oracle(lv, oracle, scene_small):
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    rng = np.random.default_rng(4)
+    x, P = sc["x_init"].copy(), sc["P0"].copy()
+    x[14:17] = [1.5, -0.3, 0.05]      # velocity
+    x[17:20] = [0.01, -0.02, 0.005]   # gyro bias
+    x[20:23] = [0.05, 0.02, -0.03]    # accel bias
+    with capi.Context() as ctx:
+        ctx.filter_set(x, P)
+        for i in range(40):
+            acc = np.array([0.3, -0.1, 9.81]) + rng.normal(scale=0.2, size=3)
+            gyro = np.array([0.02, -0.01, 0.3]) + rng.normal(scale=0.05, size=3)
+            dt = 0.005 if i % 7 else 0.0123
+            ctx.predict(dt, _Q(), acc, gyro)
+            x, P = oracle.predict(x, P, dt, _Q(), acc, gyro)
+        xg, Pg = ctx.filter_get()
+    assert np.abs(xg - x).max() < 1e-12
+    assert np.abs(Pg - P).max() < 1e-12 * max(1.0, np.abs(P).max())
+    assert abs(np.linalg.norm(xg[23:26]) - 9.809) < 1e-9
+
+
+def test_propagate_correct_cycles(lv, oracle, scene_small):
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    tree = oracle.KdTree(sc["map_xyz"])
+    x, P = sc["x_init"].copy(), sc["P0"].copy()
+    acc, gyro = np.array([0.0, 0.0, 9.809]), np.array([0.0, 0.0, 0.0])  # static sensor: the map stays valid
+    scans = [sc["scan_xyz"][:1200], sc["scan_xyz"][600:1900], sc["scan_xyz"][100:2000]]
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.filter_set(x, P)
+        for scan in scans:
+            for _ in range(5):
+                ctx.predict(0.002, _Q(), acc, gyro)
+                x, P = oracle.predict(x, P, 0.002, _Q(), acc, gyro)
+            ctx.scan_set(scan)
+            passes = ctx.correct()
+            x, P, po, _, _ = oracle.update(x, P, sc["map_xyz"], scan, tree=tree)
+            assert passes == po
+            xg, Pg = ctx.filter_get()
+            assert np.abs(xg - x).max() < 1e-8, np.abs(xg - x).max()
+            assert np.abs(Pg - P).max() < 1e-8 * max(1.0, np.abs(P).max())
+            x, P = xg, Pg  # continue from the device state so rounding does not accumulate in the comparison
+    assert np.linalg.norm(x[:3] - sc["x_true"][:3]) < 5e-3
