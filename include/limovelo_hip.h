@@ -119,6 +119,27 @@ int    lv_map_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
  * Uploads the scan (LiDAR frame) once per correct(); it is invariant across IKFoM passes. */
 int lv_scan_set(lv_ctx* ctx, const void* points, size_t stride, size_t n);
 
+/* ---- row f-2: Compensator on the device ------------------------------------------------------------------
+ * f32 members of the reference's `State` that State::propagate_f reads (include/Headers/Objects.hpp:97-137,
+ * src/Objects/State.cpp:94-110); matrices row-major.  184 bytes. */
+typedef struct lv_motion_state {
+    float R[9], pos[3], vel[3], bw[3], ba[3], g[3], RLI[9], tLI[3], a[3], w[3];
+    float pad_[2];
+    double time;
+} lv_motion_state;
+
+/* Compensator::compensate(states, Xt2, points) + Compensator::downsample (src/Modules/Compensator.cpp:123-163):
+ * de-skews a time-stamped raw scan (records: x,y,z floats at offset 0, a double time stamp at `time_offset`
+ * bytes — 16 for the reference's Point) with the piecewise-constant-IMU motion model of State::propagate_f
+ * over `states` (time-ordered, surrounding the points), moves every point into the LiDAR frame of Xt2 and,
+ * if downsample_prec > 0, voxel-grid down-samples it (pcl::VoxelGrid semantics: centroid per leaf).  The
+ * result becomes the current scan exactly as if lv_scan_set had been called with it. */
+int lv_scan_deskew(lv_ctx* ctx, const void* points, size_t stride, size_t time_offset, size_t n,
+                   const lv_motion_state* states, size_t n_states, const lv_motion_state* Xt2, float downsample_prec);
+/* number of points of the current scan / copy them out (xyz packed, de-skew output order) */
+size_t lv_scan_size(lv_ctx* ctx);
+int    lv_scan_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
+
 /* One IKFoM::h_share_model evaluation (registered at src/Modules/Localizator.cpp:112) =
  * Mapper::match (Mapper.cpp:40-56) + Localizator::calculate_H (Localizator.cpp:29-57), reduced to
  * H^T H / H^T h on the GPU.  Synchronous. */

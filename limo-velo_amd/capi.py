@@ -21,7 +21,7 @@ NS = 23
 # every symbol include/limovelo_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
-    "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_iterate",
+    "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
 ]
@@ -73,6 +73,8 @@ def load_library() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
         lib.lv_last_error.restype = C.c_char_p
         lib.lv_version.restype = C.c_char_p
+        lib.lv_scan_size.restype = C.c_size_t
+        lib.lv_scan_size.argtypes = [C.c_void_p]
         lib.lv_map_size.restype = C.c_size_t
         lib.lv_map_size.argtypes = [C.c_void_p]
         lib.lv_get_stream.restype = C.c_void_p
@@ -165,6 +167,29 @@ class Context:
         a, stride, n = _points(pts)
         self._n = n
         self._check(self.lib.lv_scan_set(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(stride), C.c_size_t(n)))
+
+    def scan_deskew(self, xyz, times, states, Xt2, downsample_prec=0.5):
+        """xyz [N,3] f32, times [N] f64, states / Xt2: numpy records with the lv_motion_state layout (184 B)."""
+        n = len(xyz)
+        rec = np.zeros(n, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("pad", "f4"), ("time", "f8"), ("intensity", "f4"), ("range", "f4")])
+        xyz = np.asarray(xyz, np.float32)
+        rec["x"], rec["y"], rec["z"], rec["time"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], np.asarray(times, np.float64)
+        st = np.ascontiguousarray(states)
+        x2 = np.ascontiguousarray(Xt2)
+        assert st.dtype.itemsize == 184 and x2.dtype.itemsize == 184
+        self._check(self.lib.lv_scan_deskew(self.h, rec.ctypes.data_as(C.c_void_p), C.c_size_t(32), C.c_size_t(16), C.c_size_t(n),
+                                            st.ctypes.data_as(C.c_void_p), C.c_size_t(len(st)), x2.ctypes.data_as(C.c_void_p),
+                                            C.c_float(downsample_prec)))
+        self._n = self.scan_size()
+
+    def scan_size(self) -> int:
+        return int(self.lib.lv_scan_size(self.h))
+
+    def scan_fetch(self) -> np.ndarray:
+        n = self.scan_size()
+        out = np.empty((n, 3), np.float32)
+        self._check(self.lib.lv_scan_fetch(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        return out
 
     def iterate(self, state) -> dict:
         s = np.ascontiguousarray(state, np.float64)

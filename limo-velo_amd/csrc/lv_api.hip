@@ -401,6 +401,50 @@ int lv_scan_set(lv_ctx* c, const void* points, size_t stride, size_t n) {
     return c->scan.sort(c->stream, bmin, c->prm.voxel_size);
 }
 
+int lv_scan_deskew(lv_ctx* c, const void* points, size_t stride, size_t time_offset, size_t n, const lv_motion_state* states,
+                   size_t n_states, const lv_motion_state* Xt2, float downsample_prec) {
+    LV_CHECK_CTX(c);
+    static_assert(sizeof(lv_motion_state) == sizeof(MotionState), "lv_motion_state layout");
+    if (n && (!points || stride < 12 || time_offset + 8 > stride)) { set_error("bad point array (stride %zu, time offset %zu)", stride, time_offset); return LV_EINVAL; }
+    if (!states || n_states < 2 || !Xt2) { set_error("need >= 2 surrounding states and Xt2"); return LV_EINVAL; }
+    if (n > 0xFFFFFFF0ull) { set_error("scan too large"); return LV_EINVAL; }
+    c->dbg_valid = false;
+    c->scan.n = 0;
+    if (n == 0) return LV_OK;
+    int rc = ensure_stage(c, n + (n + 1) / 2);  // float4 xyz + packed doubles behind them
+    if (rc) return rc;
+    rc = c->scan.reserve_raw(n, n_states);
+    if (rc) return rc;
+    LV_HIP(hipStreamSynchronize(c->stream));  // staging buffer reuse
+    double* h_times = reinterpret_cast<double*>(c->h_stage + n);
+    for (size_t i = 0; i < n; ++i) {
+        float x, y, z;
+        read_xyz(points, stride, i, x, y, z);
+        c->h_stage[i] = make_float4(x, y, z, 0.f);
+        std::memcpy(&h_times[i], reinterpret_cast<const char*>(points) + i * stride + time_offset, sizeof(double));
+    }
+    LV_HIP(hipMemcpyAsync(c->scan.d_in, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    LV_HIP(hipMemcpyAsync(c->scan.d_times, h_times, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LV_HIP(hipMemcpyAsync(c->scan.d_states, states, n_states * sizeof(MotionState), hipMemcpyHostToDevice, c->stream));
+    MotionState xt2;
+    std::memcpy(&xt2, Xt2, sizeof(xt2));
+    return c->scan.deskew_downsample(c->stream, (uint32_t)n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size);
+}
+
+size_t lv_scan_size(lv_ctx* c) { return c ? c->scan.n : 0; }
+
+int lv_scan_fetch(lv_ctx* c, float* xyz_out, size_t capacity) {
+    LV_CHECK_CTX(c);
+    const size_t n = c->scan.n;
+    if (capacity < n || (!xyz_out && capacity)) { set_error("capacity too small"); return LV_EINVAL; }
+    if (n == 0) return LV_OK;
+    std::vector<float4> tmp(n);
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(tmp.data(), c->scan.d_raw, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) { xyz_out[3 * i] = tmp[i].x; xyz_out[3 * i + 1] = tmp[i].y; xyz_out[3 * i + 2] = tmp[i].z; }
+    return LV_OK;
+}
+
 int lv_set_capture(lv_ctx* c, int enabled) {
     LV_CHECK_CTX(c);
     c->capture = enabled != 0;

@@ -183,6 +183,84 @@ __device__ inline void compute_pose_consts(const double* x, PoseConsts* out) {
     quat_to_rot(qc, out->I_R_L_inv);
 }
 
+// ---- row f-2: the reference's f32 motion model (State::propagate_f, src/Objects/State.cpp:94-110) ------
+struct MotionState {  // == lv_motion_state (include/limovelo_hip.h): f32 members of the reference's State
+    float R[9], pos[3], vel[3], bw[3], ba[3], g[3], RLI[9], tLI[3], a[3], w[3];
+    float pad_[2];
+    double time;
+};
+
+// sin / cos of an f32 argument through a fixed f64 polynomial (Cody-Waite + Taylor), rounded to f32: the
+// same operation sequence as the oracle's, so both produce the same bits (std::sin(float) of
+// SO3Math::Exp, include/Headers/Utils.hpp:45, is libm- and platform-dependent in the last ulp).
+__device__ inline void sincos_f32(float xf, float& sn, float& cs) {
+    const double x = (double)xf;
+    const double k = rint(x * 0.63661977236758134308);
+    double r = x - k * 1.57079632673412561417e+00;
+    r = r - k * 6.07710050650619224932e-11;
+    r = r - k * 2.02226624879595063154e-21;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z - 2.50507602534068634195e-08;
+    ps = ps * z + 2.75573137070700676789e-06;
+    ps = ps * z - 1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03;
+    ps = ps * z - 1.66666666666666324348e-01;
+    const double s0 = r + r * z * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09;
+    pc = pc * z - 2.75573143513906633035e-07;
+    pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z - 1.38888888888741095749e-03;
+    pc = pc * z + 4.16666666666666019037e-02;
+    const double c0 = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)k & 3;
+    const double sd = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
+    const double cd = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
+    sn = (float)sd;
+    cs = (float)cd;
+}
+
+// SO3Math::Exp<float,float>(ang_vel, dt) — reference include/Headers/Utils.hpp:30-53
+__device__ inline void so3_exp_f32(const float w[3], float dt, float E[9]) {
+    const float nrm = sqrtf(dot3f(w[0], w[0], w[1], w[1], w[2], w[2]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = (i % 4 == 0) ? 1.f : 0.f;
+    if (!((double)nrm > 0.0000001)) return;
+    const float r[3] = {w[0] / nrm, w[1] / nrm, w[2] / nrm};
+    const float K[9] = {0.f, -r[2], r[1], r[2], 0.f, -r[0], -r[1], r[0], 0.f};
+    const float r_ang = nrm * dt;
+    float sn, cs;
+    sincos_f32(r_ang, sn, cs);
+    const float c = (float)(1.0 - (double)cs);
+    float cK[9], cKK[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cK[i] = c * K[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cKK[i * 3 + j] = dot3f(cK[i * 3], K[j], cK[i * 3 + 1], K[3 + j], cK[i * 3 + 2], K[6 + j]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = (E[i] + sn * K[i]) + cKK[i];
+}
+
+// State::propagate_f (State.cpp:94-110): pose part only (what de-skewing needs): R, pos after dt
+__device__ inline void motion_integrate_pose(const MotionState& s, float dt, float Rn[9], float posn[3]) {
+    const float wm[3] = {s.w[0] - s.bw[0], s.w[1] - s.bw[1], s.w[2] - s.bw[2]};
+    float E[9];
+    so3_exp_f32(wm, dt, E);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = dot3f(s.R[i * 3], E[j], s.R[i * 3 + 1], E[3 + j], s.R[i * 3 + 2], E[6 + j]);
+    const float am[3] = {s.a[0] - s.ba[0], s.a[1] - s.ba[1], s.a[2] - s.ba[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float v = dot3f(s.R[i * 3], am[0], s.R[i * 3 + 1], am[1], s.R[i * 3 + 2], am[2]) - s.g[i];
+        posn[i] = s.pos[i] + (s.vel[i] * dt + ((0.5f * v) * dt) * dt);
+    }
+}
+
 // voxel coordinates -----------------------------------------------------------------------------
 __device__ __forceinline__ int cell_coord(float p, float origin, float inv_cell) {
     float f = floorf((p - origin) * inv_cell);

@@ -105,7 +105,24 @@ struct ScanStore {
     size_t sort_tmp_bytes = 0;
     size_t capacity = 0;
     uint32_t n = 0;
+    // row f-2 (de-skew + voxel grid): raw time-stamped input and work buffers
+    float4* d_in = nullptr;
+    double* d_times = nullptr;
+    float4* d_desk = nullptr;
+    MotionState* d_states = nullptr;
+    uint64_t* d_vkeys = nullptr;
+    uint64_t* d_vkeys_sorted = nullptr;
+    uint32_t* d_vidx = nullptr;
+    uint32_t* d_vidx_sorted = nullptr;
+    uint32_t* d_heads = nullptr;
+    uint32_t* d_hpos = nullptr;
+    unsigned* d_bounds = nullptr;
+    void* d_vsort_tmp = nullptr;
+    void* d_vscan_tmp = nullptr;
+    size_t vsort_tmp_bytes = 0, vscan_tmp_bytes = 0, raw_cap = 0, states_cap = 0;
     int reserve(size_t cap);
+    int reserve_raw(size_t cap, size_t n_states);
+    int deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf, float sort_cell);
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
     void release();
 };

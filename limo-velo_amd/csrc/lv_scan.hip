@@ -5,6 +5,8 @@
 // record carries its original index in .w.
 #include "lv_host.hpp"
 
+#include <cstring>
+
 #include <hipcub/hipcub.hpp>
 
 namespace lv {
@@ -37,11 +39,188 @@ __global__ void scan_gather_kernel(const float4* __restrict__ pts, const uint32_
     sorted[i] = pts[idx_sorted[i]];
 }
 
+// ---- row f-2: Compensator::compensate + voxelgrid_downsample on the device ------------------------------
+// de-skew: one lane per raw point (reference src/Modules/Compensator.cpp:123-146)
+__global__ void deskew_kernel(const float4* __restrict__ raw, const double* __restrict__ times, uint32_t n,
+                              const MotionState* __restrict__ states, uint32_t n_states, MotionState xt2,
+                              float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = raw[i];
+    const double t = times[i];
+    const float qnan = __uint_as_float(0x7fc00000u);
+    float4 o = make_float4(qnan, qnan, qnan, __uint_as_float(i));
+    // the reference's two-pointer walk puts a point into the FIRST interval [states[s].time, states[s+1].time]
+    // that contains its time
+    if (n_states >= 2 && t >= states[0].time && t <= states[n_states - 1].time) {
+        uint32_t lo = 0, hi = n_states - 2;  // smallest s with t <= states[s+1].time
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (t <= states[mid + 1].time) hi = mid; else lo = mid + 1;
+        }
+        const MotionState st = states[lo];
+        const float dt = (float)(t - st.time);
+        RT32 X, LI;
+        motion_integrate_pose(st, dt, X.R, X.t);                         // Xtp += IMU(states[s].a, states[s].w, t)  :133-134
+#pragma unroll
+        for (int k = 0; k < 9; ++k) LI.R[k] = st.RLI[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) LI.t[k] = st.tLI[k];
+        float gx, gy, gz;
+        const RT32 T = rt_compose(X, LI);
+        rt_apply(T, p.x, p.y, p.z, gx, gy, gz);                          // global_p = Xtp * Xtp.I_Rt_L() * p   :137
+        RT32 X2, LI2;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { X2.R[k] = xt2.R[k]; LI2.R[k] = xt2.RLI[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { X2.t[k] = xt2.pos[k]; LI2.t[k] = xt2.tLI[k]; }
+        const RT32 back = rt_compose(rt_inv(LI2), rt_inv(X2));            // Xt2.I_Rt_L().inv() * Xt2.inv()      :138
+        rt_apply(back, gx, gy, gz, o.x, o.y, o.z);
+    }
+    out[i] = o;
+}
+
+// pcl::VoxelGrid [UPSTREAM-RECALL PCL 1.8 applyFilter]: bounds -> leaf index -> sort -> centroid per leaf
+__device__ __forceinline__ unsigned flip_f32(float f) {  // order-preserving float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unflip_f32(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__global__ void vg_bounds_kernel(const float4* __restrict__ pts, uint32_t n, unsigned* __restrict__ bounds /*min xyz, max xyz*/) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return;
+    atomicMin(&bounds[0], flip_f32(p.x)); atomicMin(&bounds[1], flip_f32(p.y)); atomicMin(&bounds[2], flip_f32(p.z));
+    atomicMax(&bounds[3], flip_f32(p.x)); atomicMax(&bounds[4], flip_f32(p.y)); atomicMax(&bounds[5], flip_f32(p.z));
+}
+__global__ void vg_keys_kernel(const float4* __restrict__ pts, uint32_t n, const unsigned* __restrict__ bounds, float inv_leaf,
+                               uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    idx[i] = i;
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = ~0ull >> 1; return; }  // dropped (sorted last)
+    long long minb[3], divb[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        minb[a] = (long long)floorf(unflip_f32(bounds[a]) * inv_leaf);
+        divb[a] = (long long)floorf(unflip_f32(bounds[3 + a]) * inv_leaf) - minb[a] + 1;
+    }
+    const long long i0 = (long long)floorf(p.x * inv_leaf) - minb[0], i1 = (long long)floorf(p.y * inv_leaf) - minb[1],
+                    i2 = (long long)floorf(p.z * inv_leaf) - minb[2];
+    keys[i] = (uint64_t)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
+}
+// head of every leaf: sequential f32 sum of its points in input order (stable sort), centroid = sum / count
+__global__ void vg_heads_kernel(const uint64_t* __restrict__ keys_sorted, uint32_t n, uint32_t* __restrict__ heads) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys_sorted[i];
+    heads[i] = (k != (~0ull >> 1) && (i == 0 || keys_sorted[i - 1] != k)) ? 1u : 0u;
+}
+__global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint64_t* __restrict__ keys_sorted,
+                                   const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ heads,
+                                   const uint32_t* __restrict__ hpos, uint32_t n, float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !heads[i]) return;
+    const uint64_t k = keys_sorted[i];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    uint32_t j = i;
+    for (; j < n && keys_sorted[j] == k; ++j) {
+        const float4 p = pts[idx_sorted[j]];
+        sx += p.x; sy += p.y; sz += p.z;
+    }
+    const float cnt = (float)(j - i);
+    const uint32_t o = hpos[i];
+    out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
+}
+
+int ScanStore::reserve_raw(size_t cap, size_t n_states) {
+    if (cap > raw_cap) {
+        size_t ncap = raw_cap ? raw_cap : 4096;
+        while (ncap < cap) ncap *= 2;
+        hipFree(d_in); hipFree(d_times); hipFree(d_desk); hipFree(d_vkeys); hipFree(d_vkeys_sorted); hipFree(d_vidx);
+        hipFree(d_vidx_sorted); hipFree(d_heads); hipFree(d_hpos); hipFree(d_vsort_tmp); hipFree(d_vscan_tmp);
+        d_in = d_desk = nullptr; d_times = nullptr; d_vkeys = d_vkeys_sorted = nullptr;
+        d_vidx = d_vidx_sorted = d_heads = d_hpos = nullptr; d_vsort_tmp = d_vscan_tmp = nullptr;
+        LV_HIP(hipMalloc(&d_in, ncap * sizeof(float4)));
+        LV_HIP(hipMalloc(&d_times, ncap * sizeof(double)));
+        LV_HIP(hipMalloc(&d_desk, ncap * sizeof(float4)));
+        LV_HIP(hipMalloc(&d_vkeys, ncap * sizeof(uint64_t)));
+        LV_HIP(hipMalloc(&d_vkeys_sorted, ncap * sizeof(uint64_t)));
+        LV_HIP(hipMalloc(&d_vidx, ncap * sizeof(uint32_t)));
+        LV_HIP(hipMalloc(&d_vidx_sorted, ncap * sizeof(uint32_t)));
+        LV_HIP(hipMalloc(&d_heads, ncap * sizeof(uint32_t)));
+        LV_HIP(hipMalloc(&d_hpos, ncap * sizeof(uint32_t)));
+        vsort_tmp_bytes = 0;
+        LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(nullptr, vsort_tmp_bytes, d_vkeys, d_vkeys_sorted, d_vidx, d_vidx_sorted,
+                                                               (int)ncap, 0, 63, (hipStream_t)0));
+        LV_HIP(hipMalloc(&d_vsort_tmp, vsort_tmp_bytes));
+        vscan_tmp_bytes = 0;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, vscan_tmp_bytes, d_heads, d_hpos, (int)ncap, (hipStream_t)0));
+        LV_HIP(hipMalloc(&d_vscan_tmp, vscan_tmp_bytes));
+        raw_cap = ncap;
+    }
+    if (n_states > states_cap) {
+        hipFree(d_states);
+        d_states = nullptr;
+        LV_HIP(hipMalloc(&d_states, n_states * sizeof(MotionState)));
+        states_cap = n_states;
+    }
+    if (!d_bounds) LV_HIP(hipMalloc(&d_bounds, 8 * sizeof(unsigned)));
+    return LV_OK;
+}
+
+// d_in / d_times / d_states hold the uploaded raw scan; leaves the de-skewed (and, if leaf > 0, voxel-grid
+// down-sampled) points in d_raw[0 .. n) in output order and Morton-sorts them into d_sorted
+int ScanStore::deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf,
+                                 float sort_cell) {
+    const int B = 256;
+    const uint32_t grid = (n_in + B - 1) / B;
+    int rc = reserve(n_in);
+    if (rc) return rc;
+    float4* desk = leaf > 0.f ? d_desk : d_raw;
+    hipLaunchKernelGGL(deskew_kernel, dim3(grid), dim3(B), 0, stream, d_in, d_times, n_in, d_states, n_states, xt2, desk);
+    const unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    LV_HIP(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(vg_bounds_kernel, dim3(grid), dim3(B), 0, stream, desk, n_in, d_bounds);
+    uint32_t n_out = n_in;
+    uint32_t last_pos = 0, last_head = 0;
+    if (leaf > 0.f) {
+        hipLaunchKernelGGL(vg_keys_kernel, dim3(grid), dim3(B), 0, stream, d_desk, n_in, d_bounds, 1.0f / leaf, d_vkeys, d_vidx);
+        size_t tmp = vsort_tmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_vsort_tmp, tmp, d_vkeys, d_vkeys_sorted, d_vidx, d_vidx_sorted, (int)n_in,
+                                                               0, 63, stream));
+        hipLaunchKernelGGL(vg_heads_kernel, dim3(grid), dim3(B), 0, stream, d_vkeys_sorted, n_in, d_heads);
+        size_t stmp = vscan_tmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_vscan_tmp, stmp, d_heads, d_hpos, (int)n_in, stream));
+        hipLaunchKernelGGL(vg_centroid_kernel, dim3(grid), dim3(B), 0, stream, d_desk, d_vkeys_sorted, d_vidx_sorted, d_heads, d_hpos,
+                           n_in, d_raw);
+        LV_HIP(hipMemcpyAsync(&last_pos, d_hpos + (n_in - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipMemcpyAsync(&last_head, d_heads + (n_in - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
+    unsigned hb[8];
+    LV_HIP(hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    if (leaf > 0.f) n_out = last_pos + last_head;
+    n = n_out;
+    if (hb[0] == 0xFFFFFFFFu) n = 0;  // no finite point survived
+    if (n == 0) return LV_OK;
+    auto unflip = [](unsigned u) { unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
+    const float bmin[3] = {unflip(hb[0]), unflip(hb[1]), unflip(hb[2])};
+    return sort(stream, bmin, sort_cell);   // Morton order for the match kernel, exactly as lv_scan_set does
+}
+
 int ScanStore::reserve(size_t cap) {
     if (cap <= capacity) return LV_OK;
     size_t ncap = capacity ? capacity : 4096;
     while (ncap < cap) ncap *= 2;
-    release();
+    hipFree(d_raw); hipFree(d_sorted); hipFree(d_keys); hipFree(d_keys_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
+    hipFree(d_sort_tmp);
+    d_raw = d_sorted = nullptr; d_keys = d_keys_sorted = d_idx = d_idx_sorted = nullptr; d_sort_tmp = nullptr;
+    capacity = 0;
     LV_HIP(hipMalloc(&d_raw, ncap * sizeof(float4)));
     LV_HIP(hipMalloc(&d_sorted, ncap * sizeof(float4)));
     LV_HIP(hipMalloc(&d_keys, ncap * sizeof(uint32_t)));
@@ -58,6 +237,9 @@ int ScanStore::reserve(size_t cap) {
 void ScanStore::release() {
     hipFree(d_raw); hipFree(d_sorted); hipFree(d_keys); hipFree(d_keys_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
     hipFree(d_sort_tmp);
+    hipFree(d_in); hipFree(d_times); hipFree(d_desk); hipFree(d_vkeys); hipFree(d_vkeys_sorted); hipFree(d_vidx);
+    hipFree(d_vidx_sorted); hipFree(d_heads); hipFree(d_hpos); hipFree(d_vsort_tmp); hipFree(d_vscan_tmp); hipFree(d_states);
+    hipFree(d_bounds);
     *this = ScanStore();
 }
 

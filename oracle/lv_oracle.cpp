@@ -1212,4 +1212,134 @@ size_t lvo_map_add(const float* map_xyz, size_t m, const float* new_xyz, size_t 
     return n;
 }
 
+// ---- row f-2 ------------------------------------------------------------------------------------------
+// sin / cos for f32 arguments: evaluated through a fixed f64 polynomial and rounded to f32, so that the
+// oracle and the device produce the same bits (libm's sinf / cosf differ between platforms by an ulp; the
+// reference calls std::sin(float) in SO3Math::Exp, include/Headers/Utils.hpp:45).
+static void sincos_f32(float xf, float& sn, float& cs) {
+    const double x = (double)xf;
+    const double k = std::rint(x * 0.63661977236758134308);
+    double r = x - k * 1.57079632673412561417e+00;
+    r = r - k * 6.07710050650619224932e-11;
+    r = r - k * 2.02226624879595063154e-21;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z - 2.50507602534068634195e-08;
+    ps = ps * z + 2.75573137070700676789e-06;
+    ps = ps * z - 1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03;
+    ps = ps * z - 1.66666666666666324348e-01;
+    const double s0 = r + r * z * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09;
+    pc = pc * z - 2.75573143513906633035e-07;
+    pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z - 1.38888888888741095749e-03;
+    pc = pc * z + 4.16666666666666019037e-02;
+    const double c0 = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)k & 3;
+    const double sd = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
+    const double cd = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
+    sn = (float)sd;
+    cs = (float)cd;
+}
+
+// SO3Math::Exp<float,float>(ang_vel, dt) — include/Headers/Utils.hpp:30-53
+static void so3_exp_f32(const float w[3], float dt, float E[9]) {
+    const float nrm = std::sqrt(dot3f(w[0], w[0], w[1], w[1], w[2], w[2]));
+    for (int i = 0; i < 9; ++i) E[i] = (i % 4 == 0) ? 1.f : 0.f;
+    if (!((double)nrm > 0.0000001)) return;
+    const float r[3] = {w[0] / nrm, w[1] / nrm, w[2] / nrm};
+    const float K[9] = {0.f, -r[2], r[1], r[2], 0.f, -r[0], -r[1], r[0], 0.f};
+    const float r_ang = nrm * dt;
+    float sn, cs;
+    sincos_f32(r_ang, sn, cs);
+    const float c = (float)(1.0 - (double)cs);
+    float cK[9], cKK[9];
+    for (int i = 0; i < 9; ++i) cK[i] = c * K[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) cKK[i * 3 + j] = dot3f(cK[i * 3], K[j], cK[i * 3 + 1], K[3 + j], cK[i * 3 + 2], K[6 + j]);
+    for (int i = 0; i < 9; ++i) E[i] = (E[i] + sn * K[i]) + cKK[i];
+}
+
+// State::propagate_f + the time bookkeeping of State::update — src/Objects/State.cpp:94-121
+void lvo_state_integrate(lvo_motion_state* s, const float a[3], const float w[3], double t) {
+    const float dt = (float)(t - s->time);
+    const float wm[3] = {w[0] - s->bw[0], w[1] - s->bw[1], w[2] - s->bw[2]};
+    float E[9], Rn[9];
+    so3_exp_f32(wm, dt, E);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = dot3f(s->R[i * 3], E[j], s->R[i * 3 + 1], E[3 + j], s->R[i * 3 + 2], E[6 + j]);
+    const float am[3] = {a[0] - s->ba[0], a[1] - s->ba[1], a[2] - s->ba[2]};
+    float v[3];
+    for (int i = 0; i < 3; ++i) v[i] = dot3f(s->R[i * 3], am[0], s->R[i * 3 + 1], am[1], s->R[i * 3 + 2], am[2]) - s->g[i];
+    float veln[3], posn[3];
+    for (int i = 0; i < 3; ++i) {
+        veln[i] = s->vel[i] + v[i] * dt;
+        posn[i] = s->pos[i] + (s->vel[i] * dt + ((0.5f * v[i]) * dt) * dt);
+    }
+    for (int i = 0; i < 9; ++i) s->R[i] = Rn[i];
+    for (int i = 0; i < 3; ++i) { s->vel[i] = veln[i]; s->pos[i] = posn[i]; }
+    s->time = t;
+    for (int i = 0; i < 3; ++i) { s->a[i] = 0.5f * s->a[i] + 0.5f * a[i]; s->w[i] = 0.5f * s->w[i] + 0.5f * w[i]; }
+}
+
+void lvo_deskew(const float* xyz, const double* times, size_t n, const lvo_motion_state* states, size_t n_states,
+                const lvo_motion_state* Xt2, float* out_xyz) {
+    RT32 X2, LI2;
+    std::memcpy(X2.R, Xt2->R, sizeof(X2.R)); std::memcpy(X2.t, Xt2->pos, sizeof(X2.t));
+    std::memcpy(LI2.R, Xt2->RLI, sizeof(LI2.R)); std::memcpy(LI2.t, Xt2->tLI, sizeof(LI2.t));
+    const RT32 back = rt_compose(rt_inv(LI2), rt_inv(X2));  // Xt2.I_Rt_L().inv() * Xt2.inv()  (Compensator.cpp:138)
+    size_t p = 0;
+    for (size_t s = 0; s + 1 < n_states; ++s) {             // the reference's two-pointer walk (:130-143)
+        while (p < n && states[s].time <= times[p] && times[p] <= states[s + 1].time) {
+            lvo_motion_state Xtp = states[s];
+            lvo_state_integrate(&Xtp, states[s].a, states[s].w, times[p]);  // :133-134
+            RT32 X, LI;
+            std::memcpy(X.R, Xtp.R, sizeof(X.R)); std::memcpy(X.t, Xtp.pos, sizeof(X.t));
+            std::memcpy(LI.R, Xtp.RLI, sizeof(LI.R)); std::memcpy(LI.t, Xtp.tLI, sizeof(LI.t));
+            float g[3];
+            rt_apply(rt_compose(X, LI), xyz + 3 * p, g);    // :137
+            rt_apply(back, g, out_xyz + 3 * p);             // :138
+            ++p;
+        }
+    }
+    for (; p < n; ++p) { out_xyz[3 * p] = out_xyz[3 * p + 1] = out_xyz[3 * p + 2] = std::numeric_limits<float>::quiet_NaN(); }
+}
+
+size_t lvo_voxelgrid(const float* xyz, size_t n, float leaf, float* out_xyz) {
+    if (n == 0) return 0;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], xyz[3 * i + a]); mx[a] = std::max(mx[a], xyz[3 * i + a]); }
+    const float inv = 1.0f / leaf;
+    int64_t minb[3], divb[3];
+    for (int a = 0; a < 3; ++a) {
+        minb[a] = (int64_t)std::floor(mn[a] * inv);
+        divb[a] = (int64_t)std::floor(mx[a] * inv) - minb[a] + 1;
+    }
+    std::vector<std::pair<int64_t, uint32_t>> iv(n);
+    for (size_t i = 0; i < n; ++i) {
+        int64_t ijk[3];
+        for (int a = 0; a < 3; ++a) ijk[a] = (int64_t)std::floor(xyz[3 * i + a] * inv) - minb[a];
+        iv[i] = {ijk[0] + ijk[1] * divb[0] + ijk[2] * divb[0] * divb[1], (uint32_t)i};
+    }
+    std::stable_sort(iv.begin(), iv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    size_t out = 0, i = 0;
+    while (i < n) {
+        size_t j = i;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        while (j < n && iv[j].first == iv[i].first) {
+            const float* p = xyz + 3 * (size_t)iv[j].second;
+            sx += p[0]; sy += p[1]; sz += p[2];
+            ++j;
+        }
+        const float cnt = (float)(j - i);
+        out_xyz[3 * out] = sx / cnt; out_xyz[3 * out + 1] = sy / cnt; out_xyz[3 * out + 2] = sz / cnt;
+        ++out;
+        i = j;
+    }
+    return out;
+}
+
 }  // extern "C"

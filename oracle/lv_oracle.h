@@ -140,6 +140,29 @@ void lvo_predict(lvo_state* x, double* P, double dt, const double* Q, const doub
 size_t lvo_map_add(const float* map_xyz, size_t m, const float* new_xyz, size_t k, int downsample, float box_length,
                    float* out_xyz);
 
+/* ---- row f-2: Compensator (de-skew + voxel-grid down-sampling) ---------------------------------------- */
+/* f32 members of the reference's State that State::propagate_f reads (src/Objects/State.cpp:94-110;
+ * include/Headers/Objects.hpp:97-137).  Row-major matrices. */
+typedef struct lvo_motion_state {
+    float R[9], pos[3], vel[3], bw[3], ba[3], g[3], RLI[9], tLI[3], a[3], w[3];
+    float pad_[2];
+    double time;
+} lvo_motion_state;   /* 184 bytes */
+
+/* State::operator+=(IMU(a, w, t)) = State::update -> propagate_f (State.cpp:94-121), f32. */
+void lvo_state_integrate(lvo_motion_state* s, const float a[3], const float w[3], double t);
+
+/* Compensator::compensate(states, Xt2, points) (src/Modules/Compensator.cpp:123-146): for every point (xyz +
+ * time, time-sorted) take the surrounding state, integrate it to the point's time with its own last IMU, move
+ * the point to the world and back into the LiDAR frame at t2.  out_xyz: n x 3. */
+void lvo_deskew(const float* xyz, const double* times, size_t n, const lvo_motion_state* states, size_t n_states,
+                const lvo_motion_state* Xt2, float* out_xyz);
+
+/* Compensator::voxelgrid_downsample (Compensator.cpp:148-163) = pcl::VoxelGrid with leaf size `leaf`
+ * [UPSTREAM-RECALL PCL 1.8 VoxelGrid::applyFilter]: centroid (f32 sums in input order / count) of every
+ * occupied leaf, leaves in ascending index order i + j*dx + k*dx*dy.  Returns the number of output points. */
+size_t lvo_voxelgrid(const float* xyz, size_t n, float leaf, float* out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

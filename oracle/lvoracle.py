@@ -65,6 +65,7 @@ def lib():
         _lib.lvo_update.restype = C.c_int
         _lib.lvo_kf_step.restype = C.c_int
         _lib.lvo_map_add.restype = C.c_size_t
+        _lib.lvo_voxelgrid.restype = C.c_size_t
     return _lib
 
 
@@ -256,4 +257,44 @@ def map_add(map_xyz, new_xyz, downsample=True, box_length=0.2):
     out = np.empty((len(m) + len(k), 3), np.float32)
     n = lib().lvo_map_add(_p(m, C.c_float), C.c_size_t(len(m)), _p(k, C.c_float), C.c_size_t(len(k)), int(downsample),
                           C.c_float(box_length), _p(out, C.c_float))
+    return out[:n].copy()
+
+
+MOTION_DTYPE = np.dtype([("R", "f4", 9), ("pos", "f4", 3), ("vel", "f4", 3), ("bw", "f4", 3), ("ba", "f4", 3), ("g", "f4", 3),
+                         ("RLI", "f4", 9), ("tLI", "f4", 3), ("a", "f4", 3), ("w", "f4", 3), ("pad_", "f4", 2), ("time", "f8")])
+assert MOTION_DTYPE.itemsize == 184
+
+
+def motion_state(R=None, pos=(0, 0, 0), vel=(0, 0, 0), a=(0, 0, 9.807), w=(0, 0, 0), time=0.0, RLI=None, tLI=(0, 0, 0),
+                 g=(0, 0, -9.807), bw=(0, 0, 0), ba=(0, 0, 0)):
+    s = np.zeros(1, MOTION_DTYPE)
+    s["R"] = np.eye(3, dtype=np.float32).ravel() if R is None else np.asarray(R, np.float32).ravel()
+    s["RLI"] = np.eye(3, dtype=np.float32).ravel() if RLI is None else np.asarray(RLI, np.float32).ravel()
+    for k, v in (("pos", pos), ("vel", vel), ("a", a), ("w", w), ("tLI", tLI), ("g", g), ("bw", bw), ("ba", ba)):
+        s[k] = np.asarray(v, np.float32)
+    s["time"] = time
+    return s
+
+
+def state_integrate(state, a, w, t):
+    s = state.copy()
+    av, wv = _f32(a), _f32(w)
+    lib().lvo_state_integrate(s.ctypes.data_as(C.c_void_p), _p(av, C.c_float), _p(wv, C.c_float), C.c_double(t))
+    return s
+
+
+def deskew(xyz, times, states, Xt2):
+    p = _f32(xyz).reshape(-1, 3)
+    t = _f64(times)
+    st = np.ascontiguousarray(states)
+    out = np.empty_like(p)
+    lib().lvo_deskew(_p(p, C.c_float), _p(t, C.c_double), C.c_size_t(len(p)), st.ctypes.data_as(C.c_void_p), C.c_size_t(len(st)),
+                     np.ascontiguousarray(Xt2).ctypes.data_as(C.c_void_p), _p(out, C.c_float))
+    return out
+
+
+def voxelgrid(xyz, leaf):
+    p = _f32(xyz).reshape(-1, 3)
+    out = np.empty_like(p)
+    n = lib().lvo_voxelgrid(_p(p, C.c_float), C.c_size_t(len(p)), C.c_float(leaf), _p(out, C.c_float))
     return out[:n].copy()

@@ -241,3 +241,16 @@ def test_map_add_box_rule(oracle):
     out = oracle.map_add(old, np.array([[0.1, 0.1, 0.1], [2.0, 2.0, 2.0]], f))
     assert out.tolist() == np.array([[1.01, 0, 0], [1.02, 0, 0], [0.1, 0.1, 0.1], [2.0, 2.0, 2.0]], f).tolist()
     assert len(oracle.map_add(old, old, downsample=False)) == 6
+
+
+def test_motion_model_and_voxelgrid(oracle):
+    """State::propagate_f restatement: constant yaw rate + constant world velocity against the closed form;
+    voxel grid: centroids of occupied leaves in leaf-index order."""
+    s0 = oracle.motion_state(vel=(10, 0, 0), a=(0, 0, -9.807), w=(0, 0, 1.0), time=0.0)  # a - g == 0: no acceleration
+    s1 = oracle.state_integrate(s0, s0["a"][0], s0["w"][0], 0.05)
+    R = s1["R"].reshape(3, 3)
+    assert np.allclose(R[:2, :2], [[np.cos(0.05), -np.sin(0.05)], [np.sin(0.05), np.cos(0.05)]], atol=1e-6)
+    assert np.allclose(s1["pos"], [[0.5, 0, 0]], atol=1e-6) and s1["time"][0] == 0.05
+    pts = np.array([[0.1, 0.1, 0.1], [0.3, 0.1, 0.1], [0.9, 0.1, 0.1], [-0.2, 0.1, 0.1]], np.float32)
+    v = oracle.voxelgrid(pts, 0.5)
+    assert np.allclose(v, [[-0.2, 0.1, 0.1], [0.2, 0.1, 0.1], [0.9, 0.1, 0.1]], atol=1e-7)
