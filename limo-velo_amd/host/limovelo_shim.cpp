@@ -48,11 +48,25 @@ void HipRuntime::shutdown() {
     g_ctx = nullptr;
 }
 
-// State::State(const state_ikfom&, double) — reference src/Objects/State.cpp:51-62 (pose members only)
-State::State(const state_ikfom& s, double t) {
+// State::State() — reference src/Objects/State.cpp:19-39
+State::State() {
     std::memset(this, 0, sizeof(*this));
+    for (int i = 0; i < 3; ++i) {
+        g[i] = i < (int)Config.initial_gravity.size() ? Config.initial_gravity[i] : 0.f;
+        tLI[i] = i < (int)Config.I_Translation_L.size() ? Config.I_Translation_L[i] : 0.f;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) RLI[i * 3 + j] = Config.I_Rotation_L.size() == 9 ? Config.I_Rotation_L[i * 3 + j] : (i == j);
+    R[0] = R[4] = R[8] = 1.f;
+    x.rot[3] = 1.0;
+    x.offset_R_L_I[3] = 1.0;
+}
+
+// State::State(const state_ikfom&, double) — reference src/Objects/State.cpp:51-62
+State::State(const state_ikfom& s, double t) : State() {
     time = t;
     x = s;
+    for (int i = 0; i < 3; ++i) { vel[i] = (float)s.vel[i]; bw[i] = (float)s.bg[i]; ba[i] = (float)s.ba[i]; }
     auto q2r = [](const double q[4], float R[9]) {  // Eigen Quaternion::toRotationMatrix, then cast<float>
         const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
         const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
@@ -65,6 +79,94 @@ State::State(const state_ikfom& s, double t) {
     q2r(s.rot, R);
     q2r(s.offset_R_L_I, RLI);
     for (int i = 0; i < 3; ++i) { pos[i] = (float)s.pos[i]; tLI[i] = (float)s.offset_T_L_I[i]; }
+}
+
+namespace {
+inline float dot3(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
+// sin / cos of an f32 argument through the same fixed f64 polynomial the device uses (lv_device.hpp sincos_f32)
+void sincos_f32(float xf, float& sn, float& cs) {
+    const double x = (double)xf;
+    const double k = std::rint(x * 0.63661977236758134308);
+    double r = x - k * 1.57079632673412561417e+00;
+    r = r - k * 6.07710050650619224932e-11;
+    r = r - k * 2.02226624879595063154e-21;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z - 2.50507602534068634195e-08; ps = ps * z + 2.75573137070700676789e-06; ps = ps * z - 1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03; ps = ps * z - 1.66666666666666324348e-01;
+    const double s0 = r + r * z * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09; pc = pc * z - 2.75573143513906633035e-07; pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z - 1.38888888888741095749e-03; pc = pc * z + 4.16666666666666019037e-02;
+    const double c0 = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)k & 3;
+    sn = (float)((q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0);
+    cs = (float)((q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0);
+}
+}  // namespace
+
+// State::update / propagate_f — reference src/Objects/State.cpp:94-121 (SO3Math::Exp: Utils.hpp:30-53)
+void State::operator+=(const IMU& imu) {
+    const float dt = (float)(imu.time - time);
+    const float wm[3] = {imu.w[0] - bw[0], imu.w[1] - bw[1], imu.w[2] - bw[2]};
+    float E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const float nrm = std::sqrt(dot3(wm[0], wm[0], wm[1], wm[1], wm[2], wm[2]));
+    if ((double)nrm > 0.0000001) {
+        const float r[3] = {wm[0] / nrm, wm[1] / nrm, wm[2] / nrm};
+        const float K[9] = {0.f, -r[2], r[1], r[2], 0.f, -r[0], -r[1], r[0], 0.f};
+        float sn, cs;
+        sincos_f32(nrm * dt, sn, cs);
+        const float c = (float)(1.0 - (double)cs);
+        float cK[9], cKK[9];
+        for (int i = 0; i < 9; ++i) cK[i] = c * K[i];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) cKK[i * 3 + j] = dot3(cK[i * 3], K[j], cK[i * 3 + 1], K[3 + j], cK[i * 3 + 2], K[6 + j]);
+        for (int i = 0; i < 9; ++i) E[i] = (E[i] + sn * K[i]) + cKK[i];
+    }
+    float Rn[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = dot3(R[i * 3], E[j], R[i * 3 + 1], E[3 + j], R[i * 3 + 2], E[6 + j]);
+    const float am[3] = {imu.a[0] - ba[0], imu.a[1] - ba[1], imu.a[2] - ba[2]};
+    float veln[3], posn[3];
+    for (int i = 0; i < 3; ++i) {
+        const float v = dot3(R[i * 3], am[0], R[i * 3 + 1], am[1], R[i * 3 + 2], am[2]) - g[i];
+        veln[i] = vel[i] + v * dt;
+        posn[i] = pos[i] + (vel[i] * dt + ((0.5f * v) * dt) * dt);
+    }
+    for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    for (int i = 0; i < 3; ++i) { vel[i] = veln[i]; pos[i] = posn[i]; }
+    time = imu.time;
+    for (int i = 0; i < 3; ++i) { a[i] = 0.5f * a[i] + 0.5f * imu.a[i]; w[i] = 0.5f * w[i] + 0.5f * imu.w[i]; }
+}
+
+lv_motion_state State::motion() const {
+    lv_motion_state m;
+    std::memset(&m, 0, sizeof(m));
+    std::memcpy(m.R, R, sizeof(m.R)); std::memcpy(m.pos, pos, sizeof(m.pos)); std::memcpy(m.vel, vel, sizeof(m.vel));
+    std::memcpy(m.bw, bw, sizeof(m.bw)); std::memcpy(m.ba, ba, sizeof(m.ba)); std::memcpy(m.g, g, sizeof(m.g));
+    std::memcpy(m.RLI, RLI, sizeof(m.RLI)); std::memcpy(m.tLI, tLI, sizeof(m.tLI));
+    std::memcpy(m.a, a, sizeof(m.a)); std::memcpy(m.w, w, sizeof(m.w));
+    m.time = time;
+    return m;
+}
+
+// ---- Compensator (reference src/Modules/Compensator.cpp:123-163) -----------------------------------------
+Points Compensator::compensate(const States& states, const State& Xt2, const Points& points, float downsample_prec) {
+    Points out;
+    if (points.empty() || states.size() < 2) return out;
+    lv_ctx* c = HipRuntime::ctx();
+    PointVector v = as_vector(points);
+    std::vector<lv_motion_state> ms;
+    ms.reserve(states.size());
+    for (const State& s : states) ms.push_back(s.motion());
+    const lv_motion_state x2 = Xt2.motion();
+    check(lv_scan_deskew(c, v.data(), sizeof(Point), offsetof(Point, time), v.size(), ms.data(), ms.size(), &x2, downsample_prec),
+          "lv_scan_deskew");
+    const size_t n = lv_scan_size(c);
+    std::vector<float> xyz(3 * n);
+    check(lv_scan_fetch(c, xyz.data(), n), "lv_scan_fetch");
+    for (size_t i = 0; i < n; ++i) out.push_back(Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], Xt2.time));
+    return out;
 }
 
 // ---- Mapper (reference src/Modules/Mapper.cpp) ---------------------------------------------------

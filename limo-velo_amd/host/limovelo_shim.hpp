@@ -20,6 +20,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -43,6 +44,7 @@ struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107)
     double LiDAR_noise = 0.001;
     double cov_acc = 1.e-2, cov_gyro = 1.e-4, cov_bias_acc = 1.e-4, cov_bias_gyro = 1.e-5;  // config/params.yaml:39-42
     double full_rotation_time = 0.1;
+    float downsample_prec = 0.5f;
     std::vector<float> initial_gravity = {0.f, 0.f, -9.807f};
     std::vector<float> I_Rotation_L = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     std::vector<float> I_Translation_L = {0, 0, 0};
@@ -111,13 +113,25 @@ class Match {  // reference Objects.hpp:181-190
 };
 typedef std::vector<Match> Matches;
 
-class State {  // f32 mirror of the filter state (reference Objects.hpp:97-137); only the pose members
+class State {  // f32 mirror of the filter state (reference Objects.hpp:97-137), row-major matrices
   public:
-    float R[9], pos[3], RLI[9], tLI[3];
+    float R[9], pos[3], vel[3], bw[3], ba[3], g[3];
+    float RLI[9], tLI[3];
     TimeType time = 0;
-    state_ikfom x;  // the f64 source it was built from
-    State() { std::memset(this, 0, sizeof(*this)); }
+    float a[3], w[3];  // last controls
+    state_ikfom x;     // the f64 source it was built from
+    State();
     State(const state_ikfom& s, double t);
+    void operator+=(const IMU& imu);  // State::update -> propagate_f (State.cpp:94-121); host math for single states
+    lv_motion_state motion() const;   // the record lv_scan_deskew consumes
+};
+typedef std::deque<State> States;
+
+class Compensator {  // reference include/Headers/Compensator.hpp; the Accumulator-bound overloads are host plumbing
+  public:
+    // Compensator::compensate(states, Xt2, points) (Compensator.cpp:123-146) followed by
+    // Compensator::downsample (:104-107,148-163) with leaf = downsample_prec; <= 0 skips the voxel grid
+    Points compensate(const States& states, const State& Xt2, const Points& points, float downsample_prec);
 };
 
 // One GPU context shared by the two singletons (the reference's singletons share the process).

@@ -96,5 +96,6 @@ def test_cpp_shim_builds_with_reference_method_names(capi):
     subprocess.check_call(["make", "-s", "-C", host])
     syms = subprocess.check_output(["nm", "-DC", os.path.join(ROOT, "limo-velo_amd", "liblimovelo_shim.so")], text=True)
     for name in ("Mapper::add(", "Mapper::match(", "Mapper::exists()", "Mapper::size()", "Mapper::hasToMap(",
-                 "Localizator::correct(", "Localizator::calculate_H(", "Localizator::latest_state()"):
+                 "Localizator::correct(", "Localizator::calculate_H(", "Localizator::latest_state()",
+                 "Localizator::propagate_to(", "Localizator::propagate(", "Compensator::compensate(", "State::operator+=("):
         assert name in syms, name
