@@ -11,6 +11,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch ships its own ROCm runtime libraries; when a process uses both torch.cuda and liblimovelo_hip.so,
+    # torch's runtime has to be initialised FIRST (the later-loaded copy reuses the already-loaded libamdhip64;
+    # the other order leaves torch without devices).  bench.py imports torch first for the same reason.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
