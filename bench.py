@@ -38,13 +38,13 @@ def b_alg(m: int) -> int:
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per match_reduce_kernel launch from the committed rocprofv3 PMC pass of this same
-    command (profiles/pmc_match_reduce_*.json, produced by scripts/gpu_profile.sh).  Per
+    """HBM bytes per launch of the dominant kernel (lv::search_kernel) from the committed rocprofv3 PMC pass
+    of this same command (profiles/pmc_search_*.json, produced by scripts/gpu_profile.sh).  Per
     MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE reports half of
     the bytes of wide coalesced reads, so it is doubled.  None if no PMC summary is committed."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_match_reduce_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_search_*.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -206,7 +206,7 @@ def main() -> None:
             "knn_mpts_per_s": n_local * world / avg_kernel_s / 1e6 if avg_kernel_s > 0 else None,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "lv::match_reduce_kernel",
+                "kernel": "lv::search_kernel" if os.environ.get("LV_FUSED", "0") in ("", "0") else "lv::match_reduce_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -216,6 +216,7 @@ def main() -> None:
                 "alg_bytes_per_launch": alg_bytes,
                 "alg_bytes_per_point_pass": b_alg(M_POINTS),
                 "avg_kernel_us": avg_kernel_s * 1e6,
+                "avg_fit_plus_solve_us": solve_ms / max(kern_cnt, 1) * 1e3,
                 "avg_solve_us": solve_ms / max(kern_cnt, 1) * 1e3,
                 "last_update_match_us_per_pass": [round(v * 1e3, 1) for v in ctx.timing()["pass_match_ms"][:4]],
             },

@@ -48,6 +48,10 @@ struct lv_ctx {
     double* h_sums = nullptr;  // pinned
     int max_blocks = 1024;
     int grid = 1;
+    bool fold_direct = false;      // this pass: solve_kernel reads the block partials directly
+    bool split = true;             // search_kernel + fit_reduce_kernel (default) or the fused match_reduce_kernel
+    float4* d_qrec = nullptr;      // split form: 8 float4 planes of qstride entries (one record per scan point)
+    uint32_t qstride = 0;
 
     // capture (debug / API-parity) buffers, sized for the current scan
     bool capture = false;
@@ -141,7 +145,17 @@ void unpack_sums(const double* rec, lv_sums* out) {
 int begin_device(lv_ctx* c) {
     int rc = launch_kf_begin(c->stream, c->d_kf);
     if (rc) return rc;
-    c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks);
+    c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks, c->split);
+    if (c->split && (uint32_t)c->scan.n > c->qstride) {
+        uint32_t cap = c->qstride ? c->qstride : 4096;
+        while (cap < (uint32_t)c->scan.n) cap *= 2;
+        LV_HIP(hipStreamSynchronize(c->stream));
+        hipFree(c->d_qrec);
+        c->d_qrec = nullptr;
+        c->qstride = 0;
+        LV_HIP(hipMalloc(&c->d_qrec, (size_t)cap * 8 * sizeof(float4)));
+        c->qstride = cap;
+    }
     return LV_OK;
 }
 
@@ -173,11 +187,26 @@ int pass_reduce(lv_ctx* c, bool finalize) {
     if (c->phase_clocks) {
         if (!c->d_clk) LV_HIP(hipMalloc(&c->d_clk, (size_t)(c->max_blocks + 8) * 16 * sizeof(long long)));
         dbg.clk = c->d_clk;
+        dbg.clk_blocks = c->grid;
     }
-    int rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
+    int rc;
+    if (c->split) {
+        rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
+                           c->qstride, dbg);
+        if (rc) return rc;
+        if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
+        rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
+        if (rc) return rc;
+    } else {
+        rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
                                  c->d_partials, c->grid, dbg);
-    if (rc) return rc;
-    if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));
+        if (rc) return rc;
+        if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));
+    }
+    // few enough block partials (a 64k-point scan leaves 256): solve_kernel folds them itself in one memory
+    // round trip; otherwise stage 1 of the reduction runs as its own kernel
+    c->fold_direct = !finalize && c->grid <= solve_direct_records();
+    if (c->fold_direct) return LV_OK;
     rc = launch_reduce_groups(c->stream, c->d_partials, c->grid, c->d_groups, &c->ngroups, c->d_kf);
     if (rc) return rc;
     if (finalize) return launch_reduce_final(c->stream, c->d_groups, c->ngroups, c->d_sums, c->d_kf);
@@ -191,6 +220,7 @@ int pass_solve(lv_ctx* c, bool from_groups) {
     for (int i = 0; i < NS; ++i) sp.limits[i] = c->prm.LIMITS[i];
     sp.maximum_iter = c->prm.MAX_NUM_ITERS;
     sp.estimate_extrinsics = c->prm.estimate_extrinsics;
+    if (from_groups && c->fold_direct) return launch_solve(c->stream, c->d_kf, c->d_partials, c->grid, c->d_sums, sp);
     if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_groups, c->ngroups, c->d_sums, sp);
     return launch_solve(c->stream, c->d_kf, c->d_sums, 1, nullptr, sp);
 }
@@ -239,6 +269,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipGetDeviceProperties(&prop, device));
     int per_cu = 4;
     if (const char* e = getenv("LV_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;  // tuning knob
+    if (const char* e = getenv("LV_FUSED")) c->split = atoi(e) == 0;                      // A/B knob: fused match kernel
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -276,7 +307,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_filter) hipHostFree(c->h_filter);
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
-    hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
+    hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (auto ev : c->ev_pass) hipEventDestroy(ev);

@@ -15,6 +15,7 @@ constexpr int KNN = 5;              // NUM_MATCH_POINTS (config/params.yaml:48)
 constexpr int NS = 23;              // state dof
 constexpr int NX = 26;              // state doubles (lv_state)
 constexpr int SUMS_LEN = 96;        // per-pass reduction record (include/limovelo_hip.h)
+constexpr int PARTIAL_GROUP = 32;  // block partials folded per group record (stage 1 of the reduction)
 constexpr int N_OUT = 92;           // used entries of the record
 constexpr int CELL_OFFSET = 1 << 20;
 constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-force path
@@ -102,6 +103,7 @@ struct DebugOut {  // all optional (nullptr = skip); indexed by ORIGINAL scan in
     double* rows;       // N x 12
     double* h;          // N
     long long* clk;     // instrumentation: 8 shader-clock stamps per workgroup (first block iteration)
+    int clk_blocks;     // workgroups that have a stamp slot (wall-clock records follow at clk + clk_blocks * 8)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -71,12 +71,20 @@ struct MapStore {
 };
 
 // lv_match.hip
+// split form (default): search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride
+// entries), fit_reduce_kernel turns them into `grid` block partials
+int launch_search(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
+                  float4* qrec, uint32_t qstride, const DebugOut& dbg);
+int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
+                      double* partials, int grid, const DebugOut& dbg);
+// fused form (LV_FUSED=1, A/B reference)
 int launch_match_reduce(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n,
                         KfDev* kf, const MatchParams& prm, double* partials, int grid, const DebugOut& dbg);
-int match_grid_size(int lanes_per_query, uint32_t n, int max_blocks);
+int match_grid_size(int lanes_per_query, uint32_t n, int max_blocks, bool split);
 // lv_solve.hip
 int launch_kf_begin(hipStream_t stream, KfDev* kf);
 int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf);
+int solve_direct_records();  // most records solve_kernel folds in one round trip
 int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf);
 struct SolveParams {
     double R;

@@ -298,6 +298,138 @@ __device__ __forceinline__ void out_pair(int t, int& a, int& b, int& rec) {
     }
 }
 
+// Exact 5-NN of the world point (qx, qy, qz): executed by the S lanes of a lane group (gl = lane in group).
+// On return every lane of the group holds the same sorted keys k[]; src >= 0: bucket level the winners came
+// from (key low word = position inside the bucket starting at bstart), src < 0: generic path (low word =
+// original map index).  clk != nullptr (DBG builds): phase-stamp slot of this workgroup.
+template <int S, bool DBG>
+__device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
+                                           kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist) {
+    if (map.m == 0) return;
+    const float tx = (qx - map.origin[0]) * map.inv_cell, ty = (qy - map.origin[1]) * map.inv_cell,
+                tz = (qz - map.origin[2]) * map.inv_cell;
+    const int c0x = cell_coord(qx, map.origin[0], map.inv_cell);
+    const int c0y = cell_coord(qy, map.origin[1], map.inv_cell);
+    const int c0z = cell_coord(qz, map.origin[2], map.inv_cell);
+    const int amax = max(abs(c0x - CELL_OFFSET), max(abs(c0y - CELL_OFFSET), abs(c0z - CELL_OFFSET)));
+    const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
+    const bool in_range = finite && amax < CELL_FAR;
+    bool decided = false;
+    int level = in_range ? 0 : map.n_levels;
+    // guaranteed search radius of the 27-voxel block at `lvl` for THIS query: one voxel edge
+    // plus the distance to the nearest wall of its own voxel, shrunk by 1e-3 relative and by
+    // the f32 rounding bound of the voxel coordinates (see file header).
+    auto radius = [&](int lvl) -> float {
+        const float scale = (float)(1 << lvl);
+        const float bx = (float)((((c0x >> lvl) << lvl)) - CELL_OFFSET), by = (float)((((c0y >> lvl) << lvl)) - CELL_OFFSET),
+                    bz = (float)((((c0z >> lvl) << lvl)) - CELL_OFFSET);
+        const float mx = fminf(tx - bx, scale - (tx - bx)), my = fminf(ty - by, scale - (ty - by)),
+                    mz = fminf(tz - bz, scale - (tz - bz));
+        const float marg = fmaxf(fminf(mx, fminf(my, mz)), 0.f);
+        return map.cell * ((scale + marg) * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)amax + 2.f * scale));
+    };
+    // fast path: per level ONE probe of the bucket table and ONE coalesced stream over the
+    // neighbourhood bucket.  A miss means the whole 27-voxel block is empty.
+    if (in_range) {
+        for (int bl = 0; bl < map.n_bucket_levels && !decided; ++bl) {
+            const GridLevel g = map.bt[bl];
+            const uint64_t key = pack_cell((uint32_t)(c0x >> bl), (uint32_t)(c0y >> bl), (uint32_t)(c0z >> bl));
+            uint32_t slot = hash_cell(key, g.shift) & g.mask;
+            uint32_t bcount = 0;
+            for (;;) {
+                const uint4 e = g.table[slot];
+                const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                if (ek == key) { bstart = e.z; bcount = e.w; break; }
+                if (ek == EMPTY_KEY) break;
+                slot = (slot + 1) & g.mask;
+            }
+            level = bl + 1;
+            if (DBG && clk && bl == 0) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
+            if (bcount >= KNN) {
+                constexpr int U = 8;
+                const float4* __restrict__ bp = map.bucket[bl] + bstart;
+                for (uint32_t base = 0; base < bcount; base += S * U) {
+                    float4 mpt[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t j = base + (uint32_t)(u * S + gl);
+                        mpt[u] = bp[j < bcount ? j : 0];
+                    }
+#ifdef LV_FINE_STAMPS
+                    if (DBG && clk && bl == 0 && base == 0) { asm volatile("" :: "v"(mpt[0].x), "v"(mpt[7].x), "v"(mpt[3].x), "v"(mpt[5].x)); clk[3] = clock64(); }
+#endif
+                    kkey ck[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t j = base + (uint32_t)(u * S + gl);
+                        ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
+                    }
+                    sort8(ck);
+                    merge5(k, ck);
+#ifdef LV_FINE_STAMPS
+                    if (DBG && clk && bl == 0 && base == 0) { asm volatile("" :: "v"(k[0]), "v"(k[4])); clk[4] = clock64(); }
+#endif
+                }
+#ifdef LV_FINE_STAMPS
+                if (DBG && clk && bl == 0) { asm volatile("" :: "v"(k[0]), "v"(k[4])); clk[5] = clock64(); }
+#endif
+                merge_group<S>(k);
+#ifdef LV_FINE_STAMPS
+                if (DBG && clk && bl == 0) { asm volatile("" :: "v"(k[0]), "v"(k[4])); clk[6] = clock64(); }
+#endif
+                const float r = radius(bl);
+                const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+                if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
+                    decided = true;
+                    src = bl;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+                }
+            }
+        }
+    }
+    const bool fell_back = !decided;
+    while (!decided) {  // generic path: 27 probes per level over the Morton-sorted array, then brute force
+        if (level < map.n_levels) {
+            const GridLevel gl_ = map.lv[level];
+            const int clx = c0x >> level, cly = c0y >> level, clz = c0z >> level;
+            for (int c = gl; c < 27; c += S) {
+                const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+                const uint32_t nx = (uint32_t)(clx + dx), ny = (uint32_t)(cly + dy), nz = (uint32_t)(clz + dz);
+                if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) continue;
+                const uint64_t key = pack_cell(nx, ny, nz);
+                uint32_t slot = hash_cell(key, gl_.shift) & gl_.mask;
+                uint32_t start = 0, count = 0;
+                for (;;) {
+                    const uint4 e = gl_.table[slot];
+                    const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                    if (ek == key) { start = e.z; count = e.w; break; }
+                    if (ek == EMPTY_KEY) break;
+                    slot = (slot + 1) & gl_.mask;
+                }
+                scan_range(map.sorted, start, count, qx, qy, qz, k);
+            }
+            merge_group<S>(k);
+            const float r = radius(level);
+            const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+            if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
+                decided = true;
+            } else {
+#pragma unroll
+                for (int j = 0; j < KNN; ++j) k[j] = none_key();
+                ++level;
+            }
+        } else {
+            for (uint32_t j = gl; j < map.m; j += S) scan_range(map.sorted, j, 1, qx, qy, qz, k);
+            merge_group<S>(k);
+            decided = true;
+        }
+    }
+    if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
+    if (DBG && hist && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
+}
+
 struct QueryStage {     // kNN result of one scan point, handed from the search lanes to the fit lane
     float qx, qy, qz;
     uint32_t oq;        // original scan index
@@ -307,6 +439,100 @@ struct QueryStage {     // kNN result of one scan point, handed from the search 
     int src;            // bucket level the winners came from, -1 = generic path (pos = map index)
     int found;
 };
+
+// Plane fit + gates + Jacobian row of ONE scan point (one lane): Plane.cpp:19-55, Utils.cpp:32-66,
+// Match.cpp:18-22, Localizator.cpp:36-56.  P / nidx / dbits: the 5 nearest map points in (distance, index)
+// order; found < 0 marks a padding lane.  The row {J[0..W), h, valid} goes to srow (LDS).
+template <int W, bool EXT, bool DBG>
+__device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams& prm, const DebugOut& dbg, int found,
+                                        const float (&P)[KNN][3], const uint32_t (&nidx)[KNN], const uint32_t (&dbits)[KNN],
+                                        float qx, float qy, float qz, uint32_t oq, double* srow) {
+    double row[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) row[i] = 0.0;
+    double hres = 0.0;
+    bool chosen = false;
+    float abcd[4] = {0.f, 0.f, 0.f, 0.f};
+    float dist = 0.f;
+    if (found >= KNN) {                                                   // Plane.cpp:36-38
+        const float d5 = __uint_as_float(dbits[KNN - 1]);
+        if ((double)d5 < prm.max_dist_plane_sq) {                         // Plane.cpp:40-43
+            float A[KNN][3];
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) { A[j][0] = P[j][0]; A[j][1] = P[j][1]; A[j][2] = P[j][2]; }
+            float nv[3];
+            plane_qr_solve(A, nv);                                        // Utils.cpp:47
+            const float nrm = sqrtf(dot3f(nv[0], nv[0], nv[1], nv[1], nv[2], nv[2]));  // Utils.cpp:50
+            const float e0 = nv[0] / nrm, e1 = nv[1] / nrm, e2 = nv[2] / nrm;
+            const float e3 = (float)(1.0 / (double)nrm);                  // Utils.cpp:54
+            bool ok = true;                                               // Utils.cpp:59-66
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) {
+                const float res = e0 * P[j][0] + e1 * P[j][1] + e2 * P[j][2] + e3;
+                if (fabsf(res) > prm.planes_threshold) ok = false;
+            }
+            if (ok) {
+                chosen = true;
+                abcd[0] = e0; abcd[1] = e1; abcd[2] = e2; abcd[3] = e3;
+                dist = e0 * qx + e1 * qy + e2 * qz + e3;                  // Plane.cpp:27-29, Match.cpp:21
+            }
+        }
+    }
+    // ---- Localizator::calculate_H row (Localizator.cpp:36-56) ------------------------------
+    if (chosen) {
+        float plx, ply, plz, pix, piy, piz;
+        rt_apply(pc.back, qx, qy, qz, plx, ply, plz);                     // :38
+        rt_apply(pc.LI, plx, ply, plz, pix, piy, piz);                    // :39
+        const double n0 = (double)abcd[0], n1 = (double)abcd[1], n2 = (double)abcd[2];
+        const double* Ri = pc.R_inv;
+        const double C0 = dot3d(Ri[0], n0, Ri[1], n1, Ri[2], n2);         // :47
+        const double C1 = dot3d(Ri[3], n0, Ri[4], n1, Ri[5], n2);
+        const double C2 = dot3d(Ri[6], n0, Ri[7], n1, Ri[8], n2);
+        const double ix = (double)pix, iy = (double)piy, iz = (double)piz;
+        row[0] = n0; row[1] = n1; row[2] = n2;                            // :51
+        row[3] = iy * C2 - iz * C1;                                       // A = p_imu x C  :49
+        row[4] = iz * C0 - ix * C2;
+        row[5] = ix * C1 - iy * C0;
+        if (EXT) {                                                        // :52
+            const double* Li = pc.I_R_L_inv;
+            const double t0 = dot3d(Li[0], C0, Li[1], C1, Li[2], C2);
+            const double t1 = dot3d(Li[3], C0, Li[4], C1, Li[5], C2);
+            const double t2 = dot3d(Li[6], C0, Li[7], C1, Li[8], C2);
+            const double lx = (double)plx, ly = (double)ply, lz = (double)plz;
+            row[W - 6] = ly * t2 - lz * t1;                               // B = p_lidar x (I_R_L_inv C)  :48
+            row[W - 5] = lz * t0 - lx * t2;
+            row[W - 4] = lx * t1 - ly * t0;
+            row[W - 3] = C0; row[W - 2] = C1; row[W - 1] = C2;
+        }
+        hres = -(double)dist;                                             // :55
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) srow[j] = row[j];
+    srow[W] = hres;
+    srow[W + 1] = chosen ? 1.0 : 0.0;
+    if (DBG && found >= 0) {
+        if (dbg.knn_idx) {
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) {
+                const bool have = j < found;
+                dbg.knn_idx[(size_t)oq * KNN + j] = have ? nidx[j] : 0xFFFFFFFFu;
+                dbg.knn_d2[(size_t)oq * KNN + j] = have ? __uint_as_float(dbits[j]) : __uint_as_float(0x7f800000u);
+            }
+        }
+        if (dbg.valid) dbg.valid[oq] = chosen ? 1 : 0;
+        if (dbg.p_world) { dbg.p_world[(size_t)oq * 3] = qx; dbg.p_world[(size_t)oq * 3 + 1] = qy; dbg.p_world[(size_t)oq * 3 + 2] = qz; }
+        if (dbg.abcd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dbg.abcd[(size_t)oq * 4 + j] = abcd[j];
+        }
+        if (dbg.dist) dbg.dist[oq] = dist;
+        if (dbg.rows) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) dbg.rows[(size_t)oq * 12 + j] = (j < W) ? row[j < W ? j : 0] : 0.0;
+            dbg.h[oq] = hres;
+        }
+    }
+}
 
 #ifndef LV_MATCH_BOUNDS
 #define LV_MATCH_BOUNDS __launch_bounds__(256)
@@ -348,8 +574,9 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
 #define LV_STAMP(i) do { if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t qbase = (it * gridDim.x + vb) * (uint32_t)G;
-        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(gridDim.x + blockIdx.x) * 8 + 0] = wall_clock64();
+        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 0] = wall_clock64();
         LV_STAMP(0);
+        long long* stamp_slot = (DBG && dbg.clk && tid == 0 && it == 0) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
         // ================= phase 1: S lanes per scan point — exact 5-NN =========================
 #pragma unroll 1
         for (int sub = 0; sub < SUB; ++sub) {
@@ -366,118 +593,7 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
                 oq = __float_as_uint(sp.w);
                 rt_apply(pc.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
                 if (DBG && dbg.clk) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); LV_STAMP(1); }
-                if (map.m > 0) {
-                    const float tx = (qx - map.origin[0]) * map.inv_cell, ty = (qy - map.origin[1]) * map.inv_cell,
-                                tz = (qz - map.origin[2]) * map.inv_cell;
-                    const int c0x = cell_coord(qx, map.origin[0], map.inv_cell);
-                    const int c0y = cell_coord(qy, map.origin[1], map.inv_cell);
-                    const int c0z = cell_coord(qz, map.origin[2], map.inv_cell);
-                    const int amax = max(abs(c0x - CELL_OFFSET), max(abs(c0y - CELL_OFFSET), abs(c0z - CELL_OFFSET)));
-                    const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
-                    const bool in_range = finite && amax < CELL_FAR;
-                    bool decided = false;
-                    int level = in_range ? 0 : map.n_levels;
-                    // guaranteed search radius of the 27-voxel block at `lvl` for THIS query: one voxel edge
-                    // plus the distance to the nearest wall of its own voxel, shrunk by 1e-3 relative and by
-                    // the f32 rounding bound of the voxel coordinates (see file header).
-                    auto radius = [&](int lvl) -> float {
-                        const float scale = (float)(1 << lvl);
-                        const float bx = (float)((((c0x >> lvl) << lvl)) - CELL_OFFSET), by = (float)((((c0y >> lvl) << lvl)) - CELL_OFFSET),
-                                    bz = (float)((((c0z >> lvl) << lvl)) - CELL_OFFSET);
-                        const float mx = fminf(tx - bx, scale - (tx - bx)), my = fminf(ty - by, scale - (ty - by)),
-                                    mz = fminf(tz - bz, scale - (tz - bz));
-                        const float marg = fmaxf(fminf(mx, fminf(my, mz)), 0.f);
-                        return map.cell * ((scale + marg) * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)amax + 2.f * scale));
-                    };
-                    // fast path: per level ONE probe of the bucket table and ONE coalesced stream over the
-                    // neighbourhood bucket.  A miss means the whole 27-voxel block is empty.
-                    if (in_range) {
-                        for (int bl = 0; bl < map.n_bucket_levels && !decided; ++bl) {
-                            const GridLevel g = map.bt[bl];
-                            const uint64_t key = pack_cell((uint32_t)(c0x >> bl), (uint32_t)(c0y >> bl), (uint32_t)(c0z >> bl));
-                            uint32_t slot = hash_cell(key, g.shift) & g.mask;
-                            uint32_t bcount = 0;
-                            for (;;) {
-                                const uint4 e = g.table[slot];
-                                const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                                if (ek == key) { bstart = e.z; bcount = e.w; break; }
-                                if (ek == EMPTY_KEY) break;
-                                slot = (slot + 1) & g.mask;
-                            }
-                            level = bl + 1;
-                            if (DBG && dbg.clk && bl == 0) { asm volatile("" :: "v"(bcount)); LV_STAMP(2); }
-                            if (bcount >= KNN) {
-                                constexpr int U = 8;
-                                const float4* __restrict__ bp = map.bucket[bl] + bstart;
-                                for (uint32_t base = 0; base < bcount; base += S * U) {
-                                    float4 mpt[U];
-#pragma unroll
-                                    for (int u = 0; u < U; ++u) {
-                                        const uint32_t j = base + (uint32_t)(u * S + gl);
-                                        mpt[u] = bp[j < bcount ? j : 0];
-                                    }
-                                    kkey ck[U];
-#pragma unroll
-                                    for (int u = 0; u < U; ++u) {
-                                        const uint32_t j = base + (uint32_t)(u * S + gl);
-                                        ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
-                                    }
-                                    sort8(ck);
-                                    merge5(k, ck);
-                                }
-                                merge_group<S>(k);
-                                const float r = radius(bl);
-                                const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-                                if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
-                                    decided = true;
-                                    src = bl;
-                                } else {
-#pragma unroll
-                                    for (int j = 0; j < KNN; ++j) k[j] = none_key();
-                                }
-                            }
-                        }
-                    }
-                    const bool fell_back = !decided;
-                    while (!decided) {  // generic path: 27 probes per level over the Morton-sorted array, then brute force
-                        if (level < map.n_levels) {
-                            const GridLevel gl_ = map.lv[level];
-                            const int clx = c0x >> level, cly = c0y >> level, clz = c0z >> level;
-                            for (int c = gl; c < 27; c += S) {
-                                const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
-                                const uint32_t nx = (uint32_t)(clx + dx), ny = (uint32_t)(cly + dy), nz = (uint32_t)(clz + dz);
-                                if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) continue;
-                                const uint64_t key = pack_cell(nx, ny, nz);
-                                uint32_t slot = hash_cell(key, gl_.shift) & gl_.mask;
-                                uint32_t start = 0, count = 0;
-                                for (;;) {
-                                    const uint4 e = gl_.table[slot];
-                                    const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                                    if (ek == key) { start = e.z; count = e.w; break; }
-                                    if (ek == EMPTY_KEY) break;
-                                    slot = (slot + 1) & gl_.mask;
-                                }
-                                scan_range(map.sorted, start, count, qx, qy, qz, k);
-                            }
-                            merge_group<S>(k);
-                            const float r = radius(level);
-                            const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-                            if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
-                                decided = true;
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < KNN; ++j) k[j] = none_key();
-                                ++level;
-                            }
-                        } else {
-                            for (uint32_t j = gl; j < map.m; j += S) scan_range(map.sorted, j, 1, qx, qy, qz, k);
-                            merge_group<S>(k);
-                            decided = true;
-                        }
-                    }
-                    if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
-                    if (DBG && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
-                }
+                knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
             }
             if (DBG && dbg.clk) { asm volatile("" :: "v"(k[0]), "v"(k[4])); LV_STAMP(3); }
             if (gl == 0) {
@@ -502,108 +618,20 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
         // ================= phase 2: one lane per scan point — plane fit, gates, Jacobian row ==========
         if (tid < G) {
             const QueryStage st = s_q[tid];
-            double row[W];
-#pragma unroll
-            for (int i = 0; i < W; ++i) row[i] = 0.0;
-            double hres = 0.0;
-            bool chosen = false;
-            float abcd[4] = {0.f, 0.f, 0.f, 0.f};
-            float dist = 0.f;
-            const float qx = st.qx, qy = st.qy, qz = st.qz;
+            float P[KNN][3];
             uint32_t nidx[KNN];
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) nidx[j] = 0xFFFFFFFFu;
-            if (st.found >= KNN) {                                                // Plane.cpp:36-38
-                float P[KNN][3];
-#pragma unroll
-                for (int j = 0; j < KNN; ++j) {
+            for (int j = 0; j < KNN; ++j) {
+                nidx[j] = 0xFFFFFFFFu;
+                P[j][0] = P[j][1] = P[j][2] = 0.f;
+                if (j < st.found) {
                     float4 nb;
                     if (st.src >= 0) { nb = map.bucket[st.src][(size_t)st.bstart + st.pos[j]]; nidx[j] = __float_as_uint(nb.w); }
                     else { nb = map.orig[st.pos[j]]; nidx[j] = st.pos[j]; }
                     P[j][0] = nb.x; P[j][1] = nb.y; P[j][2] = nb.z;
                 }
-                const float d5 = __uint_as_float(st.dbits[KNN - 1]);
-                if ((double)d5 < prm.max_dist_plane_sq) {                         // Plane.cpp:40-43
-                    float A[KNN][3];
-#pragma unroll
-                    for (int j = 0; j < KNN; ++j) { A[j][0] = P[j][0]; A[j][1] = P[j][1]; A[j][2] = P[j][2]; }
-                    float nv[3];
-                    plane_qr_solve(A, nv);                                        // Utils.cpp:47
-                    const float nrm = sqrtf(dot3f(nv[0], nv[0], nv[1], nv[1], nv[2], nv[2]));  // Utils.cpp:50
-                    const float e0 = nv[0] / nrm, e1 = nv[1] / nrm, e2 = nv[2] / nrm;
-                    const float e3 = (float)(1.0 / (double)nrm);                  // Utils.cpp:54
-                    bool ok = true;                                               // Utils.cpp:59-66
-#pragma unroll
-                    for (int j = 0; j < KNN; ++j) {
-                        const float res = e0 * P[j][0] + e1 * P[j][1] + e2 * P[j][2] + e3;
-                        if (fabsf(res) > prm.planes_threshold) ok = false;
-                    }
-                    if (ok) {
-                        chosen = true;
-                        abcd[0] = e0; abcd[1] = e1; abcd[2] = e2; abcd[3] = e3;
-                        dist = e0 * qx + e1 * qy + e2 * qz + e3;                  // Plane.cpp:27-29, Match.cpp:21
-                    }
-                }
-            } else if (DBG && st.found > 0) {
-#pragma unroll
-                for (int j = 0; j < KNN; ++j)
-                    if (j < st.found) nidx[j] = st.src >= 0 ? __float_as_uint(map.bucket[st.src][(size_t)st.bstart + st.pos[j]].w) : st.pos[j];
             }
-            // ---- Localizator::calculate_H row (Localizator.cpp:36-56) ------------------------------
-            if (chosen) {
-                float plx, ply, plz, pix, piy, piz;
-                rt_apply(pc.back, qx, qy, qz, plx, ply, plz);                     // :38
-                rt_apply(pc.LI, plx, ply, plz, pix, piy, piz);                    // :39
-                const double n0 = (double)abcd[0], n1 = (double)abcd[1], n2 = (double)abcd[2];
-                const double* Ri = pc.R_inv;
-                const double C0 = dot3d(Ri[0], n0, Ri[1], n1, Ri[2], n2);         // :47
-                const double C1 = dot3d(Ri[3], n0, Ri[4], n1, Ri[5], n2);
-                const double C2 = dot3d(Ri[6], n0, Ri[7], n1, Ri[8], n2);
-                const double ix = (double)pix, iy = (double)piy, iz = (double)piz;
-                row[0] = n0; row[1] = n1; row[2] = n2;                            // :51
-                row[3] = iy * C2 - iz * C1;                                       // A = p_imu x C  :49
-                row[4] = iz * C0 - ix * C2;
-                row[5] = ix * C1 - iy * C0;
-                if (EXT) {                                                        // :52
-                    const double* Li = pc.I_R_L_inv;
-                    const double t0 = dot3d(Li[0], C0, Li[1], C1, Li[2], C2);
-                    const double t1 = dot3d(Li[3], C0, Li[4], C1, Li[5], C2);
-                    const double t2 = dot3d(Li[6], C0, Li[7], C1, Li[8], C2);
-                    const double lx = (double)plx, ly = (double)ply, lz = (double)plz;
-                    row[W - 6] = ly * t2 - lz * t1;                               // B = p_lidar x (I_R_L_inv C)  :48
-                    row[W - 5] = lz * t0 - lx * t2;
-                    row[W - 4] = lx * t1 - ly * t0;
-                    row[W - 3] = C0; row[W - 2] = C1; row[W - 1] = C2;
-                }
-                hres = -(double)dist;                                             // :55
-            }
-#pragma unroll
-            for (int j = 0; j < W; ++j) s_rows[tid][j] = row[j];
-            s_rows[tid][W] = hres;
-            s_rows[tid][W + 1] = chosen ? 1.0 : 0.0;
-            if (DBG && st.found >= 0) {
-                const uint32_t oq = st.oq;
-                if (dbg.knn_idx) {
-#pragma unroll
-                    for (int j = 0; j < KNN; ++j) {
-                        const bool have = j < st.found;
-                        dbg.knn_idx[(size_t)oq * KNN + j] = have ? nidx[j] : 0xFFFFFFFFu;
-                        dbg.knn_d2[(size_t)oq * KNN + j] = have ? __uint_as_float(st.dbits[j]) : __uint_as_float(0x7f800000u);
-                    }
-                }
-                if (dbg.valid) dbg.valid[oq] = chosen ? 1 : 0;
-                if (dbg.p_world) { dbg.p_world[(size_t)oq * 3] = qx; dbg.p_world[(size_t)oq * 3 + 1] = qy; dbg.p_world[(size_t)oq * 3 + 2] = qz; }
-                if (dbg.abcd) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dbg.abcd[(size_t)oq * 4 + j] = abcd[j];
-                }
-                if (dbg.dist) dbg.dist[oq] = dist;
-                if (dbg.rows) {
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) dbg.rows[(size_t)oq * 12 + j] = (j < W) ? row[j < W ? j : 0] : 0.0;
-                    dbg.h[oq] = hres;
-                }
-            }
+            fit_row<W, EXT, DBG>(pc, prm, dbg, st.found, P, nidx, st.dbits, st.qx, st.qy, st.qz, st.oq, s_rows[tid]);
         }
         __syncthreads();
         LV_STAMP(6);
@@ -614,7 +642,7 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
         }
         __syncthreads();
         LV_STAMP(7);
-        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(gridDim.x + blockIdx.x) * 8 + 1] = wall_clock64();
+        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 1] = wall_clock64();
     }
 #undef LV_STAMP
     if (tid < NOUT) s_out[orec] = acc;
@@ -622,9 +650,173 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
     if (tid < SUMS_LEN) partials[(size_t)blockIdx.x * SUMS_LEN + tid] = s_out[tid];
 }
 
-int match_grid_size(int S, uint32_t n, int max_blocks) {
+// ------------------------------------------------------------------------------------------------------
+// Split form of the pass (default): the search and the fit have very different register needs (the search
+// wants many waves in flight to hide its dependent loads, the QR fit wants ~100 VGPRs), so each gets its own
+// kernel and register budget.  search_kernel hands one 128-byte record per scan point to fit_reduce_kernel
+// through HBM/L2, slot-major (8 float4 planes of qstride entries) so both sides are coalesced:
+//   slots 0-4  the 5 nearest map points {x, y, z, original index}   (fetched here, while L2-hot)
+//   slot  5    {world x, y, z, original scan index}
+//   slot  6    squared distances 0..3 (bits)      slot 7  {distance 4 (bits), found, -, -}
+constexpr int QREC_SLOTS = 8;
+#ifdef LV_SEARCH_WAVES
+#define LV_SEARCH_BOUNDS __launch_bounds__(256, LV_SEARCH_WAVES)
+#else
+#define LV_SEARCH_BOUNDS __launch_bounds__(256)
+#endif
+
+template <int S, bool DBG>
+__global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
+                                                     KfDev* __restrict__ kf, float4* __restrict__ qrec, uint32_t qstride,
+                                                     DebugOut dbg) {
+    constexpr int GS = 256 / S;
+    if (kf->done) return;
+    const int tid = threadIdx.x;
+    const int gq = tid / S, gl = tid % S;
+    // XCD-aware tile order (see match_reduce_kernel); gridDim.x % 8 == 0
+    const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
+    const uint32_t q = vb * (uint32_t)GS + (uint32_t)gq;
+    long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
+    if (DBG && stamp_slot) { stamp_slot[0] = clock64(); dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 0] = wall_clock64(); }
+    if (q >= n) return;   // whole lane groups leave together
+    kkey k[KNN];
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    uint32_t bstart = 0;
+    int src = -1;
+    const float4 sp = scan[q];
+    float qx, qy, qz;
+    rt_apply(kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
+    if (DBG && stamp_slot) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); stamp_slot[1] = clock64(); }
+    knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
+#ifndef LV_FINE_STAMPS
+    if (DBG && stamp_slot) { asm volatile("" :: "v"(k[0]), "v"(k[4])); stamp_slot[3] = clock64(); }
+#endif
+    int found = 0;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) found += is_none(k[j]) ? 0 : 1;
+#pragma unroll
+    for (int slot0 = 0; slot0 < QREC_SLOTS; slot0 += S) {
+        const int slot = slot0 + gl;
+        if (slot >= QREC_SLOTS) break;
+        float4 v;
+        if (slot < KNN) {
+            kkey kk = k[0];
+#pragma unroll
+            for (int j = 1; j < KNN; ++j) kk = (slot == j) ? k[j] : kk;
+            v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+            if (!is_none(kk)) {
+                const uint32_t pos = key_lo(kk);
+                if (src >= 0) v = map.bucket[src][(size_t)bstart + pos];
+                else { v = map.orig[pos]; v.w = __uint_as_float(pos); }
+            }
+        } else if (slot == 5) {
+            v = make_float4(qx, qy, qz, sp.w);
+        } else if (slot == 6) {
+            v = make_float4(__uint_as_float(key_hi(k[0])), __uint_as_float(key_hi(k[1])), __uint_as_float(key_hi(k[2])),
+                            __uint_as_float(key_hi(k[3])));
+        } else {
+            v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(found), 0.f, 0.f);
+        }
+        qrec[(size_t)slot * qstride + q] = v;
+    }
+#ifdef LV_FINE_STAMPS
+    if (DBG && stamp_slot) stamp_slot[7] = clock64();
+#else
+    if (DBG && stamp_slot) stamp_slot[4] = clock64();
+#endif
+    if (DBG && stamp_slot) { dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 1] = wall_clock64(); }
+}
+
+// One lane per scan point: fit + row (fit_row); each of the workgroup's 4 wavefronts then contracts its own 64
+// staged rows in f64, and the 4 wave sums are combined in a fixed order into the block partial: FIT_POINTS
+// scan points per workgroup iteration, so a 64k-point scan leaves 256 partials that solve_kernel folds itself.
+constexpr int FIT_POINTS = 256;
+template <bool EXT, bool DBG>
+__global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __restrict__ qrec, uint32_t qstride, uint32_t n,
+                                                                KfDev* __restrict__ kf, MatchParams prm,
+                                                                double* __restrict__ partials, DebugOut dbg) {
+    constexpr int G = FIT_POINTS;
+    constexpr int NWAVE = G / 64;
+    constexpr int W = EXT ? 12 : 6;
+    constexpr int ROW_W = W + 2;
+    constexpr int NOUT = W * (W + 1) / 2 + W + 2;
+    constexpr int NACC = (NOUT + 63) / 64;
+    __shared__ double s_rows[G][ROW_W];
+    __shared__ double s_out[NWAVE][SUMS_LEN];
+    if (kf->done) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const PoseConsts& pc = kf->pose;
+    int oa[NACC], ob[NACC], orec[NACC];
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        oa[a] = ob[a] = orec[a] = 0;
+        acc[a] = 0.0;
+        if (lane + a * 64 < NOUT) out_pair<W>(lane + a * 64, oa[a], ob[a], orec[a]);
+    }
+    for (int t = tid; t < NWAVE * SUMS_LEN; t += G) (&s_out[0][0])[t] = 0.0;
+    const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
+    const uint32_t per_iter = (uint32_t)G * gridDim.x;
+    const uint32_t iters = (n + per_iter - 1) / per_iter;
+#ifdef LV_FINE_STAMPS
+    long long* stamp_slot = nullptr;
+#else
+    long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
+#endif
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t q = (it * gridDim.x + vb) * (uint32_t)G + (uint32_t)tid;
+        if (DBG && stamp_slot && it == 0) stamp_slot[5] = clock64();
+        float P[KNN][3];
+        uint32_t nidx[KNN], dbits[KNN];
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        uint32_t oq = 0;
+        int found = -1;
+#pragma unroll
+        for (int j = 0; j < KNN; ++j) { P[j][0] = P[j][1] = P[j][2] = 0.f; nidx[j] = 0xFFFFFFFFu; dbits[j] = 0x7f800000u; }
+        if (q < n) {
+            float4 r[QREC_SLOTS];
+#pragma unroll
+            for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = qrec[(size_t)sl * qstride + q];
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) { P[j][0] = r[j].x; P[j][1] = r[j].y; P[j][2] = r[j].z; nidx[j] = __float_as_uint(r[j].w); }
+            qx = r[5].x; qy = r[5].y; qz = r[5].z; oq = __float_as_uint(r[5].w);
+            dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
+            dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
+            found = __float_as_int(r[7].y);
+        }
+        fit_row<W, EXT, DBG>(pc, prm, dbg, found, P, nidx, dbits, qx, qy, qz, oq, s_rows[tid]);
+        __syncthreads();
+        if (DBG && stamp_slot && it == 0) stamp_slot[6] = clock64();
+        const double (*rows)[ROW_W] = s_rows + wave * 64;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            if (lane + a * 64 < NOUT) {
+                double sacc = acc[a];
+#pragma unroll 8
+                for (int p = 0; p < 64; ++p) sacc += rows[p][oa[a]] * rows[p][ob[a]];
+                acc[a] = sacc;
+            }
+        }
+        __syncthreads();
+        if (DBG && stamp_slot && it == 0) stamp_slot[7] = clock64();
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+        if (lane + a * 64 < NOUT) s_out[wave][orec[a]] = acc[a];
+    __syncthreads();
+    if (tid < SUMS_LEN) {
+        double s = s_out[0][tid];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) s += s_out[w][tid];
+        partials[(size_t)blockIdx.x * SUMS_LEN + tid] = s;
+    }
+}
+
+int match_grid_size(int S, uint32_t n, int max_blocks, bool split) {
     const uint32_t sub = (LV_FIT_POINTS * S) / 256 > 1 ? (LV_FIT_POINTS * S) / 256 : 1;
-    const uint32_t G = sub * (256 / S);
+    const uint32_t G = split ? (uint32_t)FIT_POINTS : sub * (256 / S);
     uint32_t need = (n + G - 1) / G;
     if (need < 1) need = 1;
     uint32_t grid = need < (uint32_t)max_blocks ? need : (uint32_t)max_blocks;
@@ -642,9 +834,55 @@ static void launch_s(hipStream_t stream, bool dbg_on, bool ext, int grid, const 
 #undef LV_LAUNCH
 }
 
+template <int S>
+static void launch_search(hipStream_t stream, bool dbg_on, const MapView& map, const float4* scan, uint32_t n, KfDev* kf,
+                          float4* qrec, uint32_t qstride, const DebugOut& dbg) {
+    constexpr uint32_t GS = 256 / S;
+    uint32_t grid = (n + GS - 1) / GS;
+    grid = (grid + 7u) & ~7u;
+    if (grid == 0) grid = 8;
+    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, dbg);
+    else hipLaunchKernelGGL((search_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, dbg);
+}
+
+static bool debug_requested(const DebugOut& dbg) {
+    return dbg.knn_idx || dbg.valid || dbg.p_world || dbg.abcd || dbg.dist || dbg.rows || dbg.clk;
+}
+
+// split form, kernel 1: exact 5-NN of every scan point -> qrec
+int launch_search(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf, float4* qrec,
+                  uint32_t qstride, const DebugOut& dbg) {
+    const bool dbg_on = debug_requested(dbg);
+    switch (S) {
+        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
+        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
+        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
+        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
+        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
+        default: set_error("lanes_per_query must be 1,2,4,8 or 16 (got %d)", S); return LV_EINVAL;
+    }
+    LV_HIP(hipGetLastError());
+    return LV_OK;
+}
+
+// split form, kernel 2: qrec -> plane fits, Jacobian rows, `grid` block partials
+int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
+                      double* partials, int grid, const DebugOut& dbg) {
+    const bool dbg_on = debug_requested(dbg);
+    const bool ext = prm.estimate_extrinsics != 0;
+#define LV_LAUNCH(EXT_, DBG_) \
+    hipLaunchKernelGGL((fit_reduce_kernel<EXT_, DBG_>), dim3(grid), dim3(FIT_POINTS), 0, stream, qrec, qstride, n, kf, prm, partials, dbg)
+    if (ext) { if (dbg_on) LV_LAUNCH(true, true); else LV_LAUNCH(true, false); }
+    else { if (dbg_on) LV_LAUNCH(false, true); else LV_LAUNCH(false, false); }
+#undef LV_LAUNCH
+    LV_HIP(hipGetLastError());
+    return LV_OK;
+}
+
+// fused form (A/B reference, LV_FUSED=1): one kernel does search + fit + contraction
 int launch_match_reduce(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
                         const MatchParams& prm, double* partials, int grid, const DebugOut& dbg) {
-    const bool dbg_on = dbg.knn_idx || dbg.valid || dbg.p_world || dbg.abcd || dbg.dist || dbg.rows || dbg.clk;
+    const bool dbg_on = debug_requested(dbg);
     const bool ext = prm.estimate_extrinsics != 0;
     switch (S) {
         case 1: launch_s<1>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;

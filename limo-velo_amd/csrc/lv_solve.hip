@@ -68,6 +68,8 @@ __global__ __launch_bounds__(SUMS_LEN) void reduce_final_kernel(const double* __
 // ---- solve ------------------------------------------------------------------------------------------
 constexpr int LD = NS + 1;  // padded leading dimension in LDS
 constexpr int SOLVE_THREADS = 576;
+constexpr int FOLD_PARTS = SOLVE_THREADS / SUMS_LEN;  // 6
+constexpr int FOLD_DEPTH = 44;                       // x 6 parts: up to 264 records folded in one memory round trip
 
 __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double (*b)[LD], bool b_transposed, int tid) {
     if (tid < NS * NS) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     __shared__ double sW[2][12][13], sT[12][12];
     __shared__ double sX[NS][12], sG[NS][12], sKx[NS][12], sHTH[12][12], sHTh[12];
     __shared__ double sdx[NS], sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
-    __shared__ double s_part[32][SUMS_LEN];
+    __shared__ double s_part[FOLD_PARTS][SUMS_LEN];
     __shared__ double sRot[4][9];
     __shared__ PoseConsts s_pose;
     __shared__ int s_last, s_conv;
@@ -206,12 +208,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     const int wave = tid >> 6, lane = tid & 63;
     // every global read of this kernel is issued up front (one memory round trip): the group records, x,
     // x_prop, P_prop — independent of the done / passes words read next
-    if (nrec <= 32) {
+    // records are folded in registers: thread (o, part) owns records part, part + 6, ... (<= FOLD_DEPTH of them)
+    const int fo = tid % SUMS_LEN, fpart = tid / SUMS_LEN;
+    double fv[FOLD_DEPTH];
+    if (nrec <= FOLD_PARTS * FOLD_DEPTH) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const int e = tid + r * SOLVE_THREADS;
-            const int g = e / SUMS_LEN, o = e % SUMS_LEN;
-            if (g < nrec) s_part[g][o] = recs[(size_t)g * SUMS_LEN + o];
+        for (int i = 0; i < FOLD_DEPTH; ++i) {
+            const int g = fpart + FOLD_PARTS * i;
+            fv[i] = g < nrec ? recs[(size_t)g * SUMS_LEN + fo] : 0.0;
         }
     }
     if (tid >= 128 && tid < 128 + NX) { sx[tid - 128] = kf->x[tid - 128]; sxp[tid - 128] = kf->x_prop[tid - 128]; }
@@ -221,15 +225,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
 #define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
     SV_STAMP(0);
     __syncthreads();
+    if (nrec <= FOLD_PARTS * FOLD_DEPTH) {  // fixed order: sequential inside a part, parts combined pairwise
+        double s = fv[0];
+#pragma unroll
+        for (int i = 1; i < FOLD_DEPTH; ++i) s += fv[i];
+        s_part[fpart][fo] = s;
+    }
+    __syncthreads();
     if (tid < SUMS_LEN) {
         double s = 0.0;
-        if (nrec <= 32) {  // four interleaved accumulators, combined in a fixed order (deterministic)
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            for (int g = 0; g + 3 < nrec; g += 4) {
-                a0 += s_part[g][tid]; a1 += s_part[g + 1][tid]; a2 += s_part[g + 2][tid]; a3 += s_part[g + 3][tid];
-            }
-            for (int g = nrec & ~3; g < nrec; ++g) a0 += s_part[g][tid];
-            s = (a0 + a1) + (a2 + a3);
+        if (nrec <= FOLD_PARTS * FOLD_DEPTH) {
+            s = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + (s_part[4][tid] + s_part[5][tid]);
         } else {
             for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid];
         }
@@ -423,13 +429,14 @@ int launch_kf_begin(hipStream_t stream, KfDev* kf) {
     return LV_OK;
 }
 int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf) {
-    const int group = 32;
+    const int group = PARTIAL_GROUP;
     const int ngroups = (nblocks + group - 1) / group;
     hipLaunchKernelGGL(reduce_groups_kernel, dim3(ngroups), dim3(RG_THREADS), 0, stream, partials, nblocks, group, groups, kf);
     LV_HIP(hipGetLastError());
     *ngroups_out = ngroups;
     return LV_OK;
 }
+int solve_direct_records() { return FOLD_PARTS * FOLD_DEPTH; }
 int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf) {
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(SUMS_LEN), 0, stream, groups, ngroups, sums, kf);
     LV_HIP(hipGetLastError());

@@ -23,11 +23,11 @@ for sub, names in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_tcc", ["WRITE_SIZE", "TC
     for f in glob.glob(out + "/" + sub + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "match_reduce" in r["Kernel_Name"]:
+            if "search_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             res[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-json.dump(res, open(out + "/pmc_match_reduce_$R.json", "w"), indent=1)
+json.dump(res, open(out + "/pmc_search_$R.json", "w"), indent=1)
 print(res)
 PY
 find $OUT -name "*counter_collection.csv" -delete

@@ -13,7 +13,7 @@ for sub in ("sq", "sq2", "fetch", "tcc"):
     order = collections.defaultdict(int)
     seen = {}
     for r in csv.DictReader(open(f)):
-        if "match_reduce" not in r["Kernel_Name"]:
+        if "search_kernel" not in r["Kernel_Name"]:
             continue
         did = r["Dispatch_Id"]
         if did not in seen:

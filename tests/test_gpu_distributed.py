@@ -1,6 +1,7 @@
 """The multi-GPU engine (HipEngine, split-form C-ABI, RCCL all-reduce on the torch tensor that backs the sums
 record) exercised on ONE GPU: a world-size-1 `nccl` group drives exactly the code path bench.py uses for
---gpus N, and must reproduce the fused single-GPU update bit for bit."""
+--gpus N, and must reproduce the single-GPU update (same arithmetic, different but fixed summation order of the
+block partials: group records + final record here, one direct fold inside solve_kernel there)."""
 import os
 import socket
 
@@ -47,7 +48,9 @@ def test_split_path_with_rccl_world1(lv, scene_small):
             torch.cuda.synchronize()
             rec = eng.sums.cpu().numpy()
         assert p1 == p2
-        assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
+        # summation-order difference only: ~1e-16 relative on H^T H -> far below 1e-12 on the state / covariance
+        np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(P2, P1, rtol=1e-9, atol=1e-15)
         assert rec[90] > 1500  # n_valid of the last pass sits in the all-reduced record
     finally:
         dist.destroy_process_group()

@@ -240,7 +240,11 @@ def test_update_split_form_matches_fused(capi, scene_small):
             ctx.pass_reduce()
             ctx.pass_solve()
         x2, P2, p2 = ctx.update_end()
-    assert p1 == p2 and np.array_equal(x1, x2) and np.array_equal(P1, P2)
+    # same arithmetic; the block partials are summed in a different (fixed) order: group records + final record
+    # in the split form, one direct fold inside solve_kernel in lv_update
+    assert p1 == p2
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(P2, P1, rtol=1e-9, atol=1e-15)
 
 
 def test_large_cfg3_like(capi, oracle, lv):
