@@ -39,7 +39,9 @@ struct lv_ctx {
     FilterDev* d_filter = nullptr;  // x, P resident between lv_predict / lv_correct (row f-3)
     FilterDev* h_filter = nullptr;  // pinned staging
     bool filter_set = false;
-    KfDev* h_kf = nullptr;  // pinned mirror
+    KfDev* h_kf = nullptr;  // pinned mirror (logs / trace downloads)
+    KfHostIO* h_io = nullptr;  // pinned, host-mapped mailbox: update inputs and results (no copy kernels)
+    KfHostIO* d_io = nullptr;  // its device address
     double* d_partials = nullptr;
     double* d_groups = nullptr;    // group records (reduce stage 1)
     int ngroups = 0;
@@ -141,9 +143,10 @@ void unpack_sums(const double* rec, lv_sums* out) {
     out->sum_h2 = rec[91];
 }
 
-// x / P_prop of d_kf are in place (uploaded or copied from the resident filter): derive the pass constants
-int begin_device(lv_ctx* c) {
-    int rc = launch_kf_begin(c->stream, c->d_kf);
+// from_host: x / P_prop wait in the pinned mailbox (lv_update_begin), otherwise they are in d_kf already (copied
+// from the resident filter): take them over, derive the pass constants
+int begin_device(lv_ctx* c, bool from_host) {
+    int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, from_host);
     if (rc) return rc;
     c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks, c->split);
     if (c->split && (uint32_t)c->scan.n > c->qstride) {
@@ -160,16 +163,14 @@ int begin_device(lv_ctx* c) {
 }
 
 int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
-    KfDev* h = c->h_kf;
-    std::memcpy(h->x, x, sizeof(double) * NX);
+    KfHostIO* io = c->h_io;
+    std::memcpy(io->x_in, x, sizeof(double) * NX);
     if (P) {
-        std::memcpy(h->P_prop, P, sizeof(double) * NS * NS);
+        std::memcpy(io->P_in, P, sizeof(double) * NS * NS);
     } else {
-        for (int i = 0; i < NS * NS; ++i) h->P_prop[i] = (i / NS == i % NS) ? 1.0 : 0.0;
+        for (int i = 0; i < NS * NS; ++i) io->P_in[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
-    const size_t head = offsetof(KfDev, P_post);  // upload region: x, P_prop
-    LV_HIP(hipMemcpyAsync(c->d_kf, h, head, hipMemcpyHostToDevice, c->stream));
-    return begin_device(c);
+    return begin_device(c, true);   // kf_begin_kernel reads the mailbox across PCIe: no upload on the stream
 }
 
 int pass_reduce(lv_ctx* c, bool finalize) {
@@ -220,9 +221,9 @@ int pass_solve(lv_ctx* c, bool from_groups) {
     for (int i = 0; i < NS; ++i) sp.limits[i] = c->prm.LIMITS[i];
     sp.maximum_iter = c->prm.MAX_NUM_ITERS;
     sp.estimate_extrinsics = c->prm.estimate_extrinsics;
-    if (from_groups && c->fold_direct) return launch_solve(c->stream, c->d_kf, c->d_partials, c->grid, c->d_sums, sp);
-    if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_groups, c->ngroups, c->d_sums, sp);
-    return launch_solve(c->stream, c->d_kf, c->d_sums, 1, nullptr, sp);
+    if (from_groups && c->fold_direct) return launch_solve(c->stream, c->d_kf, c->d_io, c->d_partials, c->grid, c->d_sums, sp);
+    if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_io, c->d_groups, c->ngroups, c->d_sums, sp);
+    return launch_solve(c->stream, c->d_kf, c->d_io, c->d_sums, 1, nullptr, sp);
 }
 
 }  // namespace
@@ -281,6 +282,9 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipHostMalloc((void**)&c->h_filter, sizeof(FilterDev), hipHostMallocDefault));
     LV_HIP(hipHostMalloc((void**)&c->h_kf, sizeof(KfDev), hipHostMallocDefault));
     std::memset(c->h_kf, 0, sizeof(KfDev));
+    LV_HIP(hipHostMalloc((void**)&c->h_io, sizeof(KfHostIO), hipHostMallocMapped));
+    std::memset(c->h_io, 0, sizeof(KfHostIO));
+    LV_HIP(hipHostGetDevicePointer((void**)&c->d_io, c->h_io, 0));
     LV_HIP(hipMalloc(&c->d_partials, (size_t)(c->max_blocks + 8) * SUMS_LEN * sizeof(double)));
     LV_HIP(hipMalloc(&c->d_groups, (size_t)(c->max_blocks / 32 + 2) * SUMS_LEN * sizeof(double)));
     LV_HIP(hipMalloc(&c->d_sums_own, SUMS_LEN * sizeof(double)));
@@ -304,6 +308,7 @@ void lv_destroy(lv_ctx* c) {
     free_capture(c);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_kf) hipHostFree(c->h_kf);
+    if (c->h_io) hipHostFree(c->h_io);
     if (c->h_filter) hipHostFree(c->h_filter);
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -541,13 +546,16 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
     LV_CHECK_CTX(c);
     if (!c->in_update) { set_error("lv_update_end without lv_update_begin"); return LV_ESTATE; }
     c->in_update = false;
-    const size_t bytes = c->want_log ? offsetof(KfDev, pose) : offsetof(KfDev, x_prop);
-    LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, bytes, hipMemcpyDeviceToHost, c->stream));
+    // results were stored into the pinned mailbox by kf_begin_kernel / solve_kernel; the device copy of the logs
+    // is only downloaded when the caller asked for them
+    if (c->want_log) LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, offsetof(KfDev, pose), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
-    c->timing.fallback_queries = c->h_kf->fallback_queries;
-    if (x) std::memcpy(x, c->h_kf->x, sizeof(double) * NX);
-    if (P) std::memcpy(P, c->h_kf->P_post, sizeof(double) * NS * NS);
-    if (passes) *passes = c->h_kf->passes;
+    const KfHostIO* io = c->h_io;
+    c->timing.fallback_queries = io->fallback_queries;
+    if (x) std::memcpy(x, io->x, sizeof(double) * NX);
+    if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
+    if (passes) *passes = io->passes;
+    c->h_kf->passes = io->passes;
     c->timing.last_passes = c->h_kf->passes;
     return LV_OK;
 }
@@ -642,7 +650,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     if (c->map.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
     if (rc) return rc;
-    rc = begin_device(c);
+    rc = begin_device(c, false);
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
@@ -662,9 +670,8 @@ int lv_correct(lv_ctx* c, int* passes) {
     rc = launch_kf_to_filter(c->stream, c->d_kf, c->d_filter);
     if (rc) return rc;
     if (passes) {  // optional: the only synchronisation point
-        LV_HIP(hipMemcpyAsync(&c->h_kf->passes, &c->d_kf->passes, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         LV_HIP(hipStreamSynchronize(c->stream));
-        *passes = c->h_kf->passes;
+        *passes = c->h_io->passes;   // stored by solve_kernel into the pinned mailbox
     }
     return LV_OK;
 }

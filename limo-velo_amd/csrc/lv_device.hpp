@@ -58,6 +58,18 @@ struct KfDev {
     int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / generic levels / brute force
 };
 
+// Pinned, host-mapped mailbox of one update: the 4.4 KB of inputs are read by kf_begin_kernel and the results are
+// stored by solve_kernel straight across PCIe, so an update needs no copy kernels on either side.
+struct KfHostIO {
+    double x_in[NX];
+    double P_in[NS * NS];
+    double x[NX];
+    double P_post[NS * NS];
+    int passes;
+    int fallback_queries;
+    int pad_[2];
+};
+
 // Filter state resident on the device between lv_predict / lv_correct calls (row f-3).
 struct FilterDev {
     double x[NX];

@@ -82,7 +82,7 @@ int launch_match_reduce(hipStream_t stream, int lanes_per_query, const MapView& 
                         KfDev* kf, const MatchParams& prm, double* partials, int grid, const DebugOut& dbg);
 int match_grid_size(int lanes_per_query, uint32_t n, int max_blocks, bool split);
 // lv_solve.hip
-int launch_kf_begin(hipStream_t stream, KfDev* kf);
+int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, bool from_host);  // io: device pointer of the pinned mailbox
 int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf);
 int solve_direct_records();  // most records solve_kernel folds in one round trip
 int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf);
@@ -93,7 +93,7 @@ struct SolveParams {
     int maximum_iter;
     int estimate_extrinsics;
 };
-int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
+int launch_solve(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
 // lv_predict.hip
 int launch_predict(hipStream_t stream, FilterDev* f, double dt, const double* Q, const double* acc, const double* gyro);
 int launch_filter_to_kf(hipStream_t stream, const FilterDev* f, KfDev* kf);

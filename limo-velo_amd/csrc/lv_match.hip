@@ -355,9 +355,6 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
                         const uint32_t j = base + (uint32_t)(u * S + gl);
                         mpt[u] = bp[j < bcount ? j : 0];
                     }
-#ifdef LV_FINE_STAMPS
-                    if (DBG && clk && bl == 0 && base == 0) { asm volatile("" :: "v"(mpt[0].x), "v"(mpt[7].x), "v"(mpt[3].x), "v"(mpt[5].x)); clk[3] = clock64(); }
-#endif
                     kkey ck[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -366,17 +363,8 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
                     }
                     sort8(ck);
                     merge5(k, ck);
-#ifdef LV_FINE_STAMPS
-                    if (DBG && clk && bl == 0 && base == 0) { asm volatile("" :: "v"(k[0]), "v"(k[4])); clk[4] = clock64(); }
-#endif
                 }
-#ifdef LV_FINE_STAMPS
-                if (DBG && clk && bl == 0) { asm volatile("" :: "v"(k[0]), "v"(k[4])); clk[5] = clock64(); }
-#endif
                 merge_group<S>(k);
-#ifdef LV_FINE_STAMPS
-                if (DBG && clk && bl == 0) { asm volatile("" :: "v"(k[0]), "v"(k[4])); clk[6] = clock64(); }
-#endif
                 const float r = radius(bl);
                 const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
                 if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
@@ -689,9 +677,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     rt_apply(kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
     if (DBG && stamp_slot) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); stamp_slot[1] = clock64(); }
     knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
-#ifndef LV_FINE_STAMPS
     if (DBG && stamp_slot) { asm volatile("" :: "v"(k[0]), "v"(k[4])); stamp_slot[3] = clock64(); }
-#endif
     int found = 0;
 #pragma unroll
     for (int j = 0; j < KNN; ++j) found += is_none(k[j]) ? 0 : 1;
@@ -720,11 +706,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
         }
         qrec[(size_t)slot * qstride + q] = v;
     }
-#ifdef LV_FINE_STAMPS
-    if (DBG && stamp_slot) stamp_slot[7] = clock64();
-#else
     if (DBG && stamp_slot) stamp_slot[4] = clock64();
-#endif
     if (DBG && stamp_slot) { dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 1] = wall_clock64(); }
 }
 
@@ -760,11 +742,7 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
     const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
     const uint32_t per_iter = (uint32_t)G * gridDim.x;
     const uint32_t iters = (n + per_iter - 1) / per_iter;
-#ifdef LV_FINE_STAMPS
-    long long* stamp_slot = nullptr;
-#else
     long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
-#endif
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t q = (it * gridDim.x + vb) * (uint32_t)G + (uint32_t)tid;
         if (DBG && stamp_slot && it == 0) stamp_slot[5] = clock64();

@@ -24,18 +24,34 @@
 
 namespace lv {
 
-__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf) {
+// from_host: x / P_prop arrive in the host mailbox (lv_update); otherwise they are already in kf (resident filter)
+__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, int from_host) {
+    __shared__ double s_x[NX];
     const int tid = threadIdx.x;
-    if (tid < NS * NS) kf->P_post[tid] = kf->P_prop[tid];
-    if (tid < NX) kf->x_prop[tid] = kf->x[tid];
+    if (tid < NS * NS) {
+        const double p = from_host ? io->P_in[tid] : kf->P_prop[tid];
+        if (from_host) kf->P_prop[tid] = p;
+        kf->P_post[tid] = p;
+        io->P_post[tid] = p;   // an update without a terminal pass returns the propagated covariance
+    }
+    if (tid < NX) {
+        const double v = from_host ? io->x_in[tid] : kf->x[tid];
+        if (from_host) kf->x[tid] = v;
+        kf->x_prop[tid] = v;
+        io->x[tid] = v;
+        s_x[tid] = v;
+    }
+    __syncthreads();
     if (tid == 0) {
+        io->passes = 0;
+        io->fallback_queries = 0;
         kf->t = 0;
         kf->iter = -1;  // upstream loop starts at i = -1
         kf->done = 0;
         kf->passes = 0;
         kf->fallback_queries = 0;
         for (int i = 0; i < 8; ++i) kf->level_hist[i] = 0;
-        compute_pose_consts(kf->x, &kf->pose);
+        compute_pose_consts(s_x, &kf->pose);
     }
 }
 
@@ -194,7 +210,7 @@ __device__ __forceinline__ int vect_state_index(int dof) {  // dof in {0..2, 9..
 // NW = number of Jacobian columns that can be non-zero: 6 without extrinsic estimation (H^T H lives in
 // the leading 6x6 block, only P_inv[:, 0:6] is needed), 12 with it.
 template <int NW>
-__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const double* __restrict__ recs, int nrec,
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostIO* io, const double* __restrict__ recs, int nrec,
                                                               double* __restrict__ sums_out, SolveParams prm) {
     __shared__ double sP[NS][LD], sA[NS][LD], sB[NS][LD], sJ[NS][LD];
     __shared__ double sW[2][12][13], sT[12][12];
@@ -260,6 +276,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
                 for (int i = 0; i < NX; ++i) kf->trace[pass * 49 + NS + i] = kf->x[i];
             }
             kf->passes = pass + 1;
+            io->passes = pass + 1;
+            io->fallback_queries = kf->fallback_queries;
             kf->iter += 1;
             if (kf->iter >= prm.maximum_iter) kf->done = 1;
         }
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     }
     __syncthreads();
     SV_STAMP(7);
-    if (tid < NX) kf->x[tid] = sx[tid];
+    if (tid < NX) { kf->x[tid] = sx[tid]; io->x[tid] = sx[tid]; }
     if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
         const int e = tid - 64;
         kf->trace[pass * 49 + e] = e < NS ? sdxo[e] : sx[e - NS];
@@ -383,6 +401,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
     __syncthreads();
     if (tid == 0) {
         kf->passes = pass + 1;
+        io->passes = pass + 1;
+        io->fallback_queries = kf->fallback_queries;
         kf->iter += 1;
         if (last) kf->done = 1;
         else finish_pose_consts(sx, sRot, &s_pose);
@@ -417,14 +437,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, const d
         const int i = tid / NS, j = tid % NS;
         double s = 0;
         for (int c = 0; c < NW; ++c) s += sX[i][c] * sA[c][j];
-        kf->P_post[tid] = sB[i][j] - s;
+        const double pv = sB[i][j] - s;
+        kf->P_post[tid] = pv;
+        io->P_post[tid] = pv;
     }
     SV_STAMP(9);
 #undef SV_STAMP
 }
 
-int launch_kf_begin(hipStream_t stream, KfDev* kf) {
-    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf);
+int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, bool from_host) {
+    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, from_host ? 1 : 0);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
@@ -442,11 +464,11 @@ int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, d
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
-int launch_solve(hipStream_t stream, KfDev* kf, const double* recs, int nrec, double* sums_out, const SolveParams& prm) {
+int launch_solve(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* recs, int nrec, double* sums_out, const SolveParams& prm) {
     if (prm.estimate_extrinsics)
-        hipLaunchKernelGGL((solve_kernel<12>), dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, recs, nrec, sums_out, prm);
+        hipLaunchKernelGGL((solve_kernel<12>), dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, io, recs, nrec, sums_out, prm);
     else
-        hipLaunchKernelGGL((solve_kernel<6>), dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, recs, nrec, sums_out, prm);
+        hipLaunchKernelGGL((solve_kernel<6>), dim3(1), dim3(SOLVE_THREADS), 0, stream, kf, io, recs, nrec, sums_out, prm);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
