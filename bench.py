@@ -100,6 +100,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="override lanes_per_query")
     ap.add_argument("--voxel", type=float, default=0.0, help="override voxel_size")
+    ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +126,7 @@ def main() -> None:
 
     lvamd.load()
     from limo_velo_amd import capi, synth
-    from limo_velo_amd.distributed import ShardedUpdater
+    from limo_velo_amd.distributed import HipEngine, ShardedUpdater, init_library_comm
 
     sc = synth.make_scene(M_POINTS, N_POINTS)
     kw = {}
@@ -136,7 +137,28 @@ def main() -> None:
     prm = capi.default_params(**kw)
     ctx = capi.Context(prm, device=local_rank)
     ctx.map_build(sc["map_xyz"])
-    upd = ShardedUpdater(ctx, rank, world, dist, torch)
+    collective = "none"
+    engine = ctx
+    if world > 1:
+        # preferred: RCCL issued by the library itself on its stream (no host round trip per pass); if the
+        # communicator cannot be created, the same all-reduce goes through torch.distributed pass by pass
+        try:
+            init_library_comm(ctx, dist, torch, rank, world)
+            engine = HipEngine(ctx, torch, multi=False, library_comm=True)
+            collective = "rccl (library, on the context stream)"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            collective = "rccl (torch.distributed, per pass from the host)"
+        flag = torch.tensor([1 if collective.startswith("rccl (library") else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and engine is not ctx:   # not every rank got a communicator: all fall back together
+            ctx.comm_destroy()
+            engine = ctx
+            collective = "rccl (torch.distributed, per pass from the host)"
+    if world == 1 and args.force_comm:
+        init_library_comm(ctx, None, torch, 0, 1)
+        collective = "rccl (library, on the context stream) [forced, 1 rank]"
+    upd = ShardedUpdater(engine, rank, world, dist, torch)
     upd.scan_set(sc["scan_xyz"])
     n_local = upd.n_local
 
@@ -200,6 +222,7 @@ def main() -> None:
                 "passes_per_update": total_passes / args.steps,
                 "points_per_gpu": n_local,
                 "parallelism": f"scan points sharded x{world}, map replicated, 768 B all-reduce per pass" if world > 1 else "1 GPU",
+                "collective": collective,
                 "lanes_per_query": prm.lanes_per_query,
                 "voxel_size": prm.voxel_size,
             },

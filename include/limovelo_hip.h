@@ -180,6 +180,24 @@ int   lv_set_sums_buffer(lv_ctx* ctx, void* device_ptr);
 int   lv_pass_solve(lv_ctx* ctx);
 int   lv_update_end(lv_ctx* ctx, lv_state* x, double* P, int* passes);
 
+/* ---- multi-GPU, collective inside the library (SURVEY §8 row e) --------------------------------
+ * One process per GPU; the scan is sharded (each rank calls lv_scan_set with its range), the map is
+ * replicated.  After lv_comm_init every measurement pass of lv_update / lv_correct all-reduces the
+ * 96-double record with RCCL (over xGMI) on the context stream: the whole iterated update is enqueued
+ * without a host round trip per pass, and every rank ends with the bitwise identical state.  The reference
+ * has no counterpart (single process); this replaces the same esekf call as lv_update.
+ *   rccl_library: path of librccl to bind at run time (NULL: "librccl.so.1" from the loader path).  In a
+ *                 process that also runs torch pass torch's bundled copy (<torch>/lib/librccl.so) so that
+ *                 one RCCL serves both.
+ *   lv_comm_unique_id: rank 0 creates the 128-byte id (ncclUniqueId) and hands it to the other ranks by any
+ *                 means (torch.distributed broadcast, MPI, a file); lv_comm_init is collective.
+ * lv_iterate stays per-rank (its sums describe this rank's points). */
+#define LV_COMM_ID_BYTES 128
+int lv_comm_unique_id(const char* rccl_library, void* id128);
+int lv_comm_init(lv_ctx* ctx, const char* rccl_library, const void* id128, int rank, int world);
+int lv_comm_destroy(lv_ctx* ctx);
+int lv_comm_world(lv_ctx* ctx);
+
 /* ---- API-parity / debug fetches (results of the most recent CAPTURED pass; original scan order) --
  * lv_iterate always captures; lv_update captures only after lv_set_capture(ctx, 1) (the last pass
  * executed wins).  Capturing writes ~200 B per scan point and is off on the fast path. */

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
+    "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world",
 ]
 
 
@@ -254,6 +255,25 @@ class Context:
 
     def sums_device_ptr(self) -> int:
         return int(self.lib.lv_sums_device_ptr(self.h))
+
+    # --- collective inside the library (row e)
+    def comm_unique_id(self, rccl_library: str | None = None) -> bytes:
+        buf = C.create_string_buffer(128)
+        lib = rccl_library.encode() if rccl_library else None
+        self._check(self.lib.lv_comm_unique_id(lib, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, rccl_library: str | None = None):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        lib = rccl_library.encode() if rccl_library else None
+        self._check(self.lib.lv_comm_init(self.h, lib, C.c_char_p(unique_id), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self.lib.lv_comm_destroy(self.h))
+
+    def comm_world(self) -> int:
+        return int(self.lib.lv_comm_world(self.h))
 
     def set_sums_buffer(self, device_ptr: int | None):
         self._check(self.lib.lv_set_sums_buffer(self.h, C.c_void_p(device_ptr or 0)))

@@ -50,6 +50,8 @@ struct lv_ctx {
     double* h_sums = nullptr;  // pinned
     int max_blocks = 1024;
     int grid = 1;
+    void* comm = nullptr;          // RCCL communicator (lv_comm_init): every pass all-reduces the record
+    int comm_rank = 0, comm_world = 1;
     bool fold_direct = false;      // this pass: solve_kernel reads the block partials directly
     bool split = true;             // search_kernel + fit_reduce_kernel (default) or the fused match_reduce_kernel
     float4* d_qrec = nullptr;      // split form: 8 float4 planes of qstride entries (one record per scan point)
@@ -173,6 +175,8 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
     return begin_device(c, true);   // kf_begin_kernel reads the mailbox across PCIe: no upload on the stream
 }
 
+int pass_solve(lv_ctx* c, bool from_groups);
+
 int pass_reduce(lv_ctx* c, bool finalize) {
     MatchParams mp;
     mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
@@ -208,10 +212,32 @@ int pass_reduce(lv_ctx* c, bool finalize) {
     // round trip; otherwise stage 1 of the reduction runs as its own kernel
     c->fold_direct = !finalize && c->grid <= solve_direct_records();
     if (c->fold_direct) return LV_OK;
+    if (finalize && c->grid <= solve_direct_records())   // the rank's record straight from its block partials
+        return launch_reduce_final(c->stream, c->d_partials, c->grid, c->d_sums, c->d_kf);
     rc = launch_reduce_groups(c->stream, c->d_partials, c->grid, c->d_groups, &c->ngroups, c->d_kf);
     if (rc) return rc;
     if (finalize) return launch_reduce_final(c->stream, c->d_groups, c->ngroups, c->d_sums, c->d_kf);
     return LV_OK;
+}
+
+// one measurement pass + solve as lv_update / lv_correct run it.  With a communicator (multi-GPU): the rank's
+// record is all-reduced in place on the stream and every rank solves from the identical record.
+int pass_full(lv_ctx* c) {
+    int rc;
+    if (c->scan.n == 0) {   // a rank without points contributes zeros
+        double* zero = c->comm ? c->d_sums : c->d_groups;
+        LV_HIP(hipMemsetAsync(zero, 0, SUMS_LEN * sizeof(double), c->stream));
+        c->ngroups = 1;
+        c->fold_direct = false;
+    } else {
+        rc = pass_reduce(c, c->comm != nullptr);
+        if (rc) return rc;
+    }
+    if (c->comm) {
+        rc = comm_allreduce_record(c->comm, c->d_sums, c->stream);
+        if (rc) return rc;
+    }
+    return pass_solve(c, c->comm == nullptr);
 }
 
 int pass_solve(lv_ctx* c, bool from_groups) {
@@ -302,6 +328,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
 void lv_destroy(lv_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->comm) { hipStreamSynchronize(c->stream); comm_destroy(c->comm); c->comm = nullptr; }
     hipDeviceSynchronize();
     c->map.release();
     c->scan.release();
@@ -525,6 +552,39 @@ int lv_pass_reduce(lv_ctx* c) {
     return pass_reduce(c, true);
 }
 
+// ---- multi-GPU (row e): RCCL issued from the library on the context stream ------------------------------
+int lv_comm_unique_id(const char* rccl_library, void* id128) {
+    if (!id128) { set_error("null argument"); return LV_EINVAL; }
+    return comm_unique_id(rccl_library, id128);
+}
+
+int lv_comm_init(lv_ctx* c, const char* rccl_library, const void* id128, int rank, int world) {
+    LV_CHECK_CTX(c);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { set_error("lv_comm_init: bad arguments (rank %d, world %d)", rank, world); return LV_EINVAL; }
+    if (c->in_update) { set_error("lv_comm_init inside an update"); return LV_ESTATE; }
+    if (c->comm) { set_error("communicator already initialised"); return LV_ESTATE; }
+    void* comm = nullptr;
+    int rc = comm_init(rccl_library, id128, rank, world, &comm);   // collective: every rank calls it
+    if (rc) return rc;
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return LV_OK;
+}
+
+int lv_comm_destroy(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    if (!c->comm) return LV_OK;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    int rc = comm_destroy(c->comm);
+    c->comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    return rc;
+}
+
+int lv_comm_world(lv_ctx* c) { return c ? c->comm_world : 0; }
+
 void* lv_sums_device_ptr(lv_ctx* c) { return c ? (void*)c->d_sums : nullptr; }
 
 int lv_set_sums_buffer(lv_ctx* c, void* device_ptr) {
@@ -572,16 +632,8 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     for (int i = 0; i < npass; ++i) {
         if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
         c->ev_mid = c->profiling ? c->ev_pass[3 * i + 1] : nullptr;
-        if (c->scan.n == 0) {
-            LV_HIP(hipMemsetAsync(c->d_groups, 0, SUMS_LEN * sizeof(double), c->stream));
-            c->ngroups = 1;
-            rc = LV_OK;
-        } else {
-            rc = pass_reduce(c, false);
-        }
+        rc = pass_full(c);
         c->ev_mid = nullptr;
-        if (rc) { c->in_update = false; return rc; }
-        rc = pass_solve(c, true);
         if (rc) { c->in_update = false; return rc; }
         if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
     }
@@ -655,15 +707,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     for (int i = 0; i < npass; ++i) {
-        if (c->scan.n == 0) {
-            LV_HIP(hipMemsetAsync(c->d_groups, 0, SUMS_LEN * sizeof(double), c->stream));
-            c->ngroups = 1;
-            rc = LV_OK;
-        } else {
-            rc = pass_reduce(c, false);
-        }
-        if (rc) { c->in_update = false; return rc; }
-        rc = pass_solve(c, true);
+        rc = pass_full(c);
         if (rc) { c->in_update = false; return rc; }
     }
     c->in_update = false;

@@ -70,6 +70,13 @@ struct MapStore {
     void release();
 };
 
+// lv_comm.hip — RCCL bound at run time (row e)
+struct UniqueId128 { char internal[128]; };  // ncclUniqueId
+int comm_unique_id(const char* library, void* id128);
+int comm_init(const char* library, const void* id128, int rank, int world, void** comm_out);
+int comm_destroy(void* comm);
+int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
+
 // lv_match.hip
 // split form (default): search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride
 // entries), fit_reduce_kernel turns them into `grid` block partials

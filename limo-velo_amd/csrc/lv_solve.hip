@@ -72,20 +72,54 @@ __global__ __launch_bounds__(RG_THREADS) void reduce_groups_kernel(const double*
     if (seg == 0) groups[(size_t)blockIdx.x * SUMS_LEN + o] = ((s_seg[0][o] + s_seg[1][o]) + s_seg[2][o]) + s_seg[3][o];
 }
 
-__global__ __launch_bounds__(SUMS_LEN) void reduce_final_kernel(const double* __restrict__ groups, int ngroups,
-                                                                 double* __restrict__ sums, const KfDev* kf) {
+constexpr int FOLD_THREADS = 576;
+constexpr int FOLD_PARTS = FOLD_THREADS / SUMS_LEN;  // 6
+constexpr int FOLD_DEPTH = 44;                       // x 6 parts: up to 264 records folded in one memory round trip
+// Fold of nrec <= FOLD_PARTS * FOLD_DEPTH records by a 576-thread workgroup, fixed order: thread (o, part) owns
+// records part, part + 6, ... and sums them sequentially; the 6 part sums are combined pairwise.  fold_issue
+// only issues the loads (so a caller can overlap them with its other reads), fold_finish needs a
+// __syncthreads() between its two halves and returns the total to threads tid < SUMS_LEN.
+__device__ __forceinline__ void fold_issue(double (&fv)[FOLD_DEPTH], const double* __restrict__ recs, int nrec, int tid) {
+    const int fo = tid % SUMS_LEN, fpart = tid / SUMS_LEN;
+#pragma unroll
+    for (int i = 0; i < FOLD_DEPTH; ++i) {
+        const int g = fpart + FOLD_PARTS * i;
+        fv[i] = g < nrec ? recs[(size_t)g * SUMS_LEN + fo] : 0.0;
+    }
+}
+__device__ __forceinline__ void fold_stage(const double (&fv)[FOLD_DEPTH], double (*s_part)[SUMS_LEN], int tid) {
+    double s = fv[0];
+#pragma unroll
+    for (int i = 1; i < FOLD_DEPTH; ++i) s += fv[i];
+    s_part[tid / SUMS_LEN][tid % SUMS_LEN] = s;
+}
+__device__ __forceinline__ double fold_total(const double (*s_part)[SUMS_LEN], int o) {
+    return ((s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o])) + (s_part[4][o] + s_part[5][o]);
+}
+
+// multi-GPU path: the block partials (or group records) of this rank -> its one 96-double record, which RCCL
+// then all-reduces in place
+__global__ __launch_bounds__(FOLD_THREADS) void reduce_final_kernel(const double* __restrict__ recs, int nrec,
+                                                                   double* __restrict__ sums, const KfDev* kf) {
+    __shared__ double s_part[FOLD_PARTS][SUMS_LEN];
+    const int tid = threadIdx.x;
+    double fv[FOLD_DEPTH];
+    if (nrec <= FOLD_PARTS * FOLD_DEPTH) fold_issue(fv, recs, nrec, tid);
     if (kf->done) return;
-    const int o = threadIdx.x;
-    double s = 0.0;
-    for (int g = 0; g < ngroups; ++g) s += groups[(size_t)g * SUMS_LEN + o];
-    sums[o] = s;
+    if (nrec <= FOLD_PARTS * FOLD_DEPTH) {
+        fold_stage(fv, s_part, tid);
+        __syncthreads();
+        if (tid < SUMS_LEN) sums[tid] = fold_total(s_part, tid);
+    } else if (tid < SUMS_LEN) {
+        double s = 0.0;
+        for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid];
+        sums[tid] = s;
+    }
 }
 
 // ---- solve ------------------------------------------------------------------------------------------
 constexpr int LD = NS + 1;  // padded leading dimension in LDS
-constexpr int SOLVE_THREADS = 576;
-constexpr int FOLD_PARTS = SOLVE_THREADS / SUMS_LEN;  // 6
-constexpr int FOLD_DEPTH = 44;                       // x 6 parts: up to 264 records folded in one memory round trip
+constexpr int SOLVE_THREADS = FOLD_THREADS;
 
 __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double (*b)[LD], bool b_transposed, int tid) {
     if (tid < NS * NS) {
@@ -224,16 +258,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     const int wave = tid >> 6, lane = tid & 63;
     // every global read of this kernel is issued up front (one memory round trip): the group records, x,
     // x_prop, P_prop — independent of the done / passes words read next
-    // records are folded in registers: thread (o, part) owns records part, part + 6, ... (<= FOLD_DEPTH of them)
-    const int fo = tid % SUMS_LEN, fpart = tid / SUMS_LEN;
     double fv[FOLD_DEPTH];
-    if (nrec <= FOLD_PARTS * FOLD_DEPTH) {
-#pragma unroll
-        for (int i = 0; i < FOLD_DEPTH; ++i) {
-            const int g = fpart + FOLD_PARTS * i;
-            fv[i] = g < nrec ? recs[(size_t)g * SUMS_LEN + fo] : 0.0;
-        }
-    }
+    if (nrec <= FOLD_PARTS * FOLD_DEPTH) fold_issue(fv, recs, nrec, tid);
     if (tid >= 128 && tid < 128 + NX) { sx[tid - 128] = kf->x[tid - 128]; sxp[tid - 128] = kf->x_prop[tid - 128]; }
     if (tid < NS * NS) sB[tid / NS][tid % NS] = kf->P_prop[tid];
     if (kf->done) return;
@@ -241,17 +267,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 #define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
     SV_STAMP(0);
     __syncthreads();
-    if (nrec <= FOLD_PARTS * FOLD_DEPTH) {  // fixed order: sequential inside a part, parts combined pairwise
-        double s = fv[0];
-#pragma unroll
-        for (int i = 1; i < FOLD_DEPTH; ++i) s += fv[i];
-        s_part[fpart][fo] = s;
-    }
+    if (nrec <= FOLD_PARTS * FOLD_DEPTH) fold_stage(fv, s_part, tid);
     __syncthreads();
     if (tid < SUMS_LEN) {
         double s = 0.0;
         if (nrec <= FOLD_PARTS * FOLD_DEPTH) {
-            s = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + (s_part[4][tid] + s_part[5][tid]);
+            s = fold_total(s_part, tid);
         } else {
             for (int g = 0; g < nrec; ++g) s += recs[(size_t)g * SUMS_LEN + tid];
         }
@@ -460,7 +481,7 @@ int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks
 }
 int solve_direct_records() { return FOLD_PARTS * FOLD_DEPTH; }
 int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf) {
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(SUMS_LEN), 0, stream, groups, ngroups, sums, kf);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(FOLD_THREADS), 0, stream, groups, ngroups, sums, kf);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }

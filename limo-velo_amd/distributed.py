@@ -20,12 +20,44 @@ def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def torch_rccl_path(torch) -> str:
+    """The librccl torch itself loaded (<torch>/lib/librccl.so): the library must bind the same copy."""
+    import os
+
+    return os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+
+
+def init_library_comm(ctx, dist, torch, rank: int, world: int):
+    """Creates the library-side RCCL communicator (lv_comm_init): rank 0 makes the id, torch.distributed
+    carries the 128 bytes to the other ranks, then every rank joins.  After this, plain ctx.update() on every
+    rank IS the multi-GPU update (all-reduce issued by the library on its own stream, no host round trips)."""
+    path = torch_rccl_path(torch)
+    try:  # every rank probes the binding first, so a rank that cannot load librccl does not leave the others
+        uid, ok = ctx.comm_unique_id(path), 1  # waiting inside a collective
+    except Exception:  # noqa: BLE001
+        uid, ok = None, 0
+    if world > 1:
+        t = torch.tensor([ok], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        raise RuntimeError("librccl could not be bound on every rank")
+    box = [uid if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(box[0], rank, world, path)
+
+
 class HipEngine:
     """Per-rank engine over the C-ABI split form (lv_update_begin / lv_pass_reduce / lv_pass_solve /
     lv_update_end).  The sums record lives in a torch tensor so RCCL can reduce it in place."""
 
-    def __init__(self, ctx, torch, multi: bool):
-        self.ctx, self.torch, self.multi = ctx, torch, multi
+    def __init__(self, ctx, torch, multi: bool, library_comm: bool = False):
+        # library_comm: the context owns an RCCL communicator (init_library_comm) — ctx.update() is already the
+        # multi-GPU update; multi: the collective is torch.distributed's, driven pass by pass from Python
+        self.ctx, self.torch, self.multi = ctx, torch, multi and not library_comm
+        self.library_comm = library_comm
+        multi = self.multi
         self.max_passes = ctx.params.MAX_NUM_ITERS + 1
         self.sums = None
         self.stream = None
@@ -84,7 +116,7 @@ class ShardedUpdater:
     def update(self, x, P):
         """Returns (x_post, P_post, passes).  Every rank computes the identical posterior: the solve
         consumes only the all-reduced record, which is bitwise identical on all ranks."""
-        if self.world == 1:
+        if self.world == 1 or getattr(self.engine, "library_comm", False):
             return self.engine.update_fused(x, P)
         ctx = self.engine.stream_ctx() if hasattr(self.engine, "stream_ctx") else None
         if ctx is None:

@@ -54,3 +54,40 @@ def test_split_path_with_rccl_world1(lv, scene_small):
         assert rec[90] > 1500  # n_valid of the last pass sits in the all-reduced record
     finally:
         dist.destroy_process_group()
+
+
+def test_library_communicator_world1(lv, scene_small):
+    """lv_comm_init (RCCL bound and driven by the library itself) with a one-rank communicator: the update takes
+    the multi-GPU route (rank record -> ncclAllReduce on the context stream -> solve from the record) and must
+    reproduce the plain single-GPU update bit for bit (same fold order, the all-reduce of one rank is a copy)."""
+    import torch
+
+    from limo_velo_amd import capi
+    from limo_velo_amd.distributed import torch_rccl_path
+
+    sc = scene_small
+    torch.cuda.set_device(0)
+    path = torch_rccl_path(torch)
+    with capi.Context() as ref:
+        ref.map_build(sc["map_xyz"])
+        ref.scan_set(sc["scan_xyz"])
+        x1, P1, p1, _, _ = ref.update(sc["x_init"], sc["P0"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        assert ctx.comm_world() == 1
+        uid = ctx.comm_unique_id(path)
+        assert len(uid) == 128 and any(uid)
+        ctx.comm_init(uid, 0, 1, path)
+        for _ in range(3):
+            x2, P2, p2, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+        # resident-filter route through the same pass loop
+        ctx.filter_set(sc["x_init"], sc["P0"])
+        p3 = ctx.correct()
+        x3, P3 = ctx.filter_get()
+        ctx.comm_destroy()
+        x4, P4, p4, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+    assert p1 == p2 == p3 == p4
+    assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
+    assert np.array_equal(x1, x3) and np.array_equal(P1, P3)
+    assert np.array_equal(x1, x4) and np.array_equal(P1, P4)
