@@ -53,6 +53,7 @@ struct lv_ctx {
     void* comm = nullptr;          // RCCL communicator (lv_comm_init): every pass all-reduces the record
     int comm_rank = 0, comm_world = 1;
     bool fold_direct = false;      // this pass: solve_kernel reads the block partials directly
+    bool tile_lpt = true;          // dispatch the search tiles farthest-first (LV_TILE_LPT=0: plain order, A/B knob)
     bool split = true;             // search_kernel + fit_reduce_kernel (default) or the fused match_reduce_kernel
     float4* d_qrec = nullptr;      // split form: 8 float4 planes of qstride entries (one record per scan point)
     uint32_t qstride = 0;
@@ -197,7 +198,7 @@ int pass_reduce(lv_ctx* c, bool finalize) {
     int rc;
     if (c->split) {
         rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
-                           c->qstride, dbg);
+                           c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, dbg);
         if (rc) return rc;
         if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
         rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
@@ -291,11 +292,13 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (!c) { set_error("out of host memory"); return LV_EINVAL; }
     c->prm = *params;
     c->device = device;
+    c->scan.tile_points = 256u / (uint32_t)S;
     for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
     hipDeviceProp_t prop;
     LV_HIP(hipGetDeviceProperties(&prop, device));
     int per_cu = 4;
     if (const char* e = getenv("LV_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;  // tuning knob
+    if (const char* e = getenv("LV_TILE_LPT")) c->tile_lpt = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED")) c->split = atoi(e) == 0;                      // A/B knob: fused match kernel
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;

@@ -81,7 +81,7 @@ int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
 // split form (default): search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride
 // entries), fit_reduce_kernel turns them into `grid` block partials
 int launch_search(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
-                  float4* qrec, uint32_t qstride, const DebugOut& dbg);
+                  float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg);
 int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
                       double* partials, int grid, const DebugOut& dbg);
 // fused form (LV_FUSED=1, A/B reference)
@@ -120,6 +120,9 @@ struct ScanStore {
     size_t sort_tmp_bytes = 0;
     size_t capacity = 0;
     uint32_t n = 0;
+    uint32_t* d_tile_order = nullptr;  // search-kernel tiles, farthest-from-sensor first (order_tiles)
+    uint32_t n_tiles = 0, tile_cap = 0;
+    uint32_t tile_points = 0;          // scan points per search-kernel workgroup (256 / lanes_per_query); 0: no ordering
     // row f-2 (de-skew + voxel grid): raw time-stamped input and work buffers
     float4* d_in = nullptr;
     double* d_times = nullptr;
@@ -139,6 +142,7 @@ struct ScanStore {
     int reserve_raw(size_t cap, size_t n_states);
     int deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf, float sort_cell);
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
+    int order_tiles(hipStream_t stream, uint32_t tile_points);
     void release();
 };
 

@@ -298,81 +298,157 @@ __device__ __forceinline__ void out_pair(int t, int& a, int& b, int& rec) {
     }
 }
 
+// Voxel geometry of one query: continuous and integer level-0 voxel coordinates.
+struct QGeom {
+    float tx, ty, tz;
+    int c0x, c0y, c0z, amax;
+};
+__device__ __forceinline__ QGeom make_geom(const MapView& map, float qx, float qy, float qz) {
+    QGeom g;
+    g.tx = (qx - map.origin[0]) * map.inv_cell;
+    g.ty = (qy - map.origin[1]) * map.inv_cell;
+    g.tz = (qz - map.origin[2]) * map.inv_cell;
+    g.c0x = cell_coord(qx, map.origin[0], map.inv_cell);
+    g.c0y = cell_coord(qy, map.origin[1], map.inv_cell);
+    g.c0z = cell_coord(qz, map.origin[2], map.inv_cell);
+    g.amax = max(abs(g.c0x - CELL_OFFSET), max(abs(g.c0y - CELL_OFFSET), abs(g.c0z - CELL_OFFSET)));
+    return g;
+}
+// guaranteed search radius of the 27-voxel block at `lvl` for THIS query: one voxel edge plus the distance to
+// the nearest wall of its own voxel, shrunk by 1e-3 relative and by the f32 rounding bound of the voxel
+// coordinates (see file header).
+__device__ __forceinline__ float search_radius(const MapView& map, const QGeom& g, int lvl) {
+    const float scale = (float)(1 << lvl);
+    const float bx = (float)((((g.c0x >> lvl) << lvl)) - CELL_OFFSET), by = (float)((((g.c0y >> lvl) << lvl)) - CELL_OFFSET),
+                bz = (float)((((g.c0z >> lvl) << lvl)) - CELL_OFFSET);
+    const float mx = fminf(g.tx - bx, scale - (g.tx - bx)), my = fminf(g.ty - by, scale - (g.ty - by)),
+                mz = fminf(g.tz - bz, scale - (g.tz - bz));
+    const float marg = fmaxf(fminf(mx, fminf(my, mz)), 0.f);
+    return map.cell * ((scale + marg) * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)g.amax + 2.f * scale));
+}
+
+__device__ __forceinline__ kkey shfl_xor_key(kkey v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask);
+    hi = __shfl_xor(hi, mask);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce of the sorted top-5 lists over a team of LANES consecutive lanes (LANES <= 16: merge_group over
+// DPP; 64: the whole wavefront, the two cross-row rounds go through ds_bpermute)
+template <int LANES>
+__device__ __forceinline__ void merge_team(kkey (&k)[KNN]) {
+    if (LANES <= 16) {
+        merge_group<LANES>(k);
+    } else {
+        merge_group<16>(k);
+#pragma unroll
+        for (int mask = 16; mask < LANES; mask <<= 1) {
+            kkey o[KNN];
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) o[j] = shfl_xor_key(k[j], mask);
+            merge5(k, o);
+        }
+    }
+}
+
+// One bucket-level attempt by a team of LANES lanes (tl = lane in team): ONE probe of the level's bucket table
+// and ONE coalesced stream over the neighbourhood bucket of the query's voxel (a miss means the whole
+// 27-voxel block is empty).  k is all-NONE on entry; returns true with the sorted result in k (low words =
+// positions inside the bucket starting at bstart) iff 5 candidates were found inside the guaranteed radius,
+// otherwise false with k reset to NONE.
+template <int LANES>
+__device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
+                                               kkey (&k)[KNN], uint32_t& bstart, long long* clk) {
+    const GridLevel g = map.bt[bl];
+    const uint64_t key = pack_cell((uint32_t)(geo.c0x >> bl), (uint32_t)(geo.c0y >> bl), (uint32_t)(geo.c0z >> bl));
+    uint32_t slot = hash_cell(key, g.shift) & g.mask;
+    uint32_t bcount = 0;
+    for (;;) {
+        const uint4 e = g.table[slot];
+        const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+        if (ek == key) { bstart = e.z; bcount = e.w; break; }
+        if (ek == EMPTY_KEY) break;
+        slot = (slot + 1) & g.mask;
+    }
+    if (clk) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
+    if (bcount < KNN) return false;
+    constexpr int U = 8;
+    const float4* __restrict__ bp = map.bucket[bl] + bstart;
+    for (uint32_t base = 0; base < bcount; base += LANES * U) {
+        float4 mpt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * LANES + tl);
+            mpt[u] = bp[j < bcount ? j : 0];
+        }
+        kkey ck[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * LANES + tl);
+            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
+        }
+        sort8(ck);
+        merge5(k, ck);
+    }
+    merge_team<LANES>(k);
+    const float r = search_radius(map, geo, bl);
+    const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+    if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) return true;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    return false;
+}
+
 // Exact 5-NN of the world point (qx, qy, qz): executed by the S lanes of a lane group (gl = lane in group).
 // On return every lane of the group holds the same sorted keys k[]; src >= 0: bucket level the winners came
 // from (key low word = position inside the bucket starting at bstart), src < 0: generic path (low word =
 // original map index).  clk != nullptr (DBG builds): phase-stamp slot of this workgroup.
-template <int S, bool DBG>
+// COOP_FROM < MAX_BUCKET_LEVELS (requires all 64 lanes of the wavefront active; `live` = false marks padding
+// lanes that only lend a hand): bucket levels below COOP_FROM are searched per lane group, 64 / S scan points
+// at a time; the few points still undecided are then taken one at a time by the WHOLE wavefront for the
+// remaining bucket levels.  Those buckets hold a thousand candidates or more — 20 dependent load-sort steps
+// for a lane group, 3 for a wavefront — and a launch otherwise ends with a handful of such points as its tail.
+template <int S, bool DBG, int COOP_FROM>
 __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
-                                           kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist) {
+                                           kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist,
+                                           bool live = true) {
     if (map.m == 0) return;
-    const float tx = (qx - map.origin[0]) * map.inv_cell, ty = (qy - map.origin[1]) * map.inv_cell,
-                tz = (qz - map.origin[2]) * map.inv_cell;
-    const int c0x = cell_coord(qx, map.origin[0], map.inv_cell);
-    const int c0y = cell_coord(qy, map.origin[1], map.inv_cell);
-    const int c0z = cell_coord(qz, map.origin[2], map.inv_cell);
-    const int amax = max(abs(c0x - CELL_OFFSET), max(abs(c0y - CELL_OFFSET), abs(c0z - CELL_OFFSET)));
+    const QGeom geo = make_geom(map, qx, qy, qz);
     const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
-    const bool in_range = finite && amax < CELL_FAR;
-    bool decided = false;
+    const bool in_range = live && finite && geo.amax < CELL_FAR;
+    bool decided = !live;
     int level = in_range ? 0 : map.n_levels;
-    // guaranteed search radius of the 27-voxel block at `lvl` for THIS query: one voxel edge
-    // plus the distance to the nearest wall of its own voxel, shrunk by 1e-3 relative and by
-    // the f32 rounding bound of the voxel coordinates (see file header).
-    auto radius = [&](int lvl) -> float {
-        const float scale = (float)(1 << lvl);
-        const float bx = (float)((((c0x >> lvl) << lvl)) - CELL_OFFSET), by = (float)((((c0y >> lvl) << lvl)) - CELL_OFFSET),
-                    bz = (float)((((c0z >> lvl) << lvl)) - CELL_OFFSET);
-        const float mx = fminf(tx - bx, scale - (tx - bx)), my = fminf(ty - by, scale - (ty - by)),
-                    mz = fminf(tz - bz, scale - (tz - bz));
-        const float marg = fmaxf(fminf(mx, fminf(my, mz)), 0.f);
-        return map.cell * ((scale + marg) * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)amax + 2.f * scale));
-    };
-    // fast path: per level ONE probe of the bucket table and ONE coalesced stream over the
-    // neighbourhood bucket.  A miss means the whole 27-voxel block is empty.
     if (in_range) {
-        for (int bl = 0; bl < map.n_bucket_levels && !decided; ++bl) {
-            const GridLevel g = map.bt[bl];
-            const uint64_t key = pack_cell((uint32_t)(c0x >> bl), (uint32_t)(c0y >> bl), (uint32_t)(c0z >> bl));
-            uint32_t slot = hash_cell(key, g.shift) & g.mask;
-            uint32_t bcount = 0;
-            for (;;) {
-                const uint4 e = g.table[slot];
-                const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                if (ek == key) { bstart = e.z; bcount = e.w; break; }
-                if (ek == EMPTY_KEY) break;
-                slot = (slot + 1) & g.mask;
-            }
+        const int group_levels = map.n_bucket_levels < COOP_FROM ? map.n_bucket_levels : COOP_FROM;
+        for (int bl = 0; bl < group_levels && !decided; ++bl) {
+            decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr);
+            if (decided) src = bl;
             level = bl + 1;
-            if (DBG && clk && bl == 0) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
-            if (bcount >= KNN) {
-                constexpr int U = 8;
-                const float4* __restrict__ bp = map.bucket[bl] + bstart;
-                for (uint32_t base = 0; base < bcount; base += S * U) {
-                    float4 mpt[U];
+        }
+    }
+    if (COOP_FROM < MAX_BUCKET_LEVELS && map.n_bucket_levels > COOP_FROM) {
+        const int lane = (int)(threadIdx.x & 63u);
+        unsigned long long pending = __ballot(in_range && !decided && gl == 0);
+        while (pending) {
+            const int L = __ffsll((long long)pending) - 1;   // leader lane of the scan point served now
+            pending &= pending - 1;
+            const float wx = __shfl(qx, L), wy = __shfl(qy, L), wz = __shfl(qz, L);
+            const QGeom wgeo = make_geom(map, wx, wy, wz);
+            kkey kw[KNN];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t j = base + (uint32_t)(u * S + gl);
-                        mpt[u] = bp[j < bcount ? j : 0];
-                    }
-                    kkey ck[U];
+            for (int j = 0; j < KNN; ++j) kw[j] = none_key();
+            uint32_t wstart = 0;
+            int wsrc = -1;
+            for (int bl = COOP_FROM; bl < map.n_bucket_levels && wsrc < 0; ++bl)
+                if (bucket_attempt<64>(map, bl, wgeo, wx, wy, wz, lane, kw, wstart, nullptr)) wsrc = bl;
+            if (lane / S == L / S) {
+                level = map.n_bucket_levels;
+                if (wsrc >= 0) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t j = base + (uint32_t)(u * S + gl);
-                        ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
-                    }
-                    sort8(ck);
-                    merge5(k, ck);
-                }
-                merge_group<S>(k);
-                const float r = radius(bl);
-                const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-                if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
+                    for (int j = 0; j < KNN; ++j) k[j] = kw[j];
+                    bstart = wstart;
+                    src = wsrc;
                     decided = true;
-                    src = bl;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < KNN; ++j) k[j] = none_key();
                 }
             }
         }
@@ -381,7 +457,7 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     while (!decided) {  // generic path: 27 probes per level over the Morton-sorted array, then brute force
         if (level < map.n_levels) {
             const GridLevel gl_ = map.lv[level];
-            const int clx = c0x >> level, cly = c0y >> level, clz = c0z >> level;
+            const int clx = geo.c0x >> level, cly = geo.c0y >> level, clz = geo.c0z >> level;
             for (int c = gl; c < 27; c += S) {
                 const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
                 const uint32_t nx = (uint32_t)(clx + dx), ny = (uint32_t)(cly + dy), nz = (uint32_t)(clz + dz);
@@ -399,7 +475,7 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
                 scan_range(map.sorted, start, count, qx, qy, qz, k);
             }
             merge_group<S>(k);
-            const float r = radius(level);
+            const float r = search_radius(map, geo, level);
             const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
             if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
                 decided = true;
@@ -415,7 +491,7 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
         }
     }
     if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
-    if (DBG && hist && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
+    if (DBG && hist && live && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
 }
 
 struct QueryStage {     // kNN result of one scan point, handed from the search lanes to the fit lane
@@ -581,7 +657,7 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
                 oq = __float_as_uint(sp.w);
                 rt_apply(pc.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
                 if (DBG && dbg.clk) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); LV_STAMP(1); }
-                knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
+                knn_search<S, DBG, MAX_BUCKET_LEVELS>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
             }
             if (DBG && dbg.clk) { asm volatile("" :: "v"(k[0]), "v"(k[4])); LV_STAMP(3); }
             if (gl == 0) {
@@ -647,6 +723,9 @@ __global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* _
 //   slot  5    {world x, y, z, original scan index}
 //   slot  6    squared distances 0..3 (bits)      slot 7  {distance 4 (bits), found, -, -}
 constexpr int QREC_SLOTS = 8;
+#ifndef LV_COOP_FROM
+#define LV_COOP_FROM 2   // first bucket level searched by whole wavefronts (MAX_BUCKET_LEVELS: never)
+#endif
 #ifdef LV_SEARCH_WAVES
 #define LV_SEARCH_BOUNDS __launch_bounds__(256, LV_SEARCH_WAVES)
 #else
@@ -656,57 +735,63 @@ constexpr int QREC_SLOTS = 8;
 template <int S, bool DBG>
 __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
                                                      KfDev* __restrict__ kf, float4* __restrict__ qrec, uint32_t qstride,
-                                                     DebugOut dbg) {
+                                                     const uint32_t* __restrict__ tile_order, uint32_t n_tiles, DebugOut dbg) {
     constexpr int GS = 256 / S;
     if (kf->done) return;
     const int tid = threadIdx.x;
     const int gq = tid / S, gl = tid % S;
-    // XCD-aware tile order (see match_reduce_kernel); gridDim.x % 8 == 0
-    const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
+    // tile order: farthest-from-sensor tiles first (ScanStore::order_tiles).  An XCD-aware order (contiguous
+    // Morton runs per XCD, as in match_reduce_kernel) measured no different from plain round-robin here.
+    const uint32_t vb = (tile_order && blockIdx.x < n_tiles) ? tile_order[blockIdx.x] : blockIdx.x;
     const uint32_t q = vb * (uint32_t)GS + (uint32_t)gq;
     long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
     if (DBG && stamp_slot) { stamp_slot[0] = clock64(); dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 0] = wall_clock64(); }
-    if (q >= n) return;   // whole lane groups leave together
+    if (n == 0) return;
+    // no lane leaves early: the coarsest bucket levels are searched by whole wavefronts (knn_search COOP_FROM);
+    // padding lanes (q >= n) carry a copy of the last point, lend a hand and store nothing
+    const bool live = q < n;
     kkey k[KNN];
 #pragma unroll
     for (int j = 0; j < KNN; ++j) k[j] = none_key();
     uint32_t bstart = 0;
     int src = -1;
-    const float4 sp = scan[q];
+    const float4 sp = scan[live ? q : n - 1];
     float qx, qy, qz;
     rt_apply(kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
     if (DBG && stamp_slot) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); stamp_slot[1] = clock64(); }
-    knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
+    knn_search<S, DBG, LV_COOP_FROM>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk, live);
     if (DBG && stamp_slot) { asm volatile("" :: "v"(k[0]), "v"(k[4])); stamp_slot[3] = clock64(); }
     int found = 0;
 #pragma unroll
     for (int j = 0; j < KNN; ++j) found += is_none(k[j]) ? 0 : 1;
+    if (live) {
 #pragma unroll
-    for (int slot0 = 0; slot0 < QREC_SLOTS; slot0 += S) {
-        const int slot = slot0 + gl;
-        if (slot >= QREC_SLOTS) break;
-        float4 v;
-        if (slot < KNN) {
-            kkey kk = k[0];
+        for (int slot0 = 0; slot0 < QREC_SLOTS; slot0 += S) {
+            const int slot = slot0 + gl;
+            if (slot >= QREC_SLOTS) break;
+            float4 v;
+            if (slot < KNN) {
+                kkey kk = k[0];
 #pragma unroll
-            for (int j = 1; j < KNN; ++j) kk = (slot == j) ? k[j] : kk;
-            v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
-            if (!is_none(kk)) {
-                const uint32_t pos = key_lo(kk);
-                if (src >= 0) v = map.bucket[src][(size_t)bstart + pos];
-                else { v = map.orig[pos]; v.w = __uint_as_float(pos); }
+                for (int j = 1; j < KNN; ++j) kk = (slot == j) ? k[j] : kk;
+                v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+                if (!is_none(kk)) {
+                    const uint32_t pos = key_lo(kk);
+                    if (src >= 0) v = map.bucket[src][(size_t)bstart + pos];
+                    else { v = map.orig[pos]; v.w = __uint_as_float(pos); }
+                }
+            } else if (slot == 5) {
+                v = make_float4(qx, qy, qz, sp.w);
+            } else if (slot == 6) {
+                v = make_float4(__uint_as_float(key_hi(k[0])), __uint_as_float(key_hi(k[1])), __uint_as_float(key_hi(k[2])),
+                                __uint_as_float(key_hi(k[3])));
+            } else {
+                v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(found), 0.f, 0.f);
             }
-        } else if (slot == 5) {
-            v = make_float4(qx, qy, qz, sp.w);
-        } else if (slot == 6) {
-            v = make_float4(__uint_as_float(key_hi(k[0])), __uint_as_float(key_hi(k[1])), __uint_as_float(key_hi(k[2])),
-                            __uint_as_float(key_hi(k[3])));
-        } else {
-            v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(found), 0.f, 0.f);
+            qrec[(size_t)slot * qstride + q] = v;
         }
-        qrec[(size_t)slot * qstride + q] = v;
     }
-    if (DBG && stamp_slot) stamp_slot[4] = clock64();
+    if (DBG && stamp_slot) { stamp_slot[4] = clock64(); }
     if (DBG && stamp_slot) { dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 1] = wall_clock64(); }
 }
 
@@ -814,13 +899,13 @@ static void launch_s(hipStream_t stream, bool dbg_on, bool ext, int grid, const 
 
 template <int S>
 static void launch_search(hipStream_t stream, bool dbg_on, const MapView& map, const float4* scan, uint32_t n, KfDev* kf,
-                          float4* qrec, uint32_t qstride, const DebugOut& dbg) {
+                          float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg) {
     constexpr uint32_t GS = 256 / S;
     uint32_t grid = (n + GS - 1) / GS;
     grid = (grid + 7u) & ~7u;
     if (grid == 0) grid = 8;
-    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, dbg);
-    else hipLaunchKernelGGL((search_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, dbg);
+    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, dbg);
+    else hipLaunchKernelGGL((search_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, dbg);
 }
 
 static bool debug_requested(const DebugOut& dbg) {
@@ -829,14 +914,14 @@ static bool debug_requested(const DebugOut& dbg) {
 
 // split form, kernel 1: exact 5-NN of every scan point -> qrec
 int launch_search(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf, float4* qrec,
-                  uint32_t qstride, const DebugOut& dbg) {
+                  uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg) {
     const bool dbg_on = debug_requested(dbg);
     switch (S) {
-        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
-        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
-        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
-        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
-        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, dbg); break;
+        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
+        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
+        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
+        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
+        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
         default: set_error("lanes_per_query must be 1,2,4,8 or 16 (got %d)", S); return LV_EINVAL;
     }
     LV_HIP(hipGetLastError());

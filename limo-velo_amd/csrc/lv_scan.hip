@@ -239,7 +239,7 @@ void ScanStore::release() {
     hipFree(d_sort_tmp);
     hipFree(d_in); hipFree(d_times); hipFree(d_desk); hipFree(d_vkeys); hipFree(d_vkeys_sorted); hipFree(d_vidx);
     hipFree(d_vidx_sorted); hipFree(d_heads); hipFree(d_hpos); hipFree(d_vsort_tmp); hipFree(d_vscan_tmp); hipFree(d_states);
-    hipFree(d_bounds);
+    hipFree(d_bounds); hipFree(d_tile_order);
     *this = ScanStore();
 }
 
@@ -254,6 +254,47 @@ int ScanStore::sort(hipStream_t stream, const float bbox_min[3], float cell) {
                                                            30, stream));
     hipLaunchKernelGGL(scan_gather_kernel, dim3(grid), dim3(B), 0, stream, d_raw, d_idx_sorted, n, d_sorted);
     LV_HIP(hipGetLastError());
+    return order_tiles(stream, tile_points);
+}
+
+// Dispatch order of the search kernel's point tiles: tiles whose points lie farthest from the sensor first.
+// A pose error moves a point by (translation error + rotation error x range), so the far tiles are the ones
+// that miss bucket level 0 in the first pass and run several times longer; started first they overlap with the
+// cheap tiles instead of forming the tail of the launch (longest-processing-time-first; a scheduling hint only,
+// results do not depend on it).
+__global__ void tile_range_keys_kernel(const float4* __restrict__ sorted, uint32_t n, uint32_t tile_points, uint32_t ntiles,
+                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    float r2 = 0.f;
+    const uint32_t b = t * tile_points;
+    for (uint32_t i = 0; i < tile_points && b + i < n; ++i) {
+        const float4 p = sorted[b + i];
+        r2 = fmaxf(r2, p.x * p.x + p.y * p.y + p.z * p.z);
+    }
+    keys[t] = ~__float_as_uint(r2);   // ascending sort of the complement = descending range (r2 >= 0)
+    ids[t] = t;
+}
+
+int ScanStore::order_tiles(hipStream_t stream, uint32_t tile_points) {
+    n_tiles = 0;
+    if (n == 0 || tile_points == 0) return LV_OK;
+    const uint32_t nt = (n + tile_points - 1) / tile_points;
+    if (nt > tile_cap) {
+        hipFree(d_tile_order);
+        d_tile_order = nullptr;
+        tile_cap = 0;
+        uint32_t cap = 1024;
+        while (cap < nt) cap *= 2;
+        LV_HIP(hipMalloc(&d_tile_order, cap * sizeof(uint32_t)));
+        tile_cap = cap;
+    }
+    // d_keys / d_idx / d_keys_sorted are free again once the points are gathered (nt <= n <= capacity)
+    hipLaunchKernelGGL(tile_range_keys_kernel, dim3((nt + 255) / 256), dim3(256), 0, stream, d_sorted, n, tile_points, nt, d_keys, d_idx);
+    size_t tmp = sort_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tmp, d_keys, d_keys_sorted, d_idx, d_tile_order, (int)nt, 0, 32,
+                                                           stream));
+    n_tiles = nt;
     return LV_OK;
 }
 
