@@ -54,8 +54,7 @@ struct lv_ctx {
     int comm_rank = 0, comm_world = 1;
     bool fold_direct = false;      // this pass: solve_kernel reads the block partials directly
     bool tile_lpt = true;          // dispatch the search tiles farthest-first (LV_TILE_LPT=0: plain order, A/B knob)
-    bool split = true;             // search_kernel + fit_reduce_kernel (default) or the fused match_reduce_kernel
-    float4* d_qrec = nullptr;      // split form: 8 float4 planes of qstride entries (one record per scan point)
+    float4* d_qrec = nullptr;      // search -> fit hand-over: 8 float4 planes of qstride entries (one record per scan point)
     uint32_t qstride = 0;
 
     // capture (debug / API-parity) buffers, sized for the current scan
@@ -151,8 +150,8 @@ void unpack_sums(const double* rec, lv_sums* out) {
 int begin_device(lv_ctx* c, bool from_host) {
     int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, from_host);
     if (rc) return rc;
-    c->grid = match_grid_size(c->prm.lanes_per_query, c->scan.n, c->max_blocks, c->split);
-    if (c->split && (uint32_t)c->scan.n > c->qstride) {
+    c->grid = fit_grid_size(c->scan.n, c->max_blocks);
+    if ((uint32_t)c->scan.n > c->qstride) {
         uint32_t cap = c->qstride ? c->qstride : 4096;
         while (cap < (uint32_t)c->scan.n) cap *= 2;
         LV_HIP(hipStreamSynchronize(c->stream));
@@ -180,6 +179,7 @@ int pass_solve(lv_ctx* c, bool from_groups);
 
 int pass_reduce(lv_ctx* c, bool finalize) {
     MatchParams mp;
+    mp.R_inv = 1.0 / c->prm.LiDAR_noise;
     mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
     mp.planes_threshold = c->prm.PLANES_THRESHOLD;
     mp.estimate_extrinsics = c->prm.estimate_extrinsics;
@@ -195,20 +195,14 @@ int pass_reduce(lv_ctx* c, bool finalize) {
         dbg.clk = c->d_clk;
         dbg.clk_blocks = c->grid;
     }
-    int rc;
-    if (c->split) {
+    int rc = LV_OK;
+    if (c->scan.n > 0)
         rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
                            c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, dbg);
-        if (rc) return rc;
-        if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
-        rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
-        if (rc) return rc;
-    } else {
-        rc = launch_match_reduce(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, mp,
-                                 c->d_partials, c->grid, dbg);
-        if (rc) return rc;
-        if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));
-    }
+    if (rc) return rc;
+    if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
+    rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
+    if (rc) return rc;
     // few enough block partials (a 64k-point scan leaves 256): solve_kernel folds them itself in one memory
     // round trip; otherwise stage 1 of the reduction runs as its own kernel
     c->fold_direct = !finalize && c->grid <= solve_direct_records();
@@ -224,16 +218,9 @@ int pass_reduce(lv_ctx* c, bool finalize) {
 // one measurement pass + solve as lv_update / lv_correct run it.  With a communicator (multi-GPU): the rank's
 // record is all-reduced in place on the stream and every rank solves from the identical record.
 int pass_full(lv_ctx* c) {
-    int rc;
-    if (c->scan.n == 0) {   // a rank without points contributes zeros
-        double* zero = c->comm ? c->d_sums : c->d_groups;
-        LV_HIP(hipMemsetAsync(zero, 0, SUMS_LEN * sizeof(double), c->stream));
-        c->ngroups = 1;
-        c->fold_direct = false;
-    } else {
-        rc = pass_reduce(c, c->comm != nullptr);
-        if (rc) return rc;
-    }
+    // (a rank without points still runs the pass: its partials are zeros and solve_prep must run)
+    int rc = pass_reduce(c, c->comm != nullptr);
+    if (rc) return rc;
     if (c->comm) {
         rc = comm_allreduce_record(c->comm, c->d_sums, c->stream);
         if (rc) return rc;
@@ -299,7 +286,6 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     int per_cu = 4;
     if (const char* e = getenv("LV_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;  // tuning knob
     if (const char* e = getenv("LV_TILE_LPT")) c->tile_lpt = atoi(e) != 0;
-    if (const char* e = getenv("LV_FUSED")) c->split = atoi(e) == 0;                      // A/B knob: fused match kernel
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -548,10 +534,6 @@ int lv_update_begin(lv_ctx* c, const lv_state* x, const double* P) {
 int lv_pass_reduce(lv_ctx* c) {
     LV_CHECK_CTX(c);
     if (!c->in_update) { set_error("lv_pass_reduce outside lv_update_begin/end"); return LV_ESTATE; }
-    if (c->map.m == 0 || c->scan.n == 0) {
-        LV_HIP(hipMemsetAsync(c->d_sums, 0, SUMS_LEN * sizeof(double), c->stream));
-        return LV_OK;
-    }
     return pass_reduce(c, true);
 }
 

@@ -55,6 +55,10 @@ struct KfDev {
     double sums_log[MAX_PASSES * SUMS_LEN];
     PoseConsts pose;
     long long solve_clk[MAX_PASSES * 16];  // instrumentation: shader-clock stamps of solve_kernel phases
+    // record-independent half of the next solve, left here by fit_reduce_kernel's extra workgroup (solve_prep)
+    double prep_dxnew[NS];
+    double prep_P[NS * NS];
+    double prep_A1[12 * 12];
     int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / generic levels / brute force
 };
 
@@ -100,6 +104,7 @@ struct MapView {
 };
 
 struct MatchParams {
+    double R_inv;               // 1 / LiDAR_noise (solve_prep)
     double max_dist_plane_sq;  // MAX_DIST_PLANE * MAX_DIST_PLANE (f64, Plane.cpp:42)
     float planes_threshold;
     int estimate_extrinsics;

@@ -78,16 +78,13 @@ int comm_destroy(void* comm);
 int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
 
 // lv_match.hip
-// split form (default): search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride
-// entries), fit_reduce_kernel turns them into `grid` block partials
+// search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries);
+// fit_reduce_kernel turns them into `grid` block partials (and one extra workgroup runs solve_prep)
 int launch_search(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
                   float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg);
 int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
                       double* partials, int grid, const DebugOut& dbg);
-// fused form (LV_FUSED=1, A/B reference)
-int launch_match_reduce(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n,
-                        KfDev* kf, const MatchParams& prm, double* partials, int grid, const DebugOut& dbg);
-int match_grid_size(int lanes_per_query, uint32_t n, int max_blocks, bool split);
+int fit_grid_size(uint32_t n, int max_blocks);
 // lv_solve.hip
 int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, bool from_host);  // io: device pointer of the pinned mailbox
 int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf);

@@ -24,6 +24,7 @@
 // scratch, and after the last level a brute-force scan of all M points decides.  Hence the result
 // equals exhaustive search under the (d, index) order for every query.
 #include "lv_host.hpp"
+#include "lv_solve_dev.hpp"   // solve_prep (restores -ffp-contract=off for everything below)
 
 namespace lv {
 
@@ -494,16 +495,6 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     if (DBG && hist && live && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
 }
 
-struct QueryStage {     // kNN result of one scan point, handed from the search lanes to the fit lane
-    float qx, qy, qz;
-    uint32_t oq;        // original scan index
-    uint32_t pos[KNN];  // bucket positions (src >= 0) or original map indices (src < 0)
-    uint32_t dbits[KNN];
-    uint32_t bstart;
-    int src;            // bucket level the winners came from, -1 = generic path (pos = map index)
-    int found;
-};
-
 // Plane fit + gates + Jacobian row of ONE scan point (one lane): Plane.cpp:19-55, Utils.cpp:32-66,
 // Match.cpp:18-22, Localizator.cpp:36-56.  P / nidx / dbits: the 5 nearest map points in (distance, index)
 // order; found < 0 marks a padding lane.  The row {J[0..W), h, valid} goes to srow (LDS).
@@ -598,124 +589,8 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
     }
 }
 
-#ifndef LV_MATCH_BOUNDS
-#define LV_MATCH_BOUNDS __launch_bounds__(256)
-#endif
-#ifndef LV_FIT_POINTS
-#define LV_FIT_POINTS 64   // scan points fitted together per workgroup iteration
-#endif
-template <int S, bool EXT, bool DBG>
-__global__ LV_MATCH_BOUNDS void match_reduce_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
-                                                           KfDev* __restrict__ kf, MatchParams prm,
-                                                           double* __restrict__ partials, DebugOut dbg) {
-    // A workgroup searches SUB sub-tiles of 256/S points back to back and then fits all G of them at once:
-    // the plane-fit phase is a ~10k-cycle dependent chain executed by G lanes, so it should always see a
-    // full wavefront (G = 64) instead of being paid once per 32 or 16 points.
-    constexpr int SUB = (LV_FIT_POINTS * S) / 256 > 1 ? (LV_FIT_POINTS * S) / 256 : 1;
-    constexpr int GS = 256 / S;            // scan points searched concurrently
-    constexpr int G = SUB * GS;            // scan points per block iteration (64 for S >= 4)
-    constexpr int W = EXT ? 12 : 6;        // live Jacobian columns
-    constexpr int ROW_W = W + 2;           // + h, valid
-    constexpr int NOUT = W * (W + 1) / 2 + W + 2;
-    __shared__ QueryStage s_q[G];
-    __shared__ double s_rows[G][ROW_W];
-    __shared__ double s_out[SUMS_LEN];
-    if (kf->done) return;
-    const int tid = threadIdx.x;
-    const int gq = tid / S, gl = tid % S;
-    const PoseConsts& pc = kf->pose;
-
-    int oa = 0, ob = 0, orec = 0;
-    if (tid < NOUT) out_pair<W>(tid, oa, ob, orec);
-    double acc = 0.0;
-    if (tid < SUMS_LEN) s_out[tid] = 0.0;
-
-    // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed placement, used for L2
-    // affinity only); every XCD gets a contiguous run of Morton-ordered query tiles.  gridDim.x % 8 == 0.
-    const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
-    const uint32_t per_iter = (uint32_t)G * gridDim.x;
-    const uint32_t iters = (n + per_iter - 1) / per_iter;
-#define LV_STAMP(i) do { if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
-    for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t qbase = (it * gridDim.x + vb) * (uint32_t)G;
-        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 0] = wall_clock64();
-        LV_STAMP(0);
-        long long* stamp_slot = (DBG && dbg.clk && tid == 0 && it == 0) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
-        // ================= phase 1: S lanes per scan point — exact 5-NN =========================
-#pragma unroll 1
-        for (int sub = 0; sub < SUB; ++sub) {
-            const int sq = sub * GS + gq;   // staging slot of this lane group's point
-            const uint32_t q = qbase + (uint32_t)sq;
-            kkey k[KNN];
-#pragma unroll
-            for (int j = 0; j < KNN; ++j) k[j] = none_key();
-            float qx = 0.f, qy = 0.f, qz = 0.f;
-            uint32_t oq = 0, bstart = 0;
-            int src = -1;
-            if (q < n) {
-                const float4 sp = scan[q];
-                oq = __float_as_uint(sp.w);
-                rt_apply(pc.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
-                if (DBG && dbg.clk) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); LV_STAMP(1); }
-                knn_search<S, DBG, MAX_BUCKET_LEVELS>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk);
-            }
-            if (DBG && dbg.clk) { asm volatile("" :: "v"(k[0]), "v"(k[4])); LV_STAMP(3); }
-            if (gl == 0) {
-                QueryStage& st = s_q[sq];
-                st.qx = qx; st.qy = qy; st.qz = qz;
-                st.oq = oq;
-                st.bstart = bstart;
-                st.src = src;
-                int found = 0;
-#pragma unroll
-                for (int j = 0; j < KNN; ++j) {
-                    st.pos[j] = key_lo(k[j]);
-                    st.dbits[j] = key_hi(k[j]);
-                    found += is_none(k[j]) ? 0 : 1;
-                }
-                st.found = (q < n) ? found : -1;
-            }
-        }
-        LV_STAMP(4);
-        __syncthreads();
-        LV_STAMP(5);
-        // ================= phase 2: one lane per scan point — plane fit, gates, Jacobian row ==========
-        if (tid < G) {
-            const QueryStage st = s_q[tid];
-            float P[KNN][3];
-            uint32_t nidx[KNN];
-#pragma unroll
-            for (int j = 0; j < KNN; ++j) {
-                nidx[j] = 0xFFFFFFFFu;
-                P[j][0] = P[j][1] = P[j][2] = 0.f;
-                if (j < st.found) {
-                    float4 nb;
-                    if (st.src >= 0) { nb = map.bucket[st.src][(size_t)st.bstart + st.pos[j]]; nidx[j] = __float_as_uint(nb.w); }
-                    else { nb = map.orig[st.pos[j]]; nidx[j] = st.pos[j]; }
-                    P[j][0] = nb.x; P[j][1] = nb.y; P[j][2] = nb.z;
-                }
-            }
-            fit_row<W, EXT, DBG>(pc, prm, dbg, st.found, P, nidx, st.dbits, st.qx, st.qy, st.qz, st.oq, s_rows[tid]);
-        }
-        __syncthreads();
-        LV_STAMP(6);
-        // ================= phase 3: contract the staged rows into the block partial =====================
-        if (tid < NOUT) {
-#pragma unroll 8
-            for (int p = 0; p < G; ++p) acc += s_rows[p][oa] * s_rows[p][ob];
-        }
-        __syncthreads();
-        LV_STAMP(7);
-        if (DBG && dbg.clk && tid == 0 && it == 0) dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 1] = wall_clock64();
-    }
-#undef LV_STAMP
-    if (tid < NOUT) s_out[orec] = acc;
-    __syncthreads();
-    if (tid < SUMS_LEN) partials[(size_t)blockIdx.x * SUMS_LEN + tid] = s_out[tid];
-}
-
 // ------------------------------------------------------------------------------------------------------
-// Split form of the pass (default): the search and the fit have very different register needs (the search
+// The pass runs as two kernels: the search and the fit have very different register needs (the search
 // wants many waves in flight to hide its dependent loads, the QR fit wants ~100 VGPRs), so each gets its own
 // kernel and register budget.  search_kernel hands one 128-byte record per scan point to fit_reduce_kernel
 // through HBM/L2, slot-major (8 float4 planes of qstride entries) so both sides are coalesced:
@@ -741,7 +616,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     const int tid = threadIdx.x;
     const int gq = tid / S, gl = tid % S;
     // tile order: farthest-from-sensor tiles first (ScanStore::order_tiles).  An XCD-aware order (contiguous
-    // Morton runs per XCD, as in match_reduce_kernel) measured no different from plain round-robin here.
+    // Morton runs per XCD) measured no different from plain round-robin here.
     const uint32_t vb = (tile_order && blockIdx.x < n_tiles) ? tile_order[blockIdx.x] : blockIdx.x;
     const uint32_t q = vb * (uint32_t)GS + (uint32_t)gq;
     long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
@@ -812,6 +687,11 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
     __shared__ double s_rows[G][ROW_W];
     __shared__ double s_out[NWAVE][SUMS_LEN];
     if (kf->done) return;
+    if (blockIdx.x == 0) {   // rides along: the half of the coming solve that does not need this pass' record
+        solve_prep<W, FIT_POINTS>(kf, prm.R_inv);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - 1u, nfit = gridDim.x - 1u;   // plane-fitting workgroups
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const PoseConsts& pc = kf->pose;
@@ -824,12 +704,12 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
         if (lane + a * 64 < NOUT) out_pair<W>(lane + a * 64, oa[a], ob[a], orec[a]);
     }
     for (int t = tid; t < NWAVE * SUMS_LEN; t += G) (&s_out[0][0])[t] = 0.0;
-    const uint32_t vb = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
-    const uint32_t per_iter = (uint32_t)G * gridDim.x;
+    const uint32_t vb = (bid % 8u) * (nfit / 8u) + bid / 8u;
+    const uint32_t per_iter = (uint32_t)G * nfit;
     const uint32_t iters = (n + per_iter - 1) / per_iter;
-    long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
+    long long* stamp_slot = (DBG && dbg.clk && tid == 0 && bid < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)bid * 8 : nullptr;
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t q = (it * gridDim.x + vb) * (uint32_t)G + (uint32_t)tid;
+        const uint32_t q = (it * nfit + vb) * (uint32_t)G + (uint32_t)tid;
         if (DBG && stamp_slot && it == 0) stamp_slot[5] = clock64();
         float P[KNN][3];
         uint32_t nidx[KNN], dbits[KNN];
@@ -873,28 +753,17 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
         double s = s_out[0][tid];
 #pragma unroll
         for (int w = 1; w < NWAVE; ++w) s += s_out[w][tid];
-        partials[(size_t)blockIdx.x * SUMS_LEN + tid] = s;
+        partials[(size_t)bid * SUMS_LEN + tid] = s;
     }
 }
 
-int match_grid_size(int S, uint32_t n, int max_blocks, bool split) {
-    const uint32_t sub = (LV_FIT_POINTS * S) / 256 > 1 ? (LV_FIT_POINTS * S) / 256 : 1;
-    const uint32_t G = split ? (uint32_t)FIT_POINTS : sub * (256 / S);
-    uint32_t need = (n + G - 1) / G;
+// workgroups of fit_reduce_kernel that fit planes (one more is launched for solve_prep)
+int fit_grid_size(uint32_t n, int max_blocks) {
+    uint32_t need = (n + (uint32_t)FIT_POINTS - 1) / (uint32_t)FIT_POINTS;
     if (need < 1) need = 1;
     uint32_t grid = need < (uint32_t)max_blocks ? need : (uint32_t)max_blocks;
     grid = (grid + 7u) & ~7u;  // multiple of 8 (XCD-aware tile order)
     return (int)grid;
-}
-
-template <int S>
-static void launch_s(hipStream_t stream, bool dbg_on, bool ext, int grid, const MapView& map, const float4* scan, uint32_t n,
-                     KfDev* kf, const MatchParams& prm, double* partials, const DebugOut& dbg) {
-#define LV_LAUNCH(EXT_, DBG_) \
-    hipLaunchKernelGGL((match_reduce_kernel<S, EXT_, DBG_>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, prm, partials, dbg)
-    if (ext) { if (dbg_on) LV_LAUNCH(true, true); else LV_LAUNCH(true, false); }
-    else { if (dbg_on) LV_LAUNCH(false, true); else LV_LAUNCH(false, false); }
-#undef LV_LAUNCH
 }
 
 template <int S>
@@ -934,27 +803,10 @@ int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, 
     const bool dbg_on = debug_requested(dbg);
     const bool ext = prm.estimate_extrinsics != 0;
 #define LV_LAUNCH(EXT_, DBG_) \
-    hipLaunchKernelGGL((fit_reduce_kernel<EXT_, DBG_>), dim3(grid), dim3(FIT_POINTS), 0, stream, qrec, qstride, n, kf, prm, partials, dbg)
+    hipLaunchKernelGGL((fit_reduce_kernel<EXT_, DBG_>), dim3(grid + 1), dim3(FIT_POINTS), 0, stream, qrec, qstride, n, kf, prm, partials, dbg)
     if (ext) { if (dbg_on) LV_LAUNCH(true, true); else LV_LAUNCH(true, false); }
     else { if (dbg_on) LV_LAUNCH(false, true); else LV_LAUNCH(false, false); }
 #undef LV_LAUNCH
-    LV_HIP(hipGetLastError());
-    return LV_OK;
-}
-
-// fused form (A/B reference, LV_FUSED=1): one kernel does search + fit + contraction
-int launch_match_reduce(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
-                        const MatchParams& prm, double* partials, int grid, const DebugOut& dbg) {
-    const bool dbg_on = debug_requested(dbg);
-    const bool ext = prm.estimate_extrinsics != 0;
-    switch (S) {
-        case 1: launch_s<1>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
-        case 2: launch_s<2>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
-        case 4: launch_s<4>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
-        case 8: launch_s<8>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
-        case 16: launch_s<16>(stream, dbg_on, ext, grid, map, scan_sorted, n, kf, prm, partials, dbg); break;
-        default: set_error("lanes_per_query must be 1,2,4,8 or 16 (got %d)", S); return LV_EINVAL;
-    }
     LV_HIP(hipGetLastError());
     return LV_OK;
 }

@@ -20,7 +20,10 @@
 // (the naive S = I + Pr11 HTH solve loses ~6 digits in the posterior covariance; measured in
 // tests/test_oracle_numerics.py).  Algebraically identical to upstream, rounding-level different.
 #include "lv_host.hpp"
-#include "lv_manifold.hpp"
+#include "lv_solve_dev.hpp"
+
+// the 23-dof algebra of this file is compared with the oracle at 1e-9, not bitwise (see lv_manifold.hpp)
+#pragma clang fp contract(fast)
 
 namespace lv {
 
@@ -118,128 +121,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void reduce_final_kernel(const double
 }
 
 // ---- solve ------------------------------------------------------------------------------------------
-constexpr int LD = NS + 1;  // padded leading dimension in LDS
 constexpr int SOLVE_THREADS = FOLD_THREADS;
-
-__device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double (*b)[LD], bool b_transposed, int tid) {
-    if (tid < NS * NS) {
-        const int i = tid / NS, j = tid % NS;
-        double s = 0.0;
-#pragma unroll 1
-        for (int c = 0; c < NS; ++c) s += a[i][c] * (b_transposed ? b[j][c] : b[c][j]);
-        out[i][j] = s;
-    }
-}
-// in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix (NW = 6 or 12); all threads call,
-// tid < NW*NW work; one reciprocal per step
-template <int NW>
-__device__ inline void gj_spd(double (*W)[12][13], int& cur, int tid) {
-    for (int k = 0; k < NW; ++k) {
-        if (tid < NW * NW) {
-            const int i = tid / NW, j = tid % NW;
-            const double rp = ddiv(1.0, W[cur][k][k]);
-            double v;
-            if (i == k) {
-                v = (j == k) ? rp : W[cur][k][j] * rp;
-            } else {
-                const double f = W[cur][i][k];
-                v = (j == k) ? -(f * rp) : W[cur][i][j] - f * (W[cur][k][j] * rp);
-            }
-            W[cur ^ 1][i][j] = v;
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-}
-
-// out = J in J^T for J = identity except the 3x3 blocks at 3 and 6 and the 2x2 block at 21: every output
-// element touches at most 3 x 3 inputs, so the congruence is one pass (no intermediate product)
-__device__ __forceinline__ void blk_range(int i, int& lo, int& n) {
-    if (i >= 3 && i < 6) { lo = 3; n = 3; }
-    else if (i >= 6 && i < 9) { lo = 6; n = 3; }
-    else if (i >= 21) { lo = 21; n = 2; }
-    else { lo = i; n = 1; }
-}
-__device__ inline void congruence(double (*out)[LD], const double (*J)[LD], const double (*in)[LD], int tid) {
-    if (tid < NS * NS) {
-        const int i = tid / NS, j = tid % NS;
-        int ia, na, jb, nb;
-        blk_range(i, ia, na);
-        blk_range(j, jb, nb);
-        double s = 0.0;
-        for (int a = 0; a < na; ++a) {
-            double t = 0.0;
-            for (int b = 0; b < nb; ++b) t += in[ia + a][jb + b] * J[j][jb + b];
-            s += J[i][ia + a] * t;
-        }
-        out[i][j] = s;
-    }
-}
-
-__device__ inline void set_identity(double (*J)[LD], int tid) {
-    if (tid < NS * NS) J[tid / NS][tid % NS] = (tid / NS == tid % NS) ? 1.0 : 0.0;
-}
-
-// compute_pose_consts (lv_device.hpp) with the four quaternion -> matrix conversions already done
-__device__ inline void finish_pose_consts(const double* x, const double (*rot)[9], PoseConsts* out) {
-#pragma clang fp contract(off)
-    RT32 X, LI;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { X.R[i] = (float)rot[0][i]; LI.R[i] = (float)rot[1][i]; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { X.t[i] = (float)x[i]; LI.t[i] = (float)x[11 + i]; }
-    out->Tc = rt_compose(X, LI);
-    out->back = rt_compose(rt_inv(LI), rt_inv(X));
-    out->LI = LI;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { out->R_inv[i] = rot[2][i]; out->I_R_L_inv[i] = rot[3][i]; }
-}
-
-// The three manifold blocks are independent: wave 0 / 1 / 2 (lane 0 of each) compute them concurrently
-// on different SIMDs.  part 0: rot (dof 3), 1: offset_R_L_I (dof 6), 2: grav (dof 21).
-// mode 0: seg = x [-] x_prop for this block (written to dx), then the projection block from seg
-// mode 1: projection block from the given tangent `seg_in`
-__device__ inline void manifold_block(int part, int mode, const double* x, const double* xp, const double* seg_in, double* dx,
-                                      double (*J)[LD]) {
-    if (part < 2) {
-        const int idx = part == 0 ? 3 : 6, q = part == 0 ? 3 : 7;
-        double seg[3];
-        if (mode == 0) {
-            double c[4] = {-xp[q], -xp[q + 1], -xp[q + 2], xp[q + 3]}, qq[4];
-            d_quat_mul(c, x + q, qq);
-            d_so3_log(qq, seg);
-            dx[idx] = seg[0]; dx[idx + 1] = seg[1]; dx[idx + 2] = seg[2];
-        } else {
-            seg[0] = seg_in[idx]; seg[1] = seg_in[idx + 1]; seg[2] = seg_in[idx + 2];
-        }
-        double A[9];
-        d_A_matrix(seg, A);
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) J[idx + r][idx + c] = A[c * 3 + r];  // res_temp_SO3 = A^T
-    } else {
-        double seg[2];
-        if (mode == 0) {
-            d_s2_boxminus(x + 23, xp + 23, seg);
-            dx[21] = seg[0]; dx[22] = seg[1];
-        } else {
-            seg[0] = seg_in[21]; seg[1] = seg_in[22];
-        }
-        double T[4];
-        d_s2_proj(x + 23, xp + 23, seg, T);
-        J[21][21] = T[0]; J[21][22] = T[1]; J[22][21] = T[2]; J[22][22] = T[3];
-    }
-}
-
-__device__ inline void boxplus_block(int part, double* x, const double* d) {
-    if (part == 0) { double e[4], o[4]; d_so3_exp(d + 3, 1.0, e); d_quat_mul(x + 3, e, o); for (int i = 0; i < 4; ++i) x[3 + i] = o[i]; }
-    else if (part == 1) { double e[4], o[4]; d_so3_exp(d + 6, 1.0, e); d_quat_mul(x + 7, e, o); for (int i = 0; i < 4; ++i) x[7 + i] = o[i]; }
-    else d_s2_boxplus(x + 23, d + 21);
-}
-
-// dof index -> offset in the 26-double state for the vect components
-__device__ __forceinline__ int vect_state_index(int dof) {  // dof in {0..2, 9..20}
-    return dof < 3 ? dof : dof + 2;                         // 9..11 -> 11..13, 12..14 -> 14..16, ...
-}
 
 // NW = number of Jacobian columns that can be non-zero: 6 without extrinsic estimation (H^T H lives in
 // the leading 6x6 block, only P_inv[:, 0:6] is needed), 12 with it.
@@ -256,12 +138,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __shared__ int s_last, s_conv;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    // every global read of this kernel is issued up front (one memory round trip): the group records, x,
-    // x_prop, P_prop — independent of the done / passes words read next
+    // every global read of this kernel is issued up front (one memory round trip): the records, x, x_prop and
+    // the prepared half — independent of the done / passes words read next
     double fv[FOLD_DEPTH];
     if (nrec <= FOLD_PARTS * FOLD_DEPTH) fold_issue(fv, recs, nrec, tid);
     if (tid >= 128 && tid < 128 + NX) { sx[tid - 128] = kf->x[tid - 128]; sxp[tid - 128] = kf->x_prop[tid - 128]; }
-    if (tid < NS * NS) sB[tid / NS][tid % NS] = kf->P_prop[tid];
+    // the record-independent half of this pass was computed by fit_reduce_kernel's extra workgroup (solve_prep)
+    if (tid < NS * NS) sP[tid / NS][tid % NS] = kf->prep_P[tid];
+    if (tid < NS) sdxnew[tid] = kf->prep_dxnew[tid];
+    if (tid >= 192 && tid < 192 + NW * NW) sG[(tid - 192) / NW][(tid - 192) % NW] = kf->prep_A1[tid - 192];
     if (kf->done) return;
     const int pass = kf->passes;
 #define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
@@ -281,7 +166,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = s;
     }
     if (tid == 200) s_conv = 1;
-    set_identity(sJ, tid);
     __syncthreads();
     if (tid < 144) {
         const int a = tid / 12, b = tid % 12;
@@ -306,44 +190,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     }
 
     SV_STAMP(1);
-    // dx = x [-] x_prop and the projection J(dx): three manifold blocks on three waves, vect parts on wave 3
-    if (wave < 3 && lane == 0) manifold_block(wave, 0, sx, sxp, nullptr, sdx, sJ);
-    if (wave == 3 && lane < 15) {
-        const int dof = lane < 3 ? lane : lane + 6;  // 0..2, 9..20
-        const int si = vect_state_index(dof);
-        sdx[dof] = sx[si] - sxp[si];
-    }
-    __syncthreads();
-    if (tid < NS) {  // dx_new = J dx (identity outside the blocks)
-        double s = 0.0;
-        const int b = (tid >= 3 && tid < 6) ? 3 : (tid >= 6 && tid < 9) ? 6 : (tid >= 21) ? 21 : -1;
-        if (b < 0) s = sdx[tid];
-        else if (b == 21) s = sJ[tid][21] * sdx[21] + sJ[tid][22] * sdx[22];
-        else s = dot3d(sJ[tid][b], sdx[b], sJ[tid][b + 1], sdx[b + 1], sJ[tid][b + 2], sdx[b + 2]);
-        sdxnew[tid] = s;
-    }
-    SV_STAMP(2);
-    // P_ = J P_prop J^T
-    congruence(sP, sJ, sB, tid);
-    __syncthreads();
-    // Pr = P_/R -> sA ; G = Pr[:, :12] HTH -> sG
+    __syncthreads();   // sHTH / sHTh complete
+    // P_ (sP), dx_new and A1 = (P_/R)_ww^-1 (sG) come from solve_prep.  Pr = P_/R -> sA
     if (tid < NS * NS) sA[tid / NS][tid % NS] = sP[tid / NS][tid % NS] * prm.R_inv;
-    __syncthreads();
-    SV_STAMP(3);
-    // X = P_inv[:, 0:NW]:  X_top = (Pr_ww^-1 + HTH_ww)^-1 (two unpivoted Gauss-Jordan inversions of SPD
-    // NW x NW matrices),  X_bot = Pr[NW:, 0:NW] Pr_ww^-1 X_top
-    if (tid < NW * NW) sW[0][tid / NW][tid % NW] = sA[tid / NW][tid % NW];
-    __syncthreads();
+    // X = P_inv[:, 0:NW]:  X_top = (Pr_ww^-1 + HTH_ww)^-1 (unpivoted Gauss-Jordan inversion of an SPD NW x NW
+    // matrix),  X_bot = Pr[NW:, 0:NW] Pr_ww^-1 X_top
     int cur = 0;
-    gj_spd<NW>(sW, cur, tid);
-    SV_STAMP(4);
     if (tid < NW * NW) {
         const int i = tid / NW, j = tid % NW;
-        const double a1 = sW[cur][i][j];
-        sG[i][j] = a1;                      // keep A1 = Pr_ww^-1
-        sW[cur][i][j] = a1 + sHTH[i][j];
+        sW[cur][i][j] = sG[i][j] + sHTH[i][j];
     }
     __syncthreads();
+    SV_STAMP(4);
     gj_spd<NW>(sW, cur, tid);               // sW[cur] = X_top
     SV_STAMP(5);
     if (tid < NW * NW) {                    // T = A1 X_top
@@ -440,12 +298,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 
     // terminal pass: L_ = J2 P_ J2^T, K_x rows projected, P_ <- P_ J2^T, P = L_ - K_x[:, :12] P_[0:12, :]
     __syncthreads();
-    set_identity(sJ, tid);
+    set_identity<SOLVE_THREADS>(sJ, tid);
     __syncthreads();
     if (wave < 3 && lane == 0) manifold_block(wave, 1, sx, sxp, sdxo, nullptr, sJ);
     __syncthreads();
-    congruence(sB, sJ, sP, tid);  // sB = L_ = J2 P_ J2^T
-    mm(sA, sP, sJ, true, tid);    // sA = P_ J2^T
+    congruence<SOLVE_THREADS>(sB, sJ, sP, tid);  // sB = L_ = J2 P_ J2^T
+    mm<SOLVE_THREADS>(sA, sP, sJ, true, tid);    // sA = P_ J2^T
     __syncthreads();
     if (tid < NS * NW) {         // K_x <- J2 K_x (rows)
         const int i = tid / NW, c = tid % NW;

@@ -1,0 +1,183 @@
+// lv_solve_dev.hpp — device building blocks of the per-pass filter algebra (esekf::update_iterated_dyn_share_modified,
+// [IKFoM absent from the reference mount; UPSTREAM-RECALL]; call site reference src/Modules/Localizator.cpp:132),
+// shared by solve_kernel (lv_solve.hip) and by the record-independent half that rides along in
+// fit_reduce_kernel (lv_match.hip): solve_prep.
+#pragma once
+
+#include "lv_device.hpp"
+#include "lv_manifold.hpp"
+
+namespace lv {
+
+constexpr int LD = NS + 1;  // padded leading dimension in LDS
+
+template <int NT>
+__device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double (*b)[LD], bool b_transposed, int tid) {
+    for (int e = tid; e < NS * NS; e += NT) {
+        const int i = e / NS, j = e % NS;
+        double s = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < NS; ++c) s += a[i][c] * (b_transposed ? b[j][c] : b[c][j]);
+        out[i][j] = s;
+    }
+}
+// in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix (NW = 6 or 12); all threads call,
+// tid < NW*NW work; one reciprocal per step
+template <int NW>
+__device__ inline void gj_spd(double (*W)[12][13], int& cur, int tid) {
+    for (int k = 0; k < NW; ++k) {
+        if (tid < NW * NW) {
+            const int i = tid / NW, j = tid % NW;
+            const double rp = ddiv(1.0, W[cur][k][k]);
+            double v;
+            if (i == k) {
+                v = (j == k) ? rp : W[cur][k][j] * rp;
+            } else {
+                const double f = W[cur][i][k];
+                v = (j == k) ? -(f * rp) : W[cur][i][j] - f * (W[cur][k][j] * rp);
+            }
+            W[cur ^ 1][i][j] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// out = J in J^T for J = identity except the 3x3 blocks at 3 and 6 and the 2x2 block at 21: every output
+// element touches at most 3 x 3 inputs, so the congruence is one pass (no intermediate product)
+__device__ __forceinline__ void blk_range(int i, int& lo, int& n) {
+    if (i >= 3 && i < 6) { lo = 3; n = 3; }
+    else if (i >= 6 && i < 9) { lo = 6; n = 3; }
+    else if (i >= 21) { lo = 21; n = 2; }
+    else { lo = i; n = 1; }
+}
+template <int NT>
+__device__ inline void congruence(double (*out)[LD], const double (*J)[LD], const double (*in)[LD], int tid) {
+    for (int e = tid; e < NS * NS; e += NT) {
+        const int i = e / NS, j = e % NS;
+        int ia, na, jb, nb;
+        blk_range(i, ia, na);
+        blk_range(j, jb, nb);
+        double s = 0.0;
+        for (int a = 0; a < na; ++a) {
+            double t = 0.0;
+            for (int b = 0; b < nb; ++b) t += in[ia + a][jb + b] * J[j][jb + b];
+            s += J[i][ia + a] * t;
+        }
+        out[i][j] = s;
+    }
+}
+
+template <int NT>
+__device__ inline void set_identity(double (*J)[LD], int tid) {
+    for (int e = tid; e < NS * NS; e += NT) J[e / NS][e % NS] = (e / NS == e % NS) ? 1.0 : 0.0;
+}
+
+// compute_pose_consts (lv_device.hpp) with the four quaternion -> matrix conversions already done
+__device__ inline void finish_pose_consts(const double* x, const double (*rot)[9], PoseConsts* out) {
+#pragma clang fp contract(off)
+    RT32 X, LI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { X.R[i] = (float)rot[0][i]; LI.R[i] = (float)rot[1][i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { X.t[i] = (float)x[i]; LI.t[i] = (float)x[11 + i]; }
+    out->Tc = rt_compose(X, LI);
+    out->back = rt_compose(rt_inv(LI), rt_inv(X));
+    out->LI = LI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { out->R_inv[i] = rot[2][i]; out->I_R_L_inv[i] = rot[3][i]; }
+}
+
+// The three manifold blocks are independent: wave 0 / 1 / 2 (lane 0 of each) compute them concurrently
+// on different SIMDs.  part 0: rot (dof 3), 1: offset_R_L_I (dof 6), 2: grav (dof 21).
+// mode 0: seg = x [-] x_prop for this block (written to dx), then the projection block from seg
+// mode 1: projection block from the given tangent `seg_in`
+__device__ inline void manifold_block(int part, int mode, const double* x, const double* xp, const double* seg_in, double* dx,
+                                      double (*J)[LD]) {
+    if (part < 2) {
+        const int idx = part == 0 ? 3 : 6, q = part == 0 ? 3 : 7;
+        double seg[3];
+        if (mode == 0) {
+            double c[4] = {-xp[q], -xp[q + 1], -xp[q + 2], xp[q + 3]}, qq[4];
+            d_quat_mul(c, x + q, qq);
+            d_so3_log(qq, seg);
+            dx[idx] = seg[0]; dx[idx + 1] = seg[1]; dx[idx + 2] = seg[2];
+        } else {
+            seg[0] = seg_in[idx]; seg[1] = seg_in[idx + 1]; seg[2] = seg_in[idx + 2];
+        }
+        double A[9];
+        d_A_matrix(seg, A);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) J[idx + r][idx + c] = A[c * 3 + r];  // res_temp_SO3 = A^T
+    } else {
+        double seg[2];
+        if (mode == 0) {
+            d_s2_boxminus(x + 23, xp + 23, seg);
+            dx[21] = seg[0]; dx[22] = seg[1];
+        } else {
+            seg[0] = seg_in[21]; seg[1] = seg_in[22];
+        }
+        double T[4];
+        d_s2_proj(x + 23, xp + 23, seg, T);
+        J[21][21] = T[0]; J[21][22] = T[1]; J[22][21] = T[2]; J[22][22] = T[3];
+    }
+}
+
+__device__ inline void boxplus_block(int part, double* x, const double* d) {
+    if (part == 0) { double e[4], o[4]; d_so3_exp(d + 3, 1.0, e); d_quat_mul(x + 3, e, o); for (int i = 0; i < 4; ++i) x[3 + i] = o[i]; }
+    else if (part == 1) { double e[4], o[4]; d_so3_exp(d + 6, 1.0, e); d_quat_mul(x + 7, e, o); for (int i = 0; i < 4; ++i) x[7 + i] = o[i]; }
+    else d_s2_boxplus(x + 23, d + 21);
+}
+
+// dof index -> offset in the 26-double state for the vect components
+__device__ __forceinline__ int vect_state_index(int dof) {  // dof in {0..2, 9..20}
+    return dof < 3 ? dof : dof + 2;                         // 9..11 -> 11..13, 12..14 -> 14..16, ...
+}
+
+// The half of a pass that does not depend on the measurement record: dx = x [-] x_prop with its projection J,
+// dx_new = J dx, P_ = J P_prop J^T and A1 = (P_/R)_ww^-1.  It only needs the state the previous pass left in kf,
+// so one extra workgroup of fit_reduce_kernel computes it while the other workgroups fit planes; solve_kernel
+// picks the results up from kf->prep_* and starts at the record.  NT threads (>= 256), all must call.
+template <int NW, int NT>
+__device__ inline void solve_prep(KfDev* __restrict__ kf, double R_inv) {
+    __shared__ double pP[NS][LD], pB[NS][LD], pJ[NS][LD];
+    __shared__ double pW[2][12][13];
+    __shared__ double px[NX], pxp[NX], pdx[NS];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < NS * NS; e += NT) pB[e / NS][e % NS] = kf->P_prop[e];
+    if (tid < NX) { px[tid] = kf->x[tid]; pxp[tid] = kf->x_prop[tid]; }
+    set_identity<NT>(pJ, tid);
+    __syncthreads();
+    // three manifold blocks on three waves, vect parts on wave 3
+    if (wave < 3 && lane == 0) manifold_block(wave, 0, px, pxp, nullptr, pdx, pJ);
+    if (wave == 3 && lane < 15) {
+        const int dof = lane < 3 ? lane : lane + 6;  // 0..2, 9..20
+        const int si = vect_state_index(dof);
+        pdx[dof] = px[si] - pxp[si];
+    }
+    __syncthreads();
+    if (tid < NS) {  // dx_new = J dx (identity outside the blocks)
+        double s = 0.0;
+        const int b = (tid >= 3 && tid < 6) ? 3 : (tid >= 6 && tid < 9) ? 6 : (tid >= 21) ? 21 : -1;
+        if (b < 0) s = pdx[tid];
+        else if (b == 21) s = pJ[tid][21] * pdx[21] + pJ[tid][22] * pdx[22];
+        else s = dot3d(pJ[tid][b], pdx[b], pJ[tid][b + 1], pdx[b + 1], pJ[tid][b + 2], pdx[b + 2]);
+        kf->prep_dxnew[tid] = s;
+    }
+    congruence<NT>(pP, pJ, pB, tid);  // P_ = J P_prop J^T
+    __syncthreads();
+    for (int e = tid; e < NS * NS; e += NT) kf->prep_P[e] = pP[e / NS][e % NS];
+    if (tid < NW * NW) pW[0][tid / NW][tid % NW] = pP[tid / NW][tid % NW] * R_inv;
+    __syncthreads();
+    int cur = 0;
+    gj_spd<NW>(pW, cur, tid);
+    if (tid < NW * NW) kf->prep_A1[tid] = pW[cur][tid / NW][tid % NW];
+}
+
+}  // namespace lv
+
+// lv_manifold.hpp switched FMA contraction on for the filter algebra above; the includer's own code goes back to
+// the build default (off: the f32 path is bit-exact against the FMA-free reference arithmetic).  lv_solve.hip
+// re-enables it for its kernels.
+#pragma clang fp contract(off)
