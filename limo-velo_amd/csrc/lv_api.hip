@@ -7,6 +7,9 @@
 
 #include "lv_host.hpp"
 
+#include <atomic>
+#include <chrono>
+
 namespace lv {
 
 static thread_local char g_err[512] = "";
@@ -42,6 +45,8 @@ struct lv_ctx {
     KfDev* h_kf = nullptr;  // pinned mirror (logs / trace downloads)
     KfHostIO* h_io = nullptr;  // pinned, host-mapped mailbox: update inputs and results (no copy kernels)
     KfHostIO* d_io = nullptr;  // its device address
+    int update_seq = 0;        // number of the update in flight (the finishing pass echoes it into h_io->seq)
+    bool spin_wait = true;     // lv_update_end polls the mailbox before falling back to hipStreamSynchronize (LV_SPIN_WAIT=0: off)
     double* d_partials = nullptr;
     double* d_groups = nullptr;    // group records (reduce stage 1)
     int ngroups = 0;
@@ -172,6 +177,7 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
     } else {
         for (int i = 0; i < NS * NS; ++i) io->P_in[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
+    c->update_seq = (c->update_seq + 1) & 0x3fffffff;
     return begin_device(c, true);   // kf_begin_kernel reads the mailbox across PCIe: no upload on the stream
 }
 
@@ -235,6 +241,7 @@ int pass_solve(lv_ctx* c, bool from_groups) {
     for (int i = 0; i < NS; ++i) sp.limits[i] = c->prm.LIMITS[i];
     sp.maximum_iter = c->prm.MAX_NUM_ITERS;
     sp.estimate_extrinsics = c->prm.estimate_extrinsics;
+    sp.seq = c->update_seq;
     if (from_groups && c->fold_direct) return launch_solve(c->stream, c->d_kf, c->d_io, c->d_partials, c->grid, c->d_sums, sp);
     if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_io, c->d_groups, c->ngroups, c->d_sums, sp);
     return launch_solve(c->stream, c->d_kf, c->d_io, c->d_sums, 1, nullptr, sp);
@@ -286,6 +293,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     int per_cu = 4;
     if (const char* e = getenv("LV_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;  // tuning knob
     if (const char* e = getenv("LV_TILE_LPT")) c->tile_lpt = atoi(e) != 0;
+    if (const char* e = getenv("LV_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -593,8 +601,25 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
     c->in_update = false;
     // results were stored into the pinned mailbox by kf_begin_kernel / solve_kernel; the device copy of the logs
     // is only downloaded when the caller asked for them
-    if (c->want_log) LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, offsetof(KfDev, pose), hipMemcpyDeviceToHost, c->stream));
-    LV_HIP(hipStreamSynchronize(c->stream));
+    if (c->want_log) {
+        LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, offsetof(KfDev, pose), hipMemcpyDeviceToHost, c->stream));
+        LV_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        // The pass that finishes the update stores the sequence number after all results (system-scope fence):
+        // poll it for a bounded time (an update takes ~0.2 ms) instead of paying the stream-synchronise wake-up;
+        // anything unusual (errors, very long updates) still ends in hipStreamSynchronize.
+        bool seen = false;
+        if (c->spin_wait && !c->profiling && !c->phase_clocks && !c->capture) {
+            volatile const int* seq = &c->h_io->seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int it = 0;; ++it) {
+                if (*seq == c->update_seq) { seen = true; break; }
+                if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
+    }
     const KfHostIO* io = c->h_io;
     c->timing.fallback_queries = io->fallback_queries;
     if (x) std::memcpy(x, io->x, sizeof(double) * NX);

@@ -71,7 +71,8 @@ struct KfHostIO {
     double P_post[NS * NS];
     int passes;
     int fallback_queries;
-    int pad_[2];
+    int seq;   // sequence number of the last FINISHED update (stored after all results, system-scope fence)
+    int pad_;
 };
 
 // Filter state resident on the device between lv_predict / lv_correct calls (row f-3).

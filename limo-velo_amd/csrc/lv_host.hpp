@@ -96,6 +96,7 @@ struct SolveParams {
     double limits[NS];
     int maximum_iter;
     int estimate_extrinsics;
+    int seq;   // written to the host mailbox by the pass that finishes the update
 };
 int launch_solve(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
 // lv_predict.hip

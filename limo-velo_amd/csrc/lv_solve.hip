@@ -184,7 +184,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
             io->passes = pass + 1;
             io->fallback_queries = kf->fallback_queries;
             kf->iter += 1;
-            if (kf->iter >= prm.maximum_iter) kf->done = 1;
+            if (kf->iter >= prm.maximum_iter) {
+                kf->done = 1;
+                __threadfence_system();
+                io->seq = prm.seq;   // the update is final: the host may stop waiting
+            }
         }
         return;
     }
@@ -321,6 +325,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         io->P_post[tid] = pv;
     }
     SV_STAMP(9);
+    // the update is final (kf->done was set above): every result store is ordered before the sequence number
+    // the host waits on
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) io->seq = prm.seq;
 #undef SV_STAMP
 }
 
