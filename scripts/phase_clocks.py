@@ -1,4 +1,4 @@
-"""Per-phase shader-clock breakdown of the match kernel (instrumentation, GPU only)."""
+"""Per-phase shader-clock breakdown of search_kernel / fit_reduce_kernel / solve_kernel (instrumentation, GPU only)."""
 import sys
 
 import numpy as np
@@ -17,7 +17,7 @@ ctx.scan_set(sc["scan_xyz"])
 for _ in range(3):
     ctx.update(sc["x_init"], sc["P0"], want_trace=False)
 ctx.set_profiling(2)
-names = ["scan+pose", "probe", "stream+sel", "stage", "barrier1", "fit", "reduce"]
+names = ["search: scan+pose", "search: probe", "search: stream+select", "search: winners+store", "(kernel boundary)", "fit: record+fit", "fit: contraction"]
 for state, label in ((sc["x_true"], "converged pose"), (sc["x_init"], "perturbed pose")):
     ctx.update_begin(state, sc["P0"])
     ctx.pass_reduce()
@@ -34,12 +34,19 @@ for state, label in ((sc["x_true"], "converged pose"), (sc["x_init"], "perturbed
     print(label, "blocks", len(clk), "| per-block total cycles mean %.0f max %.0f | first start -> last end %.0f" % (tot.mean(), tot.max(), span))
     print("   start spread (cycles):", clk[:, 0].max() - clk[:, 0].min())
     for i, nm in enumerate(names):
-        print("   %-11s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
+        print("   %-24s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
 
 ctx.set_profiling(0)
 ctx.update(sc["x_init"], sc["P0"], want_trace=False)
 sclk = ctx.solve_clocks()
-snames = ["fold+load", "manifold", "dxnew", "mm x2+Pr", "gj#1", "gj#2", "X,Kx,Kh,dx", "boxplus", "store+pose", "terminal"]
+stamps = {0: "loads issued", 1: "fold + HTH", 4: "Pr, W = A1 + HTH", 5: "gauss-jordan", 6: "X, K, dx", 7: "boxplus", 8: "store + pose consts", 9: "terminal P"}
 for p in range(4):
-    d = np.diff(sclk[p, :10])
-    print("solve pass", p, "total", sclk[p, 9 if sclk[p, 9] else 8] - sclk[p, 0], dict(zip(snames[1:], d.tolist())))
+    row, prev = [], None
+    for i in sorted(stamps):
+        v = int(sclk[p, i])
+        if v == 0:
+            continue
+        if prev is not None:
+            row.append("%s %d" % (stamps[i], v - prev))
+        prev = v
+    print("solve pass", p, "|", " | ".join(row))
