@@ -1,21 +1,21 @@
 // lv_match.hip — the measurement-model pass: world transform -> exact 5-NN in the voxel hash ->
 // plane fit + gates -> point-to-plane residual + Jacobian row -> block-level H^T H / H^T h partials.
 //
-// One launch replaces, for all N scan points (reference call stack SURVEY.md §3.1):
-//   Mapper::match            src/Modules/Mapper.cpp:40-56   (transform :51, match_plane :82-90)
-//   KD_TREE::Nearest_Search  call site Mapper.cpp:86        [ikd-Tree, absent; exact kNN restated]
-//   Plane::Plane / fit_plane src/Objects/Plane.cpp:19-55
-//   R3Math::estimate_plane / is_plane   src/Utils/Utils.cpp:32-66
-//   Match::Match             src/Objects/Match.cpp:18-22
-//   Localizator::calculate_H src/Modules/Localizator.cpp:29-57
-//   esekf h_x^T h_x, h_x^T h products   [IKFoM, absent]     -> never materialises the N x 12 H
+// Two launches replace, for all N scan points (reference call stack SURVEY.md §3.1):
+//   search_kernel      Mapper::match            src/Modules/Mapper.cpp:40-56   (transform :51, match_plane :82-90)
+//                      KD_TREE::Nearest_Search  call site Mapper.cpp:86        [ikd-Tree, absent; exact kNN restated]
+//   fit_reduce_kernel  Plane::Plane / fit_plane src/Objects/Plane.cpp:19-55
+//                      R3Math::estimate_plane / is_plane   src/Utils/Utils.cpp:32-66
+//                      Match::Match             src/Objects/Match.cpp:18-22
+//                      Localizator::calculate_H src/Modules/Localizator.cpp:29-57
+//                      esekf h_x^T h_x, h_x^T h products   [IKFoM, absent]     -> never materialises the N x 12 H
 //
-// Work decomposition (wave64): S lanes of a wavefront cooperate on one scan point ("point tile"):
-// they split the 27 neighbour voxels of the search, keep private sorted top-5 lists of packed
-// (distance bits << 32 | map index) keys — one u64 compare is the reference's (d, index)
-// lexicographic order — and merge them with xor-shuffles.  The plane fit / Jacobian is then
-// evaluated redundantly by the S lanes (no divergence), group lane 0 stages the 12-wide row in
-// LDS and the block contracts the staged rows into its 92 partial sums in f64, fixed order.
+// Work decomposition (wave64).  Search: S lanes of a wavefront cooperate on one scan point: they stream the
+// neighbourhood bucket of its voxel 8 loads per lane in flight, keep private sorted top-5 lists of packed
+// (distance bits << 32 | position) keys — one f64 min/max pair is the reference's (d, index) lexicographic
+// compare-exchange — and merge them across lanes with DPP moves; the 5 winners go to a 128-byte record.
+// Fit: one lane per scan point runs the QR plane fit, the gates and the Jacobian row, stages the row in LDS,
+// and each wavefront contracts its 64 rows into the 29 (92) sums of the block partial in f64, fixed order.
 //
 // Exactness of the voxel search: the query's level-l voxel and its 26 neighbours cover every point
 // within (2^l * cell) of the query up to rounding of the voxel coordinates; a level is accepted only
