@@ -137,6 +137,49 @@ typedef struct lv_motion_state {
 int lv_scan_deskew(lv_ctx* ctx, const void* points, size_t stride, size_t time_offset, size_t n,
                    const lv_motion_state* states, size_t n_states, const lv_motion_state* Xt2, float downsample_prec);
 /* number of points of the current scan / copy them out (xyz packed, de-skew output order) */
+/* ---- row f-4: LiDAR wire formats (sensor_msgs/PointCloud2 -> the reference's time-stamped Points) -------------
+ * lv_cloud_ingest = Accumulator::process (src/Modules/Accumulator.cpp:143-153): PointCloudProcessor::msg2points
+ * for the velodyne / hesai / ouster / custom point types (src/Utils/PointCloudProcessor.cpp:24-97 with the time
+ * rules of src/Objects/Point.cpp:37-111), ::downsample (every downsample_rate-th point whose |p| > min_dist,
+ * :99-110) and ::sort_points (by time, :112-121), followed by Accumulator::push of every point (:141) — into a
+ * device-resident LiDAR buffer (BUFFER_L).  `data` = msg.data (n_points records of format->point_step bytes; the
+ * field offsets come from msg.fields, lv_cloud_format_preset gives the PCL in-memory layouts of
+ * include/Headers/Common.hpp:109-221).  lv_cloud_fetch = Accumulator::get_points(t1, t2) (t1 <= time <= t2, oldest
+ * first; records are the reference's 32-byte Point: x,y,z floats, double time at 16, intensity, range);
+ * lv_cloud_clear = Accumulator::clear_lidar(t) (drops time <= t from the old end);
+ * lv_scan_deskew_window = the point half of Compensator::compensate(t1, t2) (src/Modules/Compensator.cpp:18-35):
+ * the buffered points of [t1, t2] are de-skewed exactly as lv_scan_deskew does, without leaving the device. */
+enum { LV_LIDAR_VELODYNE = 0, LV_LIDAR_HESAI = 1, LV_LIDAR_OUSTER = 2, LV_LIDAR_CUSTOM = 3 };
+enum { LV_TIME_F32_SEC = 0, LV_TIME_F64_SEC = 1, LV_TIME_U32_NSEC = 2 };
+enum { LV_ATTR_NONE = 0, LV_ATTR_F32 = 1, LV_ATTR_U8 = 2, LV_ATTR_U16 = 3, LV_ATTR_U32 = 4 };
+typedef struct lv_cloud_format {
+    uint32_t point_step;            /* msg.point_step */
+    uint32_t off_x, off_y, off_z;   /* FLOAT32 fields */
+    uint32_t off_time;              /* velodyne `time` (F32 s), hesai / custom `timestamp` (F64 s), ouster `t` (U32 ns) */
+    int time_type;                  /* LV_TIME_* */
+    uint32_t off_intensity;         /* `intensity` (F32; hesai U8) or ouster `reflectivity` (U16) */
+    int intensity_type;             /* LV_ATTR_* */
+    uint32_t off_range;             /* ouster `range` (U32); LV_ATTR_NONE: range = |p| */
+    int range_type;
+    int relative_time;              /* 1: stamps relative to the header stamp (velodyne, ouster); 0: absolute */
+} lv_cloud_format;
+typedef struct lv_ingest_params {   /* config/params.yaml:29-35 */
+    uint64_t header_stamp_usec;     /* pcl header stamp (microseconds) */
+    int stamp_beginning;
+    int offset_beginning;
+    double full_rotation_time;
+    int downsample_rate;
+    float min_dist;
+} lv_ingest_params;
+int    lv_cloud_format_preset(int lidar_type, lv_cloud_format* out);
+int    lv_cloud_ingest(lv_ctx* ctx, const void* data, size_t n_points, const lv_cloud_format* format, const lv_ingest_params* params,
+                       size_t* n_kept);
+size_t lv_cloud_size(lv_ctx* ctx);
+int    lv_cloud_fetch(lv_ctx* ctx, double t1, double t2, void* points_out, size_t capacity, size_t* n);
+int    lv_cloud_clear(lv_ctx* ctx, double t);
+int    lv_scan_deskew_window(lv_ctx* ctx, double t1, double t2, const lv_motion_state* states, size_t n_states,
+                             const lv_motion_state* Xt2, float downsample_prec, size_t* n_window);
+
 size_t lv_scan_size(lv_ctx* ctx);
 int    lv_scan_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
 

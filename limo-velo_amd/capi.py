@@ -25,7 +25,23 @@ ABI_SYMBOLS = [
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world",
+    "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
 ]
+
+
+class CloudFormat(C.Structure):  # lv_cloud_format
+    _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32), ("off_z", C.c_uint32),
+                ("off_time", C.c_uint32), ("time_type", C.c_int), ("off_intensity", C.c_uint32), ("intensity_type", C.c_int),
+                ("off_range", C.c_uint32), ("range_type", C.c_int), ("relative_time", C.c_int)]
+
+
+class IngestParams(C.Structure):  # lv_ingest_params
+    _fields_ = [("header_stamp_usec", C.c_uint64), ("stamp_beginning", C.c_int), ("offset_beginning", C.c_int),
+                ("full_rotation_time", C.c_double), ("downsample_rate", C.c_int), ("min_dist", C.c_float)]
+
+
+POINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("pad_", "f4"), ("time", "f8"), ("intensity", "f4"), ("range", "f4")])
+LIDAR_VELODYNE, LIDAR_HESAI, LIDAR_OUSTER, LIDAR_CUSTOM = 0, 1, 2, 3
 
 
 class Params(C.Structure):
@@ -77,6 +93,8 @@ def load_library() -> C.CDLL:
         lib.lv_scan_size.restype = C.c_size_t
         lib.lv_scan_size.argtypes = [C.c_void_p]
         lib.lv_map_size.restype = C.c_size_t
+        lib.lv_cloud_size.restype = C.c_size_t
+        lib.lv_cloud_size.argtypes = [C.c_void_p]
         lib.lv_map_size.argtypes = [C.c_void_p]
         lib.lv_get_stream.restype = C.c_void_p
         lib.lv_get_stream.argtypes = [C.c_void_p]
@@ -182,6 +200,41 @@ class Context:
                                             st.ctypes.data_as(C.c_void_p), C.c_size_t(len(st)), x2.ctypes.data_as(C.c_void_p),
                                             C.c_float(downsample_prec)))
         self._n = self.scan_size()
+
+    # --- row f-4: LiDAR wire formats
+    def cloud_format_preset(self, lidar_type: int) -> CloudFormat:
+        f = CloudFormat()
+        self._check(self.lib.lv_cloud_format_preset(int(lidar_type), C.byref(f)))
+        return f
+
+    def cloud_ingest(self, raw: bytes, n: int, fmt: CloudFormat, prm: IngestParams) -> int:
+        buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+        kept = C.c_size_t(0)
+        self._check(self.lib.lv_cloud_ingest(self.h, buf, C.c_size_t(n), C.byref(fmt), C.byref(prm), C.byref(kept)))
+        return int(kept.value)
+
+    def cloud_size(self) -> int:
+        return int(self.lib.lv_cloud_size(self.h))
+
+    def cloud_fetch(self, t1: float, t2: float) -> np.ndarray:
+        cap = max(self.cloud_size(), 1)
+        out = np.zeros(cap, POINT_DTYPE)
+        n = C.c_size_t(0)
+        self._check(self.lib.lv_cloud_fetch(self.h, C.c_double(t1), C.c_double(t2), out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(n)))
+        return out[: n.value].copy()
+
+    def cloud_clear(self, t: float):
+        self._check(self.lib.lv_cloud_clear(self.h, C.c_double(t)))
+
+    def scan_deskew_window(self, t1, t2, states, Xt2, downsample_prec=0.5) -> int:
+        st = np.ascontiguousarray(states)
+        x2 = np.ascontiguousarray(Xt2)
+        assert st.dtype.itemsize == 184 and x2.dtype.itemsize == 184
+        nw = C.c_size_t(0)
+        self._check(self.lib.lv_scan_deskew_window(self.h, C.c_double(t1), C.c_double(t2), st.ctypes.data_as(C.c_void_p), C.c_size_t(len(st)),
+                                                   x2.ctypes.data_as(C.c_void_p), C.c_float(downsample_prec), C.byref(nw)))
+        self._n = self.scan_size()
+        return int(nw.value)
 
     def scan_size(self) -> int:
         return int(self.lib.lv_scan_size(self.h))

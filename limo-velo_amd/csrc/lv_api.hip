@@ -35,6 +35,7 @@ struct lv_ctx {
     float map_bbox_min[3], map_bbox_max[3];
 
     ScanStore scan;
+    CloudStore cloud;   // row f-4: device-resident LiDAR buffer
     float4* h_stage = nullptr;  // pinned upload staging
     size_t h_stage_cap = 0;
 
@@ -325,6 +326,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
 void lv_destroy(lv_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    c->cloud.release();
     if (c->comm) { hipStreamSynchronize(c->stream); comm_destroy(c->comm); c->comm = nullptr; }
     hipDeviceSynchronize();
     c->map.release();
@@ -489,6 +491,127 @@ int lv_scan_deskew(lv_ctx* c, const void* points, size_t stride, size_t time_off
     MotionState xt2;
     std::memcpy(&xt2, Xt2, sizeof(xt2));
     return c->scan.deskew_downsample(c->stream, (uint32_t)n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size);
+}
+
+// ---- row f-4: LiDAR wire formats ----------------------------------------------------------------------------
+int lv_cloud_format_preset(int lidar_type, lv_cloud_format* out) {
+    if (!out) { set_error("null argument"); return LV_EINVAL; }
+    std::memset(out, 0, sizeof(*out));
+    out->off_x = 0; out->off_y = 4; out->off_z = 8;   // PCL_ADD_POINT4D
+    switch (lidar_type) {
+        case LV_LIDAR_VELODYNE:   // velodyne_ros::Point, Common.hpp:109-117
+            out->point_step = 32; out->off_intensity = 16; out->intensity_type = LV_ATTR_F32;
+            out->off_time = 20; out->time_type = LV_TIME_F32_SEC; out->relative_time = 1;
+            break;
+        case LV_LIDAR_HESAI:      // hesai_ros::Point, :119-127
+            out->point_step = 48; out->off_intensity = 16; out->intensity_type = LV_ATTR_U8;
+            out->off_time = 24; out->time_type = LV_TIME_F64_SEC; out->relative_time = 0;
+            break;
+        case LV_LIDAR_OUSTER:     // ouster_ros::Point, :155-165 (intensity <- reflectivity, range <- range: Point.cpp:173-176)
+            out->point_step = 32; out->off_intensity = 24; out->intensity_type = LV_ATTR_U16;
+            out->off_time = 20; out->time_type = LV_TIME_U32_NSEC; out->relative_time = 1;
+            out->off_range = 28; out->range_type = LV_ATTR_U32;
+            break;
+        case LV_LIDAR_CUSTOM:     // custom::Point == full_info::Point, :129-153
+            out->point_step = 48; out->off_intensity = 20; out->intensity_type = LV_ATTR_F32;
+            out->off_time = 32; out->time_type = LV_TIME_F64_SEC; out->relative_time = 0;
+            break;
+        default: set_error("unknown LiDAR type %d", lidar_type); return LV_EINVAL;
+    }
+    return LV_OK;
+}
+
+namespace {
+double microsec_to_sec(uint64_t t) {   // Conversions::microsec2Sec (src/Utils/Utils.cpp:18-23): int arithmetic as there
+    const int order = 1000000;
+    const int secs = (int)(t / (uint64_t)order);
+    const int musecs = (int)(t % (uint64_t)order);
+    return secs + musecs * 1e-6;
+}
+double nanosec_to_sec_host(uint32_t t) {   // Conversions::nanosec2Sec (:25-30)
+    const int order = 1000000000;
+    const int secs = (int)(t / (uint32_t)order);
+    const int nsecs = (int)(t % (uint32_t)order);
+    return secs + nsecs * 1e-9;
+}
+double raw_time(const unsigned char* rec, const lv_cloud_format& f) {
+    if (f.time_type == LV_TIME_F32_SEC) { float v; std::memcpy(&v, rec + f.off_time, 4); return (double)v; }
+    if (f.time_type == LV_TIME_U32_NSEC) { uint32_t v; std::memcpy(&v, rec + f.off_time, 4); return nanosec_to_sec_host(v); }
+    double v; std::memcpy(&v, rec + f.off_time, 8); return v;
+}
+}  // namespace
+
+int lv_cloud_ingest(lv_ctx* c, const void* data, size_t n, const lv_cloud_format* f, const lv_ingest_params* prm, size_t* n_kept) {
+    LV_CHECK_CTX(c);
+    static_assert(sizeof(lv_cloud_format) == sizeof(CloudFormat) && sizeof(lv_ingest_params) == sizeof(IngestParams), "f-4 struct layouts");
+    if (n_kept) *n_kept = 0;
+    if (!f || !prm || (n && !data)) { set_error("null argument"); return LV_EINVAL; }
+    const uint32_t tsz = f->time_type == LV_TIME_F64_SEC ? 8u : 4u;
+    if (f->point_step < 12 || f->off_x + 4 > f->point_step || f->off_y + 4 > f->point_step || f->off_z + 4 > f->point_step ||
+        f->off_time + tsz > f->point_step || f->time_type < 0 || f->time_type > 2 ||
+        (f->intensity_type != LV_ATTR_NONE && f->off_intensity + 4 > f->point_step + 3) || f->off_range + 4 > f->point_step + 4) {
+        set_error("bad cloud format (point_step %u)", f->point_step);
+        return LV_EINVAL;
+    }
+    if (n > 0x7FFFFFF0ull) { set_error("message too large"); return LV_EINVAL; }
+    if (n == 0) return LV_OK;
+    // PointCloudProcessor::get_begin_time (PointCloudProcessor.cpp:43-47,57-60,70-74,84-91)
+    double begin = 0.0;
+    if (f->relative_time) {
+        const unsigned char* raw = static_cast<const unsigned char*>(data);
+        const double front = raw_time(raw, *f), back = raw_time(raw + (n - 1) * (size_t)f->point_step, *f);
+        begin = microsec_to_sec(prm->header_stamp_usec) + front;
+        if (!prm->stamp_beginning) begin = begin - back;
+    }
+    CloudFormat cf;
+    IngestParams ip;
+    std::memcpy(&cf, f, sizeof(cf));
+    std::memcpy(&ip, prm, sizeof(ip));
+    return c->cloud.ingest(c->stream, data, n, cf, ip, begin, n_kept);
+}
+
+size_t lv_cloud_size(lv_ctx* c) { return c ? (size_t)(c->cloud.size - c->cloud.head) : 0; }
+
+int lv_cloud_fetch(lv_ctx* c, double t1, double t2, void* out, size_t capacity, size_t* n) {
+    LV_CHECK_CTX(c);
+    if (n) *n = 0;
+    uint32_t lo = 0, hi = 0;
+    int rc = c->cloud.window(c->stream, t1, t2, &lo, &hi);
+    if (rc) return rc;
+    const size_t cnt = hi - lo;
+    if (n) *n = cnt;
+    if (cnt == 0) return LV_OK;
+    if (!out || capacity < cnt) { set_error("capacity %zu too small for %zu points", capacity, cnt); return LV_EINVAL; }
+    LV_HIP(hipMemcpy(out, c->cloud.d_buf + lo, cnt * sizeof(CloudPoint), hipMemcpyDeviceToHost));
+    return LV_OK;
+}
+
+int lv_cloud_clear(lv_ctx* c, double t) {
+    LV_CHECK_CTX(c);
+    return c->cloud.clear_before(c->stream, t);
+}
+
+int lv_scan_deskew_window(lv_ctx* c, double t1, double t2, const lv_motion_state* states, size_t n_states, const lv_motion_state* Xt2,
+                          float downsample_prec, size_t* n_window) {
+    LV_CHECK_CTX(c);
+    if (n_window) *n_window = 0;
+    if (!states || n_states < 2 || !Xt2) { set_error("need >= 2 surrounding states and Xt2"); return LV_EINVAL; }
+    c->dbg_valid = false;
+    c->scan.n = 0;
+    uint32_t lo = 0, hi = 0;
+    int rc = c->cloud.window(c->stream, t1, t2, &lo, &hi);
+    if (rc) return rc;
+    const uint32_t n = hi - lo;
+    if (n_window) *n_window = n;
+    if (n == 0) return LV_OK;   // Compensator::compensate returns no points (Compensator.cpp:24)
+    rc = c->scan.reserve_raw(n, n_states);
+    if (rc) return rc;
+    rc = c->cloud.unpack(c->stream, lo, n, c->scan.d_in, c->scan.d_times);
+    if (rc) return rc;
+    LV_HIP(hipMemcpyAsync(c->scan.d_states, states, n_states * sizeof(MotionState), hipMemcpyHostToDevice, c->stream));
+    MotionState xt2;
+    std::memcpy(&xt2, Xt2, sizeof(xt2));
+    return c->scan.deskew_downsample(c->stream, n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size);
 }
 
 size_t lv_scan_size(lv_ctx* c) { return c ? c->scan.n : 0; }

@@ -144,4 +144,57 @@ struct ScanStore {
     void release();
 };
 
+// ---- row f-4: LiDAR wire formats -> device-resident LiDAR buffer (lv_cloud.hip) ----------------------------
+struct CloudFormat {   // == lv_cloud_format
+    uint32_t point_step, off_x, off_y, off_z, off_time;
+    int time_type;
+    uint32_t off_intensity;
+    int intensity_type;
+    uint32_t off_range;
+    int range_type;
+    int relative_time;
+};
+struct IngestParams {  // == lv_ingest_params
+    uint64_t header_stamp_usec;
+    int stamp_beginning, offset_beginning;
+    double full_rotation_time;
+    int downsample_rate;
+    float min_dist;
+};
+struct CloudPoint {    // the reference's Point (include/Headers/Objects.hpp:20-28), 32 bytes
+    float x, y, z, pad_;
+    double time;
+    float intensity, range;
+};
+static_assert(sizeof(CloudPoint) == 32, "reference Point layout");
+
+struct CloudStore {
+    CloudPoint* d_buf = nullptr;   // BUFFER_L: time ordered, live range [head, size)
+    uint32_t head = 0, size = 0;
+    size_t buf_cap = 0;
+    unsigned char* d_rawmsg = nullptr;
+    unsigned char* h_rawmsg = nullptr;   // pinned
+    size_t raw_cap = 0;
+    CloudPoint* d_decoded = nullptr;
+    CloudPoint* d_kept = nullptr;
+    unsigned char* d_keep = nullptr;
+    uint64_t* d_keys = nullptr;
+    uint64_t* d_keys_sorted = nullptr;
+    uint32_t* d_ids = nullptr;
+    uint32_t* d_ids_sorted = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0, msg_cap = 0;
+    uint32_t* d_count = nullptr;
+    uint32_t* h_count = nullptr;   // pinned
+    int init();
+    int reserve_msg(size_t n, size_t bytes);
+    int reserve_buffer(hipStream_t stream, size_t total);
+    int ingest(hipStream_t stream, const void* data, size_t n, const CloudFormat& fmt, const IngestParams& prm, double begin_time,
+               size_t* n_kept);
+    int window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi);
+    int clear_before(hipStream_t stream, double t);
+    int unpack(hipStream_t stream, uint32_t lo, uint32_t n, float4* xyz, double* times);
+    void release();
+};
+
 }  // namespace lv

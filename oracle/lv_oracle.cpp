@@ -1343,3 +1343,63 @@ size_t lvo_voxelgrid(const float* xyz, size_t n, float leaf, float* out_xyz) {
 }
 
 }  // extern "C"
+
+// ---- row f-4 ----------------------------------------------------------------------------------------------
+namespace {
+double o_microsec2sec(uint64_t t) {   // Conversions::microsec2Sec, src/Utils/Utils.cpp:18-23
+    int order = 1e6;
+    int secs = t / order;
+    int musecs = t % order;
+    return secs + musecs * 1e-6;
+}
+double o_nanosec2sec(uint32_t t) {    // Conversions::nanosec2Sec, :25-30
+    int order = 1e9;
+    int secs = t / order;
+    int nsecs = t % order;
+    return secs + nsecs * 1e-9;
+}
+double o_raw_time(const unsigned char* rec, const lvo_cloud_format& f) {
+    if (f.time_type == 0) { float v; std::memcpy(&v, rec + f.off_time, 4); return (double)v; }
+    if (f.time_type == 2) { uint32_t v; std::memcpy(&v, rec + f.off_time, 4); return o_nanosec2sec(v); }
+    double v; std::memcpy(&v, rec + f.off_time, 8); return v;
+}
+}  // namespace
+
+extern "C" size_t lvo_cloud_ingest(const void* data, size_t n, const lvo_cloud_format* f, const lvo_ingest_params* prm, lvo_point* out) {
+    if (n == 0) return 0;
+    const unsigned char* raw = static_cast<const unsigned char*>(data);
+    // get_begin_time: relative stamps hang off the header stamp and the first (and last) raw point
+    double begin = 0.0;
+    if (f->relative_time) {
+        const double front = o_raw_time(raw, *f), back = o_raw_time(raw + (n - 1) * (size_t)f->point_step, *f);
+        begin = o_microsec2sec(prm->header_stamp_usec) + front;
+        if (!prm->stamp_beginning) begin = begin - back;
+    }
+    std::vector<lvo_point> kept;
+    int ds_counter = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char* p = raw + i * (size_t)f->point_step;
+        lvo_point o;
+        std::memcpy(&o.x, p + f->off_x, 4);
+        std::memcpy(&o.y, p + f->off_y, 4);
+        std::memcpy(&o.z, p + f->off_z, 4);
+        o.pad_ = 0.f;
+        const float nrm = std::sqrt(dot3f(o.x, o.x, o.y, o.y, o.z, o.z));   // Eigen Vector3f::norm()
+        switch (f->intensity_type) {
+            case 1: std::memcpy(&o.intensity, p + f->off_intensity, 4); break;
+            case 2: o.intensity = (float)p[f->off_intensity]; break;
+            case 3: { uint16_t v; std::memcpy(&v, p + f->off_intensity, 2); o.intensity = (float)v; break; }
+            default: o.intensity = 0.f; break;
+        }
+        if (f->range_type == 4) { uint32_t v; std::memcpy(&v, p + f->off_range, 4); o.range = (float)v; }
+        else o.range = nrm;
+        double t = o_raw_time(p, *f);
+        if (f->relative_time && !prm->offset_beginning) t = prm->full_rotation_time + t;
+        o.time = t + begin;
+        const bool keep_point = prm->downsample_rate <= 1 || ++ds_counter % prm->downsample_rate == 0;   // PointCloudProcessor.cpp:105
+        if (keep_point && prm->min_dist < nrm) kept.push_back(o);
+    }
+    std::stable_sort(kept.begin(), kept.end(), [](const lvo_point& a, const lvo_point& b) { return a.time < b.time; });
+    for (size_t i = 0; i < kept.size(); ++i) out[i] = kept[i];
+    return kept.size();
+}

@@ -163,6 +163,37 @@ void lvo_deskew(const float* xyz, const double* times, size_t n, const lvo_motio
  * occupied leaf, leaves in ascending index order i + j*dx + k*dx*dy.  Returns the number of output points. */
 size_t lvo_voxelgrid(const float* xyz, size_t n, float leaf, float* out_xyz);
 
+/* ---- row f-4: LiDAR wire formats (PointCloud2 -> time-stamped Points) -------------------------------------- */
+/* Field layout of one point record (msg.fields / msg.point_step).  time_type: 0 = F32 seconds (velodyne `time`),
+ * 1 = F64 seconds (hesai / custom `timestamp`), 2 = U32 nanoseconds (ouster `t`); intensity_type / range_type:
+ * 0 none, 1 F32, 2 U8, 3 U16, 4 U32. */
+typedef struct lvo_cloud_format {
+    uint32_t point_step, off_x, off_y, off_z, off_time;
+    int time_type;
+    uint32_t off_intensity;
+    int intensity_type;
+    uint32_t off_range;
+    int range_type;
+    int relative_time;
+} lvo_cloud_format;
+typedef struct lvo_ingest_params {
+    uint64_t header_stamp_usec;
+    int stamp_beginning, offset_beginning;
+    double full_rotation_time;
+    int downsample_rate;
+    float min_dist;
+} lvo_ingest_params;
+typedef struct lvo_point {   /* reference Point, include/Headers/Objects.hpp:20-28 */
+    float x, y, z, pad_;
+    double time;
+    float intensity, range;
+} lvo_point;
+/* Accumulator::process (src/Modules/Accumulator.cpp:143-153): PointCloudProcessor::msg2points (per-sensor time
+ * rules of src/Objects/Point.cpp:37-111 and get_begin_time, src/Utils/PointCloudProcessor.cpp:43-91), ::downsample
+ * (:99-110) and ::sort_points (:112-121; stable here — std::sort leaves the order of equal stamps unspecified).
+ * out: capacity n records; returns the number of points kept. */
+size_t lvo_cloud_ingest(const void* data, size_t n, const lvo_cloud_format* f, const lvo_ingest_params* prm, lvo_point* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,3 +298,28 @@ def voxelgrid(xyz, leaf):
     out = np.empty_like(p)
     n = lib().lvo_voxelgrid(_p(p, C.c_float), C.c_size_t(len(p)), C.c_float(leaf), _p(out, C.c_float))
     return out[:n].copy()
+
+
+# ---- row f-4: LiDAR wire formats ---------------------------------------------------------------------------
+class CloudFormat(C.Structure):
+    _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32), ("off_z", C.c_uint32),
+                ("off_time", C.c_uint32), ("time_type", C.c_int), ("off_intensity", C.c_uint32), ("intensity_type", C.c_int),
+                ("off_range", C.c_uint32), ("range_type", C.c_int), ("relative_time", C.c_int)]
+
+
+class IngestParams(C.Structure):
+    _fields_ = [("header_stamp_usec", C.c_uint64), ("stamp_beginning", C.c_int), ("offset_beginning", C.c_int),
+                ("full_rotation_time", C.c_double), ("downsample_rate", C.c_int), ("min_dist", C.c_float)]
+
+
+POINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("pad_", "f4"), ("time", "f8"), ("intensity", "f4"), ("range", "f4")])
+assert POINT_DTYPE.itemsize == 32
+
+
+def cloud_ingest(raw: bytes, n: int, fmt: CloudFormat, prm: IngestParams) -> np.ndarray:
+    """Accumulator::process restated: returns the kept, time-sorted reference Points (POINT_DTYPE)."""
+    out = np.zeros(max(n, 1), POINT_DTYPE)
+    buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+    lib().lvo_cloud_ingest.restype = C.c_size_t
+    k = lib().lvo_cloud_ingest(buf, C.c_size_t(n), C.byref(fmt), C.byref(prm), out.ctypes.data_as(C.c_void_p))
+    return out[:k].copy()

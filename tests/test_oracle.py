@@ -254,3 +254,42 @@ def test_motion_model_and_voxelgrid(oracle):
     pts = np.array([[0.1, 0.1, 0.1], [0.3, 0.1, 0.1], [0.9, 0.1, 0.1], [-0.2, 0.1, 0.1]], np.float32)
     v = oracle.voxelgrid(pts, 0.5)
     assert np.allclose(v, [[-0.2, 0.1, 0.1], [0.2, 0.1, 0.1], [0.9, 0.1, 0.1]], atol=1e-7)
+
+
+def test_cloud_ingest_time_rules_known_answer(oracle):
+    """Row f-4, pinned by hand: 6 velodyne points, stamp at the END of the sweep, offsets relative to the END
+    (params.yaml:30-31 defaults): begin = stamp + front.time - back.time, point time = full_rotation_time + time + begin
+    (Point.cpp:57-60, PointCloudProcessor.cpp:43-47); every 2nd point kept (counter pre-incremented), |p| > min_dist."""
+    import struct
+
+    stamp_usec = 1_000_000_500_000  # 1 000 000.5 s
+    times = [-0.10, -0.08, -0.06, -0.04, -0.02, 0.0]
+    xs = [10.0, 3.0, 10.0, 10.0, 10.0, 2.0]   # index 1 is kept by the counter but is 3 m away, index 5 is 2 m away
+    raw = b"".join(struct.pack("<ffffffHxxxxxx", x, 0.0, 0.0, 0.0, 7.0, t, 1) for x, t in zip(xs, times))
+    assert len(raw) == 6 * 32
+    fmt = oracle.CloudFormat(32, 0, 4, 8, 20, 0, 16, 1, 0, 0, 1)
+    prm = oracle.IngestParams(stamp_usec, 0, 0, 0.1, 2, 4.0)
+    pts = oracle.cloud_ingest(raw, 6, fmt, prm)
+    # kept by the counter: indices 1, 3, 5; min_dist drops 1 and 5
+    assert len(pts) == 1 and pts["x"][0] == 10.0 and pts["intensity"][0] == 7.0 and pts["range"][0] == 10.0
+    begin = (1_000_000 + 500_000 * 1e-6) + float(np.float32(-0.10)) - float(np.float32(0.0))
+    assert pts["time"][0] == (0.1 + float(np.float32(-0.04))) + begin
+    # stamp at the beginning, offsets relative to the beginning
+    prm2 = oracle.IngestParams(stamp_usec, 1, 1, 0.1, 1, 0.0)
+    pts2 = oracle.cloud_ingest(raw, 6, fmt, prm2)
+    assert len(pts2) == 6
+    begin2 = (1_000_000 + 500_000 * 1e-6) + float(np.float32(-0.10))
+    assert np.array_equal(pts2["time"], np.array([float(np.float32(t)) + begin2 for t in times]))
+
+
+def test_cloud_ingest_sorted_and_stable(oracle):
+    import cloud_messages as cm
+
+    for kind in ("velodyne", "hesai", "ouster", "custom"):
+        raw, f, stamp = cm.make_message(kind, 5000, seed=3, wire=(kind in ("velodyne", "hesai")))
+        fmt = oracle.CloudFormat(f["point_step"], f["off_x"], f["off_y"], f["off_z"], f["off_time"], f["time_type"], f["off_intensity"],
+                                 f["intensity_type"], f["off_range"], f["range_type"], f["relative_time"])
+        pts = oracle.cloud_ingest(raw, 5000, fmt, oracle.IngestParams(stamp, 0, 0, 0.1, 4, 4.0))
+        assert 0 < len(pts) <= 1250
+        assert np.all(np.diff(pts["time"]) >= 0)
+        assert np.all(pts["range"] > 4.0) or kind == "ouster"
