@@ -122,6 +122,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void reduce_final_kernel(const double
 
 // ---- solve ------------------------------------------------------------------------------------------
 constexpr int SOLVE_THREADS = FOLD_THREADS;
+// store to the pinned host mailbox that bypasses the device caches (system-scope, relaxed)
+#define IO_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
 // NW = number of Jacobian columns that can be non-zero: 6 without extrinsic estimation (H^T H lives in
 // the leading 6x6 block, only P_inv[:, 0:6] is needed), 12 with it.
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __shared__ double s_part[FOLD_PARTS][SUMS_LEN];
     __shared__ double sRot[4][9];
     __shared__ PoseConsts s_pose;
+    __shared__ float s_ptmp[8];
     __shared__ int s_last, s_conv;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -149,6 +152,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     if (tid >= 192 && tid < 192 + NW * NW) sG[(tid - 192) / NW][(tid - 192) % NW] = kf->prep_A1[tid - 192];
     if (kf->done) return;
     const int pass = kf->passes;
+    // loop bookkeeping words, read once up front (a late global read would sit on the critical path of one lane)
+    const int kf_t = kf->t, kf_iter = kf->iter, kf_fallback = kf->fallback_queries;
 #define SV_STAMP(i) do { if (tid == 0 && pass < MAX_PASSES) kf->solve_clk[pass * 16 + (i)] = clock64(); } while (0)
     SV_STAMP(0);
     __syncthreads();
@@ -181,13 +186,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
                 for (int i = 0; i < NX; ++i) kf->trace[pass * 49 + NS + i] = kf->x[i];
             }
             kf->passes = pass + 1;
-            io->passes = pass + 1;
-            io->fallback_queries = kf->fallback_queries;
-            kf->iter += 1;
-            if (kf->iter >= prm.maximum_iter) {
+            IO_STORE(&io->passes, pass + 1);
+            IO_STORE(&io->fallback_queries, kf_fallback);
+            kf->iter = kf_iter + 1;
+            if (kf_iter + 1 >= prm.maximum_iter) {
                 kf->done = 1;
-                __threadfence_system();
-                io->seq = prm.seq;   // the update is final: the host may stop waiting
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through mailbox stores above have retired
+                __hip_atomic_store(&io->seq, prm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // final: the host may stop waiting
             }
         }
         return;
@@ -261,14 +266,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         sx[vect_state_index(dof)] += sdxo[dof];
     }
     if (tid == 256) {
-        int t = kf->t;
+        int t = kf_t;
         if (s_conv) t++;
         kf->t = t;
-        s_last = (t > 1 || kf->iter == prm.maximum_iter - 1) ? 1 : 0;
+        s_last = (t > 1 || kf_iter == prm.maximum_iter - 1) ? 1 : 0;
     }
     __syncthreads();
     SV_STAMP(7);
-    if (tid < NX) { kf->x[tid] = sx[tid]; io->x[tid] = sx[tid]; }
+    if (tid < NX) { kf->x[tid] = sx[tid]; IO_STORE(&io->x[tid], sx[tid]); }
     if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
         const int e = tid - 64;
         kf->trace[pass * 49 + e] = e < NS ? sdxo[e] : sx[e - NS];
@@ -284,13 +289,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __syncthreads();
     if (tid == 0) {
         kf->passes = pass + 1;
-        io->passes = pass + 1;
-        io->fallback_queries = kf->fallback_queries;
-        kf->iter += 1;
+        IO_STORE(&io->passes, pass + 1);
+        IO_STORE(&io->fallback_queries, kf_fallback);
+        kf->iter = kf_iter + 1;
         if (last) kf->done = 1;
-        else finish_pose_consts(sx, sRot, &s_pose);
     }
-    if (!last) {  // publish the next pass' constants with coalesced stores
+    if (!last) {  // the next pass' constants: finish_pose_consts spread over one wavefront, then coalesced stores
+        if (tid >= 64 && tid < 128) pose_consts_stage_a(tid - 64, sx, sRot, &s_pose, s_ptmp);
+        __syncthreads();
+        if (tid >= 64 && tid < 128) pose_consts_stage_b(tid - 64, sRot, &s_pose, s_ptmp);
         __syncthreads();
         constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_pose);
@@ -322,14 +329,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         for (int c = 0; c < NW; ++c) s += sX[i][c] * sA[c][j];
         const double pv = sB[i][j] - s;
         kf->P_post[tid] = pv;
-        io->P_post[tid] = pv;
+        IO_STORE(&io->P_post[tid], pv);
     }
     SV_STAMP(9);
     // the update is final (kf->done was set above): every result store is ordered before the sequence number
     // the host waits on
-    __threadfence_system();
+    // (every mailbox store of this kernel is a system-scope write-through store, IO_STORE: once a lane's stores
+    // have retired they are visible to the host; a system-scope release fence would also write back the whole
+    // L2, ~4 us — and plain stores without it were observed to arrive after the sequence number)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) io->seq = prm.seq;
+    if (tid == 0) __hip_atomic_store(&io->seq, prm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #undef SV_STAMP
 }
 

@@ -88,6 +88,48 @@ __device__ inline void finish_pose_consts(const double* x, const double (*rot)[9
     for (int i = 0; i < 9; ++i) { out->R_inv[i] = rot[2][i]; out->I_R_L_inv[i] = rot[3][i]; }
 }
 
+// finish_pose_consts spread over lanes (same dot3f calls, same operand order => same bits): stage A by lanes
+// 0..26 of the calling range (lane = tid - base), stage B by lanes 0..2 after a barrier.  tmp: 6 floats (the
+// translations of inv(X), inv(LI)).
+__device__ inline void pose_consts_stage_a(int lane, const double* x, const double (*rot)[9], PoseConsts* out, float* tmp) {
+#pragma clang fp contract(off)
+    if (lane < 12) {            // Tc = X * LI   (rt_compose)
+        const int i = lane < 9 ? lane / 3 : lane - 9;
+        const float a0 = (float)rot[0][i * 3 + 0], a1 = (float)rot[0][i * 3 + 1], a2 = (float)rot[0][i * 3 + 2];
+        if (lane < 9) {
+            const int j = lane % 3;
+            out->Tc.R[lane] = dot3f(a0, (float)rot[1][0 * 3 + j], a1, (float)rot[1][1 * 3 + j], a2, (float)rot[1][2 * 3 + j]);
+        } else {
+            out->Tc.t[i] = dot3f(a0, (float)x[11], a1, (float)x[12], a2, (float)x[13]) + (float)x[i];
+        }
+    } else if (lane < 21) {     // back.R = LI^T * X^T
+        const int e = lane - 12, i = e / 3, j = e % 3;
+        // inv(LI).R[i][k] = LI.R[k][i], inv(X).R[k][j] = X.R[j][k]
+        out->back.R[e] = dot3f((float)rot[1][0 * 3 + i], (float)rot[0][j * 3 + 0], (float)rot[1][1 * 3 + i], (float)rot[0][j * 3 + 1],
+                               (float)rot[1][2 * 3 + i], (float)rot[0][j * 3 + 2]);
+    } else if (lane < 27) {     // translations of inv(X) (tmp[0..2]) and inv(LI) (tmp[3..5])   (rt_inv)
+        const int which = (lane - 21) / 3, i = (lane - 21) % 3;
+        const double (*r) = rot[which];
+        const int tb = which ? 11 : 0;
+        tmp[which * 3 + i] = dot3f(-(float)r[0 * 3 + i], (float)x[tb], -(float)r[1 * 3 + i], (float)x[tb + 1], -(float)r[2 * 3 + i], (float)x[tb + 2]);
+    } else if (lane < 39) {     // LI itself
+        const int e = lane - 27;
+        if (e < 9) out->LI.R[e] = (float)rot[1][e];
+        else out->LI.t[e - 9] = (float)x[11 + e - 9];
+    } else if (lane < 57) {
+        const int e = lane - 39;
+        if (e < 9) out->R_inv[e] = rot[2][e];
+        else out->I_R_L_inv[e - 9] = rot[3][e - 9];
+    }
+}
+__device__ inline void pose_consts_stage_b(int lane, const double (*rot)[9], PoseConsts* out, const float* tmp) {
+#pragma clang fp contract(off)
+    if (lane < 3) {             // back.t = inv(LI).R * inv(X).t + inv(LI).t
+        const int i = lane;
+        out->back.t[i] = dot3f((float)rot[1][0 * 3 + i], tmp[0], (float)rot[1][1 * 3 + i], tmp[1], (float)rot[1][2 * 3 + i], tmp[2]) + tmp[3 + i];
+    }
+}
+
 // The three manifold blocks are independent: wave 0 / 1 / 2 (lane 0 of each) compute them concurrently
 // on different SIMDs.  part 0: rot (dof 3), 1: offset_R_L_I (dof 6), 2: grav (dof 21).
 // mode 0: seg = x [-] x_prop for this block (written to dx), then the projection block from seg

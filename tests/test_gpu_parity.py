@@ -258,3 +258,55 @@ def test_large_cfg3_like(capi, oracle, lv):
         ctx.scan_set(sc["scan_xyz"])
         g, o = _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
         assert g["n_valid"] > 200_000
+
+
+def test_pass_constants_of_the_solve_match_a_fresh_start(capi, oracle, scene_small):
+    """The f32 pose constants that solve_kernel leaves for the next pass (spread over lanes) must be bit-identical
+    to those a fresh lv_iterate derives from the same state (kf_begin_kernel, serial): compare the captured world
+    points, plane coefficients and Jacobian rows of pass 2 of an update with lv_iterate at the state after pass 1,
+    for both extrinsic modes."""
+    sc = scene_small
+    for ext in (0, 1):
+        with capi.Context(capi.default_params(estimate_extrinsics=ext)) as ctx:
+            ctx.map_build(sc["map_xyz"])
+            ctx.scan_set(sc["scan_xyz"])
+            ctx.set_capture(True)
+            ctx.update_begin(sc["x_init"], sc["P0"])
+            ctx.pass_reduce()
+            ctx.pass_solve()
+            ctx.pass_reduce()          # pass 2: constants written by solve_kernel
+            v2, pw2, abcd2, d2 = ctx.fetch_matches()
+            H2, h2 = ctx.fetch_rows()
+            ctx.pass_solve()
+            _, _, _ = ctx.update_end()
+            ctx.set_capture(False)
+            x, _, passes, tr, _ = ctx.update(sc["x_init"], sc["P0"])   # trace: state after every pass
+            x1 = tr[0][23:49]
+            ctx.iterate(x1)            # constants derived by kf_begin_kernel from the same state
+            v, pw, abcd, d = ctx.fetch_matches()
+            H, h = ctx.fetch_rows()
+        assert np.array_equal(v, v2) and pw.tobytes() == pw2.tobytes()
+        assert abcd.tobytes() == abcd2.tobytes() and d.tobytes() == d2.tobytes()
+        assert H.tobytes() == H2.tobytes() and h.tobytes() == h2.tobytes()
+
+
+def test_mailbox_results_are_never_torn(capi, scene_small):
+    """lv_update returns as soon as the finishing pass has stored its sequence number into the pinned mailbox:
+    every one of many back-to-back updates (deterministic, so identical) must return the complete state and
+    covariance — a store that overtook the sequence number would show up as a stale word."""
+    sc = scene_small
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x0, P0, p0, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+        alt = sc["x_true"]
+        for i in range(3000):
+            # alternate two different inputs so that a stale mailbox word cannot pass as the right answer
+            if i % 2:
+                xa, Pa, pa, _, _ = ctx.update(alt, sc["P0"] * 2.0, want_trace=False)
+                if i == 1:
+                    xa0, Pa0, pa0 = xa, Pa, pa
+                assert pa == pa0 and np.array_equal(xa, xa0) and np.array_equal(Pa, Pa0), i
+            else:
+                x, P, p, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+                assert p == p0 and np.array_equal(x, x0) and np.array_equal(P, P0), i
