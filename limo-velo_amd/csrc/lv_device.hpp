@@ -101,7 +101,8 @@ struct MapView {
     // {key lo, key hi, bucket start, bucket count}.
     int n_bucket_levels;
     GridLevel bt[MAX_BUCKET_LEVELS];
-    const float4* bucket[MAX_BUCKET_LEVELS];
+    const float* bxyz[MAX_BUCKET_LEVELS];      // bucket points, 3 packed floats each (12 B per candidate streamed)
+    const uint32_t* bidx[MAX_BUCKET_LEVELS];   // their original map indices (fetched for the winners only)
 };
 
 struct MatchParams {

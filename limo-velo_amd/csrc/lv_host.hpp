@@ -37,7 +37,10 @@ struct MapStore {
     // neighbourhood buckets (levels 0..MAX_BUCKET_LEVELS-1)
     uint4* d_btable[MAX_BUCKET_LEVELS] = {};
     uint32_t btable_size[MAX_BUCKET_LEVELS] = {};
-    float4* d_bucket[MAX_BUCKET_LEVELS] = {};
+    float4* d_bucket_tmp = nullptr;   // build scratch: one level's buckets as float4 {x,y,z,idx} (fill + sort), then packed
+    size_t bucket_tmp_cap = 0;
+    float* d_bxyz[MAX_BUCKET_LEVELS] = {};      // 12-byte points: what the search kernel streams
+    uint32_t* d_bidx[MAX_BUCKET_LEVELS] = {};   // original indices, read for the 5 winners only
     size_t bucket_cap[MAX_BUCKET_LEVELS] = {};
     size_t bucket_points[MAX_BUCKET_LEVELS] = {};
     uint32_t n_bcells[MAX_BUCKET_LEVELS] = {};

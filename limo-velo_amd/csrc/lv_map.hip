@@ -414,7 +414,8 @@ void MapStore::release() {
     hipFree(d_sort_tmp); hipFree(d_counts);
     hipFree(d_orig2); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
-    for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bucket[l]); }
+    for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bxyz[l]); hipFree(d_bidx[l]); }
+    hipFree(d_bucket_tmp);
     for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
     *this = MapStore();
 }
@@ -491,6 +492,17 @@ int MapStore::rebuild(hipStream_t stream, float cell, const float bbox_min[3], c
     return LV_OK;
 }
 
+// the sorted float4 buckets -> 12-byte points (what the search kernel streams) + a parallel index array
+__global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    xyz[(size_t)i * 3] = p.x;
+    xyz[(size_t)i * 3 + 1] = p.y;
+    xyz[(size_t)i * 3 + 2] = p.z;
+    idx[i] = __float_as_uint(p.w);
+}
+
 int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) {
     if (!d_flags) LV_HIP(hipMalloc(&d_flags, 2 * sizeof(uint32_t)));
     GridLevelW occ{d_tables[level], view.lv[level].mask, view.lv[level].shift};
@@ -545,22 +557,36 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         const uint64_t total = (uint64_t)last_off + last_cnt;
         if (total > 0xFFFFFFF0ull) { set_error("bucket array exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
         bucket_points[level] = (size_t)total;
-        if (bucket_points[level] > bucket_cap[level]) {
-            hipFree(d_bucket[level]);
-            d_bucket[level] = nullptr;
+        if (bucket_points[level] > bucket_tmp_cap) {
+            hipFree(d_bucket_tmp);
+            d_bucket_tmp = nullptr;
+            bucket_tmp_cap = 0;
             size_t cap = bucket_points[level] + bucket_points[level] / 8;
-            LV_HIP(hipMalloc(&d_bucket[level], cap * sizeof(float4)));
+            LV_HIP(hipMalloc(&d_bucket_tmp, cap * sizeof(float4)));
+            bucket_tmp_cap = cap;
+        }
+        if (bucket_points[level] > bucket_cap[level]) {
+            hipFree(d_bxyz[level]); hipFree(d_bidx[level]);
+            d_bxyz[level] = nullptr; d_bidx[level] = nullptr;
+            bucket_cap[level] = 0;
+            size_t cap = bucket_points[level] + bucket_points[level] / 8;
+            LV_HIP(hipMalloc(&d_bxyz[level], (cap * 3 + 4) * sizeof(float)));
+            LV_HIP(hipMalloc(&d_bidx[level], cap * sizeof(uint32_t)));
             bucket_cap[level] = cap;
         }
         hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
-                           d_boff, d_bucket[level]);
-        hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket[level]);
-        hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket[level]);
+                           d_boff, d_bucket_tmp);
+        hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
+        hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
+        if (total > 0)
+            hipLaunchKernelGGL(bucket_pack_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_bucket_tmp, (uint32_t)total,
+                               d_bxyz[level], d_bidx[level]);
         LV_HIP(hipGetLastError());
         view.bt[level].table = d_btable[level];
         view.bt[level].mask = size - 1;
         view.bt[level].shift = (uint32_t)(64 - lg);
-        view.bucket[level] = d_bucket[level];
+        view.bxyz[level] = d_bxyz[level];
+        view.bidx[level] = d_bidx[level];
         return LV_OK;
     }
 }

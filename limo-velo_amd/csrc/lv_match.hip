@@ -90,8 +90,9 @@ __device__ __forceinline__ void merge5(kkey (&k)[KNN], const T& o) {
 template <int CTRL>
 __device__ __forceinline__ kkey dpp_key(kkey v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // all source lanes of these permutations are enabled: bound_ctrl only spares the `old` operand its zeroing move
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
@@ -118,6 +119,15 @@ __device__ __forceinline__ void insert1(kkey (&k)[KNN], kkey x) {  // generic pa
 }
 
 // [UPSTREAM-RECALL ikd-Tree calc_dist]: (ax-bx)^2 + (ay-by)^2 + (az-bz)^2, f32, left to right, unfused
+struct __attribute__((packed, aligned(4))) Xyz {   // one bucket point as streamed: 12 bytes
+    float x, y, z;
+};
+__device__ __forceinline__ float calc_dist(float qx, float qy, float qz, Xyz m) {
+    float dx = qx - m.x, dy = qy - m.y, dz = qz - m.z;
+    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    float s = sx + sy;
+    return s + sz;
+}
 __device__ __forceinline__ float calc_dist(float qx, float qy, float qz, float4 m) {
     float dx = qx - m.x, dy = qy - m.y, dz = qz - m.z;
     float sx = dx * dx, sy = dy * dy, sz = dz * dz;
@@ -374,9 +384,9 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     if (clk) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
     if (bcount < KNN) return false;
     constexpr int U = 8;
-    const float4* __restrict__ bp = map.bucket[bl] + bstart;
+    const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
     for (uint32_t base = 0; base < bcount; base += LANES * U) {
-        float4 mpt[U];
+        Xyz mpt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = base + (uint32_t)(u * LANES + tl);
@@ -389,7 +399,12 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
             ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
         }
         sort8(ck);
-        merge5(k, ck);
+        if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
+#pragma unroll
+            for (int i = 0; i < KNN; ++i) k[i] = ck[i];
+        } else {
+            merge5(k, ck);
+        }
     }
     merge_team<LANES>(k);
     const float r = search_radius(map, geo, bl);
@@ -652,8 +667,13 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
                 v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
                 if (!is_none(kk)) {
                     const uint32_t pos = key_lo(kk);
-                    if (src >= 0) v = map.bucket[src][(size_t)bstart + pos];
-                    else { v = map.orig[pos]; v.w = __uint_as_float(pos); }
+                    if (src >= 0) {
+                        const Xyz w = reinterpret_cast<const Xyz*>(map.bxyz[src])[(size_t)bstart + pos];
+                        v = make_float4(w.x, w.y, w.z, __uint_as_float(map.bidx[src][(size_t)bstart + pos]));
+                    } else {
+                        v = map.orig[pos];
+                        v.w = __uint_as_float(pos);
+                    }
                 }
             } else if (slot == 5) {
                 v = make_float4(qx, qy, qz, sp.w);
