@@ -153,8 +153,8 @@ void unpack_sums(const double* rec, lv_sums* out) {
 
 // from_host: x / P_prop wait in the pinned mailbox (lv_update_begin), otherwise they are in d_kf already (copied
 // from the resident filter): take them over, derive the pass constants
-int begin_device(lv_ctx* c, bool from_host) {
-    int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, from_host);
+int begin_device(lv_ctx* c, const double* x_host) {
+    int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, x_host);
     if (rc) return rc;
     c->grid = fit_grid_size(c->scan.n, c->max_blocks);
     if ((uint32_t)c->scan.n > c->qstride) {
@@ -179,7 +179,7 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
         for (int i = 0; i < NS * NS; ++i) io->P_in[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;
-    return begin_device(c, true);   // kf_begin_kernel reads the mailbox across PCIe: no upload on the stream
+    return begin_device(c, io->x_in);   // the state rides in the kernel arguments, P is read from the mailbox across PCIe
 }
 
 int pass_solve(lv_ctx* c, bool from_groups);
@@ -835,7 +835,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     if (c->map.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
     if (rc) return rc;
-    rc = begin_device(c, false);
+    rc = begin_device(c, nullptr);
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;

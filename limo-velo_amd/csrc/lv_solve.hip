@@ -19,6 +19,8 @@
 // two 12x12 SPD inversions (unpivoted Gauss-Jordan) instead of two 23x23 ones, no cancellation
 // (the naive S = I + Pr11 HTH solve loses ~6 digits in the posterior covariance; measured in
 // tests/test_oracle_numerics.py).  Algebraically identical to upstream, rounding-level different.
+#include <cstring>
+
 #include "lv_host.hpp"
 #include "lv_solve_dev.hpp"
 
@@ -27,24 +29,26 @@
 
 namespace lv {
 
-// from_host: x / P_prop arrive in the host mailbox (lv_update); otherwise they are already in kf (resident filter)
-__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, int from_host) {
+// from_host: the state comes as a kernel argument and P_prop waits in the pinned host mailbox (lv_update);
+// otherwise both are already in kf (resident filter).  The mailbox read crosses PCIe (~2 us): it is issued first and
+// consumed last, the pose constants of pass 0 are derived from the argument meanwhile.
+struct StateArg {
+    double v[NX];
+};
+__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, int from_host, StateArg xin) {
     __shared__ double s_x[NX];
+    __shared__ double s_rot[4][9];
+    __shared__ float s_tmp[8];
     const int tid = threadIdx.x;
-    if (tid < NS * NS) {
-        const double p = from_host ? io->P_in[tid] : kf->P_prop[tid];
-        if (from_host) kf->P_prop[tid] = p;
-        kf->P_post[tid] = p;
-        io->P_post[tid] = p;   // an update without a terminal pass returns the propagated covariance
-    }
+    double p = 0.0;
+    if (tid < NS * NS) p = from_host ? io->P_in[tid] : kf->P_prop[tid];
     if (tid < NX) {
-        const double v = from_host ? io->x_in[tid] : kf->x[tid];
+        const double v = from_host ? xin.v[tid] : kf->x[tid];
         if (from_host) kf->x[tid] = v;
         kf->x_prop[tid] = v;
         io->x[tid] = v;
         s_x[tid] = v;
     }
-    __syncthreads();
     if (tid == 0) {
         io->passes = 0;
         io->fallback_queries = 0;
@@ -54,7 +58,25 @@ __global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, 
         kf->passes = 0;
         kf->fallback_queries = 0;
         for (int i = 0; i < 8; ++i) kf->level_hist[i] = 0;
-        compute_pose_consts(s_x, &kf->pose);
+    }
+    __syncthreads();
+    // compute_pose_consts (lv_device.hpp) spread over lanes: four quaternion -> matrix conversions, then the
+    // composed transforms (same operations, same order => same bits as the serial form)
+    if (tid >= 64 && tid < 68) {
+        const int w = tid - 64;                // 0: rot, 1: offset_R_L_I, 2: conj(rot), 3: conj(offset_R_L_I)
+        const int q = (w & 1) ? 7 : 3;
+        const double sg = (w & 2) ? -1.0 : 1.0;
+        const double qq[4] = {sg * s_x[q], sg * s_x[q + 1], sg * s_x[q + 2], s_x[q + 3]};
+        quat_to_rot(qq, &s_rot[w][0]);
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < 128) pose_consts_stage_a(tid - 64, s_x, s_rot, &kf->pose, s_tmp);
+    __syncthreads();
+    if (tid >= 64 && tid < 128) pose_consts_stage_b(tid - 64, s_rot, &kf->pose, s_tmp);
+    if (tid < NS * NS) {
+        if (from_host) kf->P_prop[tid] = p;
+        kf->P_post[tid] = p;
+        io->P_post[tid] = p;   // an update without a terminal pass returns the propagated covariance
     }
 }
 
@@ -133,7 +155,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __shared__ double sP[NS][LD], sA[NS][LD], sB[NS][LD], sJ[NS][LD];
     __shared__ double sW[2][12][13], sT[12][12];
     __shared__ double sX[NS][12], sG[NS][12], sKx[NS][12], sHTH[12][12], sHTh[12];
-    __shared__ double sdx[NS], sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
+    __shared__ double sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
     __shared__ double s_part[FOLD_PARTS][SUMS_LEN];
     __shared__ double sRot[4][9];
     __shared__ PoseConsts s_pose;
@@ -343,8 +365,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 #undef SV_STAMP
 }
 
-int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, bool from_host) {
-    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, from_host ? 1 : 0);
+int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host) {
+    StateArg xin;
+    if (x_host) std::memcpy(xin.v, x_host, sizeof(xin.v));
+    else std::memset(xin.v, 0, sizeof(xin.v));
+    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, x_host ? 1 : 0, xin);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }

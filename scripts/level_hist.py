@@ -3,7 +3,7 @@ sys.path.insert(0, ".")
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth
 sc = synth.make_scene(1_048_576, 65_536)
-for vox in (0.5, 0.6, 0.7):
+for vox in ([float(v) for v in sys.argv[1:]] or [0.5, 0.6, 0.7]):
     ctx = capi.Context(capi.default_params(voxel_size=vox))
     ctx.map_build(sc["map_xyz"]); ctx.scan_set(sc["scan_xyz"])
     ctx.iterate(sc["x_init"]); h1 = ctx.level_histogram()
