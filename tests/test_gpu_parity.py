@@ -310,3 +310,22 @@ def test_mailbox_results_are_never_torn(capi, scene_small):
             else:
                 x, P, p, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
                 assert p == p0 and np.array_equal(x, x0) and np.array_equal(P, P0), i
+
+
+def test_cfg2_like_update(capi, oracle, lv):
+    """120k-pt scan vs 2M-pt map, 4 IKFoM passes (BASELINE configs[2] sizes): single-pass per-point parity and the
+    iterated update against the oracle."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(2_000_000, 120_000)
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    assert passes == po == 4
+    assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+    assert np.abs(tr - tro).max() < TOL_STATE
+    assert np.abs(x - xo).max() < TOL_STATE
