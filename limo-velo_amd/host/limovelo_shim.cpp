@@ -169,6 +169,48 @@ Points Compensator::compensate(const States& states, const State& Xt2, const Poi
     return out;
 }
 
+Points Compensator::compensate(const States& states, const State& Xt2, double t1, double t2, float downsample_prec) {
+    Points out;
+    if (states.size() < 2) return out;
+    lv_ctx* c = HipRuntime::ctx();
+    std::vector<lv_motion_state> ms;
+    ms.reserve(states.size());
+    for (const State& s : states) ms.push_back(s.motion());
+    const lv_motion_state x2 = Xt2.motion();
+    size_t nw = 0;
+    check(lv_scan_deskew_window(c, t1, t2, ms.data(), ms.size(), &x2, downsample_prec, &nw), "lv_scan_deskew_window");
+    if (nw == 0) return out;   // Compensator.cpp:24
+    const size_t n = lv_scan_size(c);
+    std::vector<float> xyz(3 * n);
+    check(lv_scan_fetch(c, xyz.data(), n), "lv_scan_fetch");
+    for (size_t i = 0; i < n; ++i) out.push_back(Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], Xt2.time));
+    return out;
+}
+
+// ---- LiDAR buffer (reference src/Modules/Accumulator.cpp, src/Utils/PointCloudProcessor.cpp) ----------------
+size_t LidarBuffer::process(const void* data, size_t n_points, const lv_cloud_format& format, uint64_t header_stamp_usec) {
+    lv_ingest_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.header_stamp_usec = header_stamp_usec;
+    p.stamp_beginning = Config.stamp_beginning ? 1 : 0;
+    p.offset_beginning = Config.offset_beginning ? 1 : 0;
+    p.full_rotation_time = Config.full_rotation_time;
+    p.downsample_rate = Config.downsample_rate;
+    p.min_dist = Config.min_dist;
+    size_t kept = 0;
+    check(lv_cloud_ingest(HipRuntime::ctx(), data, n_points, &format, &p, &kept), "lv_cloud_ingest");
+    return kept;
+}
+Points LidarBuffer::get_points(double t1, double t2) {
+    lv_ctx* c = HipRuntime::ctx();
+    std::vector<Point> v(lv_cloud_size(c) + 1);
+    size_t n = 0;
+    check(lv_cloud_fetch(c, t1, t2, v.data(), v.size(), &n), "lv_cloud_fetch");
+    return Points(v.begin(), v.begin() + (std::ptrdiff_t)n);
+}
+void LidarBuffer::clear_lidar(double t) { check(lv_cloud_clear(HipRuntime::ctx(), t), "lv_cloud_clear"); }
+size_t LidarBuffer::size() { return lv_cloud_size(HipRuntime::ctx()); }
+
 // ---- Mapper (reference src/Modules/Mapper.cpp) ---------------------------------------------------
 bool Mapper::exists() { return size() > 0; }                             // :36-38,78-80
 int Mapper::size() { return (int)lv_map_size(HipRuntime::ctx()); }       // :32-34

@@ -44,6 +44,9 @@ struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107)
     double LiDAR_noise = 0.001;
     double cov_acc = 1.e-2, cov_gyro = 1.e-4, cov_bias_acc = 1.e-4, cov_bias_gyro = 1.e-5;  // config/params.yaml:39-42
     double full_rotation_time = 0.1;
+    bool stamp_beginning = false, offset_beginning = false;   // config/params.yaml:30-31
+    int downsample_rate = 4;                                 // :35
+    float min_dist = 4.f;                                    // :34
     float downsample_prec = 0.5f;
     std::vector<float> initial_gravity = {0.f, 0.f, -9.807f};
     std::vector<float> I_Rotation_L = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -132,6 +135,24 @@ class Compensator {  // reference include/Headers/Compensator.hpp; the Accumulat
     // Compensator::compensate(states, Xt2, points) (Compensator.cpp:123-146) followed by
     // Compensator::downsample (:104-107,148-163) with leaf = downsample_prec; <= 0 skips the voxel grid
     Points compensate(const States& states, const State& Xt2, const Points& points, float downsample_prec);
+    // Compensator::compensate(t1, t2) (Compensator.cpp:18-35) with the points taken from the device LiDAR buffer
+    Points compensate(const States& states, const State& Xt2, double t1, double t2, float downsample_prec);
+};
+
+// LiDAR side of the reference's Accumulator (include/Headers/Accumulator.hpp): the buffer of processed, time-stamped
+// points lives on the device.  process() = Accumulator::process + push of every point (Accumulator.cpp:141-153) for
+// the payload of one sensor_msgs/PointCloud2 (msg->data; `format` from msg->fields);
+// get_points / clear_lidar as in Accumulator.cpp:64-70,93-95.
+class LidarBuffer {
+  public:
+    size_t process(const void* data, size_t n_points, const lv_cloud_format& format, uint64_t header_stamp_usec);
+    Points get_points(double t1, double t2);
+    void clear_lidar(double t);
+    size_t size();
+    static LidarBuffer& getInstance() {
+        static LidarBuffer* b = new LidarBuffer();
+        return *b;
+    }
 };
 
 // One GPU context shared by the two singletons (the reference's singletons share the process).

@@ -2,7 +2,9 @@
 // (map.add -> loc.correct -> loc.latest_state), plus Mapper::match / Localizator::calculate_H.
 // Input/Output are raw little-endian files so tests/test_gpu_shim.py can compare with the oracle.
 //   shim_demo <map.f32> <scan.f32> <state26.f64> <P529.f64> <out.bin>
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -68,6 +70,49 @@ int main(int argc, char** argv) {
         }
         std::printf("shim_demo: map %d pts, %zu matches, %d passes, pos %.6f %.6f %.6f\n", map.size(), matches.size(),
                     loc.last_passes, loc.get_x().pos[0], loc.get_x().pos[1], loc.get_x().pos[2]);
+        // ---- LiDAR wire format -> device buffer -> windowed de-skew (row f-4), self-checked ------------------------
+        {
+            struct VelodynePoint { float x, y, z, pad, intensity, time; uint16_t ring; uint8_t fill[6]; };   // velodyne_ros::Point
+            static_assert(sizeof(VelodynePoint) == 32, "velodyne_ros::Point layout");
+            const size_t n = 20000;
+            std::vector<VelodynePoint> msg(n);
+            for (size_t i = 0; i < n; ++i) {
+                const float az = 6.2831853f * (float)i / (float)n;
+                const float r = 5.f + (float)(i % 37);
+                msg[i] = VelodynePoint{r * std::cos(az), r * std::sin(az), 0.1f * (float)(i % 11), 0.f, (float)(i % 255),
+                                       -0.1f + 0.1f * (float)i / (float)n, (uint16_t)(i % 16), {0, 0, 0, 0, 0, 0}};
+            }
+            lv_cloud_format fmt;
+            if (lv_cloud_format_preset(LV_LIDAR_VELODYNE, &fmt) != LV_OK) throw std::runtime_error("preset");
+            LidarBuffer& buf = LidarBuffer::getInstance();
+            const size_t kept = buf.process(msg.data(), n, fmt, 1000000000ull /* 1000 s */);
+            Points all = buf.get_points(-1e300, 1e300);
+            if (kept == 0 || all.size() != kept || buf.size() != kept) throw std::runtime_error("LidarBuffer: count mismatch");
+            for (size_t i = 1; i < all.size(); ++i)
+                if (all[i].time < all[i - 1].time) throw std::runtime_error("LidarBuffer: not time ordered");
+            const double t1 = all[all.size() / 4].time, t2 = all[3 * all.size() / 4].time;
+            Points win = buf.get_points(t1, t2);
+            States path;
+            State s0;
+            s0.time = t1 - 0.01;
+            s0.vel[0] = 3.f; s0.w[2] = 0.3f; s0.a[2] = 9.807f;
+            path.push_back(s0);
+            for (int k = 1; k <= 12; ++k) {
+                State sk = path.back();
+                float a[3] = {0.1f, 0.f, 9.807f}, w[3] = {0.f, 0.f, 0.3f};
+                sk += IMU(a, w, s0.time + 0.01 * k);
+                path.push_back(sk);
+            }
+            Compensator comp;
+            Points a = comp.compensate(path, path.back(), win, 0.5f);
+            Points b = comp.compensate(path, path.back(), t1, t2, 0.5f);
+            if (a.size() != b.size() || a.empty()) throw std::runtime_error("windowed de-skew: size mismatch");
+            for (size_t i = 0; i < a.size(); ++i)
+                if (std::memcmp(&a[i].x, &b[i].x, 12) != 0) throw std::runtime_error("windowed de-skew differs from de-skew of the fetched points");
+            buf.clear_lidar(t2);
+            if (buf.size() != kept - buf.get_points(-1e300, t2).size() && buf.size() >= kept) throw std::runtime_error("clear_lidar");
+            std::printf("shim_demo: lidar buffer %zu of %zu points kept, window %zu -> %zu de-skewed points\n", kept, n, win.size(), a.size());
+        }
         HipRuntime::shutdown();
     } catch (const std::exception& e) {
         std::cerr << "shim_demo failed: " << e.what() << "\n";
