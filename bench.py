@@ -186,7 +186,7 @@ def main() -> None:
     # durations themselves are unaffected and must agree with the rocprofv3 summary under profiles/)
     ctx.set_profiling(True)
     kern_ms, kern_cnt, solve_ms = 0.0, 0, 0.0
-    if world == 1:
+    if world == 1 or collective.startswith("rccl (library"):   # lv_update itself runs the passes: per-kernel events exist
         for _ in range(args.steps):
             _, _, p = upd.update(sc["x_init"], sc["P0"])
             tm = ctx.timing()
@@ -234,7 +234,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes()[0],
+                "traffic": pmc_traffic_bytes()[0] if world == 1 else None,
                 "traffic_source": pmc_traffic_bytes()[1],
                 "alg_bytes_per_launch": alg_bytes,
                 "alg_bytes_per_point_pass": b_alg(M_POINTS),
