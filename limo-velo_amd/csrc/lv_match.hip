@@ -705,7 +705,7 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
     constexpr int NOUT = W * (W + 1) / 2 + W + 2;
     constexpr int NACC = (NOUT + 63) / 64;
     __shared__ double s_rows[G][ROW_W];
-    __shared__ double s_out[NWAVE][SUMS_LEN];
+    __shared__ double s_out[NWAVE][2][SUMS_LEN];
     if (kf->done) return;
     if (blockIdx.x == 0) {   // rides along: the half of the coming solve that does not need this pass' record
         solve_prep<W, FIT_POINTS>(kf, prm.R_inv);
@@ -717,13 +717,17 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
     const PoseConsts& pc = kf->pose;
     int oa[NACC], ob[NACC], orec[NACC];
     double acc[NACC];
+    // NOUT <= 32 (no extrinsics): the two half-wavefronts each contract 32 of the wavefront's 64 rows
+    constexpr bool HALVES = NOUT <= 32;
+    const int olane = HALVES ? (lane & 31) : lane;       // output owned by this lane
+    const int prow0 = HALVES ? (lane >> 5) * 32 : 0;     // first row of its share
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
         oa[a] = ob[a] = orec[a] = 0;
         acc[a] = 0.0;
-        if (lane + a * 64 < NOUT) out_pair<W>(lane + a * 64, oa[a], ob[a], orec[a]);
+        if (olane + a * 64 < NOUT) out_pair<W>(olane + a * 64, oa[a], ob[a], orec[a]);
     }
-    for (int t = tid; t < NWAVE * SUMS_LEN; t += G) (&s_out[0][0])[t] = 0.0;
+    for (int t = tid; t < 2 * NWAVE * SUMS_LEN; t += G) (&s_out[0][0][0])[t] = 0.0;
     const uint32_t vb = (bid % 8u) * (nfit / 8u) + bid / 8u;
     const uint32_t per_iter = (uint32_t)G * nfit;
     const uint32_t iters = (n + per_iter - 1) / per_iter;
@@ -755,10 +759,10 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
         const double (*rows)[ROW_W] = s_rows + wave * 64;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
-            if (lane + a * 64 < NOUT) {
+            if (olane + a * 64 < NOUT) {
                 double sacc = acc[a];
 #pragma unroll 8
-                for (int p = 0; p < 64; ++p) sacc += rows[p][oa[a]] * rows[p][ob[a]];
+                for (int p = 0; p < (HALVES ? 32 : 64); ++p) sacc += rows[prow0 + p][oa[a]] * rows[prow0 + p][ob[a]];
                 acc[a] = sacc;
             }
         }
@@ -767,12 +771,12 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
     }
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
-        if (lane + a * 64 < NOUT) s_out[wave][orec[a]] = acc[a];
+        if (olane + a * 64 < NOUT) s_out[wave][HALVES ? (lane >> 5) : 0][orec[a]] = acc[a];
     __syncthreads();
-    if (tid < SUMS_LEN) {
-        double s = s_out[0][tid];
+    if (tid < SUMS_LEN) {   // fixed order: (half 0 + half 1) of wave 0, then the other waves likewise
+        double s = s_out[0][0][tid] + s_out[0][1][tid];
 #pragma unroll
-        for (int w = 1; w < NWAVE; ++w) s += s_out[w][tid];
+        for (int w = 1; w < NWAVE; ++w) s += s_out[w][0][tid] + s_out[w][1][tid];
         partials[(size_t)bid * SUMS_LEN + tid] = s;
     }
 }
