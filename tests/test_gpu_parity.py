@@ -329,3 +329,26 @@ def test_cfg2_like_update(capi, oracle, lv):
     assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
     assert np.abs(tr - tro).max() < TOL_STATE
     assert np.abs(x - xo).max() < TOL_STATE
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 31, 33, 255, 257, 1000])
+def test_ragged_scan_sizes(capi, oracle, scene_small, n):
+    """Scan sizes around the tile (32 points at 8 lanes per point) and wavefront boundaries, including the empty
+    scan: padding lanes lend a hand in the wavefront-cooperative level and must not leak into results."""
+    sc = scene_small
+    scan = sc["scan_xyz"][:n]
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(scan)
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+        if n:
+            ctx.iterate(sc["x_init"])
+            idx, d2 = ctx.fetch_knn()
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], scan)
+    assert passes == po
+    assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+    assert np.abs(x - xo).max() < TOL_STATE
+    assert np.abs(P - Po).max() < 1e-9 * max(1.0, np.abs(Po).max())
+    if n:
+        oi, od, _, _ = oracle.knn_brute(sc["map_xyz"], oracle.transform_scan(sc["x_init"], scan))
+        assert np.array_equal(idx, oi) and np.array_equal(_bits(d2), _bits(od))
