@@ -113,10 +113,12 @@ __device__ __forceinline__ void fold_issue(double (&fv)[FOLD_DEPTH], const doubl
     }
 }
 __device__ __forceinline__ void fold_stage(const double (&fv)[FOLD_DEPTH], double (*s_part)[SUMS_LEN], int tid) {
-    double s = fv[0];
+    // four interleaved running sums, combined pairwise: a quarter of the dependent-add chain, still a fixed order
+    double a0 = fv[0], a1 = fv[1], a2 = fv[2], a3 = fv[3];
 #pragma unroll
-    for (int i = 1; i < FOLD_DEPTH; ++i) s += fv[i];
-    s_part[tid / SUMS_LEN][tid % SUMS_LEN] = s;
+    for (int i = 4; i + 3 < FOLD_DEPTH; i += 4) { a0 += fv[i]; a1 += fv[i + 1]; a2 += fv[i + 2]; a3 += fv[i + 3]; }
+    static_assert(FOLD_DEPTH % 4 == 0, "fold_stage assumes a multiple of four");
+    s_part[tid / SUMS_LEN][tid % SUMS_LEN] = (a0 + a1) + (a2 + a3);
 }
 __device__ __forceinline__ double fold_total(const double (*s_part)[SUMS_LEN], int o) {
     return ((s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o])) + (s_part[4][o] + s_part[5][o]);

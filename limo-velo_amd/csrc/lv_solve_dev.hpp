@@ -25,6 +25,34 @@ __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double
 // tid < NW*NW work; one reciprocal per step
 template <int NW>
 __device__ inline void gj_spd(double (*W)[12][13], int& cur, int tid) {
+    if (NW * NW <= 64) {
+        // the whole matrix lives in wavefront 0: its LDS operations execute in order, so the NW elimination steps
+        // need no workgroup barrier in between (the other wavefronts just wait at the one barrier below)
+        if (tid < 64) {
+            int c = cur;
+            for (int k = 0; k < NW; ++k) {
+                if (tid < NW * NW) {
+                    const int i = tid / NW, j = tid % NW;
+                    const double rp = ddiv(1.0, W[c][k][k]);
+                    double v;
+                    if (i == k) {
+                        v = (j == k) ? rp : W[c][k][j] * rp;
+                    } else {
+                        const double f = W[c][i][k];
+                        v = (j == k) ? -(f * rp) : W[c][i][j] - f * (W[c][k][j] * rp);
+                    }
+                    W[c ^ 1][i][j] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                c ^= 1;
+            }
+        }
+        cur ^= (NW & 1);
+        __syncthreads();
+        return;
+    }
     for (int k = 0; k < NW; ++k) {
         if (tid < NW * NW) {
             const int i = tid / NW, j = tid % NW;
