@@ -369,7 +369,9 @@ __device__ __forceinline__ void merge_team(kkey (&k)[KNN]) {
 // otherwise false with k reset to NONE.
 template <int LANES>
 __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
-                                               kkey (&k)[KNN], uint32_t& bstart, long long* clk) {
+                                               kkey (&k)[KNN], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
+    // stage (LDS, LANES * 8 entries of this team, or nullptr): the first chunk's candidates are kept there by
+    // position, so that the caller can pick the winners up without another trip to memory
     const GridLevel g = map.bt[bl];
     const uint64_t key = pack_cell((uint32_t)(geo.c0x >> bl), (uint32_t)(geo.c0y >> bl), (uint32_t)(geo.c0z >> bl));
     uint32_t slot = hash_cell(key, g.shift) & g.mask;
@@ -391,6 +393,10 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
         for (int u = 0; u < U; ++u) {
             const uint32_t j = base + (uint32_t)(u * LANES + tl);
             mpt[u] = bp[j < bcount ? j : 0];
+        }
+        if (stage && base == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) stage[u * LANES + tl] = mpt[u];
         }
         kkey ck[U];
 #pragma unroll
@@ -427,7 +433,7 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
 template <int S, bool DBG, int COOP_FROM>
 __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
                                            kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist,
-                                           bool live = true) {
+                                           bool live = true, Xyz* stage0 = nullptr) {
     if (map.m == 0) return;
     const QGeom geo = make_geom(map, qx, qy, qz);
     const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
@@ -437,7 +443,8 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     if (in_range) {
         const int group_levels = map.n_bucket_levels < COOP_FROM ? map.n_bucket_levels : COOP_FROM;
         for (int bl = 0; bl < group_levels && !decided; ++bl) {
-            decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr);
+            decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
+                                        bl == 0 ? stage0 : nullptr);
             if (decided) src = bl;
             level = bl + 1;
         }
@@ -627,6 +634,8 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
                                                      KfDev* __restrict__ kf, float4* __restrict__ qrec, uint32_t qstride,
                                                      const uint32_t* __restrict__ tile_order, uint32_t n_tiles, DebugOut dbg) {
     constexpr int GS = 256 / S;
+    constexpr int STAGE = S * 8;   // candidates of a lane group's first level-0 chunk, kept in LDS by position
+    __shared__ Xyz s_stage[GS][STAGE];
     if (kf->done) return;
     const int tid = threadIdx.x;
     const int gq = tid / S, gl = tid % S;
@@ -649,7 +658,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     float qx, qy, qz;
     rt_apply(kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
     if (DBG && stamp_slot) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); stamp_slot[1] = clock64(); }
-    knn_search<S, DBG, LV_COOP_FROM>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk, live);
+    knn_search<S, DBG, LV_COOP_FROM>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk, live, s_stage[gq]);
     if (DBG && stamp_slot) { asm volatile("" :: "v"(k[0]), "v"(k[4])); stamp_slot[3] = clock64(); }
     int found = 0;
 #pragma unroll
@@ -667,7 +676,13 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
                 v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
                 if (!is_none(kk)) {
                     const uint32_t pos = key_lo(kk);
-                    if (src >= 0) {
+                    if (src == 0 && pos < (uint32_t)STAGE && !DBG) {
+                        // decided at level 0 inside its first chunk (the common case): the point is still in LDS
+                        // (same wavefront wrote it, LDS operations of a wavefront execute in order); its original
+                        // index is only reported by capturing (DBG) launches
+                        const Xyz w = s_stage[gq][pos];
+                        v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
+                    } else if (src >= 0) {
                         const Xyz w = reinterpret_cast<const Xyz*>(map.bxyz[src])[(size_t)bstart + pos];
                         v = make_float4(w.x, w.y, w.z, __uint_as_float(map.bidx[src][(size_t)bstart + pos]));
                     } else {
