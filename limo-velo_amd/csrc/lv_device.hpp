@@ -21,6 +21,7 @@ constexpr int CELL_OFFSET = 1 << 20;
 constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-force path
 constexpr int MAX_LEVELS = 16;
 constexpr int MAX_BUCKET_LEVELS = 3;
+constexpr int SORTED_BUCKET_LEVELS = 2;   // levels 0, 1: the common path; level 2 serves a handful of points per scan
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr int MAX_PASSES = 16;
 
@@ -101,8 +102,11 @@ struct MapView {
     // {key lo, key hi, bucket start, bucket count}.
     int n_bucket_levels;
     GridLevel bt[MAX_BUCKET_LEVELS];
-    const float* bxyz[MAX_BUCKET_LEVELS];      // bucket points, 3 packed floats each (12 B per candidate streamed)
-    const uint32_t* bidx[MAX_BUCKET_LEVELS];   // their original map indices (fetched for the winners only)
+    // levels < SORTED_BUCKET_LEVELS: buckets sorted by original index, 12-byte points (what the search streams) + a
+    // parallel index array; coarser levels: unsorted {x, y, z, index} records (bucket4), searched with index keys
+    const float* bxyz[MAX_BUCKET_LEVELS];
+    const uint32_t* bidx[MAX_BUCKET_LEVELS];
+    const float4* bucket4[MAX_BUCKET_LEVELS];
 };
 
 struct MatchParams {

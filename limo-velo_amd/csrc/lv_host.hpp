@@ -41,6 +41,7 @@ struct MapStore {
     size_t bucket_tmp_cap = 0;
     float* d_bxyz[MAX_BUCKET_LEVELS] = {};      // 12-byte points: what the search kernel streams
     uint32_t* d_bidx[MAX_BUCKET_LEVELS] = {};   // original indices, read for the 5 winners only
+    float4* d_bucket4[MAX_BUCKET_LEVELS] = {};  // levels >= 1: unsorted {x,y,z,idx} buckets (no sort at build time)
     size_t bucket_cap[MAX_BUCKET_LEVELS] = {};
     size_t bucket_points[MAX_BUCKET_LEVELS] = {};
     uint32_t n_bcells[MAX_BUCKET_LEVELS] = {};

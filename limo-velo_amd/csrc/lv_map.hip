@@ -228,12 +228,26 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
     const uint32_t n = bcount[cell];
     if (n <= 64) return;  // handled by bucket_sort_wave_kernel
     float4* g = bucket + boff[cell];
-    const bool in_lds = n <= BSORT_LDS;
-    float4* a = in_lds ? s_pts : g;
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) s_pts[i] = g[i];
+    if (n <= BSORT_LDS) {
+        // rank by counting: original indices are unique, so the rank of a point is the number of points with a
+        // smaller index — n compares per point out of LDS (broadcast reads), no barriers between steps; for the
+        // few-hundred-point buckets this beats the bitonic network (log^2 n barrier-separated stages) severalfold
+        __shared__ uint32_t s_idx[BSORT_LDS];
+        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+            const float4 p = g[i];
+            s_pts[i] = p;
+            s_idx[i] = __float_as_uint(p.w);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+            const uint32_t mine = s_idx[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) rank += s_idx[j] < mine ? 1u : 0u;
+            g[rank] = s_pts[i];
+        }
+        return;
     }
-    __syncthreads();
+    float4* a = g;
     for (uint32_t k = 2; (k >> 1) < n; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             const bool flip = (j == (k >> 1));
@@ -246,9 +260,6 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
             }
             __syncthreads();
         }
-    }
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) g[i] = s_pts[i];
     }
 }
 
@@ -414,7 +425,7 @@ void MapStore::release() {
     hipFree(d_sort_tmp); hipFree(d_counts);
     hipFree(d_orig2); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
-    for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bxyz[l]); hipFree(d_bidx[l]); }
+    for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bxyz[l]); hipFree(d_bidx[l]); hipFree(d_bucket4[l]); }
     hipFree(d_bucket_tmp);
     for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
     *this = MapStore();
@@ -557,36 +568,50 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         const uint64_t total = (uint64_t)last_off + last_cnt;
         if (total > 0xFFFFFFF0ull) { set_error("bucket array exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
         bucket_points[level] = (size_t)total;
-        if (bucket_points[level] > bucket_tmp_cap) {
-            hipFree(d_bucket_tmp);
-            d_bucket_tmp = nullptr;
-            bucket_tmp_cap = 0;
-            size_t cap = bucket_points[level] + bucket_points[level] / 8;
-            LV_HIP(hipMalloc(&d_bucket_tmp, cap * sizeof(float4)));
-            bucket_tmp_cap = cap;
+        if (level < SORTED_BUCKET_LEVELS) {   // sorted by original index, then packed to 12-byte points + index array
+            if (bucket_points[level] > bucket_tmp_cap) {
+                hipFree(d_bucket_tmp);
+                d_bucket_tmp = nullptr;
+                bucket_tmp_cap = 0;
+                size_t cap = bucket_points[level] + bucket_points[level] / 8;
+                LV_HIP(hipMalloc(&d_bucket_tmp, cap * sizeof(float4)));
+                bucket_tmp_cap = cap;
+            }
+            if (bucket_points[level] > bucket_cap[level]) {
+                hipFree(d_bxyz[level]); hipFree(d_bidx[level]);
+                d_bxyz[level] = nullptr; d_bidx[level] = nullptr;
+                bucket_cap[level] = 0;
+                size_t cap = bucket_points[level] + bucket_points[level] / 8;
+                LV_HIP(hipMalloc(&d_bxyz[level], (cap * 3 + 4) * sizeof(float)));
+                LV_HIP(hipMalloc(&d_bidx[level], cap * sizeof(uint32_t)));
+                bucket_cap[level] = cap;
+            }
+            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
+                               d_boff, d_bucket_tmp);
+            hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
+            if (total > 0)
+                hipLaunchKernelGGL(bucket_pack_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_bucket_tmp,
+                                   (uint32_t)total, d_bxyz[level], d_bidx[level]);
+        } else {            // coarse levels: candidates are ordered by (distance, index) keys, the bucket stays unsorted
+            if (bucket_points[level] > bucket_cap[level]) {
+                hipFree(d_bucket4[level]);
+                d_bucket4[level] = nullptr;
+                bucket_cap[level] = 0;
+                size_t cap = bucket_points[level] + bucket_points[level] / 8;
+                LV_HIP(hipMalloc(&d_bucket4[level], cap * sizeof(float4)));
+                bucket_cap[level] = cap;
+            }
+            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
+                               d_boff, d_bucket4[level]);
         }
-        if (bucket_points[level] > bucket_cap[level]) {
-            hipFree(d_bxyz[level]); hipFree(d_bidx[level]);
-            d_bxyz[level] = nullptr; d_bidx[level] = nullptr;
-            bucket_cap[level] = 0;
-            size_t cap = bucket_points[level] + bucket_points[level] / 8;
-            LV_HIP(hipMalloc(&d_bxyz[level], (cap * 3 + 4) * sizeof(float)));
-            LV_HIP(hipMalloc(&d_bidx[level], cap * sizeof(uint32_t)));
-            bucket_cap[level] = cap;
-        }
-        hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
-                           d_boff, d_bucket_tmp);
-        hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
-        hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
-        if (total > 0)
-            hipLaunchKernelGGL(bucket_pack_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_bucket_tmp, (uint32_t)total,
-                               d_bxyz[level], d_bidx[level]);
         LV_HIP(hipGetLastError());
         view.bt[level].table = d_btable[level];
         view.bt[level].mask = size - 1;
         view.bt[level].shift = (uint32_t)(64 - lg);
         view.bxyz[level] = d_bxyz[level];
         view.bidx[level] = d_bidx[level];
+        view.bucket4[level] = d_bucket4[level];
         return LV_OK;
     }
 }

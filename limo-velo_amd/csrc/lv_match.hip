@@ -367,7 +367,10 @@ __device__ __forceinline__ void merge_team(kkey (&k)[KNN]) {
 // 27-voxel block is empty).  k is all-NONE on entry; returns true with the sorted result in k (low words =
 // positions inside the bucket starting at bstart) iff 5 candidates were found inside the guaranteed radius,
 // otherwise false with k reset to NONE.
-template <int LANES>
+// BY_INDEX (bucket levels >= 1): the bucket is an UNSORTED run of {x, y, z, original index} records and the key's
+// low word is the original map index — the reference's (distance, index) order needs no sorted bucket then, and
+// the map build skips the sort of the big coarse-level buckets; the winners are read from map.orig afterwards.
+template <int LANES, bool BY_INDEX>
 __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
                                                kkey (&k)[KNN], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
     // stage (LDS, LANES * 8 entries of this team, or nullptr): the first chunk's candidates are kept there by
@@ -386,30 +389,55 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     if (clk) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
     if (bcount < KNN) return false;
     constexpr int U = 8;
-    const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
-    for (uint32_t base = 0; base < bcount; base += LANES * U) {
-        Xyz mpt[U];
+    if (BY_INDEX) {
+        const float4* __restrict__ bp = map.bucket4[bl] + bstart;
+        for (uint32_t base = 0; base < bcount; base += LANES * U) {
+            float4 mpt[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = base + (uint32_t)(u * LANES + tl);
-            mpt[u] = bp[j < bcount ? j : 0];
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                mpt[u] = bp[j < bcount ? j : 0];
+            }
+            kkey ck[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();
+            }
+            sort8(ck);
+            if (base == 0) {
+#pragma unroll
+                for (int i = 0; i < KNN; ++i) k[i] = ck[i];
+            } else {
+                merge5(k, ck);
+            }
         }
-        if (stage && base == 0) {
+    } else {
+        const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
+        for (uint32_t base = 0; base < bcount; base += LANES * U) {
+            Xyz mpt[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) stage[u * LANES + tl] = mpt[u];
-        }
-        kkey ck[U];
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                mpt[u] = bp[j < bcount ? j : 0];
+            }
+            if (stage && base == 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = base + (uint32_t)(u * LANES + tl);
-            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
-        }
-        sort8(ck);
-        if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
+                for (int u = 0; u < U; ++u) stage[u * LANES + tl] = mpt[u];
+            }
+            kkey ck[U];
 #pragma unroll
-            for (int i = 0; i < KNN; ++i) k[i] = ck[i];
-        } else {
-            merge5(k, ck);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
+            }
+            sort8(ck);
+            if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
+#pragma unroll
+                for (int i = 0; i < KNN; ++i) k[i] = ck[i];
+            } else {
+                merge5(k, ck);
+            }
         }
     }
     merge_team<LANES>(k);
@@ -440,12 +468,18 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     const bool in_range = live && finite && geo.amax < CELL_FAR;
     bool decided = !live;
     int level = in_range ? 0 : map.n_levels;
+    int hist_bin = -1;   // bucket level that decided (instrumentation)
     if (in_range) {
         const int group_levels = map.n_bucket_levels < COOP_FROM ? map.n_bucket_levels : COOP_FROM;
         for (int bl = 0; bl < group_levels && !decided; ++bl) {
-            decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
-                                        bl == 0 ? stage0 : nullptr);
-            if (decided) src = bl;
+            if (bl < SORTED_BUCKET_LEVELS) {
+                decided = bucket_attempt<S, false>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
+                                                   bl == 0 ? stage0 : nullptr);
+                if (decided) src = bl;
+            } else {
+                decided = bucket_attempt<S, true>(map, bl, geo, qx, qy, qz, gl, k, bstart, nullptr);   // src stays -1: map indices
+            }
+            if (decided) hist_bin = bl;
             level = bl + 1;
         }
     }
@@ -462,15 +496,15 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
             for (int j = 0; j < KNN; ++j) kw[j] = none_key();
             uint32_t wstart = 0;
             int wsrc = -1;
+            static_assert(COOP_FROM >= SORTED_BUCKET_LEVELS, "the wavefront-cooperative levels use index keys");
             for (int bl = COOP_FROM; bl < map.n_bucket_levels && wsrc < 0; ++bl)
-                if (bucket_attempt<64>(map, bl, wgeo, wx, wy, wz, lane, kw, wstart, nullptr)) wsrc = bl;
+                if (bucket_attempt<64, true>(map, bl, wgeo, wx, wy, wz, lane, kw, wstart, nullptr)) wsrc = bl;
             if (lane / S == L / S) {
                 level = map.n_bucket_levels;
-                if (wsrc >= 0) {
+                if (wsrc >= 0) {   // (keys carry map indices: src stays -1)
 #pragma unroll
                     for (int j = 0; j < KNN; ++j) k[j] = kw[j];
-                    bstart = wstart;
-                    src = wsrc;
+                    hist_bin = wsrc;
                     decided = true;
                 }
             }
@@ -514,7 +548,7 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
         }
     }
     if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
-    if (DBG && hist && live && gl == 0) atomicAdd(&kf->level_hist[src >= 0 ? src : (level < map.n_levels ? 3 : 4)], 1);
+    if (DBG && hist && live && gl == 0) atomicAdd(&kf->level_hist[hist_bin >= 0 ? hist_bin : (level < map.n_levels ? 3 : 4)], 1);
 }
 
 // Plane fit + gates + Jacobian row of ONE scan point (one lane): Plane.cpp:19-55, Utils.cpp:32-66,
