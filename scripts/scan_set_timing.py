@@ -23,3 +23,8 @@ t3 = time.perf_counter()
 print("scan_set ms %.3f | update ms %.3f | scan_set+update ms %.3f -> %.0f iters/s PCIe-inclusive" % (
     (t1 - t0) / n * 1e3, (t2 - t1) / n * 1e3, (t3 - t2) / n * 1e3, 4 * n / (t3 - t2)))
 t0 = time.perf_counter(); ctx.map_build(sc["map_xyz"]); print("map_build (1M pts) ms %.1f" % ((time.perf_counter() - t0) * 1e3))
+# row f-1: one Mapper::add of a 64k-point scan (world frame) into the 1M-point map, with ikd-Tree down-sampling
+import numpy as np
+new_pts = (sc["map_xyz"][:65_536] + np.float32(0.013)).astype(np.float32)
+ctx.synchronize(); t0 = time.perf_counter(); ctx.map_add(new_pts, downsample=True); ctx.synchronize()
+print("map_add (64k pts into 1M, downsample) ms %.1f -> map size %d" % ((time.perf_counter() - t0) * 1e3, ctx.map_size()))
