@@ -229,7 +229,7 @@ def main() -> None:
             "knn_mpts_per_s": n_local * world / avg_kernel_s / 1e6 if avg_kernel_s > 0 else None,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "lv::search_kernel" if os.environ.get("LV_FUSED", "0") in ("", "0") else "lv::match_reduce_kernel",
+                "kernel": "lv::search_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

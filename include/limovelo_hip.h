@@ -264,16 +264,16 @@ int lv_calculate_H(lv_ctx* ctx, const lv_state* x, const float* p_world, const f
 /* ---- instrumentation ------------------------------------------------------------------------- */
 typedef struct lv_timing {
     float last_update_ms;      /* device time of the last lv_update (HIP events on the ctx stream) */
-    float last_reduce_ms;      /* average device time of the match+reduce kernel in the last lv_update */
-    float last_solve_ms;       /* average device time of the solve kernel in the last lv_update */
+    float last_reduce_ms;      /* average device time of search_kernel (the dominant kernel) in the last lv_update */
+    float last_solve_ms;       /* average device time of fit_reduce_kernel + solve_kernel in the last lv_update */
     int   last_passes;
     int   fallback_queries;    /* scan points that left the bucketed voxel levels (generic search) in the last update */
-    float pass_match_ms[8];    /* device time of the match+reduce kernel per pass of the last profiled lv_update */
-    float pass_solve_ms[8];    /* device time of reduce_groups + solve per pass */
+    float pass_match_ms[8];    /* device time of search_kernel per pass of the last profiled lv_update */
+    float pass_solve_ms[8];    /* device time of fit_reduce_kernel + solve_kernel per pass */
 } lv_timing;
 int lv_get_timing(lv_ctx* ctx, lv_timing* out);
 /* 0 = off; 1 = per-kernel HIP-event timing inside lv_update (adds event records to the stream);
- * 2 = the match kernel stamps 8 shader-clock values per workgroup (phase boundaries) */
+ * 2 = search_kernel / fit_reduce_kernel stamp 8 shader-clock values per workgroup (phase boundaries) */
 int lv_set_profiling(lv_ctx* ctx, int enabled);
 /* after a pass run with lv_set_profiling(ctx, 2): out receives n_blocks x 8 clock64() stamps */
 int lv_get_phase_clocks(lv_ctx* ctx, long long* out, int capacity_blocks, int* n_blocks);
