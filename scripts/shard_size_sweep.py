@@ -1,0 +1,19 @@
+"""What one rank of an N-GPU run sees: the 64k-point scan cut to 64k / N points against the full 1M-point map
+(no collective: an upper bound for the strong-scaling run), plus larger scans."""
+import sys, time
+sys.path.insert(0, ".")
+import torch  # noqa: F401
+import lvamd; lvamd.load()
+from limo_velo_amd import capi, synth
+sc = synth.make_scene(1_048_576, 262_144)
+ctx = capi.Context(); ctx.map_build(sc["map_xyz"])
+for n in (8192, 16384, 32768, 65536, 131072, 262144):
+    ctx.scan_set(sc["scan_xyz"][:n])
+    for _ in range(10):
+        ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+    reps = 100
+    ctx.synchronize(); t0 = time.perf_counter(); p = 0
+    for _ in range(reps):
+        p += ctx.update(sc["x_init"], sc["P0"], want_trace=False)[2]
+    dt = time.perf_counter() - t0
+    print("scan %7d points: %.1f us per update, %.0f iterations/s, %.2f Gpoint-passes/s" % (n, dt / reps * 1e6, p / dt, p * n / reps / (dt / reps) / 1e9 / (p / reps) * (p / reps)))
