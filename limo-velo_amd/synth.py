@@ -184,3 +184,65 @@ def make_scene(m_points: int, n_points: int, *, sigma: float = 0.01, extrinsics:
     dq = quat_from_rotvec(np.radians([0.5, -0.4, 0.8]))
     x_init = make_state(pos_true + np.array([0.10, -0.07, 0.05]), quat_mul(q_true, dq), offR, offT)
     return dict(map_xyz=map_xyz, scan_xyz=scan_xyz, x_true=x_true, x_init=x_init, P0=default_P0(), L=surf[4])
+
+
+def make_ring_scene(m_points: int, n_rings: int, n_az: int, *, fov_deg=(-15.0, 15.0), sigma: float = 0.01,
+                    extrinsics: str = "identity", seed_map: int = SEED_MAP, seed_scan: int = SEED_SCAN, rmin: float = 4.0,
+                    rmax: float = 80.0):
+    """Same map and poses as make_scene, but the scan is what a spinning LiDAR sees: n_rings
+    elevation rings between fov_deg, n_az azimuth steps each, every ray cast from the true sensor pose onto the
+    scene's rectangles (nearest hit within [rmin, rmax]); rays without a hit are dropped, so the scan has at most
+    n_rings * n_az points.  Returns the same dict as make_scene."""
+    rng_m = _Rng(seed_map)
+    surf = _surfaces(rng_m, m_points)
+    map_xyz = _sample(rng_m, surf, m_points, sigma).astype(np.float32)
+    o, eu, ev, _, L = surf
+
+    pos_true = np.array([3.0, -2.0, 1.5])
+    q_true = quat_from_rpy(math.radians(2.0), math.radians(-1.0), math.radians(30.0))
+    if extrinsics == "identity":
+        offR, offT = np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3)
+    elif extrinsics == "xaloc":
+        offR = quat_from_rpy(0.0, 0.0, math.radians(1.5))
+        offT = np.array(XALOC_EXTRINSICS["t"])
+    else:
+        raise ValueError(extrinsics)
+    R = quat_to_rot(q_true)
+    RLI = quat_to_rot(offR)
+    sensor = R @ offT + pos_true
+
+    el = np.radians(np.linspace(fov_deg[0], fov_deg[1], n_rings))
+    az = np.linspace(0.0, 2.0 * math.pi, n_az, endpoint=False)
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    dl = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], se * np.ones_like(az)[None, :]], axis=-1).reshape(-1, 3)
+    dw = dl @ (R @ RLI).T   # ray directions in the world
+
+    nrm = np.cross(eu, ev)
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    uu, vv = np.sum(eu * eu, axis=1), np.sum(ev * ev, axis=1)
+    best = np.full(len(dw), np.inf)
+    for c0 in range(0, len(dw), 32768):   # rays x rectangles in chunks
+        d = dw[c0:c0 + 32768]
+        den = d @ nrm.T                                         # [rays, rects]
+        num = np.sum((o - sensor) * nrm, axis=1)[None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = num / den
+        t[~np.isfinite(t) | (t < rmin) | (t > rmax)] = np.inf
+        with np.errstate(invalid="ignore"):
+            hit = sensor[None, None, :] + t[:, :, None] * d[:, None, :]
+            rel = hit - o[None, :, :]
+            a = np.sum(rel * eu[None, :, :], axis=2) / uu[None, :]
+            b = np.sum(rel * ev[None, :, :], axis=2) / vv[None, :]
+        t[(a < 0) | (a > 1) | (b < 0) | (b > 1) | ~np.isfinite(a) | ~np.isfinite(b)] = np.inf
+        best[c0:c0 + 32768] = np.min(t, axis=1)
+    ok = np.isfinite(best)
+    pw = sensor[None, :] + best[ok, None] * dw[ok]
+    rng_s = _Rng(seed_scan)
+    pw = pw + (2.0 * rng_s.uniform(len(pw) * 3).reshape(-1, 3) - 1.0) * (sigma * math.sqrt(3.0))
+    pl = ((pw - pos_true) @ R - offT) @ RLI
+    scan_xyz = pl.astype(np.float32)
+
+    x_true = make_state(pos_true, q_true, offR, offT)
+    dq = quat_from_rotvec(np.radians([0.5, -0.4, 0.8]))
+    x_init = make_state(pos_true + np.array([0.10, -0.07, 0.05]), quat_mul(q_true, dq), offR, offT)
+    return dict(map_xyz=map_xyz, scan_xyz=scan_xyz, x_true=x_true, x_init=x_init, P0=default_P0(), L=L)

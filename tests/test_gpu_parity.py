@@ -352,3 +352,25 @@ def test_ragged_scan_sizes(capi, oracle, scene_small, n):
     if n:
         oi, od, _, _ = oracle.knn_brute(sc["map_xyz"], oracle.transform_scan(sc["x_init"], scan))
         assert np.array_equal(idx, oi) and np.array_equal(_bits(d2), _bits(od))
+
+
+@pytest.mark.parametrize("m,rings,n_az,fov", [(500_000, 16, 1875, (-15.0, 15.0)), (2_000_000, 64, 2048, (-25.0, 15.0))])
+def test_ring_pattern_scans(capi, oracle, lv, m, rings, n_az, fov):
+    """Spinning-LiDAR scans (VLP-16 -> cfg1, 64 rings -> cfg2) ray-cast onto the scene instead of
+    area-sampled: dense along a ring, sparse across rings — per-point parity of one pass and the iterated update."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_ring_scene(m, rings, n_az, fov_deg=fov)
+    assert len(sc["scan_xyz"]) > 0.6 * rings * n_az
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree)
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    assert passes == po
+    assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+    assert np.abs(tr - tro).max() < TOL_STATE
+    assert np.abs(x - xo).max() < TOL_STATE
+    assert np.linalg.norm(x[:3] - sc["x_true"][:3]) < 0.01
