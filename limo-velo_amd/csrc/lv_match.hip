@@ -464,9 +464,11 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
                                            bool live = true, Xyz* stage0 = nullptr) {
     if (map.m == 0) return;
     const QGeom geo = make_geom(map, qx, qy, qz);
-    const bool finite = (qx == qx) && (qy == qy) && (qz == qz);
+    const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const bool in_range = live && finite && geo.amax < CELL_FAR;
-    bool decided = !live;
+    // a point with a NaN / infinite coordinate has no neighbours (k stays NONE, found = 0): the reference discards such
+    // a match at Plane.cpp:42 whatever its tree search returned; searching for it would mean a brute-force scan
+    bool decided = !live || !finite;
     int level = in_range ? 0 : map.n_levels;
     int hist_bin = -1;   // bucket level that decided (instrumentation)
     if (in_range) {

@@ -812,6 +812,13 @@ void lvo_knn_brute(const float* map_xyz, size_t m, const float* q_xyz, size_t n,
     for (int64_t qi = 0; qi < (int64_t)n; ++qi) {
         TopK best(k + 1 <= 16 ? k + 1 : k);  // keep k+1 to detect a tie at rank k
         const float* q = q_xyz + 3 * qi;
+        // a query with a NaN / infinite coordinate has no neighbours: the reference's tree search would compare NaN
+        // distances (an unspecified candidate set) and then discard the match at Plane.cpp:42 (NaN < MAX^2 is false);
+        // "never chosen" is the only defined outcome, found = 0 reproduces it
+        if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) {
+            write_topk(TopK(k), k, idx + (size_t)qi * k, d2 + (size_t)qi * k, found ? found + qi : nullptr);
+            continue;
+        }
         for (size_t j = 0; j < m; ++j) best.push(Cand{calc_dist(q, map_xyz + 3 * j), (uint32_t)j});
         if (best.n > k && best.c[k].d == best.c[k - 1].d) ++ties;
         TopK out(k);
@@ -839,7 +846,8 @@ void lvo_kdtree_knn(const void* tree, const float* q_xyz, size_t n, int k, uint3
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 0 ? nthreads : 1)
     for (int64_t qi = 0; qi < (int64_t)n; ++qi) {
         TopK best(k);
-        kd_search(T->root, q_xyz + 3 * qi, best);
+        const float* q = q_xyz + 3 * qi;
+        if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) kd_search(T->root, q, best);   // see lvo_knn_brute
         write_topk(best, k, idx + (size_t)qi * k, d2 + (size_t)qi * k, found ? found + qi : nullptr);
     }
 }

@@ -374,3 +374,34 @@ def test_ring_pattern_scans(capi, oracle, lv, m, rings, n_az, fov):
     assert np.abs(tr - tro).max() < TOL_STATE
     assert np.abs(x - xo).max() < TOL_STATE
     assert np.linalg.norm(x[:3] - sc["x_true"][:3]) < 0.01
+
+
+def test_non_finite_scan_points(capi, oracle, scene_small):
+    """No-return points of an organised cloud arrive as NaN / inf: they have no neighbours, are never chosen, and
+    cost nothing (no brute-force fallback); the other points are unaffected."""
+    import time
+
+    sc = scene_small
+    scan = sc["scan_xyz"].copy()
+    bad = np.arange(0, len(scan), 3)
+    scan[bad[0::3], 0] = np.nan
+    scan[bad[1::3], 1] = np.inf
+    scan[bad[2::3]] = -np.inf
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(scan)
+        t0 = time.perf_counter()
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+        assert time.perf_counter() - t0 < 0.5
+        fb = ctx.timing()["fallback_queries"]
+        ctx.iterate(sc["x_init"])
+        idx, d2 = ctx.fetch_knn()
+        valid, _, _, _ = ctx.fetch_matches()
+        good = np.setdiff1d(np.arange(len(scan)), bad)
+        ctx.scan_set(scan[good])
+        ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.timing()["fallback_queries"] == fb   # the non-finite points never reach the generic search
+    assert (idx[bad] == 0xFFFFFFFF).all() and not valid[bad].any()
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], scan)
+    assert passes == po and [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+    assert np.abs(x - xo).max() < TOL_STATE

@@ -293,3 +293,17 @@ def test_cloud_ingest_sorted_and_stable(oracle):
         assert 0 < len(pts) <= 1250
         assert np.all(np.diff(pts["time"]) >= 0)
         assert np.all(pts["range"] > 4.0) or kind == "ouster"
+
+
+def test_non_finite_queries_have_no_neighbours(oracle, scene_small):
+    sc = scene_small
+    q = oracle.transform_scan(sc["x_init"], sc["scan_xyz"])[:8].copy()
+    q[1, 0] = np.nan
+    q[3, 2] = np.inf
+    q[5] = -np.inf
+    idx, d2, found, _ = oracle.knn_brute(sc["map_xyz"], q)
+    assert list(found) == [5, 0, 5, 0, 5, 0, 5, 5]
+    assert (idx[[1, 3, 5]] == 0xFFFFFFFF).all() and np.isinf(d2[[1, 3, 5]]).all()
+    tree = oracle.KdTree(sc["map_xyz"])
+    idx2, d22, found2 = tree.knn(q)
+    assert np.array_equal(idx, idx2) and np.array_equal(found, found2)
