@@ -307,3 +307,24 @@ def test_non_finite_queries_have_no_neighbours(oracle, scene_small):
     tree = oracle.KdTree(sc["map_xyz"])
     idx2, d22, found2 = tree.knn(q)
     assert np.array_equal(idx, idx2) and np.array_equal(found, found2)
+
+
+def test_rows_golden_is_current(oracle):
+    """The committed known-answer file of rows f-1 / f-2 / f-4 is what the oracle produces today."""
+    import sys
+
+    sys.path.insert(0, "tests/golden")
+    import make_golden_rows as mg
+
+    g = np.load("tests/golden/rows_kat.npz")
+    sc, raw, fmt, prm = mg.rows_inputs()
+    pts = oracle.cloud_ingest(raw, 20_000, oracle.CloudFormat(*fmt), oracle.IngestParams(*prm))
+    assert len(pts) == int(g["ingest_n"]) and mg.digest(pts) == str(g["ingest_sha256"])
+    t1, t2 = float(g["t1"]), float(g["t2"])
+    sel = pts[(pts["time"] >= t1) & (pts["time"] <= t2)]
+    states = mg.deskew_path(oracle, t1)
+    desk = oracle.deskew(np.stack([sel["x"], sel["y"], sel["z"]], axis=1), sel["time"], states, states[-2:-1])
+    assert mg.digest(desk) == str(g["deskew_sha256"])
+    assert mg.digest(oracle.voxelgrid(desk, 0.5)) == str(g["voxelgrid_sha256"])
+    merged = oracle.map_add(sc["map_xyz"], (sc["map_xyz"][:3000] + np.float32(0.013)).astype(np.float32), downsample=True)
+    assert mg.digest(merged) == str(g["map_add_sha256"])
