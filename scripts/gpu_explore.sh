@@ -9,5 +9,5 @@ for V in ${VOXELS:-0.4 0.7}; do
   echo "== voxel $V"; timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --voxel $V 2>&1 | python scripts/summ.py
 done
 if [ "${PROF:-1}" = "1" ]; then
-cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 fi

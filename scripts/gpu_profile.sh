@@ -10,9 +10,9 @@ timeout 900 python bench.py 2>$OUT/bench.stderr | tail -1 > $OUT/bench_$R.json
 cat $OUT/bench_$R.json | python scripts/summ.py
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $R -- $CMD > $OUT/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $R -- $CMD > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -o $R -- $CMD > $OUT/pmc_tcc.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $R -- $CMD > $OUT/stats.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $R -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -o $R -- $CMD > $OUT/pmc_tcc.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.csv" | head -20
 python - <<PY

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/stats_tmp
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/log.txt 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/log.txt 2>&1
 python - <<PY
 import csv
 for r in csv.DictReader(open("$OUT/s_kernel_stats.csv")):

@@ -14,7 +14,7 @@ for _ in range(3):
     ctx.map_build(sc["map_xyz"]); ctx.synchronize()
 PY
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python /tmp/mb.py > $OUT/log.txt 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python /tmp/mb.py > $OUT/log.txt 2>&1
 python - <<PY
 import csv
 rows = list(csv.DictReader(open("$OUT/s_kernel_stats.csv")))
