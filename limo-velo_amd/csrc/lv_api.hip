@@ -179,7 +179,7 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
         for (int i = 0; i < NS * NS; ++i) io->P_in[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;
-    return begin_device(c, io->x_in);   // the state rides in the kernel arguments, P is read from the mailbox across PCIe
+    return begin_device(c, io->x_in);   // x_in and P_in (contiguous) ride in the kernel arguments
 }
 
 int pass_solve(lv_ctx* c, bool from_groups);

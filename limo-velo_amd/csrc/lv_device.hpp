@@ -63,8 +63,8 @@ struct KfDev {
     int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / generic levels / brute force
 };
 
-// Pinned, host-mapped mailbox of one update: the 4.4 KB of inputs are read by kf_begin_kernel and the results are
-// stored by solve_kernel straight across PCIe, so an update needs no copy kernels on either side.
+// Pinned, host-mapped mailbox of one update: x_in / P_in stage the inputs (handed to kf_begin_kernel as kernel
+// arguments), the results are stored by solve_kernel straight across PCIe, so an update needs no copy kernels.
 struct KfHostIO {
     double x_in[NX];
     double P_in[NS * NS];

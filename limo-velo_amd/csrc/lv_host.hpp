@@ -91,7 +91,7 @@ int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, 
 int fit_grid_size(uint32_t n, int max_blocks);
 // lv_solve.hip
 int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host);  // io: device pointer of the pinned mailbox;
-// x_host != nullptr: the state travels as a kernel argument and P_prop is read from the mailbox
+// x_host != nullptr: x (NX doubles) followed by P_prop (NS*NS doubles) on the host, passed as kernel arguments
 int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf);
 int solve_direct_records();  // most records solve_kernel folds in one round trip
 int launch_reduce_final(hipStream_t stream, const double* groups, int ngroups, double* sums, KfDev* kf);

@@ -29,11 +29,12 @@
 
 namespace lv {
 
-// from_host: the state comes as a kernel argument and P_prop waits in the pinned host mailbox (lv_update);
-// otherwise both are already in kf (resident filter).  The mailbox read crosses PCIe (~2 us): it is issued first and
-// consumed last, the pose constants of pass 0 are derived from the argument meanwhile.
+// from_host: the state and its covariance travel as kernel arguments (4.4 KB in the dispatch's kernarg buffer: no
+// upload on the stream, no read across PCIe inside the kernel — lv_update); otherwise both are already in kf
+// (resident filter).
 struct StateArg {
     double v[NX];
+    double P[NS * NS];
 };
 __global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, int from_host, StateArg xin) {
     __shared__ double s_x[NX];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, 
     __shared__ float s_tmp[8];
     const int tid = threadIdx.x;
     double p = 0.0;
-    if (tid < NS * NS) p = from_host ? io->P_in[tid] : kf->P_prop[tid];
+    if (tid < NS * NS) p = from_host ? xin.P[tid] : kf->P_prop[tid];
     if (tid < NX) {
         const double v = from_host ? xin.v[tid] : kf->x[tid];
         if (from_host) kf->x[tid] = v;
@@ -368,9 +369,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 }
 
 int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host) {
-    StateArg xin;
-    if (x_host) std::memcpy(xin.v, x_host, sizeof(xin.v));
-    else std::memset(xin.v, 0, sizeof(xin.v));
+    static StateArg xin;   // 4.4 KB of kernel arguments (copied into the dispatch packet's kernarg buffer by the launch)
+    if (x_host) { std::memcpy(xin.v, x_host, sizeof(xin.v)); std::memcpy(xin.P, x_host + NX, sizeof(xin.P)); }   // KfHostIO: x_in, P_in contiguous
+    else std::memset(&xin, 0, sizeof(xin));
     hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, x_host ? 1 : 0, xin);
     LV_HIP(hipGetLastError());
     return LV_OK;
