@@ -158,7 +158,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __shared__ double sP[NS][LD], sA[NS][LD], sB[NS][LD], sJ[NS][LD];
     __shared__ double sW[2][12][13], sT[12][12];
     __shared__ double sX[NS][12], sG[NS][12], sKx[NS][12], sHTH[12][12], sHTh[12];
-    __shared__ double sdxnew[NS], sdxo[NS], sKh[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
+    __shared__ double sv[12];
+    __shared__ double sdxnew[NS], sdxo[NS], sx[NX], sxp[NX], srec[SUMS_LEN];
     __shared__ double s_part[FOLD_PARTS][SUMS_LEN];
     __shared__ double sRot[4][9];
     __shared__ PoseConsts s_pose;
@@ -234,6 +235,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         const int i = tid / NW, j = tid % NW;
         sW[cur][i][j] = sG[i][j] + sHTH[i][j];
     }
+    // dx_ = K_h + (K_x - I) dx_new with K_h = X HTh, K_x[:, :NW] = X HTH  ==  X (HTh + HTH dx_new[:NW]) - dx_new:
+    // the NW-vector v is formed here, next to the Gauss-Jordan steps; K_x itself is only needed by the terminal pass
+    if (tid >= 64 && tid < 64 + NW) {
+        const int i = tid - 64;
+        double s = sHTh[i];
+        for (int j = 0; j < NW; ++j) s += sHTH[i][j] * sdxnew[j];
+        sv[i] = s;
+    }
     __syncthreads();
     SV_STAMP(4);
     gj_spd<NW>(sW, cur, tid);               // sW[cur] = X_top
@@ -258,27 +267,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         sX[i][c] = v;
     }
     __syncthreads();
-    // K_h = X HTh ; K_x[:, :NW] = X HTH  (columns >= NW of K_x are zero)
-    if (tid < NS * NW) {
-        const int i = tid / NW, c = tid % NW;
-        double t = 0.0;
-        for (int j = 0; j < NW; ++j) t += sX[i][j] * sHTH[j][c];
-        sKx[i][c] = t;
-    }
-    if (tid >= 320 && tid < 320 + NS) {
-        const int i = tid - 320;
+    if (tid < NS) {  // dx_ = X v - dx_new
         double s = 0.0;
-        for (int j = 0; j < NW; ++j) s += sX[i][j] * sHTh[j];
-        sKh[i] = s;
-    }
-    __syncthreads();
-    if (tid < NS) {  // dx_ = K_h + (K_x - I) dx_new
-        double s = 0.0;
-        for (int j = 0; j < NS; ++j) {
-            const double kx = j < NW ? sKx[tid][j] : 0.0;
-            s += (kx - (tid == j ? 1.0 : 0.0)) * sdxnew[j];
-        }
-        const double d = sKh[tid] + s;
+        for (int j = 0; j < NW; ++j) s += sX[tid][j] * sv[j];
+        const double d = s - sdxnew[tid];
         sdxo[tid] = d;
         if (fabs(d) > prm.limits[tid]) s_conv = 0;  // dyn_share.converge
     }
@@ -340,6 +332,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __syncthreads();
     congruence<SOLVE_THREADS>(sB, sJ, sP, tid);  // sB = L_ = J2 P_ J2^T
     mm<SOLVE_THREADS>(sA, sP, sJ, true, tid);    // sA = P_ J2^T
+    __syncthreads();
+    if (tid < NS * NW) {         // K_x[:, :NW] = X HTH (columns >= NW are zero)
+        const int i = tid / NW, c = tid % NW;
+        double t = 0.0;
+        for (int j = 0; j < NW; ++j) t += sX[i][j] * sHTH[j][c];
+        sKx[i][c] = t;
+    }
     __syncthreads();
     if (tid < NS * NW) {         // K_x <- J2 K_x (rows)
         const int i = tid / NW, c = tid % NW;
