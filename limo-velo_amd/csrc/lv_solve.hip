@@ -368,7 +368,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 }
 
 int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host) {
-    static StateArg xin;   // 4.4 KB of kernel arguments (copied into the dispatch packet's kernarg buffer by the launch)
+    StateArg xin;   // 4.4 KB of kernel arguments (copied into the kernarg buffer by the launch)
     if (x_host) { std::memcpy(xin.v, x_host, sizeof(xin.v)); std::memcpy(xin.P, x_host + NX, sizeof(xin.P)); }   // KfHostIO: x_in, P_in contiguous
     else std::memset(&xin, 0, sizeof(xin));
     hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, x_host ? 1 : 0, xin);
