@@ -100,6 +100,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="override lanes_per_query")
     ap.add_argument("--voxel", type=float, default=0.0, help="override voxel_size")
+    ap.add_argument("--extrinsics", action="store_true", help="estimate_extrinsics = true (12 live Jacobian columns; not the headline config)")
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     args = ap.parse_args()
 
@@ -134,6 +135,8 @@ def main() -> None:
         kw["lanes_per_query"] = args.lanes
     if args.voxel:
         kw["voxel_size"] = args.voxel
+    if args.extrinsics:
+        kw["estimate_extrinsics"] = 1
     prm = capi.default_params(**kw)
     ctx = capi.Context(prm, device=local_rank)
     ctx.map_build(sc["map_xyz"])
@@ -223,6 +226,7 @@ def main() -> None:
                 "points_per_gpu": n_local,
                 "parallelism": f"scan points sharded x{world}, map replicated, 768 B all-reduce per pass" if world > 1 else "1 GPU",
                 "collective": collective,
+                "estimate_extrinsics": bool(prm.estimate_extrinsics),
                 "lanes_per_query": prm.lanes_per_query,
                 "voxel_size": prm.voxel_size,
             },
