@@ -248,6 +248,13 @@ int lv_set_capture(lv_ctx* ctx, int enabled);
 /* Nearest_Search outputs: idx N x k (index into the map in insertion order, 0xFFFFFFFF = none),
  * d2 N x k squared distances ascending (+inf = none). */
 int lv_fetch_knn(lv_ctx* ctx, uint32_t* idx, float* d2);
+/* The same Nearest_Search outputs as the hand-over records of the most recent pass hold them, whatever build
+ * ran it — in particular the NON-capturing kernels of lv_update / lv_correct / lv_pass_reduce (the timed path),
+ * which carry no map indices: nbr_xyz N x 5 x 3 neighbour coordinates (zeros = none), d2 N x 5 (+inf = none),
+ * p_world N x 3 (the transformed scan point, Mapper.cpp:51), found N.  Original scan order; any pointer may be
+ * NULL.  Tests compare these with the oracle's neighbours to pin the fast build (the index-carrying lv_fetch_knn
+ * needs a capturing launch). */
+int lv_fetch_neighbors(lv_ctx* ctx, float* nbr_xyz, float* d2, float* p_world, int32_t* found);
 /* Mapper::match outputs: valid N (Match::is_chosen), p_world N x 3, abcd N x 4 (Normal A,B,C,D),
  * dist N (Match::distance).  Any pointer may be NULL. */
 int lv_fetch_matches(lv_ctx* ctx, uint8_t* valid, float* p_world, float* abcd, float* dist);

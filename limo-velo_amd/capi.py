@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
-    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
 ]
@@ -384,6 +384,18 @@ class Context:
         d2 = np.empty((n, 5), np.float32)
         self._check(self.lib.lv_fetch_knn(self.h, idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p)))
         return idx, d2
+
+    def fetch_neighbors(self):
+        """Neighbour coordinates / squared distances / world points / found counts out of the hand-over records of
+        the most recent pass (works for the non-capturing, timed kernels)."""
+        n = self._n
+        nbr = np.empty((n, 5, 3), np.float32)
+        d2 = np.empty((n, 5), np.float32)
+        pw = np.empty((n, 3), np.float32)
+        found = np.empty(n, np.int32)
+        self._check(self.lib.lv_fetch_neighbors(self.h, nbr.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p),
+                                                pw.ctypes.data_as(C.c_void_p), found.ctypes.data_as(C.c_void_p)))
+        return nbr, d2, pw, found
 
     def fetch_matches(self):
         n = self._n

@@ -68,6 +68,7 @@ struct lv_ctx {
     size_t cap_n = 0;
     DebugOut dbg{};
     bool dbg_valid = false;
+    bool qrec_valid = false;       // d_qrec holds the records of a pass over the CURRENT scan (lv_fetch_neighbors)
 
     bool in_update = false;
     bool want_log = false;         // download trace / per-pass sums at lv_update_end
@@ -101,6 +102,8 @@ int ensure_stage(lv_ctx* c, size_t n) {
     if (n <= c->h_stage_cap) return LV_OK;
     size_t cap = c->h_stage_cap ? c->h_stage_cap : 4096;
     while (cap < n) cap *= 2;
+    // a copy out of the old buffer may still be pending on the (possibly caller-supplied, non-blocking) stream
+    LV_HIP(hipStreamSynchronize(c->stream));
     if (c->h_stage) hipHostFree(c->h_stage);
     c->h_stage = nullptr;
     c->h_stage_cap = 0;
@@ -120,6 +123,7 @@ void free_capture(lv_ctx* c) {
     c->dbg = DebugOut{};
     c->cap_n = 0;
     c->dbg_valid = false;
+    c->qrec_valid = false;
 }
 
 int ensure_capture(lv_ctx* c, size_t n) {
@@ -203,6 +207,7 @@ int pass_reduce(lv_ctx* c, bool finalize) {
         dbg.clk_blocks = c->grid;
     }
     int rc = LV_OK;
+    c->qrec_valid = c->scan.n > 0;
     if (c->scan.n > 0)
         rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
                            c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, dbg);
@@ -458,6 +463,7 @@ int lv_scan_set(lv_ctx* c, const void* points, size_t stride, size_t n) {
     }
     c->scan.n = (uint32_t)n;
     c->dbg_valid = false;
+    c->qrec_valid = false;
     if (n == 0) return LV_OK;
     LV_HIP(hipMemcpyAsync(c->scan.d_raw, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     return c->scan.sort(c->stream, bmin, c->prm.voxel_size);
@@ -471,6 +477,7 @@ int lv_scan_deskew(lv_ctx* c, const void* points, size_t stride, size_t time_off
     if (!states || n_states < 2 || !Xt2) { set_error("need >= 2 surrounding states and Xt2"); return LV_EINVAL; }
     if (n > 0xFFFFFFF0ull) { set_error("scan too large"); return LV_EINVAL; }
     c->dbg_valid = false;
+    c->qrec_valid = false;
     c->scan.n = 0;
     if (n == 0) return LV_OK;
     int rc = ensure_stage(c, n + (n + 1) / 2);  // float4 xyz + packed doubles behind them
@@ -597,6 +604,7 @@ int lv_scan_deskew_window(lv_ctx* c, double t1, double t2, const lv_motion_state
     if (n_window) *n_window = 0;
     if (!states || n_states < 2 || !Xt2) { set_error("need >= 2 surrounding states and Xt2"); return LV_EINVAL; }
     c->dbg_valid = false;
+    c->qrec_valid = false;
     c->scan.n = 0;
     uint32_t lo = 0, hi = 0;
     int rc = c->cloud.window(c->stream, t1, t2, &lo, &hi);
@@ -878,6 +886,38 @@ int lv_fetch_matches(lv_ctx* c, uint8_t* valid, float* p_world, float* abcd, flo
     if (p_world) LV_HIP(hipMemcpy(p_world, c->dbg.p_world, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (abcd) LV_HIP(hipMemcpy(abcd, c->dbg.abcd, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
     if (dist) LV_HIP(hipMemcpy(dist, c->dbg.dist, n * sizeof(float), hipMemcpyDeviceToHost));
+    return LV_OK;
+}
+
+int lv_fetch_neighbors(lv_ctx* c, float* nbr_xyz, float* d2, float* p_world, int32_t* found) {
+    LV_CHECK_CTX(c);
+    const size_t n = c->scan.n;
+    if (n == 0) return LV_OK;
+    if (!c->qrec_valid || !c->d_qrec || c->qstride < n) { set_error("no pass has run on the current scan"); return LV_ESTATE; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float4> rec((size_t)8 * n);
+    for (int sl = 0; sl < 8; ++sl)
+        LV_HIP(hipMemcpy(rec.data() + (size_t)sl * n, c->d_qrec + (size_t)sl * c->qstride, n * sizeof(float4), hipMemcpyDeviceToHost));
+    const float inf = std::numeric_limits<float>::infinity();
+    for (size_t q = 0; q < n; ++q) {   // records are in the scan's Morton order: slot 5 carries the original index
+        uint32_t oq;
+        std::memcpy(&oq, &rec[5 * n + q].w, 4);
+        if (oq >= n) { set_error("corrupt hand-over record %zu", q); return LV_ESTATE; }
+        int32_t fnd;
+        std::memcpy(&fnd, &rec[7 * n + q].y, 4);
+        const float dd[5] = {rec[6 * n + q].x, rec[6 * n + q].y, rec[6 * n + q].z, rec[6 * n + q].w, rec[7 * n + q].x};
+        for (int j = 0; j < KNN; ++j) {
+            const bool have = j < fnd;
+            if (nbr_xyz) {
+                nbr_xyz[((size_t)oq * KNN + j) * 3 + 0] = have ? rec[(size_t)j * n + q].x : 0.f;
+                nbr_xyz[((size_t)oq * KNN + j) * 3 + 1] = have ? rec[(size_t)j * n + q].y : 0.f;
+                nbr_xyz[((size_t)oq * KNN + j) * 3 + 2] = have ? rec[(size_t)j * n + q].z : 0.f;
+            }
+            if (d2) d2[(size_t)oq * KNN + j] = have ? dd[j] : inf;
+        }
+        if (p_world) { p_world[(size_t)oq * 3] = rec[5 * n + q].x; p_world[(size_t)oq * 3 + 1] = rec[5 * n + q].y; p_world[(size_t)oq * 3 + 2] = rec[5 * n + q].z; }
+        if (found) found[oq] = fnd;
+    }
     return LV_OK;
 }
 

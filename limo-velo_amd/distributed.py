@@ -52,11 +52,14 @@ class HipEngine:
     """Per-rank engine over the C-ABI split form (lv_update_begin / lv_pass_reduce / lv_pass_solve /
     lv_update_end).  The sums record lives in a torch tensor so RCCL can reduce it in place."""
 
-    def __init__(self, ctx, torch, multi: bool, library_comm: bool = False):
+    def __init__(self, ctx, torch, multi: bool, library_comm: bool = False, host_staged: bool = False):
         # library_comm: the context owns an RCCL communicator (init_library_comm) — ctx.update() is already the
         # multi-GPU update; multi: the collective is torch.distributed's, driven pass by pass from Python
         self.ctx, self.torch, self.multi = ctx, torch, multi and not library_comm
         self.library_comm = library_comm
+        # host_staged: the record crosses the process boundary through host memory (a CPU process group such as
+        # gloo): used to run several ranks on ONE GPU, where RCCL refuses duplicate devices
+        self.host_staged = host_staged
         multi = self.multi
         self.max_passes = ctx.params.MAX_NUM_ITERS + 1
         self.sums = None
@@ -90,6 +93,14 @@ class HipEngine:
     def reduce(self):
         self.ctx.pass_reduce()
         return self.sums
+
+    def allreduce(self, rec, dist):
+        if not self.host_staged:
+            dist.all_reduce(rec, op=dist.ReduceOp.SUM)   # RCCL, ordered on the engine's stream
+            return
+        host = rec.cpu()                                  # synchronises the engine's stream
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        rec.copy_(host)                                   # enqueued on the engine's stream, before the solve
 
     def solve(self):
         self.ctx.pass_solve()
@@ -127,6 +138,9 @@ class ShardedUpdater:
             self.engine.begin(x, P)
             for _ in range(self.engine.max_passes):
                 rec = self.engine.reduce()
-                self.dist.all_reduce(rec, op=self.dist.ReduceOp.SUM)
+                if hasattr(self.engine, "allreduce"):
+                    self.engine.allreduce(rec, self.dist)
+                else:
+                    self.dist.all_reduce(rec, op=self.dist.ReduceOp.SUM)
                 self.engine.solve()
             return self.engine.end()

@@ -246,3 +246,33 @@ def make_ring_scene(m_points: int, n_rings: int, n_az: int, *, fov_deg=(-15.0, 1
     dq = quat_from_rotvec(np.radians([0.5, -0.4, 0.8]))
     x_init = make_state(pos_true + np.array([0.10, -0.07, 0.05]), quat_mul(q_true, dq), offR, offT)
     return dict(map_xyz=map_xyz, scan_xyz=scan_xyz, x_true=x_true, x_init=x_init, P0=default_P0(), L=L)
+
+
+def make_extra_scan(m_points: int, n_points: int, k: int, *, sigma: float = 0.01, seed_map: int = SEED_MAP,
+                    rmin: float = 4.0, rmax: float = 80.0):
+    """k-th additional scan of the SAME scene as make_scene(m_points, ...) taken from another ground-truth pose
+    (poses spread on a circle of radius 0.45 L, heading along the tangent, small roll / pitch), with its own
+    perturbed start state.  Used by bench.py --rotate to cycle scans whose neighbourhood buckets do not all fit
+    in the Infinity Cache together.  Returns dict(scan_xyz, x_true, x_init)."""
+    rng_m = _Rng(seed_map)
+    surf = _surfaces(rng_m, m_points)
+    L = surf[4]
+    ang = 2.0 * math.pi * (k * 0.381966011)   # golden-angle spacing: any number of poses stays spread out
+    rad = 0.45 * L
+    pos_true = np.array([rad * math.cos(ang), rad * math.sin(ang), 1.5 + 0.1 * (k % 3)])
+    q_true = quat_from_rpy(math.radians(1.0 + (k % 2)), math.radians(-1.0), ang + math.pi / 2)
+    R = quat_to_rot(q_true)
+    rng_s = _Rng(SEED_SCAN + 7919 * (k + 1))
+    chunks, have = [], 0
+    while have < n_points:
+        c = _sample(rng_s, surf, max(4096, 2 * (n_points - have)), sigma)
+        r = np.linalg.norm(c - pos_true, axis=1)
+        c = c[(r >= rmin) & (r <= rmax)]
+        chunks.append(c)
+        have += len(c)
+    pw = np.concatenate(chunks)[:n_points]
+    scan_xyz = ((pw - pos_true) @ R).astype(np.float32)
+    x_true = make_state(pos_true, q_true)
+    dq = quat_from_rotvec(np.radians([0.5, -0.4, 0.8]))
+    x_init = make_state(pos_true + np.array([0.10, -0.07, 0.05]), quat_mul(q_true, dq))
+    return dict(scan_xyz=scan_xyz, x_true=x_true, x_init=x_init)

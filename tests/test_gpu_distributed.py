@@ -91,3 +91,72 @@ def test_library_communicator_world1(lv, scene_small):
     assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
     assert np.array_equal(x1, x3) and np.array_equal(P1, P3)
     assert np.array_equal(x1, x4) and np.array_equal(P1, P4)
+
+
+def _world2_worker(rank, world, port, n_scan, out_q):
+    """One rank of a world-size-2 run with BOTH ranks on GPU 0: HIP engine, split-form C-ABI, the 96-double record
+    all-reduced through a gloo group (staged through host memory — RCCL refuses two ranks on one device)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    import lvamd
+
+    lvamd.load()
+    from limo_velo_amd import capi, synth
+    from limo_velo_amd.distributed import HipEngine, ShardedUpdater
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = synth.make_scene(50_000, max(n_scan, 8))
+        scan = sc["scan_xyz"][:n_scan]
+        with capi.Context() as ctx:
+            ctx.map_build(sc["map_xyz"])
+            eng = HipEngine(ctx, torch, multi=True, host_staged=True)
+            upd = ShardedUpdater(eng, rank, world, dist, torch)
+            upd.scan_set(scan)
+            for _ in range(2):
+                x, P, passes = upd.update(sc["x_init"], sc["P0"])
+            torch.cuda.synchronize()
+        out_q.put((rank, upd.n_local, x, P, passes))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scan", [2001, 1])
+def test_world2_hip_engine_on_one_gpu(lv, n_scan):
+    """The sharded HIP path with world = 2 (uneven shards: 1001 + 1000 points; one EMPTY shard: 1 + 0): both ranks end
+    bitwise equal, and within 1e-10 of the single-process update of the whole scan (only the summation order of
+    the record differs)."""
+    import torch.multiprocessing as mp
+
+    from limo_velo_amd import capi, synth
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_world2_worker, args=(r, 2, port, n_scan, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    with capi.Context() as ref:
+        ref.map_build(sc["map_xyz"])
+        ref.scan_set(sc["scan_xyz"][:n_scan])
+        x1, P1, p1, _, _ = ref.update(sc["x_init"], sc["P0"])
+    assert res[0][1] + res[1][1] == n_scan and abs(res[0][1] - res[1][1]) <= 1
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3]) and res[0][4] == res[1][4]
+    for _, _, x, P, passes in res:
+        assert passes == p1
+        assert np.abs(x - x1).max() < 1e-10
+        assert np.abs(P - P1).max() < 1e-10 * max(1.0, np.abs(P1).max())

@@ -405,3 +405,46 @@ def test_non_finite_scan_points(capi, oracle, scene_small):
     xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], scan)
     assert passes == po and [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
     assert np.abs(x - xo).max() < TOL_STATE
+
+
+@pytest.mark.parametrize("m,n", [(50_000, 2_000), (1_048_576, 65_536), (2_000_000, 120_000)])
+def test_timed_build_is_pinned_per_pass(capi, oracle, lv, m, n):
+    """The NON-capturing kernels (search_kernel<S, false> with its LDS-staged winners, fit_reduce_kernel<.., false>) are
+    what lv_update times; lv_fetch_knn needs a capturing launch and therefore never sees them.  Pin them directly:
+    (a) the per-pass H^T H / H^T h / sum h^2 of a plain lv_update against the oracle evaluated at the state the
+        device itself held before each pass, 1e-10 relative;
+    (b) the hand-over records (5 neighbour coordinates, squared distances, world point) of pass k — the last pass
+        of an update limited to k passes — bit for bit against the oracle's neighbours at that state."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(m, n)
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+    assert passes == 4
+    states = [sc["x_init"]] + [tr[i][23:49].copy() for i in range(passes - 1)]
+    orc = [oracle.iterate(st, sc["map_xyz"], sc["scan_xyz"], tree=tree) for st in states]
+    for i, (g, o) in enumerate(zip(sums, orc)):
+        assert g["n_valid"] == o["n_valid"], f"pass {i}"
+        scale = np.abs(o["HTH"]).max()
+        assert np.abs(g["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * scale, f"pass {i}"
+        assert np.abs(g["HTh"] - o["HTh"]).max() <= TOL_SUMS_REL * max(np.abs(o["HTh"]).max(), 1.0), f"pass {i}"
+        assert abs(g["sum_h2"] - o["sum_h2"]) <= TOL_SUMS_REL * max(o["sum_h2"], 1.0), f"pass {i}"
+    for k in range(passes):
+        with capi.Context(capi.default_params(MAX_NUM_ITERS=k)) as ctx:
+            ctx.map_build(sc["map_xyz"])
+            ctx.scan_set(sc["scan_xyz"])
+            xk, _, pk, trk, _ = ctx.update(sc["x_init"], sc["P0"])
+            assert pk == k + 1
+            if k:
+                assert np.array_equal(trk[k - 1][23:49], states[k])   # deterministic: same state before pass k
+            nbr, d2, pw, found = ctx.fetch_neighbors()
+        o = orc[k]
+        have = o["knn_idx"] != 0xFFFFFFFF
+        assert np.array_equal(found, have.sum(axis=1)), f"pass {k}"
+        exp = np.where(have[..., None], sc["map_xyz"][np.where(have, o["knn_idx"], 0)], np.float32(0))
+        assert np.array_equal(_bits(nbr), _bits(exp)), f"pass {k}: neighbour coordinates differ at {(nbr != exp).any(axis=(1, 2)).sum()} points"
+        assert np.array_equal(_bits(d2), _bits(o["knn_d2"])), f"pass {k}"
+        assert np.array_equal(_bits(pw), _bits(oracle.transform_scan(states[k], sc["scan_xyz"]))), f"pass {k}"
