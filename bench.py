@@ -41,7 +41,12 @@ def pmc_traffic_bytes():
     """HBM bytes per launch of the dominant kernel (lv::search_kernel) from the committed rocprofv3 PMC pass
     of this same command (profiles/pmc_search_*.json, produced by scripts/gpu_profile.sh).  Per
     MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE reports half of
-    the bytes of wide coalesced reads, so it is doubled.  None if no PMC summary is committed."""
+    the bytes of wide coalesced reads, so it is doubled.  The factor is calibrated on known byte counts
+    (scripts/ubench/fetch_calib.hip -> profiles/fetch_calib_r02.json): exactly 2.0 for coalesced dword / dwordx3 /
+    dwordx4 streams; the search kernel's shape (8-lane groups streaming runs of 56 packed 12-byte records) reads
+    1.75x the reported figure in USEFUL bytes, i.e. 2.0x in fetched 128-byte lines (runs start and end mid-line) —
+    so 2 x FETCH_SIZE is the HBM/fabric traffic including partial-line over-fetch.  None if no PMC summary is
+    committed."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_search_*.json")))
