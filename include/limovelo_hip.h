@@ -103,16 +103,45 @@ int  lv_synchronize(lv_ctx* ctx);
 /* ---- Mapper side ---------------------------------------------------------------------------- */
 /* KD_TREE<Point>::Build(PointVector)              — call site src/Modules/Mapper.cpp:68-71 */
 int    lv_map_build(lv_ctx* ctx, const void* points, size_t stride, size_t n);
-/* KD_TREE<Point>::Add_Points(PointVector&, bool)  — call site src/Modules/Mapper.cpp:73-76.
- * downsample != 0 applies ikd-Tree's box rule with box_length 0.2 m (Mapper.cpp:65), evaluated exactly as
- * upstream's sequential loop would: in every 0.2 m box touched by new points only the point nearest to the
- * box centre survives (occupants must be strictly closer to beat a new point).  The map afterwards is
- * [surviving old points, old order] + [surviving new points, input order] — the index space of lv_fetch_knn. */
+/* Mapper::add(points, time, downsample) — src/Modules/Mapper.cpp:19-30: on an empty map the points BUILD it
+ * (KD_TREE::Build, no down-sampling), otherwise KD_TREE<Point>::Add_Points(PointVector&, bool) — call site
+ * src/Modules/Mapper.cpp:73-76.  downsample != 0 applies ikd-Tree's box rule with box_length 0.2 m (Mapper.cpp:65),
+ * evaluated exactly as upstream's sequential loop would: in every 0.2 m box touched by new points only the point
+ * nearest to the box centre survives (occupants must be strictly closer to beat a new point).  The map afterwards is
+ * [surviving old points, old order] + [surviving new points, input order] — the index space of lv_fetch_knn.
+ * INCREMENTAL: only the neighbourhood buckets / voxel lists that contain a new or a deleted point are touched
+ * (appends into slack, tombstones); the structure is re-linearised (ids compacted, everything rebuilt) when a pool,
+ * a table or the share of dead ids runs high — see lv_map_get_stats. */
 int    lv_map_add(lv_ctx* ctx, const void* points, size_t stride, size_t n, int downsample);
+/* The mapping step of the main loop without leaving the device (src/main.cpp:92,102):
+ *     Points global_ds_compensated = Xt2 * Xt2.I_Rt_L() * ds_compensated;   map.add(global_ds_compensated, t2, true);
+ * the current scan (lv_scan_set / lv_scan_deskew*) is moved to the world with the state the device holds — the
+ * resident filter's (lv_filter_set / lv_predict / lv_correct) if there is one, otherwise the result of the last
+ * lv_update — in f32 exactly as State::State(const state_ikfom&) + RotTransl do (rows a-1), and inserted in scan
+ * order.  Non-finite points are skipped. */
+int    lv_map_add_scan(lv_ctx* ctx, int downsample);
+/* Rolling window (BASELINE configs[4]; ikd-Tree's Delete_Point_Boxes, which the reference never calls —
+ * README.md:127 — but a bounded map needs): keep_inside != 0 removes every point OUTSIDE the axis-aligned box
+ * [lo, hi], keep_inside == 0 every point INSIDE it.  lv_map_evict_oldest removes the n_oldest oldest living points
+ * (map order = age).  Indices of the survivors shift down as in any deletion (lv_fetch_knn reports ranks among
+ * the living). */
+int    lv_map_evict_box(lv_ctx* ctx, const float lo[3], const float hi[3], int keep_inside, size_t* n_evicted);
+int    lv_map_evict_oldest(lv_ctx* ctx, size_t n_oldest, size_t* n_evicted);
+/* Force the periodic re-linearisation now (compaction of the ids + rebuild of every bucket). */
+int    lv_map_relinearise(lv_ctx* ctx);
 /* KD_TREE<Point>::size()                          — src/Modules/Mapper.cpp:33,79 */
 size_t lv_map_size(lv_ctx* ctx);
-/* Copy the current map points (xyz packed, insertion order = the index space of lv_fetch_knn). */
+/* Copy the current map points (xyz packed, map order = the index space of lv_fetch_knn). */
 int    lv_map_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
+typedef struct lv_map_stats {
+    uint64_t living, ids, capacity;          /* points alive / ids handed out since the last re-linearisation / id slots allocated */
+    uint64_t pool_used[4], pool_cap[4];      /* entries of the level-0 / 1 / 2 bucket pools and of the voxel-list pool */
+    uint64_t slots_used[4], slots_cap[4];    /* occupied / total slots of the four hash tables */
+    uint64_t tombstones, dropped;            /* dead bucket entries since the last rebuild; points refused (non-finite / out of range) */
+    uint64_t relinearisations, incremental_adds;
+    uint64_t bytes;                          /* device memory held by the map */
+} lv_map_stats;
+int    lv_map_get_stats(lv_ctx* ctx, lv_map_stats* out);
 
 /* ---- Localizator side ----------------------------------------------------------------------- */
 /* `this->points2match = points`                   — src/Modules/Localizator.cpp:131.

@@ -21,7 +21,8 @@ NS = 23
 # every symbol include/limovelo_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
-    "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
+    "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_add_scan", "lv_map_evict_box", "lv_map_evict_oldest", "lv_map_relinearise", "lv_map_get_stats",
+    "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world",
@@ -71,6 +72,13 @@ class Timing(C.Structure):
     _fields_ = [("last_update_ms", C.c_float), ("last_reduce_ms", C.c_float), ("last_solve_ms", C.c_float),
                 ("last_passes", C.c_int), ("fallback_queries", C.c_int), ("pass_match_ms", C.c_float * 8),
                 ("pass_solve_ms", C.c_float * 8)]
+
+
+class MapStats(C.Structure):  # lv_map_stats
+    _fields_ = [("living", C.c_uint64), ("ids", C.c_uint64), ("capacity", C.c_uint64), ("pool_used", C.c_uint64 * 4),
+                ("pool_cap", C.c_uint64 * 4), ("slots_used", C.c_uint64 * 4), ("slots_cap", C.c_uint64 * 4),
+                ("tombstones", C.c_uint64), ("dropped", C.c_uint64), ("relinearisations", C.c_uint64),
+                ("incremental_adds", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 class LvError(RuntimeError):
@@ -171,6 +179,32 @@ class Context:
         a, stride, n = _points(pts)
         self._check(self.lib.lv_map_add(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(stride), C.c_size_t(n),
                                         int(bool(downsample))))
+
+    def map_add_scan(self, downsample=True):
+        """The mapping step on the device: current scan -> world with the device-held state -> insert."""
+        self._check(self.lib.lv_map_add_scan(self.h, int(bool(downsample))))
+
+    def map_evict_box(self, lo, hi, keep_inside=True) -> int:
+        lo = np.ascontiguousarray(lo, np.float32)
+        hi = np.ascontiguousarray(hi, np.float32)
+        n = C.c_size_t(0)
+        self._check(self.lib.lv_map_evict_box(self.h, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), int(bool(keep_inside)),
+                                              C.byref(n)))
+        return int(n.value)
+
+    def map_evict_oldest(self, n_oldest: int) -> int:
+        n = C.c_size_t(0)
+        self._check(self.lib.lv_map_evict_oldest(self.h, C.c_size_t(n_oldest), C.byref(n)))
+        return int(n.value)
+
+    def map_relinearise(self):
+        self._check(self.lib.lv_map_relinearise(self.h))
+
+    def map_stats(self) -> dict:
+        st = MapStats()
+        self._check(self.lib.lv_map_get_stats(self.h, C.byref(st)))
+        return {k: (list(getattr(st, k)) if k in ("pool_used", "pool_cap", "slots_used", "slots_cap") else int(getattr(st, k)))
+                for k, _ in MapStats._fields_}
 
     def map_size(self) -> int:
         return int(self.lib.lv_map_size(self.h))

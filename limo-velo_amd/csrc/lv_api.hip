@@ -32,7 +32,6 @@ struct lv_ctx {
     hipStream_t stream = nullptr;
 
     MapStore map;
-    float map_bbox_min[3], map_bbox_max[3];
 
     ScanStore scan;
     CloudStore cloud;   // row f-4: device-resident LiDAR buffer
@@ -210,7 +209,7 @@ int pass_reduce(lv_ctx* c, bool finalize) {
     c->qrec_valid = c->scan.n > 0;
     if (c->scan.n > 0)
         rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
-                           c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, dbg);
+                           c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, mp.max_dist_plane_sq, dbg);
     if (rc) return rc;
     if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
     rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
@@ -293,7 +292,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     c->prm = *params;
     c->device = device;
     c->scan.tile_points = 256u / (uint32_t)S;
-    for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
+    c->map.cell = params->voxel_size;
     hipDeviceProp_t prop;
     LV_HIP(hipGetDeviceProperties(&prop, device));
     int per_cu = 4;
@@ -364,79 +363,143 @@ int lv_synchronize(lv_ctx* c) {
     return LV_OK;
 }
 
-// repack caller points into the pinned staging buffer (float4), grow the map bounding box, upload to
-// d_orig[offset ..)
-static int stage_map_points(lv_ctx* c, const void* points, size_t stride, size_t n, size_t offset) {
-    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
-    if (offset + n > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
+// repack caller points into the pinned staging buffer (float4) and upload them to `dst` (device)
+static int stage_map_points(lv_ctx* c, const void* points, size_t stride, size_t n, float4* dst) {
     int rc = ensure_stage(c, n);
     if (rc) return rc;
     LV_HIP(hipStreamSynchronize(c->stream));  // staging buffer reuse
-    float bmin[3] = {c->map_bbox_min[0], c->map_bbox_min[1], c->map_bbox_min[2]};
-    float bmax[3] = {c->map_bbox_max[0], c->map_bbox_max[1], c->map_bbox_max[2]};
+    for (size_t i = 0; i < n; ++i) {
+        float x, y, z;
+        read_xyz(points, stride, i, x, y, z);
+        c->h_stage[i] = make_float4(x, y, z, 0.f);
+    }
+    if (n) LV_HIP(hipMemcpyAsync(dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return LV_OK;
+}
+
+static int check_map_points(const void* points, size_t stride, size_t n) {
+    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
+    if (n > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
     for (size_t i = 0; i < n; ++i) {
         float x, y, z;
         read_xyz(points, stride, i, x, y, z);
         if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) { set_error("non-finite map point at %zu", i); return LV_EINVAL; }
-        c->h_stage[i] = make_float4(x, y, z, 0.f);
-        bmin[0] = fminf(bmin[0], x); bmax[0] = fmaxf(bmax[0], x);
-        bmin[1] = fminf(bmin[1], y); bmax[1] = fmaxf(bmax[1], y);
-        bmin[2] = fminf(bmin[2], z); bmax[2] = fmaxf(bmax[2], z);
     }
-    rc = c->map.reserve(offset + n);
-    if (rc) return rc;
-    if (n) LV_HIP(hipMemcpyAsync(c->map.d_orig + offset, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = bmin[a]; c->map_bbox_max[a] = bmax[a]; }
-    return LV_OK;
-}
-
-static int rebuild_map(lv_ctx* c) {
-    int rc = c->map.rebuild(c->stream, c->prm.voxel_size, c->map_bbox_min, c->map_bbox_max);
-    if (rc) return rc;
-    LV_HIP(hipStreamSynchronize(c->stream));
     return LV_OK;
 }
 
 int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
     LV_CHECK_CTX(c);
-    const float old_min[3] = {c->map_bbox_min[0], c->map_bbox_min[1], c->map_bbox_min[2]};
-    const float old_max[3] = {c->map_bbox_max[0], c->map_bbox_max[1], c->map_bbox_max[2]};
-    for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = INFINITY; c->map_bbox_max[a] = -INFINITY; }
-    int rc = stage_map_points(c, points, stride, n, 0);
-    if (rc) {  // leave the previous map untouched on bad input
-        for (int a = 0; a < 3; ++a) { c->map_bbox_min[a] = old_min[a]; c->map_bbox_max[a] = old_max[a]; }
-        return rc;
-    }
+    int rc = check_map_points(points, stride, n);   // bad input leaves the previous map untouched
+    if (rc) return rc;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    c->map.n_ids = 0;
+    c->map.m = 0;
+    c->map.built = false;
+    c->map.refresh_view();
+    rc = c->map.reserve(n);
+    if (rc) return rc;
+    rc = stage_map_points(c, points, stride, n, c->map.d_orig);
+    if (rc) return rc;
+    c->map.n_ids = (uint32_t)n;
     c->map.origin_set = false;
-    c->map.m = (uint32_t)n;
-    return rebuild_map(c);
+    c->map.cell = c->prm.voxel_size;
+    return c->map.rebuild(c->stream);
 }
 
 int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downsample) {
     LV_CHECK_CTX(c);
     if (n == 0) return LV_OK;
-    int rc = stage_map_points(c, points, stride, n, c->map.m);
+    int rc = check_map_points(points, stride, n);
     if (rc) return rc;
-    if (downsample) {
-        rc = c->map.add_downsample(c->stream, (uint32_t)n, 0.2f);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
-        if (rc) return rc;
-    } else {
-        c->map.m += (uint32_t)n;
-    }
-    return rebuild_map(c);
+    if ((uint64_t)c->map.n_ids + n > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
+    rc = c->map.reserve_batch(n);
+    if (rc) return rc;
+    rc = stage_map_points(c, points, stride, n, c->map.d_new);
+    if (rc) return rc;
+    return c->map.add_staged(c->stream, (uint32_t)n, downsample, 0.2f, false);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
+}
+
+namespace {
+// `Xt2 * Xt2.I_Rt_L() * p` (src/main.cpp:92; State.cpp:51-62,83-85; RotTransl.cpp:36-48) for every point of the
+// current scan, in scan order, with the state taken from the device (the resident filter or the last update)
+__global__ void scan_to_world_kernel(const double* __restrict__ x, const float4* __restrict__ scan, uint32_t n, float4* __restrict__ out) {
+    __shared__ PoseConsts s_pc;
+    if (threadIdx.x == 0) compute_pose_consts(x, &s_pc);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = scan[i];
+    float4 o;
+    rt_apply(s_pc.Tc, p.x, p.y, p.z, o.x, o.y, o.z);
+    o.w = 0.f;
+    out[i] = o;
+}
+}  // namespace
+
+int lv_map_add_scan(lv_ctx* c, int downsample) {
+    LV_CHECK_CTX(c);
+    const uint32_t n = c->scan.n;
+    if (n == 0) return LV_OK;   // Mapper::add returns on an empty cloud (Mapper.cpp:20)
+    int rc = c->map.reserve_batch(n);
+    if (rc) return rc;
+    const double* x = c->filter_set ? c->d_filter->x : c->d_kf->x;
+    hipLaunchKernelGGL(scan_to_world_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, c->scan.d_raw, n, c->map.d_new);
+    LV_HIP(hipGetLastError());
+    return c->map.add_staged(c->stream, n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
+}
+
+int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_inside, size_t* n_evicted) {
+    LV_CHECK_CTX(c);
+    if (!lo || !hi) { set_error("null argument"); return LV_EINVAL; }
+    uint32_t ne = 0;
+    int rc = c->map.evict_box(c->stream, lo, hi, keep_inside, &ne);
+    if (n_evicted) *n_evicted = ne;
+    return rc;
+}
+
+int lv_map_evict_oldest(lv_ctx* c, size_t n_oldest, size_t* n_evicted) {
+    LV_CHECK_CTX(c);
+    uint32_t ne = 0;
+    int rc = c->map.evict_oldest(c->stream, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest), &ne);
+    if (n_evicted) *n_evicted = ne;
+    return rc;
+}
+
+int lv_map_relinearise(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    if (!c->map.built) return LV_OK;
+    return c->map.relinearise(c->stream);
+}
+
+int lv_map_get_stats(lv_ctx* c, lv_map_stats* out) {
+    LV_CHECK_CTX(c);
+    if (!out) { set_error("null argument"); return LV_EINVAL; }
+    static_assert(sizeof(lv_map_stats) == sizeof(MapStats), "lv_map_stats layout");
+    MapStats st;
+    c->map.stats(&st);
+    std::memcpy(out, &st, sizeof(st));
+    return LV_OK;
 }
 
 size_t lv_map_size(lv_ctx* c) { return c ? c->map.m : 0; }
 
+// the living points in map order (ids ascending): the index space of lv_fetch_knn
 int lv_map_fetch(lv_ctx* c, float* xyz_out, size_t capacity) {
     LV_CHECK_CTX(c);
-    const size_t m = c->map.m;
+    const size_t m = c->map.m, ids = c->map.n_ids;
     if (capacity < m || (!xyz_out && capacity)) { set_error("capacity too small"); return LV_EINVAL; }
     if (m == 0) return LV_OK;
-    std::vector<float4> tmp(m);
+    std::vector<float4> tmp(ids);
     LV_HIP(hipStreamSynchronize(c->stream));
-    LV_HIP(hipMemcpy(tmp.data(), c->map.d_orig, m * sizeof(float4), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < m; ++i) { xyz_out[3 * i] = tmp[i].x; xyz_out[3 * i + 1] = tmp[i].y; xyz_out[3 * i + 2] = tmp[i].z; }
+    LV_HIP(hipMemcpy(tmp.data(), c->map.d_orig, ids * sizeof(float4), hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (size_t i = 0; i < ids && o < m; ++i) {
+        if (!std::isfinite(tmp[i].x)) continue;
+        xyz_out[3 * o] = tmp[i].x; xyz_out[3 * o + 1] = tmp[i].y; xyz_out[3 * o + 2] = tmp[i].z;
+        ++o;
+    }
+    if (o != m) { set_error("map bookkeeping: %zu living points found, %zu expected", o, m); return LV_ESTATE; }
     return LV_OK;
 }
 
@@ -646,7 +709,7 @@ int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
     LV_CHECK_CTX(c);
     if (!x || !out) { set_error("null argument"); return LV_EINVAL; }
     std::memset(out, 0, sizeof(*out));
-    if (c->map.m == 0 || c->scan.n == 0) { c->dbg_valid = false; return LV_OK; }  // Mapper.cpp:42 — empty Matches
+    if (c->map.view.m == 0 || c->scan.n == 0) { c->dbg_valid = false; return LV_OK; }  // Mapper.cpp:42 — empty Matches
     int rc = begin_common(c, x, nullptr);
     if (rc) return rc;
     const bool cap = c->capture;
@@ -765,7 +828,7 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     LV_CHECK_CTX(c);
     if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
     if (passes) *passes = 0;
-    if (c->map.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
+    if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     int rc = lv_update_begin(c, x, P);
     if (rc) return rc;
@@ -840,7 +903,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     LV_CHECK_CTX(c);
     if (!c->filter_set) { set_error("lv_correct before lv_filter_set"); return LV_ESTATE; }
     if (passes) *passes = 0;
-    if (c->map.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
+    if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
     if (rc) return rc;
     rc = begin_device(c, nullptr);
@@ -872,7 +935,19 @@ int lv_fetch_knn(lv_ctx* c, uint32_t* idx, float* d2) {
     int rc = fetch_check(c);
     if (rc) return rc;
     const size_t n = c->scan.n;
-    if (idx) LV_HIP(hipMemcpy(idx, c->dbg.knn_idx, n * KNN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (idx) {
+        LV_HIP(hipMemcpy(idx, c->dbg.knn_idx, n * KNN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (c->map.n_ids != c->map.m) {   // the kernels report point ids; the API's index space is the rank among the living
+            const size_t ids = c->map.n_ids;
+            std::vector<float4> pts(ids);
+            LV_HIP(hipMemcpy(pts.data(), c->map.d_orig, ids * sizeof(float4), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> rank(ids);
+            uint32_t r = 0;
+            for (size_t i = 0; i < ids; ++i) { rank[i] = r; r += std::isfinite(pts[i].x) ? 1u : 0u; }
+            for (size_t i = 0; i < n * KNN; ++i)
+                if (idx[i] != 0xFFFFFFFFu && idx[i] < ids) idx[i] = rank[idx[i]];
+        }
+    }
     if (d2) LV_HIP(hipMemcpy(d2, c->dbg.knn_d2, n * KNN * sizeof(float), hipMemcpyDeviceToHost));
     return LV_OK;
 }

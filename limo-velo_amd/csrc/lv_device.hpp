@@ -19,9 +19,10 @@ constexpr int PARTIAL_GROUP = 32;  // block partials folded per group record (st
 constexpr int N_OUT = 92;           // used entries of the record
 constexpr int CELL_OFFSET = 1 << 20;
 constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-force path
-constexpr int MAX_LEVELS = 16;
-constexpr int MAX_BUCKET_LEVELS = 3;
-constexpr int SORTED_BUCKET_LEVELS = 2;   // levels 0, 1: the common path; level 2 serves a handful of points per scan
+constexpr int MAX_LEVELS = 3;             // voxel levels with tables: edge voxel_size * 2^l
+constexpr int REPL_LEVELS = 3;            // levels 0, 1, 2: 27-fold replicated neighbourhood buckets
+constexpr int SORTED_LEVELS = 2;          // levels 0, 1 (the common path): buckets in ascending id, 12-byte points
+constexpr int CELL_LEVEL = 2;             // level-2 voxels also keep one plain point list each (the level-3 block = 216 lists)
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr int MAX_PASSES = 16;
 
@@ -88,25 +89,40 @@ struct GridLevel {
     uint32_t shift;      // 64 - log2(size)
 };
 
+// Per-slot bookkeeping of a bucket / cell table (parallel array): capacity of the slot's run in its pool and the
+// counters of an incremental insert in flight (lv_mapinc.hpp).
+struct SlotAux {
+    uint32_t cap;      // entries the run can hold before it has to move
+    uint32_t pending;  // entries the current insert batch will append
+    uint32_t fill;     // append cursor of the batch
+    uint32_t tail0;    // count before the batch
+};
+
+// The map as the search sees it.  Points are addressed by ID = insertion order; an id is never reused, a deleted
+// point keeps its slot with x = +inf (distance +inf: it can never win).  The order of ids equals the order of the
+// reference's map ([surviving old points] + [surviving new points]), so (distance, id) is the oracle's
+// (distance, index) order; lv_fetch_knn translates ids to ranks among the living.
 struct MapView {
-    const float4* sorted;   // xyz + original index (bits) in Morton order of level-0 cells
-    const float4* orig;     // xyz in insertion order
-    uint32_t m;
-    int n_levels;
+    const float4* orig;     // xyz by id
+    uint32_t m;             // living points
+    uint32_t n_ids;         // ids handed out so far (range of the brute-force scan)
     float origin[3];
     float cell;             // level-0 cell edge
     float inv_cell;
-    GridLevel lv[MAX_LEVELS];
-    // neighbourhood buckets for levels 0..n_bucket_levels-1: for every voxel whose 3x3x3 block holds at
-    // least one point, the points of that block copied into one contiguous run.  bt[l].table entries are
-    // {key lo, key hi, bucket start, bucket count}.
-    int n_bucket_levels;
-    GridLevel bt[MAX_BUCKET_LEVELS];
-    // levels < SORTED_BUCKET_LEVELS: buckets sorted by original index, 12-byte points (what the search streams) + a
-    // parallel index array; coarser levels: unsorted {x, y, z, index} records (bucket4), searched with index keys
-    const float* bxyz[MAX_BUCKET_LEVELS];
-    const uint32_t* bidx[MAX_BUCKET_LEVELS];
-    const float4* bucket4[MAX_BUCKET_LEVELS];
+    // levels 0, 1, 2: for every voxel whose 3x3x3 block holds at least one point, the points of that block in one
+    // contiguous run ("bucket") with slack behind it for appends.  bt[l].table entries are {key lo, key hi, bucket
+    // start, bucket count}.  Levels 0, 1: ascending id (deleted entries keep their place with x = +inf), 12-byte
+    // points (what the search streams) + a parallel id array (capturing launches / non-staged winners /
+    // deletions).  Level 2 (a handful of points per scan, ~1000 candidates each, searched by whole wavefronts with
+    // (distance, id) keys): unordered {x, y, z, id} records.
+    GridLevel bt[REPL_LEVELS];
+    const float* bxyz[SORTED_LEVELS];
+    const uint32_t* bidx[SORTED_LEVELS];
+    const float4* bucket4;
+    // one plain list of {x, y, z, id} records per level-2 voxel: the level-3 block (beyond the buckets) is searched as
+    // the 216 lists that tile it
+    GridLevel ct;
+    const float4* cell4;
 };
 
 struct MatchParams {

@@ -7,6 +7,7 @@
 
 #include "../../include/limovelo_hip.h"
 #include "lv_device.hpp"
+#include "lv_mapinc.hpp"
 
 namespace lv {
 
@@ -21,8 +22,23 @@ void set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+struct MapStats {   // == lv_map_stats (include/limovelo_hip.h)
+    uint64_t living, ids, capacity;
+    uint64_t pool_used[4], pool_cap[4];
+    uint64_t slots_used[4], slots_cap[4];
+    uint64_t tombstones, dropped;
+    uint64_t relinearisations, incremental_adds;
+    uint64_t bytes;
+};
+
 struct MapStore {
+    // ---- points by id (insertion order; deleted ids keep their slot with x = +inf)
     float4* d_orig = nullptr;
+    float4* d_orig2 = nullptr;     // compaction target (swapped with d_orig by relinearise)
+    size_t capacity = 0;           // id slots allocated
+    uint32_t n_ids = 0;            // ids handed out
+    uint32_t m = 0;                // living points
+    // ---- build scaffolding: Morton-sorted copy + per-level occupancy tables over it
     float4* d_sorted = nullptr;
     uint64_t* d_keys = nullptr;
     uint64_t* d_keys_sorted = nullptr;
@@ -31,46 +47,92 @@ struct MapStore {
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t* d_counts = nullptr;
-    uint4* d_tables[MAX_LEVELS] = {};
+    uint4* d_tables[MAX_LEVELS] = {};      // occupied voxels -> run in d_sorted; [2] lives on as the voxel-list table
     uint32_t table_size[MAX_LEVELS] = {};
     uint32_t n_cells[MAX_LEVELS] = {};
-    // neighbourhood buckets (levels 0..MAX_BUCKET_LEVELS-1)
-    uint4* d_btable[MAX_BUCKET_LEVELS] = {};
-    uint32_t btable_size[MAX_BUCKET_LEVELS] = {};
-    float4* d_bucket_tmp = nullptr;   // build scratch: one level's buckets as float4 {x,y,z,idx} (fill + sort), then packed
+    // ---- levels 0, 1: neighbourhood buckets with slack
+    uint4* d_btable[REPL_LEVELS] = {};
+    SlotAux* d_baux[REPL_LEVELS] = {};
+    uint32_t btable_size[REPL_LEVELS] = {};
+    float4* d_bucket_tmp = nullptr;   // build scratch: one level's buckets as float4 {x,y,z,id} (fill + sort), then packed
     size_t bucket_tmp_cap = 0;
-    float* d_bxyz[MAX_BUCKET_LEVELS] = {};      // 12-byte points: what the search kernel streams
-    uint32_t* d_bidx[MAX_BUCKET_LEVELS] = {};   // original indices, read for the 5 winners only
-    float4* d_bucket4[MAX_BUCKET_LEVELS] = {};  // levels >= 1: unsorted {x,y,z,idx} buckets (no sort at build time)
-    size_t bucket_cap[MAX_BUCKET_LEVELS] = {};
-    size_t bucket_points[MAX_BUCKET_LEVELS] = {};
-    uint32_t n_bcells[MAX_BUCKET_LEVELS] = {};
+    float* d_bxyz[SORTED_LEVELS] = {};    // levels 0, 1: 12-byte points: what the search kernel streams
+    uint32_t* d_bidx[SORTED_LEVELS] = {}; // ids (ascending inside a bucket)
+    float4* d_bucket4 = nullptr;          // level 2: unordered {x, y, z, id} records
+    uint32_t* d_backptr = nullptr;        // [id * 27 + c]: position of a point in the level-2 bucket of its neighbour c
+    size_t backptr_cap = 0;               // ids it is allocated for
+    size_t pool_cap[INC_LEVELS] = {};     // entries per pool ([CELL_SLOT]: d_cell4)
+    uint32_t n_bcells[REPL_LEVELS] = {};
     uint32_t* d_cell_slots = nullptr;  // scratch: table slots of the bucket voxels of the level being built
     uint32_t* d_bcount = nullptr;
+    uint32_t* d_bcap = nullptr;
     uint32_t* d_boff = nullptr;
     size_t cells_cap = 0;
     uint32_t* d_flags = nullptr;       // [0] = append cursor, [1] = overflow flag
     void* d_scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
-    int build_buckets(hipStream_t stream, int level, uint32_t n_occupied);
-    size_t capacity = 0;
-    uint32_t m = 0;
-    bool origin_set = false;
-    float origin[3] = {0, 0, 0};
-    MapView view{};
-
-    // ikd-Tree style box down-sampling on insert (lv_map.hip: add_downsample)
-    float4* d_orig2 = nullptr;     // compaction target (swapped with d_orig)
-    uint32_t* d_alive = nullptr;
+    // ---- level 2: one list per voxel
+    SlotAux* d_caux = nullptr;
+    uint32_t caux_size = 0;
+    float4* d_cell4 = nullptr;
+    // ---- incremental maintenance (lv_mapinc.hpp)
+    MapCounters* d_cnt = nullptr;
+    MapCounters* h_cnt = nullptr;      // pinned mirror
+    uint32_t* d_work[INC_LEVELS] = {};
+    uint32_t work_cap = 0;
+    float4* d_new = nullptr;           // staged batch
+    uint64_t* d_nkeys = nullptr;
+    uint64_t* d_nkeys_sorted = nullptr;
+    uint32_t* d_nidx = nullptr;
+    uint32_t* d_nidx_sorted = nullptr;
+    uint32_t* d_nalive = nullptr;
+    uint32_t* d_napos = nullptr;
+    uint32_t* d_rank = nullptr;
+    void* d_ntmp = nullptr;
+    size_t ntmp_bytes = 0, batch_cap = 0;
+    float4* d_dead = nullptr;
+    size_t dead_cap = 0;
+    uint32_t* d_alive = nullptr;       // flags / ranks over all ids (eviction of the oldest, compaction)
     uint32_t* d_apos = nullptr;
     void* d_ascan_tmp = nullptr;
-    size_t ascan_tmp_bytes = 0;
+    size_t ascan_tmp_bytes = 0, alive_cap = 0;
+    // 0.2 m boxes of ikd-Tree's down-sampling insert
+    uint4* d_box = nullptr;
+    uint32_t* d_box_next = nullptr;
+    uint32_t box_size = 0;
+    size_t box_next_cap = 0;
+    bool have_boxes = false;
 
-    int reserve(size_t cap);
-    int rebuild(hipStream_t stream, float cell, const float bbox_min[3], const float bbox_max[3]);
-    // d_orig[0..m) = current map, d_orig[m..m+k) = freshly uploaded points; applies the box rule and leaves the
-    // surviving points compacted in d_orig, updating m
-    int add_downsample(hipStream_t stream, uint32_t k, float box_length);
+    bool origin_set = false;
+    float origin[3] = {0, 0, 0};
+    float cell = 0.5f;
+    float bbox_min[3], bbox_max[3];    // of everything ever inserted since the origin was chosen
+    bool built = false;                // the search structure describes d_orig[0 .. n_ids)
+    uint64_t relinearisations = 0, incremental_adds = 0, dropped_total = 0;
+    MapView view{};
+
+    int build_buckets(hipStream_t stream, int level, uint32_t n_occupied);
+    int build_cells(hipStream_t stream, uint32_t n_occupied);
+    int reserve(size_t cap);           // room for `cap` ids (keeps d_orig[0 .. n_ids))
+    int rebuild(hipStream_t stream);   // search structure over d_orig[0 .. n_ids) (all of them living)
+    // compaction of the living (ids become ranks) + rebuild
+    int relinearise(hipStream_t stream);
+    // k points staged in d_new[0 .. k): ikd-Tree Add_Points(points, downsample) without a rebuild; falls back to
+    // relinearise when a pool or table runs full.  Synchronises the stream.
+    // build_if_empty: Mapper::add's rule (an empty map is BUILT from the points, Mapper.cpp:22-27) instead of
+    // Add_Points's (the box rule applies among the new points themselves)
+    int add_staged(hipStream_t stream, uint32_t k, int downsample, float box_length, bool build_if_empty);
+    int ensure_counters();
+    int reserve_batch(size_t k);
+    int evict_box(hipStream_t stream, const float lo[3], const float hi[3], int keep_inside, uint32_t* n_evicted);
+    int evict_oldest(hipStream_t stream, uint32_t n_oldest, uint32_t* n_evicted);
+    int kill_dead_list(hipStream_t stream, uint32_t n_dead);
+    int ensure_boxes(hipStream_t stream, float box_length);
+    int ensure_alive_scratch();
+    bool needs_relinearise(size_t incoming) const;
+    MapRW rw() const;
+    void refresh_view();
+    void stats(MapStats* out) const;
     void release();
 };
 
@@ -85,7 +147,7 @@ int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
 // search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries);
 // fit_reduce_kernel turns them into `grid` block partials (and one extra workgroup runs solve_prep)
 int launch_search(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
-                  float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg);
+                  float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg);
 int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
                       double* partials, int grid, const DebugOut& dbg);
 int fit_grid_size(uint32_t n, int max_blocks);

@@ -1,15 +1,21 @@
-// lv_map.hip — map residency: multi-level voxel hash over Morton-sorted points in HBM.
+// lv_map.hip — map residency: voxel-hashed neighbourhood buckets in HBM, built once and then maintained in place.
 //
-// Replaces ikd-Tree's Build (call site reference src/Modules/Mapper.cpp:68-71): instead of a
-// pointer kd-tree (one point per node, ~100 B/node, log2(M) dependent loads per query) the map is
-// held as
-//   * `sorted`: float4 {x,y,z, original index} in Morton order of the level-0 voxel coordinates —
-//     every voxel of every level (edge voxel_size * 2^l) is one contiguous, coalesced range;
-//   * per level l an open-addressing hash table {packed voxel coords -> (start, count)}, 16 B per
-//     slot so that one probe is one dwordx4 load, load factor <= 0.25;
-//   * `orig`: float4 in insertion order (index space of the kNN results).
-// Exactness of the search that uses these tables is argued in lv_match.hip.
+// Replaces ikd-Tree's Build / Add_Points (call sites reference src/Modules/Mapper.cpp:68-76): instead of a pointer
+// kd-tree (one point per node, ~100 B/node, log2(M) dependent loads per query) the map is held as
+//   * `orig`: float4 by point id (insertion order = the index space of the kNN results);
+//   * levels 0, 1 (voxel edge voxel_size * 2^l): for every voxel whose 3x3x3 block holds a point, the points of
+//     that block in one contiguous run with slack behind it (bucket table {voxel -> run}); one probe + one
+//     coalesced stream answer a query;
+//   * level 2: one point list per voxel (27 / 216 lists searched by a whole wavefront for the few sparse queries).
+// (Re)build: Morton sort of the points + per-level occupancy tables (scaffolding: `sorted`, `tables`) -> buckets.
+// Afterwards inserts, down-sampling deletions and evictions only touch the buckets concerned (lv_mapinc.hpp); a
+// re-linearisation (compaction of the ids + rebuild) happens when a pool, a table or the tombstones run high.
+// Exactness of the search that uses these structures is argued in lv_match.hip.
+#define LV_MAPINC_KERNELS
 #include "lv_host.hpp"
+
+#include <cstddef>
+#include <cstring>
 
 #include <hipcub/hipcub.hpp>
 
@@ -152,12 +158,17 @@ __global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridL
     flags[1] = 1;
 }
 
+// room a run of `count` entries is given when it is laid out (slack for appends; lv_mapinc.hpp relocates a run
+// that outgrows it)
+__host__ __device__ __forceinline__ uint32_t run_capacity(uint32_t count) { return count + (count / 2u > 8u ? count / 2u : 8u); }
+
 // pass 2 (count) / pass 3 (fill): one 64-lane workgroup per bucket voxel; lane c < 27 owns neighbour c
 template <bool FILL>
-__global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLevelW bt, const uint32_t* __restrict__ cell_slots,
-                                                        uint32_t n_cells, const float4* __restrict__ sorted,
-                                                        uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
-                                                        float4* __restrict__ bucket) {
+__global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLevelW bt, SlotAux* __restrict__ aux,
+                                                        const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
+                                                        const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
+                                                        uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
+                                                        float4* __restrict__ bucket, uint32_t* __restrict__ backptr) {
     const uint32_t cell = blockIdx.x;
     if (cell >= n_cells) return;
     const int lane = threadIdx.x;
@@ -179,11 +190,21 @@ __global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLeve
     }
     const uint32_t total = __shfl(incl, 63);
     if (!FILL) {
-        if (lane == 0) bcount[cell] = total;
+        if (lane == 0) { bcount[cell] = total; bcap[cell] = run_capacity(total); }
     } else {
         const uint32_t base = boff[cell] + (incl - count);
-        for (uint32_t j = 0; j < count; ++j) bucket[(size_t)base + j] = sorted[start + j];
-        if (lane == 0) { bt.table[slot].z = boff[cell]; bt.table[slot].w = total; }
+        for (uint32_t j = 0; j < count; ++j) {
+            const float4 p = sorted[start + j];
+            bucket[(size_t)base + j] = p;
+            // seen from the point, this bucket's voxel is its neighbour 26 - lane (lane = offset of the point's voxel
+            // from the bucket's voxel)
+            if (backptr) backptr[(size_t)__float_as_uint(p.w) * 27 + (uint32_t)(26 - lane)] = (incl - count) + j;
+        }
+        if (lane == 0) {
+            bt.table[slot].z = boff[cell];
+            bt.table[slot].w = total;
+            aux[slot] = SlotAux{bcap[cell], 0u, 0u, 0u};
+        }
     }
 }
 
@@ -263,247 +284,7 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
     }
 }
 
-// ---- KD_TREE::Add_Points(points, downsample = true) ------------------------------------------------
-// [UPSTREAM-RECALL ikd-Tree; call site reference src/Modules/Mapper.cpp:73-76, box_length 0.2 m :65].
-// Upstream processes the new points one by one: the point nearest to the centre of p's 0.2 m box among
-// {p} U (current occupants) survives if the box held more than one point or p is that nearest point
-// (occupants must be STRICTLY closer to beat p), otherwise the box is left alone.  The batch form below
-// reproduces exactly that sequence: all points are keyed by their box, a stable radix sort groups each box
-// with its old occupants first (old order) and the new points after (input order), and one lane replays
-// the sequential rule inside its box.  Boxes are independent, so the result equals the sequential one.
-__device__ __forceinline__ int box_coord(float v, float len) {
-    float f = floorf(v / len);
-    f = fminf(fmaxf(f, -1048000.0f), 1048000.0f);
-    return (int)f + CELL_OFFSET;
-}
-__device__ __forceinline__ float box_center_dist(float4 p, float len) {
-    const float c[3] = {p.x, p.y, p.z};
-    float mid[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float vmin = floorf(c[a] / len) * len;
-        const float vmax = vmin + len;
-        mid[a] = (float)((double)vmin + (double)(vmax - vmin) / 2.0);
-    }
-    const float dx = p.x - mid[0], dy = p.y - mid[1], dz = p.z - mid[2];  // calc_dist(point, mid_point)
-    const float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    const float s = sx + sy;
-    return s + sz;
-}
-
-__global__ void box_keys_kernel(const float4* __restrict__ pts, uint32_t total, float len, uint64_t* __restrict__ keys,
-                                uint32_t* __restrict__ idx, uint32_t* __restrict__ alive, uint32_t m_old) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const float4 p = pts[i];
-    keys[i] = pack_cell((uint32_t)box_coord(p.x, len), (uint32_t)box_coord(p.y, len), (uint32_t)box_coord(p.z, len));
-    idx[i] = i;
-    alive[i] = i < m_old ? 1u : 0u;
-}
-
-__global__ void box_rule_kernel(const float4* __restrict__ pts, const uint64_t* __restrict__ keys_sorted,
-                                const uint32_t* __restrict__ idx_sorted, uint32_t total, uint32_t m_old, float len,
-                                uint32_t* __restrict__ alive) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const uint64_t key = keys_sorted[i];
-    if (i > 0 && keys_sorted[i - 1] == key) return;  // not the head of its box
-    uint32_t end = i + 1;
-    while (end < total && keys_sorted[end] == key) ++end;
-    // old occupants come first (ascending index), new points after
-    uint32_t nE = 0;
-    while (i + nE < end && idx_sorted[i + nE] < m_old) ++nE;
-    if (i + nE == end) return;  // box untouched by new points
-    bool multi = nE > 1;
-    uint32_t cur = nE == 1 ? idx_sorted[i] : 0xFFFFFFFFu;
-    float dcur = nE == 1 ? box_center_dist(pts[cur], len) : 0.f;
-    for (uint32_t j = i + nE; j < end; ++j) {
-        const uint32_t p = idx_sorted[j];
-        uint32_t best = p;
-        float md = box_center_dist(pts[p], len);
-        if (multi) {
-            for (uint32_t e = i; e < i + nE; ++e) {
-                const uint32_t ei = idx_sorted[e];
-                const float d = box_center_dist(pts[ei], len);
-                if (d < md) { md = d; best = ei; }
-            }
-        } else if (cur != 0xFFFFFFFFu) {
-            if (dcur < md) { md = dcur; best = cur; }
-        }
-        if (multi || best == p) {
-            if (multi) { for (uint32_t e = i; e < i + nE; ++e) alive[idx_sorted[e]] = 0u; }
-            else if (cur != 0xFFFFFFFFu) alive[cur] = 0u;
-            alive[best] = 1u;
-            cur = best;
-            dcur = md;
-            multi = false;
-        }
-    }
-}
-
-__global__ void box_compact_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ alive,
-                                   const uint32_t* __restrict__ apos, uint32_t total, float4* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    if (alive[i]) out[apos[i]] = pts[i];
-}
-
-int MapStore::add_downsample(hipStream_t stream, uint32_t k, float box_length) {
-    const uint32_t total = m + k;
-    if (k == 0) return LV_OK;
-    const int B = 256;
-    const uint32_t grid = (total + B - 1) / B;
-    hipLaunchKernelGGL(box_keys_kernel, dim3(grid), dim3(B), 0, stream, d_orig, total, box_length, d_keys, d_idx, d_alive, m);
-    size_t tmp = sort_tmp_bytes;
-    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tmp, d_keys, d_keys_sorted, d_idx, d_idx_sorted, (int)total,
-                                                           0, 63, stream));
-    hipLaunchKernelGGL(box_rule_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_keys_sorted, d_idx_sorted, total, m, box_length,
-                       d_alive);
-    size_t stmp = ascan_tmp_bytes;
-    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ascan_tmp, stmp, d_alive, d_apos, (int)total, stream));
-    hipLaunchKernelGGL(box_compact_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_alive, d_apos, total, d_orig2);
-    uint32_t last_pos = 0, last_alive = 0;
-    LV_HIP(hipMemcpyAsync(&last_pos, d_apos + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipMemcpyAsync(&last_alive, d_alive + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    float4* t = d_orig;
-    d_orig = d_orig2;
-    d_orig2 = t;
-    m = last_pos + last_alive;
-    return LV_OK;
-}
-
-static inline uint32_t next_pow2(uint64_t v) {
-    uint32_t p = 64;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-int MapStore::reserve(size_t cap) {
-    if (cap <= capacity) return LV_OK;
-    size_t ncap = capacity ? capacity : 4096;
-    while (ncap < cap) ncap *= 2;
-    float4* n_orig = nullptr;
-    LV_HIP(hipMalloc(&n_orig, ncap * sizeof(float4)));
-    if (d_orig && m) LV_HIP(hipMemcpyAsync(n_orig, d_orig, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, 0));
-    LV_HIP(hipDeviceSynchronize());
-    if (d_orig) hipFree(d_orig);
-    d_orig = n_orig;
-    if (d_sorted) hipFree(d_sorted);
-    if (d_keys) hipFree(d_keys);
-    if (d_keys_sorted) hipFree(d_keys_sorted);
-    if (d_idx) hipFree(d_idx);
-    if (d_idx_sorted) hipFree(d_idx_sorted);
-    if (d_orig2) hipFree(d_orig2);
-    if (d_alive) hipFree(d_alive);
-    if (d_apos) hipFree(d_apos);
-    if (d_ascan_tmp) hipFree(d_ascan_tmp);
-    d_ascan_tmp = nullptr;
-    LV_HIP(hipMalloc(&d_orig2, ncap * sizeof(float4)));
-    LV_HIP(hipMalloc(&d_alive, ncap * sizeof(uint32_t)));
-    LV_HIP(hipMalloc(&d_apos, ncap * sizeof(uint32_t)));
-    ascan_tmp_bytes = 0;
-    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, ascan_tmp_bytes, d_alive, d_apos, (int)ncap, (hipStream_t)0));
-    LV_HIP(hipMalloc(&d_ascan_tmp, ascan_tmp_bytes));
-    LV_HIP(hipMalloc(&d_sorted, ncap * sizeof(float4)));
-    LV_HIP(hipMalloc(&d_keys, ncap * sizeof(uint64_t)));
-    LV_HIP(hipMalloc(&d_keys_sorted, ncap * sizeof(uint64_t)));
-    LV_HIP(hipMalloc(&d_idx, ncap * sizeof(uint32_t)));
-    LV_HIP(hipMalloc(&d_idx_sorted, ncap * sizeof(uint32_t)));
-    if (d_sort_tmp) hipFree(d_sort_tmp);
-    d_sort_tmp = nullptr;
-    sort_tmp_bytes = 0;
-    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
-                                                           (int)ncap, 0, 63, (hipStream_t)0));
-    LV_HIP(hipMalloc(&d_sort_tmp, sort_tmp_bytes));
-    capacity = ncap;
-    return LV_OK;
-}
-
-void MapStore::release() {
-    hipFree(d_orig); hipFree(d_sorted); hipFree(d_keys); hipFree(d_keys_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
-    hipFree(d_sort_tmp); hipFree(d_counts);
-    hipFree(d_orig2); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
-    hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
-    for (int l = 0; l < MAX_BUCKET_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_bxyz[l]); hipFree(d_bidx[l]); hipFree(d_bucket4[l]); }
-    hipFree(d_bucket_tmp);
-    for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
-    *this = MapStore();
-}
-
-// Rebuild the search structure over d_orig[0..m).  bbox = host-computed bounds of the points.
-int MapStore::rebuild(hipStream_t stream, float cell, const float bbox_min[3], const float bbox_max[3]) {
-    view = MapView();
-    view.m = m;
-    view.cell = cell;
-    view.inv_cell = 1.0f / cell;
-    if (m == 0) return LV_OK;
-    if (!origin_set) {  // origin = bbox centre snapped to the level-0 lattice; kept for the map's lifetime
-        for (int a = 0; a < 3; ++a) origin[a] = floorf(0.5f * (bbox_min[a] + bbox_max[a]) / cell) * cell;
-        origin_set = true;
-    }
-    float ext_cells = 1.f;
-    for (int a = 0; a < 3; ++a) {
-        view.origin[a] = origin[a];
-        float lo = floorf((bbox_min[a] - origin[a]) / cell), hi = floorf((bbox_max[a] - origin[a]) / cell);
-        if (!(fabsf(lo) < (float)CELL_FAR) || !(fabsf(hi) < (float)CELL_FAR)) {
-            set_error("map extent exceeds +-%d voxels of %.3f m around the map origin", CELL_FAR, cell);
-            return LV_ERANGE;
-        }
-        ext_cells = fmaxf(ext_cells, hi - lo + 1.f);
-    }
-    int n_levels = 1;
-    while ((1 << (n_levels - 1)) < (int)ext_cells && n_levels < MAX_LEVELS) ++n_levels;
-    view.n_levels = n_levels;
-
-    const int B = 256;
-    const uint32_t grid = (m + B - 1) / B;
-    hipLaunchKernelGGL(map_keys_kernel, dim3(grid), dim3(B), 0, stream, d_orig, m, origin[0], origin[1], origin[2],
-                       view.inv_cell, d_keys, d_idx);
-    size_t tmp = sort_tmp_bytes;
-    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tmp, d_keys, d_keys_sorted, d_idx, d_idx_sorted, (int)m,
-                                                           0, 63, stream));
-    hipLaunchKernelGGL(map_gather_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_idx_sorted, m, d_sorted);
-    if (!d_counts) LV_HIP(hipMalloc(&d_counts, MAX_LEVELS * sizeof(uint32_t)));
-    LV_HIP(hipMemsetAsync(d_counts, 0, MAX_LEVELS * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(map_count_heads_kernel, dim3(grid), dim3(B), 0, stream, d_keys_sorted, m, n_levels, d_counts);
-    uint32_t counts[MAX_LEVELS];
-    LV_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-
-    TablePtrs tp{};
-    for (int l = 0; l < n_levels; ++l) {
-        uint32_t size = next_pow2((uint64_t)counts[l] * 4);
-        if (size > table_size[l]) {
-            if (d_tables[l]) hipFree(d_tables[l]);
-            LV_HIP(hipMalloc(&d_tables[l], (size_t)size * sizeof(uint4)));
-            table_size[l] = size;
-        }
-        size = table_size[l];
-        LV_HIP(hipMemsetAsync(d_tables[l], 0xFF, (size_t)size * sizeof(uint4), stream));
-        int lg = 0;
-        while ((1u << lg) < size) ++lg;
-        tp.table[l] = d_tables[l];
-        tp.mask[l] = size - 1;
-        tp.shift[l] = 64 - lg;
-        view.lv[l].table = d_tables[l];
-        view.lv[l].mask = size - 1;
-        view.lv[l].shift = 64 - lg;
-        n_cells[l] = counts[l];
-    }
-    hipLaunchKernelGGL(map_insert_kernel, dim3(grid), dim3(B), 0, stream, d_keys_sorted, m, n_levels, tp);
-    LV_HIP(hipGetLastError());
-    view.sorted = d_sorted;
-    view.orig = d_orig;
-    view.n_bucket_levels = n_levels < MAX_BUCKET_LEVELS ? n_levels : MAX_BUCKET_LEVELS;
-    for (int l = 0; l < view.n_bucket_levels; ++l) {
-        int rc = build_buckets(stream, l, counts[l]);
-        if (rc) return rc;
-    }
-    return LV_OK;
-}
-
-// the sorted float4 buckets -> 12-byte points (what the search kernel streams) + a parallel index array
+// the sorted float4 buckets -> 12-byte points (what the search kernel streams) + a parallel id array
 __global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -514,37 +295,354 @@ __global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, fl
     idx[i] = __float_as_uint(p.w);
 }
 
+// ---- level 2: voxel lists -----------------------------------------------------------------------------------
+__global__ void cell_caps_kernel(const uint4* __restrict__ table, uint32_t size, uint32_t* __restrict__ ccap) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= size) return;
+    const uint4 e = table[slot];
+    const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    ccap[slot] = key == EMPTY_KEY ? 0u : run_capacity(e.w) + 8u;
+}
+// sorted[i] goes to its level-2 voxel's list, at the rank it has inside the voxel's run of `sorted`
+__global__ void cell_fill_kernel(const uint64_t* __restrict__ keys_sorted, const float4* __restrict__ sorted, uint32_t m,
+                                 GridLevelW t2, const uint32_t* __restrict__ coff, float4* __restrict__ cell4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t k0 = keys_sorted[i];
+    const uint32_t cx = compact21(k0) >> CELL_LEVEL, cy = compact21(k0 >> 1) >> CELL_LEVEL, cz = compact21(k0 >> 2) >> CELL_LEVEL;
+    const uint64_t key = pack_cell(cx, cy, cz);
+    uint32_t slot = hash_cell(key, t2.shift) & t2.mask;
+    for (;;) {
+        const uint4 e = t2.table[slot];
+        const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+        if (ek == key) { cell4[(size_t)coff[slot] + (i - e.z)] = sorted[i]; return; }
+        if (ek == EMPTY_KEY) return;   // cannot happen: every point's voxel was inserted
+        slot = (slot + 1) & t2.mask;
+    }
+}
+__global__ void cell_commit_kernel(uint4* __restrict__ table, uint32_t size, const uint32_t* __restrict__ ccap,
+                                   const uint32_t* __restrict__ coff, SlotAux* __restrict__ aux) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= size) return;
+    aux[slot] = SlotAux{ccap[slot], 0u, 0u, 0u};
+    if (ccap[slot]) table[slot].z = coff[slot];
+}
+
+// bounds of the living points (order-preserving float -> uint, atomicMin / atomicMax)
+__device__ __forceinline__ unsigned flipf(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float unflipf(unsigned u) {
+    const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+__global__ void map_bounds_kernel(const float4* __restrict__ pts, uint32_t n, unsigned* __restrict__ bounds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    if (!pt_alive(p)) return;
+    atomicMin(&bounds[0], flipf(p.x)); atomicMin(&bounds[1], flipf(p.y)); atomicMin(&bounds[2], flipf(p.z));
+    atomicMax(&bounds[3], flipf(p.x)); atomicMax(&bounds[4], flipf(p.y)); atomicMax(&bounds[5], flipf(p.z));
+}
+
+// staged points that can be inserted (finite) — used when a batch BUILDS the map (Mapper::add on an empty map)
+__global__ void staged_ok_kernel(const float4* __restrict__ pts, uint32_t k, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const float4 p = pts[i];
+    flags[i] = (pt_alive(p) && fabsf(p.y) < pos_inf() && fabsf(p.z) < pos_inf()) ? 1u : 0u;
+}
+
+static inline uint32_t next_pow2(uint64_t v) {
+    uint32_t p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+static inline int log2u(uint32_t size) {
+    int lg = 0;
+    while ((1u << lg) < size) ++lg;
+    return lg;
+}
+
+#define LV_REALLOC(ptr, type, count)                                       \
+    do {                                                                   \
+        if (ptr) hipFree(ptr);                                             \
+        ptr = nullptr;                                                     \
+        LV_HIP(hipMalloc(&ptr, (size_t)(count) * sizeof(type)));           \
+    } while (0)
+
+int MapStore::reserve(size_t cap) {
+    if (cap <= capacity) return LV_OK;
+    size_t ncap = capacity ? capacity : 4096;
+    while (ncap < cap) ncap *= 2;
+    float4* n_orig = nullptr;
+    LV_HIP(hipMalloc(&n_orig, ncap * sizeof(float4)));
+    LV_HIP(hipDeviceSynchronize());
+    if (d_orig && n_ids) LV_HIP(hipMemcpy(n_orig, d_orig, (size_t)n_ids * sizeof(float4), hipMemcpyDeviceToDevice));
+    if (d_orig) hipFree(d_orig);
+    d_orig = n_orig;
+    LV_REALLOC(d_orig2, float4, ncap);
+    LV_REALLOC(d_sorted, float4, ncap);
+    LV_REALLOC(d_keys, uint64_t, ncap);
+    LV_REALLOC(d_keys_sorted, uint64_t, ncap);
+    LV_REALLOC(d_idx, uint32_t, ncap);
+    LV_REALLOC(d_idx_sorted, uint32_t, ncap);
+    if (d_sort_tmp) hipFree(d_sort_tmp);
+    d_sort_tmp = nullptr;
+    sort_tmp_bytes = 0;
+    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
+                                                           (int)ncap, 0, 63, (hipStream_t)0));
+    LV_HIP(hipMalloc(&d_sort_tmp, sort_tmp_bytes));
+    LV_REALLOC(d_dead, float4, ncap);
+    dead_cap = ncap;
+    if (d_box_next) {   // chains are by id: keep them
+        uint32_t* nn = nullptr;
+        LV_HIP(hipMalloc(&nn, ncap * sizeof(uint32_t)));
+        if (n_ids) LV_HIP(hipMemcpy(nn, d_box_next, (size_t)n_ids * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        hipFree(d_box_next);
+        d_box_next = nn;
+        box_next_cap = ncap;
+    }
+    if (d_backptr) {   // positions inside the level-2 buckets are by id: keep them
+        uint32_t* nb = nullptr;
+        LV_HIP(hipMalloc(&nb, ncap * 27 * sizeof(uint32_t)));
+        if (n_ids) LV_HIP(hipMemcpy(nb, d_backptr, (size_t)n_ids * 27 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        hipFree(d_backptr);
+        d_backptr = nb;
+        backptr_cap = ncap;
+    }
+    capacity = ncap;
+    refresh_view();
+    return LV_OK;
+}
+
+int MapStore::ensure_alive_scratch() {
+    if (alive_cap >= capacity && d_alive) return LV_OK;
+    LV_REALLOC(d_alive, uint32_t, capacity);
+    LV_REALLOC(d_apos, uint32_t, capacity);
+    if (d_ascan_tmp) hipFree(d_ascan_tmp);
+    d_ascan_tmp = nullptr;
+    ascan_tmp_bytes = 0;
+    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, ascan_tmp_bytes, d_alive, d_apos, (int)capacity, (hipStream_t)0));
+    LV_HIP(hipMalloc(&d_ascan_tmp, ascan_tmp_bytes));
+    alive_cap = capacity;
+    return LV_OK;
+}
+
+void MapStore::release() {
+    hipFree(d_orig); hipFree(d_orig2); hipFree(d_sorted); hipFree(d_keys); hipFree(d_keys_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
+    hipFree(d_sort_tmp); hipFree(d_counts);
+    hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_bcap); hipFree(d_boff); hipFree(d_scan_tmp);
+    for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_baux[l]); }
+    for (int l = 0; l < SORTED_LEVELS; ++l) { hipFree(d_bxyz[l]); hipFree(d_bidx[l]); }
+    hipFree(d_bucket4); hipFree(d_backptr);
+    hipFree(d_bucket_tmp); hipFree(d_caux); hipFree(d_cell4);
+    for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
+    hipFree(d_cnt);
+    if (h_cnt) hipHostFree(h_cnt);
+    for (int l = 0; l < INC_LEVELS; ++l) hipFree(d_work[l]);
+    hipFree(d_new); hipFree(d_nkeys); hipFree(d_nkeys_sorted); hipFree(d_nidx); hipFree(d_nidx_sorted); hipFree(d_nalive);
+    hipFree(d_napos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
+    hipFree(d_box); hipFree(d_box_next);
+    *this = MapStore();
+}
+
+void MapStore::refresh_view() {
+    view.orig = d_orig;
+    view.m = built ? m : 0u;
+    view.n_ids = n_ids;
+    view.cell = cell;
+    view.inv_cell = 1.0f / cell;
+    for (int a = 0; a < 3; ++a) view.origin[a] = origin[a];
+    for (int l = 0; l < REPL_LEVELS; ++l) {
+        view.bt[l].table = d_btable[l];
+        view.bt[l].mask = btable_size[l] ? btable_size[l] - 1 : 0;
+        view.bt[l].shift = (uint32_t)(64 - log2u(btable_size[l] ? btable_size[l] : 1));
+    }
+    for (int l = 0; l < SORTED_LEVELS; ++l) {
+        view.bxyz[l] = d_bxyz[l];
+        view.bidx[l] = d_bidx[l];
+    }
+    view.bucket4 = d_bucket4;
+    view.ct.table = d_tables[CELL_LEVEL];
+    view.ct.mask = table_size[CELL_LEVEL] ? table_size[CELL_LEVEL] - 1 : 0;
+    view.ct.shift = (uint32_t)(64 - log2u(table_size[CELL_LEVEL] ? table_size[CELL_LEVEL] : 1));
+    view.cell4 = d_cell4;
+}
+
+MapRW MapStore::rw() const {
+    MapRW M{};
+    M.orig = d_orig;
+    for (int l = 0; l < REPL_LEVELS; ++l) {
+        M.lv[l].table = d_btable[l];
+        M.lv[l].aux = d_baux[l];
+        M.lv[l].mask = btable_size[l] - 1;
+        M.lv[l].shift = (uint32_t)(64 - log2u(btable_size[l]));
+        M.lv[l].slot_limit = (uint32_t)((uint64_t)btable_size[l] * 7 / 10);
+        M.lv[l].pool_cap = (uint32_t)(pool_cap[l] > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : pool_cap[l]);
+    }
+    for (int l = 0; l < SORTED_LEVELS; ++l) {
+        M.bxyz[l] = d_bxyz[l];
+        M.bidx[l] = d_bidx[l];
+    }
+    M.bucket4 = d_bucket4;
+    M.backptr = d_backptr;
+    M.lv[CELL_SLOT].table = d_tables[CELL_LEVEL];
+    M.lv[CELL_SLOT].aux = d_caux;
+    M.lv[CELL_SLOT].mask = table_size[CELL_LEVEL] - 1;
+    M.lv[CELL_SLOT].shift = (uint32_t)(64 - log2u(table_size[CELL_LEVEL]));
+    M.lv[CELL_SLOT].slot_limit = (uint32_t)((uint64_t)table_size[CELL_LEVEL] * 6 / 10);
+    M.lv[CELL_SLOT].pool_cap = (uint32_t)(pool_cap[CELL_SLOT] > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : pool_cap[CELL_SLOT]);
+    M.cell4 = d_cell4;
+    for (int a = 0; a < 3; ++a) M.origin[a] = origin[a];
+    M.inv_cell = 1.0f / cell;
+    M.cnt = d_cnt;
+    for (int l = 0; l < INC_LEVELS; ++l) M.work[l] = d_work[l];
+    M.work_cap = work_cap;
+    return M;
+}
+
+void MapStore::stats(MapStats* out) const {
+    *out = MapStats{};
+    out->living = m;
+    out->ids = n_ids;
+    out->capacity = capacity;
+    if (h_cnt && built) {
+        for (int l = 0; l < INC_LEVELS; ++l) { out->pool_used[l] = h_cnt->pool_used[l]; out->slots_used[l] = h_cnt->slots_used[l]; }
+        out->tombstones = h_cnt->tombstones;
+    }
+    for (int l = 0; l < INC_LEVELS; ++l) out->pool_cap[l] = pool_cap[l];
+    for (int l = 0; l < REPL_LEVELS; ++l) out->slots_cap[l] = btable_size[l];
+    out->slots_cap[CELL_SLOT] = table_size[CELL_LEVEL];
+    out->dropped = dropped_total;
+    out->relinearisations = relinearisations;
+    out->incremental_adds = incremental_adds;
+    uint64_t b = (uint64_t)capacity * (16 + 16 + 16 + 8 + 8 + 4 + 4 + 16);
+    for (int l = 0; l < REPL_LEVELS; ++l) b += (uint64_t)pool_cap[l] * 16 + (uint64_t)btable_size[l] * 32;
+    b += (uint64_t)pool_cap[CELL_SLOT] * 16 + (uint64_t)bucket_tmp_cap * 16 + (uint64_t)backptr_cap * 27 * 4;
+    for (int l = 0; l < MAX_LEVELS; ++l) b += (uint64_t)table_size[l] * 16;
+    b += (uint64_t)box_size * 16 + (uint64_t)box_next_cap * 4;
+    out->bytes = b;
+}
+
+// Search structure over d_orig[0 .. n_ids), all living (m == n_ids).
+int MapStore::rebuild(hipStream_t stream) {
+    built = false;
+    have_boxes = false;
+    view = MapView();
+    refresh_view();
+    {
+        const int rc0 = ensure_counters();
+        if (rc0) return rc0;
+    }
+    std::memset(h_cnt, 0, sizeof(MapCounters));
+    m = n_ids;
+    if (m == 0) {
+        LV_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(MapCounters), hipMemcpyHostToDevice, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        return LV_OK;   // no map: view.m stays 0
+    }
+    const int B = 256;
+    const uint32_t grid = (m + B - 1) / B;
+    if (!d_flags) LV_HIP(hipMalloc(&d_flags, 8 * sizeof(uint32_t)));
+    const unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    LV_HIP(hipMemcpyAsync(d_flags, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(map_bounds_kernel, dim3(grid), dim3(B), 0, stream, d_orig, m, d_flags);
+    unsigned hb[8];
+    LV_HIP(hipMemcpyAsync(hb, d_flags, sizeof(hb), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    for (int a = 0; a < 3; ++a) { bbox_min[a] = unflipf(hb[a]); bbox_max[a] = unflipf(hb[3 + a]); }
+    if (!origin_set) {  // origin = bbox centre snapped to the level-0 lattice; kept for the map's lifetime
+        for (int a = 0; a < 3; ++a) origin[a] = floorf(0.5f * (bbox_min[a] + bbox_max[a]) / cell) * cell;
+        origin_set = true;
+    }
+    for (int a = 0; a < 3; ++a) {
+        const float lo = floorf((bbox_min[a] - origin[a]) / cell), hi = floorf((bbox_max[a] - origin[a]) / cell);
+        if (!(fabsf(lo) < (float)CELL_FAR) || !(fabsf(hi) < (float)CELL_FAR)) {
+            set_error("map extent exceeds +-%d voxels of %.3f m around the map origin", CELL_FAR, cell);
+            return LV_ERANGE;
+        }
+    }
+    const int n_levels = MAX_LEVELS;
+    const float inv_cell = 1.0f / cell;
+    hipLaunchKernelGGL(map_keys_kernel, dim3(grid), dim3(B), 0, stream, d_orig, m, origin[0], origin[1], origin[2], inv_cell, d_keys,
+                       d_idx);
+    size_t tmp = sort_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tmp, d_keys, d_keys_sorted, d_idx, d_idx_sorted, (int)m,
+                                                           0, 63, stream));
+    hipLaunchKernelGGL(map_gather_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_idx_sorted, m, d_sorted);
+    if (!d_counts) LV_HIP(hipMalloc(&d_counts, 16 * sizeof(uint32_t)));
+    LV_HIP(hipMemsetAsync(d_counts, 0, 16 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(map_count_heads_kernel, dim3(grid), dim3(B), 0, stream, d_keys_sorted, m, n_levels, d_counts);
+    uint32_t counts[16];
+    LV_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+
+    TablePtrs tp{};
+    for (int l = 0; l < n_levels; ++l) {
+        // the level-2 table lives on as the voxel-list table of incremental inserts: give it room to grow
+        uint32_t size = next_pow2((uint64_t)counts[l] * (l == CELL_LEVEL ? 8 : 4));
+        if (size > table_size[l]) {
+            if (d_tables[l]) hipFree(d_tables[l]);
+            d_tables[l] = nullptr;
+            LV_HIP(hipMalloc(&d_tables[l], (size_t)size * sizeof(uint4)));
+            table_size[l] = size;
+        }
+        size = table_size[l];
+        LV_HIP(hipMemsetAsync(d_tables[l], 0xFF, (size_t)size * sizeof(uint4), stream));
+        tp.table[l] = d_tables[l];
+        tp.mask[l] = size - 1;
+        tp.shift[l] = (uint32_t)(64 - log2u(size));
+        n_cells[l] = counts[l];
+    }
+    hipLaunchKernelGGL(map_insert_kernel, dim3(grid), dim3(B), 0, stream, d_keys_sorted, m, n_levels, tp);
+    LV_HIP(hipGetLastError());
+    for (int l = 0; l < REPL_LEVELS; ++l) {
+        int rc = build_buckets(stream, l, counts[l]);
+        if (rc) return rc;
+    }
+    int rc = build_cells(stream, counts[CELL_LEVEL]);
+    if (rc) return rc;
+    for (int l = 0; l < REPL_LEVELS; ++l) h_cnt->slots_used[l] = n_bcells[l];
+    h_cnt->slots_used[CELL_SLOT] = counts[CELL_LEVEL];
+    LV_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(MapCounters), hipMemcpyHostToDevice, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    built = true;
+    refresh_view();
+    return LV_OK;
+}
+
 int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) {
-    if (!d_flags) LV_HIP(hipMalloc(&d_flags, 2 * sizeof(uint32_t)));
-    GridLevelW occ{d_tables[level], view.lv[level].mask, view.lv[level].shift};
-    const uint32_t occ_slots = view.lv[level].mask + 1;
+    GridLevelW occ{d_tables[level], table_size[level] - 1, (uint32_t)(64 - log2u(table_size[level]))};
+    const uint32_t occ_slots = table_size[level];
     uint32_t size = next_pow2((uint64_t)n_occupied * 16);  // dilation factor <= 8 keeps the load <= 0.5
     if (size < btable_size[level]) size = btable_size[level];
     for (;;) {
-        if (size > btable_size[level]) {
-            hipFree(d_btable[level]);
-            d_btable[level] = nullptr;
-            LV_HIP(hipMalloc(&d_btable[level], (size_t)size * sizeof(uint4)));
+        if (size > btable_size[level] || !d_btable[level]) {
+            LV_REALLOC(d_btable[level], uint4, size);
+            LV_REALLOC(d_baux[level], SlotAux, size);
             btable_size[level] = size;
         }
         const size_t need_cells = (size_t)size / 2;
         if (need_cells > cells_cap) {
-            hipFree(d_cell_slots); hipFree(d_bcount); hipFree(d_boff); hipFree(d_scan_tmp);
-            d_cell_slots = d_bcount = d_boff = nullptr;
+            LV_REALLOC(d_cell_slots, uint32_t, need_cells);
+            LV_REALLOC(d_bcount, uint32_t, need_cells);
+            LV_REALLOC(d_bcap, uint32_t, need_cells);
+            LV_REALLOC(d_boff, uint32_t, need_cells);
+            if (d_scan_tmp) hipFree(d_scan_tmp);
             d_scan_tmp = nullptr;
-            LV_HIP(hipMalloc(&d_cell_slots, need_cells * sizeof(uint32_t)));
-            LV_HIP(hipMalloc(&d_bcount, need_cells * sizeof(uint32_t)));
-            LV_HIP(hipMalloc(&d_boff, need_cells * sizeof(uint32_t)));
             scan_tmp_bytes = 0;
-            LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_bcount, d_boff, (int)need_cells, (hipStream_t)0));
+            LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_bcap, d_boff, (int)need_cells, (hipStream_t)0));
             LV_HIP(hipMalloc(&d_scan_tmp, scan_tmp_bytes));
             cells_cap = need_cells;
         }
         LV_HIP(hipMemsetAsync(d_btable[level], 0xFF, (size_t)size * sizeof(uint4), stream));
+        LV_HIP(hipMemsetAsync(d_baux[level], 0, (size_t)size * sizeof(SlotAux), stream));
         LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
-        int lg = 0;
-        while ((1u << lg) < size) ++lg;
-        GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - lg)};
+        GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - log2u(size))};
         const uint64_t threads = (uint64_t)occ_slots * 27;
         hipLaunchKernelGGL(bucket_register_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, occ, occ_slots, bt,
                            d_cell_slots, (uint32_t)(size / 2), d_flags);
@@ -557,63 +655,373 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         }
         const uint32_t nb = flags[0];
         n_bcells[level] = nb;
-        hipLaunchKernelGGL((map_bucket_kernel<false>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
-                           d_boff, (float4*)nullptr);
+        hipLaunchKernelGGL((map_bucket_kernel<false>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb, d_sorted,
+                           d_bcount, d_bcap, d_boff, (float4*)nullptr, (uint32_t*)nullptr);
         size_t stmp = scan_tmp_bytes;
-        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcount, d_boff, (int)nb, stream));
-        uint32_t last_off = 0, last_cnt = 0;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)nb, stream));
+        uint32_t last_off = 0, last_cap = 0;
         LV_HIP(hipMemcpyAsync(&last_off, d_boff + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LV_HIP(hipMemcpyAsync(&last_cnt, d_bcount + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipMemcpyAsync(&last_cap, d_bcap + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipStreamSynchronize(stream));
-        const uint64_t total = (uint64_t)last_off + last_cnt;
-        if (total > 0xFFFFFFF0ull) { set_error("bucket array exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
-        bucket_points[level] = (size_t)total;
-        if (level < SORTED_BUCKET_LEVELS) {   // sorted by original index, then packed to 12-byte points + index array
-            if (bucket_points[level] > bucket_tmp_cap) {
-                hipFree(d_bucket_tmp);
-                d_bucket_tmp = nullptr;
-                bucket_tmp_cap = 0;
-                size_t cap = bucket_points[level] + bucket_points[level] / 8;
-                LV_HIP(hipMalloc(&d_bucket_tmp, cap * sizeof(float4)));
-                bucket_tmp_cap = cap;
+        const uint64_t total = (uint64_t)last_off + last_cap;   // entries laid out, slack included
+        // the pool keeps room for runs that move and for the buckets of newly mapped space
+        const uint64_t want = total + total / 4 + (8ull << 20);
+        if (want > 0xFFFFFFF0ull) { set_error("bucket pool exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
+        if (level < SORTED_LEVELS) {   // ascending id, then packed to 12-byte points + id array
+            if (total > bucket_tmp_cap) {
+                LV_REALLOC(d_bucket_tmp, float4, total + total / 8);
+                bucket_tmp_cap = total + total / 8;
             }
-            if (bucket_points[level] > bucket_cap[level]) {
-                hipFree(d_bxyz[level]); hipFree(d_bidx[level]);
-                d_bxyz[level] = nullptr; d_bidx[level] = nullptr;
-                bucket_cap[level] = 0;
-                size_t cap = bucket_points[level] + bucket_points[level] / 8;
-                LV_HIP(hipMalloc(&d_bxyz[level], (cap * 3 + 4) * sizeof(float)));
-                LV_HIP(hipMalloc(&d_bidx[level], cap * sizeof(uint32_t)));
-                bucket_cap[level] = cap;
+            if (want > pool_cap[level]) {
+                pool_cap[level] = 0;
+                LV_REALLOC(d_bxyz[level], float, want * 3 + 4);
+                LV_REALLOC(d_bidx[level], uint32_t, want);
+                pool_cap[level] = (size_t)want;
             }
-            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
-                               d_boff, d_bucket_tmp);
+            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb,
+                               d_sorted, d_bcount, d_bcap, d_boff, d_bucket_tmp, (uint32_t*)nullptr);
             hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
             if (total > 0)
                 hipLaunchKernelGGL(bucket_pack_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_bucket_tmp,
                                    (uint32_t)total, d_bxyz[level], d_bidx[level]);
-        } else {            // coarse levels: candidates are ordered by (distance, index) keys, the bucket stays unsorted
-            if (bucket_points[level] > bucket_cap[level]) {
-                hipFree(d_bucket4[level]);
-                d_bucket4[level] = nullptr;
-                bucket_cap[level] = 0;
-                size_t cap = bucket_points[level] + bucket_points[level] / 8;
-                LV_HIP(hipMalloc(&d_bucket4[level], cap * sizeof(float4)));
-                bucket_cap[level] = cap;
+        } else {                       // level 2: unordered records, every point remembers where it sits (deletions)
+            if (want > pool_cap[level]) {
+                pool_cap[level] = 0;
+                LV_REALLOC(d_bucket4, float4, want);
+                pool_cap[level] = (size_t)want;
             }
-            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_cell_slots, nb, d_sorted, d_bcount,
-                               d_boff, d_bucket4[level]);
+            if (backptr_cap < capacity) {
+                LV_REALLOC(d_backptr, uint32_t, capacity * 27);
+                backptr_cap = capacity;
+            }
+            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb,
+                               d_sorted, d_bcount, d_bcap, d_boff, d_bucket4, d_backptr);
         }
         LV_HIP(hipGetLastError());
-        view.bt[level].table = d_btable[level];
-        view.bt[level].mask = size - 1;
-        view.bt[level].shift = (uint32_t)(64 - lg);
-        view.bxyz[level] = d_bxyz[level];
-        view.bidx[level] = d_bidx[level];
-        view.bucket4[level] = d_bucket4[level];
+        h_cnt->pool_used[level] = (uint32_t)total;
         return LV_OK;
     }
+}
+
+// level 2: the occupancy table of the level (runs of `sorted`) turns into the voxel-list table (runs of cell4)
+int MapStore::build_cells(hipStream_t stream, uint32_t n_occupied) {
+    (void)n_occupied;
+    const uint32_t size = table_size[CELL_LEVEL];
+    if (size > caux_size) {
+        LV_REALLOC(d_caux, SlotAux, size);
+        caux_size = size;
+    }
+    if ((size_t)size > cells_cap) {
+        LV_REALLOC(d_cell_slots, uint32_t, size);
+        LV_REALLOC(d_bcount, uint32_t, size);
+        LV_REALLOC(d_bcap, uint32_t, size);
+        LV_REALLOC(d_boff, uint32_t, size);
+        if (d_scan_tmp) hipFree(d_scan_tmp);
+        d_scan_tmp = nullptr;
+        scan_tmp_bytes = 0;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_bcap, d_boff, (int)size, (hipStream_t)0));
+        LV_HIP(hipMalloc(&d_scan_tmp, scan_tmp_bytes));
+        cells_cap = size;
+    }
+    const int B = 256;
+    hipLaunchKernelGGL(cell_caps_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[CELL_LEVEL], size, d_bcap);
+    size_t stmp = scan_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)size, stream));
+    uint32_t last_off = 0, last_cap = 0;
+    LV_HIP(hipMemcpyAsync(&last_off, d_boff + (size - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipMemcpyAsync(&last_cap, d_bcap + (size - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    const uint64_t total = (uint64_t)last_off + last_cap;
+    const uint64_t want = total + total / 4 + (1ull << 20);
+    if (want > 0xFFFFFFF0ull) { set_error("voxel-list pool exceeds 2^32 entries"); return LV_ERANGE; }
+    if (want > pool_cap[CELL_SLOT]) {
+        pool_cap[CELL_SLOT] = 0;
+        LV_REALLOC(d_cell4, float4, want);
+        pool_cap[CELL_SLOT] = (size_t)want;
+    }
+    GridLevelW t2{d_tables[CELL_LEVEL], size - 1, (uint32_t)(64 - log2u(size))};
+    hipLaunchKernelGGL(cell_fill_kernel, dim3((m + B - 1) / B), dim3(B), 0, stream, d_keys_sorted, d_sorted, m, t2, d_boff, d_cell4);
+    hipLaunchKernelGGL(cell_commit_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[CELL_LEVEL], size, d_bcap, d_boff, d_caux);
+    LV_HIP(hipGetLastError());
+    h_cnt->pool_used[CELL_SLOT] = (uint32_t)total;
+    return LV_OK;
+}
+
+// ---- incremental maintenance: host side ---------------------------------------------------------------------
+int MapStore::reserve_batch(size_t k) {
+    if (k <= batch_cap) return LV_OK;
+    size_t ncap = batch_cap ? batch_cap : 4096;
+    while (ncap < k) ncap *= 2;
+    LV_REALLOC(d_new, float4, ncap);
+    LV_REALLOC(d_nkeys, uint64_t, ncap);
+    LV_REALLOC(d_nkeys_sorted, uint64_t, ncap);
+    LV_REALLOC(d_nidx, uint32_t, ncap);
+    LV_REALLOC(d_nidx_sorted, uint32_t, ncap);
+    LV_REALLOC(d_nalive, uint32_t, ncap);
+    LV_REALLOC(d_napos, uint32_t, ncap);
+    LV_REALLOC(d_rank, uint32_t, ncap * 27 * SORTED_LEVELS);
+    for (int l = 0; l < INC_LEVELS; ++l) LV_REALLOC(d_work[l], uint32_t, ncap * 27);
+    work_cap = (uint32_t)(ncap * 27 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ncap * 27);
+    if (d_ntmp) hipFree(d_ntmp);
+    d_ntmp = nullptr;
+    size_t a = 0, b = 0;
+    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(nullptr, a, d_nkeys, d_nkeys_sorted, d_nidx, d_nidx_sorted, (int)ncap, 0, 63,
+                                                           (hipStream_t)0));
+    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_nalive, d_napos, (int)ncap, (hipStream_t)0));
+    ntmp_bytes = a > b ? a : b;
+    LV_HIP(hipMalloc(&d_ntmp, ntmp_bytes));
+    batch_cap = ncap;
+    return LV_OK;
+}
+
+int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
+    if (have_boxes) return LV_OK;
+    const uint32_t size = next_pow2((uint64_t)capacity * 4);
+    if (size > box_size) {
+        LV_REALLOC(d_box, uint4, size);
+        box_size = size;
+    }
+    if (box_next_cap < capacity) {
+        LV_REALLOC(d_box_next, uint32_t, capacity);
+        box_next_cap = capacity;
+    }
+    LV_HIP(hipMemsetAsync(d_box, 0xFF, (size_t)box_size * sizeof(uint4), stream));
+    LV_HIP(hipMemsetAsync(&d_cnt->box_slots_used, 0, sizeof(uint32_t), stream));
+    BoxRW Bx{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
+    if (n_ids) hipLaunchKernelGGL(box_build_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, Bx, d_orig, n_ids, d_cnt);
+    LV_HIP(hipGetLastError());
+    have_boxes = true;
+    return LV_OK;
+}
+
+bool MapStore::needs_relinearise(size_t incoming) const {
+    if (!built) return false;
+    if ((uint64_t)n_ids + incoming > 0xFFFFFFF0ull) return true;
+    const uint64_t dead = (uint64_t)n_ids - m;
+    if (dead > 65536 && dead > (uint64_t)n_ids / 3) return true;                      // a third of the id space is dead
+    return false;
+}
+
+int MapStore::relinearise(hipStream_t stream) {
+    int rc = ensure_alive_scratch();
+    if (rc) return rc;
+    if (n_ids) {
+        const uint32_t grid = (n_ids + 255) / 256;
+        hipLaunchKernelGGL(inc_alive_flags_kernel, dim3(grid), dim3(256), 0, stream, d_orig, n_ids, d_alive);
+        size_t tmp = ascan_tmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ascan_tmp, tmp, d_alive, d_apos, (int)n_ids, stream));
+        hipLaunchKernelGGL(inc_compact_kernel, dim3(grid), dim3(256), 0, stream, d_orig, d_alive, d_apos, n_ids, d_orig2);
+        uint32_t last_pos = 0, last_alive = 0;
+        LV_HIP(hipMemcpyAsync(&last_pos, d_apos + (n_ids - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipMemcpyAsync(&last_alive, d_alive + (n_ids - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        float4* t = d_orig;
+        d_orig = d_orig2;
+        d_orig2 = t;
+        n_ids = last_pos + last_alive;
+    }
+    m = n_ids;
+    ++relinearisations;
+    return rebuild(stream);
+}
+
+int MapStore::kill_dead_list(hipStream_t stream, uint32_t n_dead) {
+    if (n_dead == 0) return LV_OK;
+    const uint64_t threads = (uint64_t)n_dead * INC_SLOTS_PER_POINT;
+    hipLaunchKernelGGL(inc_kill_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, rw(), d_dead, n_dead);
+    LV_HIP(hipGetLastError());
+    return LV_OK;
+}
+
+static int reset_batch_counters(MapStore& S, hipStream_t stream) {
+    // work_n .. dropped are contiguous (MapCounters)
+    LV_HIP(hipMemsetAsync(&S.d_cnt->work_n[0], 0, offsetof(MapCounters, box_slots_used) - offsetof(MapCounters, work_n), stream));
+    return LV_OK;
+}
+
+int MapStore::ensure_counters() {
+    if (d_cnt) return LV_OK;
+    LV_HIP(hipMalloc(&d_cnt, sizeof(MapCounters)));
+    LV_HIP(hipHostMalloc((void**)&h_cnt, sizeof(MapCounters), hipHostMallocDefault));
+    std::memset(h_cnt, 0, sizeof(MapCounters));
+    LV_HIP(hipMemset(d_cnt, 0, sizeof(MapCounters)));
+    return LV_OK;
+}
+
+int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float box_length, bool build_if_empty) {
+    if (k == 0) return LV_OK;
+    int rc;
+    if ((!built || m == 0) && downsample && !build_if_empty) {
+        // KD_TREE::Add_Points(points, true) into an EMPTY map: the box rule among the new points themselves (every box
+        // keeps, of its points in input order, the one the sequential rule leaves), then a build from the survivors
+        n_ids = 0;
+        m = 0;
+        built = false;
+        rc = reserve(k);
+        if (rc) return rc;
+        rc = ensure_counters();
+        if (rc) return rc;
+        rc = reset_batch_counters(*this, stream);
+        if (rc) return rc;
+        have_boxes = false;
+        rc = ensure_boxes(stream, box_length);
+        if (rc) return rc;
+        MapRW M{};
+        M.orig = d_orig;
+        M.cnt = d_cnt;
+        const BoxRW Bx{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
+        const uint32_t gk = (k + 255) / 256;
+        hipLaunchKernelGGL(inc_box_keys_kernel, dim3(gk), dim3(256), 0, stream, M, d_new, k, box_length, d_nkeys, d_nidx, d_nalive, 1, 0);
+        size_t tmp = ntmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_ntmp, tmp, d_nkeys, d_nkeys_sorted, d_nidx, d_nidx_sorted, (int)k, 0, 63,
+                                                               stream));
+        hipLaunchKernelGGL(inc_box_rule_kernel, dim3(gk), dim3(256), 0, stream, Bx, d_orig, d_new, d_nkeys_sorted, d_nidx_sorted, k,
+                           d_nalive, d_dead, (uint32_t)dead_cap, d_cnt);
+        tmp = ntmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ntmp, tmp, d_nalive, d_napos, (int)k, stream));
+        hipLaunchKernelGGL(inc_commit_points_kernel, dim3(gk), dim3(256), 0, stream, M, Bx, 0, d_new, d_nalive, d_napos, k, 0u);
+        LV_HIP(hipGetLastError());
+        LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        n_ids = h_cnt->n_new;
+        dropped_total += h_cnt->dropped;
+        origin_set = false;
+        return rebuild(stream);
+    }
+    if (!built || m == 0) {
+        // Mapper::add on an empty map builds it from the points as they are (Mapper.cpp:22-27): keep the finite ones
+        n_ids = 0;
+        m = 0;
+        rc = reserve(k);
+        if (rc) return rc;
+        rc = ensure_alive_scratch();
+        if (rc) return rc;
+        const uint32_t grid = (k + 255) / 256;
+        hipLaunchKernelGGL(staged_ok_kernel, dim3(grid), dim3(256), 0, stream, d_new, k, d_alive);
+        size_t tmp = ascan_tmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ascan_tmp, tmp, d_alive, d_apos, (int)k, stream));
+        hipLaunchKernelGGL(inc_compact_kernel, dim3(grid), dim3(256), 0, stream, d_new, d_alive, d_apos, k, d_orig);
+        uint32_t last_pos = 0, last_ok = 0;
+        LV_HIP(hipMemcpyAsync(&last_pos, d_apos + (k - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipMemcpyAsync(&last_ok, d_alive + (k - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        n_ids = last_pos + last_ok;
+        dropped_total += k - n_ids;
+        origin_set = false;
+        return rebuild(stream);
+    }
+    if (needs_relinearise(k)) {
+        rc = relinearise(stream);
+        if (rc) return rc;
+    }
+    rc = reserve((size_t)n_ids + k);
+    if (rc) return rc;
+    if (have_boxes && box_next_cap < capacity) have_boxes = false;
+    rc = reset_batch_counters(*this, stream);
+    if (rc) return rc;
+    const MapRW M = rw();
+    BoxRW Bx{};
+    if (downsample) {
+        rc = ensure_boxes(stream, box_length);
+        if (rc) return rc;
+    }
+    if (have_boxes)
+        Bx = BoxRW{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
+    const int B = 256;
+    const uint32_t gk = (k + B - 1) / B;
+    hipLaunchKernelGGL(inc_box_keys_kernel, dim3(gk), dim3(B), 0, stream, M, d_new, k, box_length, d_nkeys, d_nidx, d_nalive, downsample, 1);
+    uint32_t n_dead = 0;
+    if (downsample) {
+        size_t tmp = ntmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_ntmp, tmp, d_nkeys, d_nkeys_sorted, d_nidx, d_nidx_sorted, (int)k, 0, 63,
+                                                               stream));
+        hipLaunchKernelGGL(inc_box_rule_kernel, dim3(gk), dim3(B), 0, stream, Bx, d_orig, d_new, d_nkeys_sorted, d_nidx_sorted, k,
+                           d_nalive, d_dead, (uint32_t)dead_cap, d_cnt);
+    }
+    {
+        size_t tmp = ntmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ntmp, tmp, d_nalive, d_napos, (int)k, stream));
+    }
+    hipLaunchKernelGGL(inc_commit_points_kernel, dim3(gk), dim3(B), 0, stream, M, Bx, have_boxes ? 1 : 0, d_new, d_nalive, d_napos, k,
+                       n_ids);
+    if (downsample) {   // the occupants that lost: how many is only known on the device
+        LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
+        rc = kill_dead_list(stream, n_dead);
+        if (rc) return rc;
+    }
+    const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
+    const uint32_t g_all = (uint32_t)((t_all + B - 1) / B), g_rep = (uint32_t)((t_rep + B - 1) / B);
+    const uint64_t w_max = t_all < work_cap ? t_all : work_cap;
+    const uint32_t g_work = (uint32_t)((w_max + B - 1) / B);
+    hipLaunchKernelGGL(inc_register_kernel, dim3(g_all), dim3(B), 0, stream, M, d_new, d_nalive, k);
+    hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_work), dim3(B), 0, stream, M);
+    hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, d_new, d_nalive, d_napos, k, n_ids);
+    hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, d_new, d_nalive, d_napos, k, n_ids, d_rank);
+    hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, d_new, d_nalive, d_napos, k, n_ids, d_rank);
+    hipLaunchKernelGGL(inc_commit_kernel, dim3(g_work), dim3(B), 0, stream, M);
+    LV_HIP(hipGetLastError());
+    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    n_ids += h_cnt->n_new;
+    m += h_cnt->n_new;
+    m -= n_dead;
+    dropped_total += h_cnt->dropped;
+    ++incremental_adds;
+    refresh_view();
+    if (h_cnt->overflow) return relinearise(stream);   // a pool / table ran full: the new points are in `orig`, rebuild around them
+    return LV_OK;
+}
+
+int MapStore::evict_box(hipStream_t stream, const float lo[3], const float hi[3], int keep_inside, uint32_t* n_evicted) {
+    if (n_evicted) *n_evicted = 0;
+    if (!built || m == 0) return LV_OK;
+    int rc = reset_batch_counters(*this, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(inc_evict_box_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, d_orig, n_ids, lo[0], lo[1], lo[2], hi[0],
+                       hi[1], hi[2], keep_inside, d_dead, (uint32_t)dead_cap, d_cnt);
+    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    const uint32_t n_dead = h_cnt->n_dead;
+    rc = kill_dead_list(stream, n_dead);
+    if (rc) return rc;
+    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    m -= n_dead;
+    if (n_evicted) *n_evicted = n_dead;
+    refresh_view();
+    if (m == 0) { n_ids = 0; return rebuild(stream); }
+    return LV_OK;
+}
+
+int MapStore::evict_oldest(hipStream_t stream, uint32_t n_oldest, uint32_t* n_evicted) {
+    if (n_evicted) *n_evicted = 0;
+    if (!built || m == 0 || n_oldest == 0) return LV_OK;
+    if (n_oldest > m) n_oldest = m;
+    int rc = ensure_alive_scratch();
+    if (rc) return rc;
+    rc = reset_batch_counters(*this, stream);
+    if (rc) return rc;
+    const uint32_t grid = (n_ids + 255) / 256;
+    hipLaunchKernelGGL(inc_alive_flags_kernel, dim3(grid), dim3(256), 0, stream, d_orig, n_ids, d_alive);
+    size_t tmp = ascan_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ascan_tmp, tmp, d_alive, d_apos, (int)n_ids, stream));
+    hipLaunchKernelGGL(inc_evict_oldest_kernel, dim3(grid), dim3(256), 0, stream, d_orig, n_ids, d_apos, n_oldest, d_dead,
+                       (uint32_t)dead_cap, d_cnt);
+    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    const uint32_t n_dead = h_cnt->n_dead;
+    rc = kill_dead_list(stream, n_dead);
+    if (rc) return rc;
+    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    m -= n_dead;
+    if (n_evicted) *n_evicted = n_dead;
+    refresh_view();
+    if (m == 0) { n_ids = 0; return rebuild(stream); }
+    return LV_OK;
 }
 
 }  // namespace lv

@@ -1,0 +1,570 @@
+// lv_mapinc.hpp — incremental maintenance of the map's search structure (row f-1 of SURVEY.md §8).
+//
+// Replaces, per mapping cycle, KD_TREE<Point>::Add_Points(points, downsample) (call site reference
+// src/Modules/Mapper.cpp:73-76, every cycle from src/main.cpp:102) without rebuilding anything: only the buckets /
+// voxel lists whose 27-block contains a new or deleted point are touched.
+//
+//   points      ids are handed out in insertion order and never reused; a deleted point keeps its slot in `orig`
+//               with x = +inf.  Relative order of the living == the reference's map order.
+//   levels 0,1  neighbourhood buckets with slack: a new point is appended to the 27 buckets of its voxel's
+//               neighbours (ids only grow, so "ascending id" survives an append once the batch's own tail is
+//               ordered); a bucket that runs out of room moves to fresh space at the end of its pool.  A deleted
+//               point is found by binary search over the bucket's ids and its x set to +inf (tombstone).
+//   level 2     the same buckets, unordered (searched with id keys): appends go anywhere in the tail; every point
+//               remembers its position in each of its 27 buckets (backptr), so a deletion is 27 direct writes.
+//   voxel lists one list per level-2 voxel, unordered: append / tombstone in the point's own voxel only.
+//   0.2 m boxes ikd-Tree's down-sampling rule needs "the points currently in this box": a hash table
+//               box -> chain of ids (box_next), built lazily by the first down-sampling insert.
+//
+// Every kernel here is one-thread-per-item with plain atomics (no wave intrinsics, no LDS, no barriers), so the
+// same source also compiles for the host in tests/emu (a sequential emulation that checks the bookkeeping against
+// the CPU restatement of the reference's rule); the product only ever runs them on the GPU.
+//
+// An insert batch of k points (already staged on the device):
+//   box_keys -> stable sort by box -> box_rule (sequential replay per box, [UPSTREAM-RECALL ikd-Tree]) -> scan
+//   -> commit_points (ids, orig, box chains) -> kill (tombstones for the occupants that lost) -> register (find /
+//   create the 27 + 27 + 1 slots of every new point, count) -> reserve (room; relocation) -> fill (ids into the
+//   tails) -> rank (order of each tail) -> place -> commit (counts).  Any pool or table running full raises
+//   `overflow`: the mutating kernels then do nothing and the host re-linearises (compaction + full rebuild).
+#pragma once
+
+#include "lv_device.hpp"
+
+namespace lv {
+
+constexpr uint32_t ID_NONE = 0xFFFFFFFFu;
+constexpr int INC_SLOTS_PER_POINT = 27 * REPL_LEVELS + 1;   // 27 buckets on each of the levels 0, 1, 2 + its level-2 voxel's list
+constexpr int INC_LEVELS = REPL_LEVELS + 1;                 // tables: bt[0], bt[1], bt[2], voxel lists
+constexpr int CELL_SLOT = REPL_LEVELS;                      // index of the voxel-list table in the per-table arrays
+
+struct MapCounters {
+    uint32_t pool_used[INC_LEVELS];    // entries handed out in the level's pool (bucket runs incl. slack)
+    uint32_t slots_used[INC_LEVELS];   // occupied table slots
+    uint32_t work_n[INC_LEVELS];       // slots touched by the batch in flight
+    uint32_t n_new;                    // surviving new points of the batch
+    uint32_t n_dead;                   // length of the dead list
+    uint32_t overflow;                 // a pool, a table or a work list ran full: re-linearise
+    uint32_t dropped;                  // new points that were not finite or outside the voxel range
+    uint32_t box_slots_used;
+    uint32_t tombstones;               // bucket / list entries turned into tombstones since the last rebuild
+    uint32_t pad_;
+};
+
+struct LevelRW {
+    uint4* table;
+    SlotAux* aux;
+    uint32_t mask;
+    uint32_t shift;
+    uint32_t slot_limit;   // occupied slots beyond this raise `overflow` (load factor guard)
+    uint32_t pool_cap;     // entries in the level's pool
+};
+
+struct MapRW {
+    float4* orig;
+    LevelRW lv[INC_LEVELS];          // [0], [1], [2]: bucket tables; [CELL_SLOT]: level-2 voxel-list table
+    float* bxyz[SORTED_LEVELS];
+    uint32_t* bidx[SORTED_LEVELS];
+    float4* bucket4;                 // level-2 buckets
+    uint32_t* backptr;               // [id * 27 + c]: position of point id inside the level-2 bucket of its neighbour c
+    float4* cell4;
+    float origin[3];
+    float inv_cell;
+    MapCounters* cnt;
+    uint32_t* work[INC_LEVELS];
+    uint32_t work_cap;
+};
+
+struct BoxRW {
+    uint4* table;        // {key lo, key hi, head id, -}; memset 0xFF: EMPTY key, head ID_NONE
+    uint32_t* next;      // chain link by id
+    uint32_t mask;
+    uint32_t shift;
+    uint32_t slot_limit;
+    float len;           // box_length (0.2 m, Mapper.cpp:65)
+};
+
+// The kernels below are compiled by ONE translation unit (lv_map.hip, or the host emulation in tests/emu): it
+// defines LV_MAPINC_KERNELS before including this header; everybody else only sees the types above.
+#ifdef LV_MAPINC_KERNELS
+
+__device__ __forceinline__ bool pt_alive(const float4& p) { return p.x < __uint_as_float(0x7F800000u) && p.x > -__uint_as_float(0x7F800000u); }
+__device__ __forceinline__ float pos_inf() { return __uint_as_float(0x7F800000u); }
+
+__device__ __forceinline__ uint64_t entry_key(const uint4& e) { return (uint64_t)e.x | ((uint64_t)e.y << 32); }
+
+// slot of `key`, or ID_NONE
+__device__ __forceinline__ uint32_t table_find(const uint4* table, uint32_t mask, uint32_t shift, uint64_t key) {
+    uint32_t slot = hash_cell(key, shift) & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        const uint64_t ek = entry_key(table[slot]);
+        if (ek == key) return slot;
+        if (ek == EMPTY_KEY) return ID_NONE;
+        slot = (slot + 1) & mask;
+    }
+    return ID_NONE;
+}
+
+// slot of `key`, inserting it (run {start 0, count 0}) if absent; ID_NONE if the table is full
+__device__ __forceinline__ uint32_t table_find_or_create(const LevelRW& L, uint64_t key, uint32_t* slots_used, uint32_t* overflow) {
+    uint32_t slot = hash_cell(key, L.shift) & L.mask;
+    for (uint32_t probes = 0; probes <= L.mask; ++probes) {
+        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&L.table[slot]);
+        const unsigned long long old = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (old == (unsigned long long)EMPTY_KEY) {
+            L.table[slot].z = 0u;
+            L.table[slot].w = 0u;
+            const uint32_t n = atomicAdd(slots_used, 1u);
+            if (n + 1u > L.slot_limit) atomicExch(overflow, 1u);
+            return slot;
+        }
+        if (old == (unsigned long long)key) return slot;
+        slot = (slot + 1) & L.mask;
+    }
+    atomicExch(overflow, 1u);
+    return ID_NONE;
+}
+
+// (level, neighbour) of work item w in [0, INC_SLOTS_PER_POINT): the key of the slot that must hold point p.
+// Returns false if the neighbour voxel is outside the coordinate range.
+__device__ __forceinline__ bool inc_slot_key(const MapRW& M, const float4& p, int w, int& level, uint64_t& key) {
+    const int cx = cell_coord(p.x, M.origin[0], M.inv_cell), cy = cell_coord(p.y, M.origin[1], M.inv_cell),
+              cz = cell_coord(p.z, M.origin[2], M.inv_cell);
+    if (w < 27 * REPL_LEVELS) {
+        level = w / 27;
+        const int c = w % 27;
+        const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+        const uint32_t nx = (uint32_t)((cx >> level) + dx), ny = (uint32_t)((cy >> level) + dy), nz = (uint32_t)((cz >> level) + dz);
+        if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) return false;
+        key = pack_cell(nx, ny, nz);
+    } else {
+        level = CELL_SLOT;
+        key = pack_cell((uint32_t)(cx >> CELL_LEVEL), (uint32_t)(cy >> CELL_LEVEL), (uint32_t)(cz >> CELL_LEVEL));
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool inc_point_ok(const MapRW& M, const float4& p) {
+    if (!(pt_alive(p) && p.y == p.y && p.z == p.z && fabsf(p.y) < pos_inf() && fabsf(p.z) < pos_inf())) return false;
+    const int cx = cell_coord(p.x, M.origin[0], M.inv_cell), cy = cell_coord(p.y, M.origin[1], M.inv_cell),
+              cz = cell_coord(p.z, M.origin[2], M.inv_cell);
+    const int amax = max(abs(cx - CELL_OFFSET), max(abs(cy - CELL_OFFSET), abs(cz - CELL_OFFSET)));
+    return amax < CELL_FAR;
+}
+
+// ---- ikd-Tree box rule --------------------------------------------------------------------------------------
+__device__ __forceinline__ int inc_box_coord(float v, float len) {
+    float f = floorf(v / len);
+    f = fminf(fmaxf(f, -1048000.0f), 1048000.0f);
+    return (int)f + CELL_OFFSET;
+}
+__device__ __forceinline__ uint64_t inc_box_key(const float4& p, float len) {
+    return pack_cell((uint32_t)inc_box_coord(p.x, len), (uint32_t)inc_box_coord(p.y, len), (uint32_t)inc_box_coord(p.z, len));
+}
+// calc_dist(point, centre of its box) [UPSTREAM-RECALL ikd-Tree Add_Points]: f32, centre = min + (max - min) / 2 with the
+// division in double as upstream writes it
+__device__ __forceinline__ float inc_box_center_dist(const float4& p, float len) {
+    const float c[3] = {p.x, p.y, p.z};
+    float mid[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float vmin = floorf(c[a] / len) * len;
+        const float vmax = vmin + len;
+        mid[a] = (float)((double)vmin + (double)(vmax - vmin) / 2.0);
+    }
+    const float dx = p.x - mid[0], dy = p.y - mid[1], dz = p.z - mid[2];
+    const float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    const float s = sx + sy;
+    return s + sz;
+}
+
+// the slot of a box, inserting the key if absent (head stays ID_NONE from the table's 0xFF fill)
+__device__ __forceinline__ uint32_t box_find_or_create(const BoxRW& B, uint64_t key, MapCounters* cnt) {
+    uint32_t slot = hash_cell(key, B.shift) & B.mask;
+    for (uint32_t probes = 0; probes <= B.mask; ++probes) {
+        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&B.table[slot]);
+        const unsigned long long old = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (old == (unsigned long long)EMPTY_KEY) {
+            const uint32_t n = atomicAdd(&cnt->box_slots_used, 1u);
+            if (n + 1u > B.slot_limit) atomicExch(&cnt->overflow, 1u);
+            return slot;
+        }
+        if (old == (unsigned long long)key) return slot;
+        slot = (slot + 1) & B.mask;
+    }
+    atomicExch(&cnt->overflow, 1u);
+    return ID_NONE;
+}
+
+// every living id -> its box chain (first down-sampling insert after a (re)build)
+__global__ void box_build_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_ids) return;
+    const float4 p = orig[id];
+    if (!pt_alive(p)) { B.next[id] = ID_NONE; return; }
+    const uint32_t slot = box_find_or_create(B, inc_box_key(p, B.len), cnt);
+    if (slot == ID_NONE) return;
+    B.next[id] = atomicExch(&B.table[slot].z, id);
+}
+
+// keys of the new points for the stable sort by box; points that cannot be inserted sort last
+// (check_range == 0: the map is empty and has no origin yet — only finiteness is checked, the build that follows
+// validates the extent)
+__global__ void inc_box_keys_kernel(MapRW M, const float4* __restrict__ newp, uint32_t k, float len, uint64_t* __restrict__ keys,
+                                    uint32_t* __restrict__ idx, uint32_t* __restrict__ alive, int downsample, int check_range) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const float4 p = newp[j];
+    idx[j] = j;
+    const bool finite = pt_alive(p) && fabsf(p.y) < pos_inf() && fabsf(p.z) < pos_inf();
+    if (!(check_range ? inc_point_ok(M, p) : finite)) {
+        keys[j] = ~0ull >> 1;
+        alive[j] = 0u;
+        atomicAdd(&M.cnt->dropped, 1u);
+        return;
+    }
+    keys[j] = inc_box_key(p, len);
+    alive[j] = downsample ? 0u : 1u;   // without down-sampling every insertable point lives
+}
+
+// One thread per box touched by the batch replays upstream's sequential rule: for every new point p of the box, in
+// input order, the point nearest to the box centre among {p} U (points currently in the box) survives if the box
+// held more than one point or p itself is that nearest point (occupants must be STRICTLY closer to beat p; among
+// equally near occupants the oldest wins); otherwise the box is left alone.  Old occupants that lose are put on
+// the dead list (coordinates + id) and their slot in `orig` is marked; `alive` flags the new points that live.
+__global__ void inc_box_rule_kernel(BoxRW B, float4* __restrict__ orig, const float4* __restrict__ newp,
+                                    const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ idx_sorted, uint32_t k,
+                                    uint32_t* __restrict__ alive, float4* __restrict__ dead, uint32_t dead_cap, MapCounters* cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const uint64_t key = keys_sorted[i];
+    if (key == (~0ull >> 1)) return;                       // dropped points
+    if (i > 0 && keys_sorted[i - 1] == key) return;        // not the head of its group
+    uint32_t end = i + 1;
+    while (end < k && keys_sorted[end] == key) ++end;
+    const uint32_t bslot = table_find(B.table, B.mask, B.shift, key);
+    const uint32_t head = bslot == ID_NONE ? ID_NONE : B.table[bslot].z;
+    // living occupants of the box
+    uint32_t nE = 0, only = ID_NONE;
+    for (uint32_t e = head; e != ID_NONE; e = B.next[e])
+        if (pt_alive(orig[e])) { ++nE; only = e; }
+    bool multi = nE > 1;
+    bool cur_new = false;                                   // survivor so far: a new point (index) or an old id
+    uint32_t cur = nE == 1 ? only : ID_NONE;
+    float dcur = nE == 1 ? inc_box_center_dist(orig[only], B.len) : 0.f;
+    bool changed = false;
+    for (uint32_t g = i; g < end; ++g) {
+        const uint32_t j = idx_sorted[g];
+        const float4 p = newp[j];
+        float md = inc_box_center_dist(p, B.len);
+        bool best_new = true;
+        uint32_t best = j;
+        if (multi) {
+            for (uint32_t e = head; e != ID_NONE; e = B.next[e]) {
+                const float4 q = orig[e];
+                if (!pt_alive(q)) continue;
+                const float d = inc_box_center_dist(q, B.len);
+                if (d < md || (d == md && !best_new && e < best)) { md = d; best = e; best_new = false; }
+            }
+        } else if (cur != ID_NONE) {
+            if (dcur < md) { md = dcur; best = cur; best_new = cur_new; }
+        }
+        if (multi || (best_new && best == j)) {
+            // everything in the box but `best` goes
+            if (multi) {
+                for (uint32_t e = head; e != ID_NONE; e = B.next[e]) {
+                    const float4 q = orig[e];
+                    if (!pt_alive(q) || (!best_new && e == best)) continue;
+                    const uint32_t di = atomicAdd(&cnt->n_dead, 1u);
+                    if (di < dead_cap) dead[di] = make_float4(q.x, q.y, q.z, __uint_as_float(e));
+                    else atomicExch(&cnt->overflow, 1u);
+                    orig[e].x = pos_inf();
+                }
+            } else if (cur != ID_NONE) {
+                if (cur_new) {
+                    alive[cur] = 0u;
+                } else {
+                    const float4 q = orig[cur];
+                    const uint32_t di = atomicAdd(&cnt->n_dead, 1u);
+                    if (di < dead_cap) dead[di] = make_float4(q.x, q.y, q.z, __uint_as_float(cur));
+                    else atomicExch(&cnt->overflow, 1u);
+                    orig[cur].x = pos_inf();
+                }
+            }
+            if (best_new) alive[best] = 1u;
+            cur = best;
+            cur_new = best_new;
+            dcur = md;
+            multi = false;
+            changed = true;
+        }
+    }
+    if (changed && bslot != ID_NONE) {
+        // the box now holds exactly one point: an old id (its chain shrinks to itself) or a new point (linked by
+        // inc_commit_points_kernel once its id is known)
+        if (cur_new) {
+            B.table[bslot].z = ID_NONE;
+        } else {
+            B.table[bslot].z = cur;
+            B.next[cur] = ID_NONE;
+        }
+    }
+}
+
+// surviving new points get their ids (id_base + rank among the survivors, input order), their slot in `orig` and,
+// if the box table exists, their place at the head of their box chain
+__global__ void inc_commit_points_kernel(MapRW M, BoxRW B, int have_boxes, const float4* __restrict__ newp,
+                                         const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                         uint32_t id_base) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    if (j == k - 1) M.cnt->n_new = apos[j] + alive[j];
+    if (!alive[j]) return;
+    const uint32_t id = id_base + apos[j];
+    const float4 p = newp[j];
+    M.orig[id] = make_float4(p.x, p.y, p.z, 0.f);
+    if (have_boxes) {
+        const uint32_t slot = box_find_or_create(B, inc_box_key(p, B.len), M.cnt);
+        if (slot == ID_NONE) return;
+        B.next[id] = atomicExch(&B.table[slot].z, id);
+    }
+}
+
+// ---- tombstones ------------------------------------------------------------------------------------------------
+// dead[j] = {x, y, z, id} of a point that left the map: one thread per (point, slot that holds it)
+__global__ void inc_kill_kernel(MapRW M, const float4* __restrict__ dead, uint32_t n_dead) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
+    const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
+    if (j >= n_dead) return;
+    const float4 p = dead[j];
+    const uint32_t id = __float_as_uint(p.w);
+    int level;
+    uint64_t key;
+    if (!inc_slot_key(M, p, w, level, key)) return;
+    const LevelRW& L = M.lv[level];
+    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
+    if (slot == ID_NONE) return;
+    const uint4 e = L.table[slot];
+    if (level < SORTED_LEVELS) {
+        const uint32_t* ids = M.bidx[level] + e.z;
+        uint32_t lo = 0, hi = e.w;        // first position with ids[pos] >= id (ids ascend, tombstones keep theirs)
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (ids[mid] < id) lo = mid + 1; else hi = mid;
+        }
+        if (lo < e.w && ids[lo] == id) {
+            M.bxyz[level][((size_t)e.z + lo) * 3] = pos_inf();
+            atomicAdd(&M.cnt->tombstones, 1u);
+        }
+    } else if (level < REPL_LEVELS) {
+        const uint32_t pos = M.backptr[(size_t)id * 27 + (uint32_t)(w % 27)];
+        if (pos < e.w && __float_as_uint(M.bucket4[(size_t)e.z + pos].w) == id) {
+            M.bucket4[(size_t)e.z + pos].x = pos_inf();
+            atomicAdd(&M.cnt->tombstones, 1u);
+        }
+    } else {
+        float4* run = M.cell4 + e.z;
+        for (uint32_t i = 0; i < e.w; ++i)
+            if (__float_as_uint(run[i].w) == id) {
+                run[i].x = pos_inf();
+                atomicAdd(&M.cnt->tombstones, 1u);
+                break;
+            }
+    }
+}
+
+// ---- appends ---------------------------------------------------------------------------------------------------
+// pass 1: find / create the slots a surviving new point goes into, count what each slot will receive, list the
+// slots touched
+__global__ void inc_register_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
+    const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
+    if (j >= k || !alive[j]) return;
+    int level;
+    uint64_t key;
+    if (!inc_slot_key(M, newp[j], w, level, key)) return;
+    const LevelRW& L = M.lv[level];
+    const uint32_t slot = table_find_or_create(L, key, &M.cnt->slots_used[level], &M.cnt->overflow);
+    if (slot == ID_NONE) return;
+    if (atomicAdd(&L.aux[slot].pending, 1u) == 0u) {
+        const uint32_t wi = atomicAdd(&M.cnt->work_n[level], 1u);
+        if (wi < M.work_cap) M.work[level][wi] = slot;
+        else atomicExch(&M.cnt->overflow, 1u);
+    }
+}
+
+// pass 2: one thread per touched slot makes room: a run that cannot take its pending entries moves to fresh
+// space at the end of the pool (old contents copied, 1.5x the new size reserved)
+__global__ void inc_reserve_kernel(MapRW M) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int level = 0; level < INC_LEVELS; ++level) {
+        if (t >= M.cnt->work_n[level] || t >= M.work_cap) continue;
+        const LevelRW& L = M.lv[level];
+        const uint32_t slot = M.work[level][t];
+        const uint4 e = L.table[slot];
+        SlotAux a = L.aux[slot];
+        const uint32_t need = e.w + a.pending;
+        if (need > a.cap) {
+            const uint32_t extra = need / 2u > 8u ? need / 2u : 8u;
+            const uint32_t ncap = need + extra;
+            const uint32_t ns = atomicAdd(&M.cnt->pool_used[level], ncap);
+            if ((uint64_t)ns + ncap > (uint64_t)L.pool_cap) {
+                atomicExch(&M.cnt->overflow, 1u);
+            } else {
+                if (level < SORTED_LEVELS) {
+                    float* xs = M.bxyz[level];
+                    uint32_t* is = M.bidx[level];
+                    for (uint32_t i = 0; i < e.w; ++i) {
+                        xs[((size_t)ns + i) * 3 + 0] = xs[((size_t)e.z + i) * 3 + 0];
+                        xs[((size_t)ns + i) * 3 + 1] = xs[((size_t)e.z + i) * 3 + 1];
+                        xs[((size_t)ns + i) * 3 + 2] = xs[((size_t)e.z + i) * 3 + 2];
+                        is[(size_t)ns + i] = is[(size_t)e.z + i];
+                    }
+                } else {
+                    float4* run = level < REPL_LEVELS ? M.bucket4 : M.cell4;
+                    for (uint32_t i = 0; i < e.w; ++i) run[(size_t)ns + i] = run[(size_t)e.z + i];
+                }
+                L.table[slot].z = ns;
+                L.aux[slot].cap = ncap;
+            }
+        }
+        L.aux[slot].tail0 = e.w;
+    }
+}
+
+// pass 3: ids into the tails of the sorted levels (arbitrary order inside a tail); the unordered runs (level-2 buckets,
+// voxel lists) take the whole record at once
+__global__ void inc_fill_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base) {
+    if (M.cnt->overflow) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
+    const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
+    if (j >= k || !alive[j]) return;
+    const float4 p = newp[j];
+    int level;
+    uint64_t key;
+    if (!inc_slot_key(M, p, w, level, key)) return;
+    const LevelRW& L = M.lv[level];
+    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
+    if (slot == ID_NONE) return;
+    const uint32_t id = id_base + apos[j];
+    const uint32_t pos = L.aux[slot].tail0 + atomicAdd(&L.aux[slot].fill, 1u);
+    const size_t at = (size_t)L.table[slot].z + pos;
+    if (level < SORTED_LEVELS) {
+        M.bidx[level][at] = id;
+    } else if (level < REPL_LEVELS) {
+        M.bucket4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+        M.backptr[(size_t)id * 27 + (uint32_t)(w % 27)] = pos;
+    } else {
+        M.cell4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+    }
+}
+
+// pass 4: rank of every new bucket entry among the ids of its tail (levels 0, 1)
+__global__ void inc_rank_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, uint32_t* __restrict__ rank) {
+    if (M.cnt->overflow) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
+    const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
+    if (j >= k || !alive[j]) return;
+    int level;
+    uint64_t key;
+    if (!inc_slot_key(M, newp[j], w, level, key)) return;
+    const LevelRW& L = M.lv[level];
+    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
+    if (slot == ID_NONE) return;
+    const SlotAux a = L.aux[slot];
+    const uint32_t* ids = M.bidx[level] + (size_t)L.table[slot].z + a.tail0;
+    const uint32_t id = id_base + apos[j];
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < a.pending; ++i) r += ids[i] < id ? 1u : 0u;
+    rank[t] = r;
+}
+
+// pass 5: every new bucket entry goes to its ranked place (all reads of pass 4 are done: kernel boundary)
+__global__ void inc_place_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {
+    if (M.cnt->overflow) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
+    const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
+    if (j >= k || !alive[j]) return;
+    const float4 p = newp[j];
+    int level;
+    uint64_t key;
+    if (!inc_slot_key(M, p, w, level, key)) return;
+    const LevelRW& L = M.lv[level];
+    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
+    if (slot == ID_NONE) return;
+    const size_t at = (size_t)L.table[slot].z + L.aux[slot].tail0 + rank[t];
+    M.bxyz[level][at * 3 + 0] = p.x;
+    M.bxyz[level][at * 3 + 1] = p.y;
+    M.bxyz[level][at * 3 + 2] = p.z;
+    M.bidx[level][at] = id_base + apos[j];
+}
+
+// pass 6: the touched slots take their tails in
+__global__ void inc_commit_kernel(MapRW M) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ovf = M.cnt->overflow != 0u;
+#pragma unroll
+    for (int level = 0; level < INC_LEVELS; ++level) {
+        if (t >= M.cnt->work_n[level] || t >= M.work_cap) continue;
+        const LevelRW& L = M.lv[level];
+        const uint32_t slot = M.work[level][t];
+        if (!ovf) L.table[slot].w += L.aux[slot].pending;
+        L.aux[slot].pending = 0u;
+        L.aux[slot].fill = 0u;
+    }
+}
+
+// ---- eviction --------------------------------------------------------------------------------------------------
+// living points outside (keep_inside != 0) / inside (keep_inside == 0) the axis-aligned box [lo, hi] leave the map
+__global__ void inc_evict_box_kernel(float4* __restrict__ orig, uint32_t n_ids, float lx, float ly, float lz, float hx, float hy,
+                                     float hz, int keep_inside, float4* __restrict__ dead, uint32_t dead_cap, MapCounters* cnt) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_ids) return;
+    const float4 p = orig[id];
+    if (!pt_alive(p)) return;
+    const bool inside = p.x >= lx && p.x <= hx && p.y >= ly && p.y <= hy && p.z >= lz && p.z <= hz;
+    if (inside == (keep_inside != 0)) return;
+    const uint32_t di = atomicAdd(&cnt->n_dead, 1u);
+    if (di < dead_cap) dead[di] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+    else atomicExch(&cnt->overflow, 1u);
+    orig[id].x = pos_inf();
+}
+
+// the n_oldest oldest living points leave the map (rank[id] = number of living ids below id)
+__global__ void inc_evict_oldest_kernel(float4* __restrict__ orig, uint32_t n_ids, const uint32_t* __restrict__ rank,
+                                        uint32_t n_oldest, float4* __restrict__ dead, uint32_t dead_cap, MapCounters* cnt) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_ids) return;
+    const float4 p = orig[id];
+    if (!pt_alive(p) || rank[id] >= n_oldest) return;
+    const uint32_t di = atomicAdd(&cnt->n_dead, 1u);
+    if (di < dead_cap) dead[di] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+    else atomicExch(&cnt->overflow, 1u);
+    orig[id].x = pos_inf();
+}
+
+__global__ void inc_alive_flags_kernel(const float4* __restrict__ orig, uint32_t n_ids, uint32_t* __restrict__ flags) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_ids) return;
+    flags[id] = pt_alive(orig[id]) ? 1u : 0u;
+}
+
+// compaction of the living into a fresh id space (re-linearisation)
+__global__ void inc_compact_kernel(const float4* __restrict__ orig, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+                                   uint32_t n_ids, float4* __restrict__ out) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_ids) return;
+    if (flags[id]) out[pos[id]] = orig[id];
+}
+
+#endif  // LV_MAPINC_KERNELS
+
+}  // namespace lv

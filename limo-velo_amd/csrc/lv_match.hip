@@ -109,15 +109,6 @@ __device__ __forceinline__ void merge_group(kkey (&k)[KNN]) {
     if (S >= 8) merge_round<0x141>(k);
     if (S >= 16) merge_round<0x140>(k);
 }
-__device__ __forceinline__ void insert1(kkey (&k)[KNN], kkey x) {  // generic path: one candidate
-#pragma unroll
-    for (int j = 0; j < KNN; ++j) {
-        const kkey lo = kmin(k[j], x), hi = kmax(k[j], x);
-        k[j] = lo;
-        x = hi;
-    }
-}
-
 // [UPSTREAM-RECALL ikd-Tree calc_dist]: (ax-bx)^2 + (ay-by)^2 + (az-bz)^2, f32, left to right, unfused
 struct __attribute__((packed, aligned(4))) Xyz {   // one bucket point as streamed: 12 bytes
     float x, y, z;
@@ -133,15 +124,6 @@ __device__ __forceinline__ float calc_dist(float qx, float qy, float qz, float4 
     float sx = dx * dx, sy = dy * dy, sz = dz * dz;
     float s = sx + sy;
     return s + sz;
-}
-
-// generic path: scan a range of the Morton-sorted array with (distance, original index) keys
-__device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, uint32_t start, uint32_t count, float qx,
-                                           float qy, float qz, kkey (&k)[KNN]) {
-    for (uint32_t j = 0; j < count; ++j) {
-        const float4 m = sorted[start + j];
-        insert1(k, make_key(calc_dist(qx, qy, qz, m), __float_as_uint(m.w)));
-    }
 }
 
 // Column-pivoted Householder QR least squares for the 5 x 3 system A n = -1, f32.  Same operation
@@ -362,15 +344,17 @@ __device__ __forceinline__ void merge_team(kkey (&k)[KNN]) {
     }
 }
 
+// a candidate key stands for a real point iff its distance is finite (NONE and the +inf distance of deleted
+// entries / ids are not)
+__device__ __forceinline__ bool key_real(kkey k) { return key_hi(k) < 0x7F800000u; }
+
 // One bucket-level attempt by a team of LANES lanes (tl = lane in team): ONE probe of the level's bucket table
 // and ONE coalesced stream over the neighbourhood bucket of the query's voxel (a miss means the whole
 // 27-voxel block is empty).  k is all-NONE on entry; returns true with the sorted result in k (low words =
 // positions inside the bucket starting at bstart) iff 5 candidates were found inside the guaranteed radius,
-// otherwise false with k reset to NONE.
-// BY_INDEX (bucket levels >= 1): the bucket is an UNSORTED run of {x, y, z, original index} records and the key's
-// low word is the original map index — the reference's (distance, index) order needs no sorted bucket then, and
-// the map build skips the sort of the big coarse-level buckets; the winners are read from map.orig afterwards.
-template <int LANES, bool BY_INDEX>
+// otherwise false with k reset to NONE.  Deleted entries stay in place with x = +inf: their distance is +inf,
+// which loses against every real candidate and fails the radius test.
+template <int LANES>
 __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
                                                kkey (&k)[KNN], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
     // stage (LDS, LANES * 8 entries of this team, or nullptr): the first chunk's candidates are kept there by
@@ -389,55 +373,30 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     if (clk) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
     if (bcount < KNN) return false;
     constexpr int U = 8;
-    if (BY_INDEX) {
-        const float4* __restrict__ bp = map.bucket4[bl] + bstart;
-        for (uint32_t base = 0; base < bcount; base += LANES * U) {
-            float4 mpt[U];
+    const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
+    for (uint32_t base = 0; base < bcount; base += LANES * U) {
+        Xyz mpt[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = base + (uint32_t)(u * LANES + tl);
-                mpt[u] = bp[j < bcount ? j : 0];
-            }
-            kkey ck[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = base + (uint32_t)(u * LANES + tl);
-                ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();
-            }
-            sort8(ck);
-            if (base == 0) {
-#pragma unroll
-                for (int i = 0; i < KNN; ++i) k[i] = ck[i];
-            } else {
-                merge5(k, ck);
-            }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * LANES + tl);
+            mpt[u] = bp[j < bcount ? j : 0];
         }
-    } else {
-        const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
-        for (uint32_t base = 0; base < bcount; base += LANES * U) {
-            Xyz mpt[U];
+        if (stage && base == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = base + (uint32_t)(u * LANES + tl);
-                mpt[u] = bp[j < bcount ? j : 0];
-            }
-            if (stage && base == 0) {
+            for (int u = 0; u < U; ++u) stage[u * LANES + tl] = mpt[u];
+        }
+        kkey ck[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) stage[u * LANES + tl] = mpt[u];
-            }
-            kkey ck[U];
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * LANES + tl);
+            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
+        }
+        sort8(ck);
+        if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = base + (uint32_t)(u * LANES + tl);
-                ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
-            }
-            sort8(ck);
-            if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
-#pragma unroll
-                for (int i = 0; i < KNN; ++i) k[i] = ck[i];
-            } else {
-                merge5(k, ck);
-            }
+            for (int i = 0; i < KNN; ++i) k[i] = ck[i];
+        } else {
+            merge5(k, ck);
         }
     }
     merge_team<LANES>(k);
@@ -449,108 +408,236 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     return false;
 }
 
-// Exact 5-NN of the world point (qx, qy, qz): executed by the S lanes of a lane group (gl = lane in group).
+// The same for a level whose buckets are UNORDERED runs of {x, y, z, id} records (level 2): the key's low word is the
+// point id, so the reference's (distance, index) order needs no ordered bucket; the winners are read from map.orig.
+template <int LANES>
+__device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
+                                                     kkey (&k)[KNN]) {
+    const GridLevel g = map.bt[bl];
+    const uint64_t key = pack_cell((uint32_t)(geo.c0x >> bl), (uint32_t)(geo.c0y >> bl), (uint32_t)(geo.c0z >> bl));
+    uint32_t slot = hash_cell(key, g.shift) & g.mask;
+    uint32_t bstart = 0, bcount = 0;
+    for (;;) {
+        const uint4 e = g.table[slot];
+        const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+        if (ek == key) { bstart = e.z; bcount = e.w; break; }
+        if (ek == EMPTY_KEY) break;
+        slot = (slot + 1) & g.mask;
+    }
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    if (bcount < KNN) return false;
+    constexpr int U = 8;
+    const float4* __restrict__ bp = map.bucket4 + bstart;
+    for (uint32_t base = 0; base < bcount; base += LANES * U) {
+        float4 mpt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * LANES + tl);
+            mpt[u] = bp[j < bcount ? j : 0];
+        }
+        kkey ck[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * LANES + tl);
+            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();
+        }
+        sort8(ck);
+        merge5(k, ck);
+    }
+    merge_team<LANES>(k);
+    const float r = search_radius(map, geo, bl);
+    const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+    if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) return true;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    return false;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The 27-voxel block of level LVL (2 or 3) searched by a WHOLE wavefront over the level-2 voxel lists (27 lists
+// at level 2, the 6 x 6 x 6 = 216 lists that tile the level-3 block at level 3): every lane probes one voxel,
+// a wave scan turns the list lengths into one virtual candidate array, and the lanes stream it 8 loads per lane in
+// flight (each load finds its list by a 6-step binary search over the prefix sums in LDS).  Keys are
+// (distance, id); on success k holds the sorted result on every lane.  s_pref / s_start: 64 words each, private
+// to this wavefront.
+template <int LVL>
+__device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& geo, float qx, float qy, float qz, int lane,
+                                              kkey (&k)[KNN], uint32_t* s_pref, uint32_t* s_start) {
+    static_assert(LVL == CELL_LEVEL || LVL == CELL_LEVEL + 1, "the level-2 block = 27 lists, the level-3 block = 216");
+    constexpr int SIDE = LVL == CELL_LEVEL ? 3 : 6;
+    constexpr int NC = SIDE * SIDE * SIDE;
+    constexpr int U = 8;
+    const int bx = LVL == CELL_LEVEL ? (geo.c0x >> 2) - 1 : ((geo.c0x >> 3) - 1) * 2;
+    const int by = LVL == CELL_LEVEL ? (geo.c0y >> 2) - 1 : ((geo.c0y >> 3) - 1) * 2;
+    const int bz = LVL == CELL_LEVEL ? (geo.c0z >> 2) - 1 : ((geo.c0z >> 3) - 1) * 2;
+    const GridLevel g = map.ct;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int r0 = 0; r0 < NC; r0 += 64) {
+        const int ci = r0 + lane;
+        uint32_t start = 0, cnt = 0;
+        if (ci < NC) {
+            const int dz = ci / (SIDE * SIDE), dy = (ci / SIDE) % SIDE, dx = ci % SIDE;
+            const uint32_t nx = (uint32_t)(bx + dx), ny = (uint32_t)(by + dy), nz = (uint32_t)(bz + dz);
+            if (nx < (1u << 19) && ny < (1u << 19) && nz < (1u << 19)) {
+                const uint64_t key = pack_cell(nx, ny, nz);
+                uint32_t slot = hash_cell(key, g.shift) & g.mask;
+                for (;;) {
+                    const uint4 e = g.table[slot];
+                    const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                    if (ek == key) { start = e.z; cnt = e.w; break; }
+                    if (ek == EMPTY_KEY) break;
+                    slot = (slot + 1) & g.mask;
+                }
+            }
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        if (total == 0) continue;
+        wave_lds_fence();   // the previous round's readers are done
+        s_pref[lane] = incl - cnt;
+        s_start[lane] = start;
+        wave_lds_fence();
+        for (uint32_t base = 0; base < total; base += 64 * U) {
+            float4 mpt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t v = base + (uint32_t)(u * 64 + lane);
+                const uint32_t vv = v < total ? v : 0u;
+                int L = 0;   // the last list whose first virtual index is <= vv (empty lists share their successor's)
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (s_pref[L + step] <= vv) L += step;
+                mpt[u] = map.cell4[(size_t)s_start[L] + (vv - s_pref[L])];
+            }
+            kkey ck[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t v = base + (uint32_t)(u * 64 + lane);
+                ck[u] = v < total ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();
+            }
+            sort8(ck);
+            merge5(k, ck);
+        }
+    }
+    merge_team<64>(k);
+    const float r = search_radius(map, geo, LVL);
+    const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
+    if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) return true;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    return false;
+}
+
+// exhaustive scan of every id by a whole wavefront, (distance, id) keys; deleted ids sit at +inf
+__device__ __forceinline__ void brute_attempt(const MapView& map, float qx, float qy, float qz, int lane, kkey (&k)[KNN]) {
+    constexpr int U = 8;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (uint32_t base = 0; base < map.n_ids; base += 64 * U) {
+        float4 mpt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * 64 + lane);
+            mpt[u] = map.orig[j < map.n_ids ? j : 0];
+        }
+        kkey ck[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)(u * 64 + lane);
+            ck[u] = j < map.n_ids ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key();
+        }
+        sort8(ck);
+        merge5(k, ck);
+    }
+    merge_team<64>(k);
+}
+
+// Exact 5-NN of the world point (qx, qy, qz): executed by the S lanes of a lane group (gl = lane in group); all 64
+// lanes of the wavefront must be active (`live` = false marks padding lanes that only lend a hand).
 // On return every lane of the group holds the same sorted keys k[]; src >= 0: bucket level the winners came
-// from (key low word = position inside the bucket starting at bstart), src < 0: generic path (low word =
-// original map index).  clk != nullptr (DBG builds): phase-stamp slot of this workgroup.
-// COOP_FROM < MAX_BUCKET_LEVELS (requires all 64 lanes of the wavefront active; `live` = false marks padding
-// lanes that only lend a hand): bucket levels below COOP_FROM are searched per lane group, 64 / S scan points
-// at a time; the few points still undecided are then taken one at a time by the WHOLE wavefront for the
-// remaining bucket levels.  Those buckets hold a thousand candidates or more — 20 dependent load-sort steps
-// for a lane group, 3 for a wavefront — and a launch otherwise ends with a handful of such points as its tail.
-template <int S, bool DBG, int COOP_FROM>
+// from (key low word = position inside the bucket starting at bstart), src < 0: low word = point id.
+// Ladder: bucket levels 0 and 1 per lane group, 64 / S scan points at a time; the few points still undecided are
+// then taken one at a time by the WHOLE wavefront: level-2 bucket (~1000 candidates: 20 dependent load-sort steps
+// for a lane group, 3 for a wavefront), level-3 block (the 216 level-2 voxel lists that tile it), finally every id.  A block of level l covers every point within r_l of the query (search_radius), so a level
+// that is not accepted proves d5 >= r_l^2.  BOUNDED launches (the timed path) stop there as soon as
+// r_l^2 >= MAX_DIST_PLANE^2: the reference discards such a match at Plane.cpp:40-43 whatever its 5 neighbours are,
+// so the point is reported without neighbours (found = 0) and the update is unchanged; capturing launches (API
+// parity: lv_iterate / lv_fetch_knn) always continue to the exact answer.
+// clk != nullptr (DBG builds): phase-stamp slot of this workgroup.
+template <int S, bool DBG>
 __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
                                            kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist,
-                                           bool live = true, Xyz* stage0 = nullptr) {
+                                           bool live, Xyz* stage0, double max_dist_sq, uint32_t* s_pref, uint32_t* s_start) {
     if (map.m == 0) return;
     const QGeom geo = make_geom(map, qx, qy, qz);
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
-    const bool in_range = live && finite && geo.amax < CELL_FAR;
+    const bool in_range = finite && geo.amax < CELL_FAR;
     // a point with a NaN / infinite coordinate has no neighbours (k stays NONE, found = 0): the reference discards such
-    // a match at Plane.cpp:42 whatever its tree search returned; searching for it would mean a brute-force scan
+    // a match at Plane.cpp:42 whatever its tree search returned
     bool decided = !live || !finite;
-    int level = in_range ? 0 : map.n_levels;
-    int hist_bin = -1;   // bucket level that decided (instrumentation)
-    if (in_range) {
-        const int group_levels = map.n_bucket_levels < COOP_FROM ? map.n_bucket_levels : COOP_FROM;
-        for (int bl = 0; bl < group_levels && !decided; ++bl) {
-            if (bl < SORTED_BUCKET_LEVELS) {
-                decided = bucket_attempt<S, false>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
-                                                   bl == 0 ? stage0 : nullptr);
-                if (decided) src = bl;
-            } else {
-                decided = bucket_attempt<S, true>(map, bl, geo, qx, qy, qz, gl, k, bstart, nullptr);   // src stays -1: map indices
-            }
-            if (decided) hist_bin = bl;
-            level = bl + 1;
-        }
-    }
-    if (COOP_FROM < MAX_BUCKET_LEVELS && map.n_bucket_levels > COOP_FROM) {
-        const int lane = (int)(threadIdx.x & 63u);
-        unsigned long long pending = __ballot(in_range && !decided && gl == 0);
-        while (pending) {
-            const int L = __ffsll((long long)pending) - 1;   // leader lane of the scan point served now
-            pending &= pending - 1;
-            const float wx = __shfl(qx, L), wy = __shfl(qy, L), wz = __shfl(qz, L);
-            const QGeom wgeo = make_geom(map, wx, wy, wz);
-            kkey kw[KNN];
+    int hist_bin = -1;   // what decided (instrumentation): 0, 1 bucket level; 2, 3 voxel lists; 4 every id; 5 bounded stop
+    if (live && in_range) {
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) kw[j] = none_key();
-            uint32_t wstart = 0;
-            int wsrc = -1;
-            static_assert(COOP_FROM >= SORTED_BUCKET_LEVELS, "the wavefront-cooperative levels use index keys");
-            for (int bl = COOP_FROM; bl < map.n_bucket_levels && wsrc < 0; ++bl)
-                if (bucket_attempt<64, true>(map, bl, wgeo, wx, wy, wz, lane, kw, wstart, nullptr)) wsrc = bl;
-            if (lane / S == L / S) {
-                level = map.n_bucket_levels;
-                if (wsrc >= 0) {   // (keys carry map indices: src stays -1)
-#pragma unroll
-                    for (int j = 0; j < KNN; ++j) k[j] = kw[j];
-                    hist_bin = wsrc;
-                    decided = true;
-                }
+        for (int bl = 0; bl < SORTED_LEVELS; ++bl) {
+            if (!decided) {
+                decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
+                                            bl == 0 ? stage0 : nullptr);
+                if (decided) { src = bl; hist_bin = bl; }
             }
         }
     }
-    const bool fell_back = !decided;
-    while (!decided) {  // generic path: 27 probes per level over the Morton-sorted array, then brute force
-        if (level < map.n_levels) {
-            const GridLevel gl_ = map.lv[level];
-            const int clx = geo.c0x >> level, cly = geo.c0y >> level, clz = geo.c0z >> level;
-            for (int c = gl; c < 27; c += S) {
-                const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
-                const uint32_t nx = (uint32_t)(clx + dx), ny = (uint32_t)(cly + dy), nz = (uint32_t)(clz + dz);
-                if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) continue;
-                const uint64_t key = pack_cell(nx, ny, nz);
-                uint32_t slot = hash_cell(key, gl_.shift) & gl_.mask;
-                uint32_t start = 0, count = 0;
-                for (;;) {
-                    const uint4 e = gl_.table[slot];
-                    const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                    if (ek == key) { start = e.z; count = e.w; break; }
-                    if (ek == EMPTY_KEY) break;
-                    slot = (slot + 1) & gl_.mask;
-                }
-                scan_range(map.sorted, start, count, qx, qy, qz, k);
-            }
-            merge_group<S>(k);
-            const float r = search_radius(map, geo, level);
-            const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-            if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) {
-                decided = true;
-            } else {
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long pending = __ballot(!decided && gl == 0);
+    while (pending) {
+        const int L = __ffsll((long long)pending) - 1;   // leader lane of the scan point served now
+        pending &= pending - 1;
+        const float wx = __shfl(qx, L), wy = __shfl(qy, L), wz = __shfl(qz, L);
+        const QGeom wgeo = make_geom(map, wx, wy, wz);
+        const bool w_in_range = wgeo.amax < CELL_FAR;
+        kkey kw[KNN];
 #pragma unroll
-                for (int j = 0; j < KNN; ++j) k[j] = none_key();
-                ++level;
+        for (int j = 0; j < KNN; ++j) kw[j] = none_key();
+        int wbin = 5;
+        bool done = false;
+        if (w_in_range) {
+            done = bucket_attempt_by_id<64>(map, 2, wgeo, wx, wy, wz, lane, kw);
+            if (done) wbin = 2;
+            // not accepted: d5 >= r^2 (f32).  The reference's gate is (double)d5 < MAX_DIST_PLANE^2 (Plane.cpp:42)
+            float r = search_radius(map, wgeo, 2);
+            bool stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
+            if (!done && !stop) {
+                if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
+                done = cells_attempt<CELL_LEVEL + 1>(map, wgeo, wx, wy, wz, lane, kw, s_pref, s_start);
+                if (done) wbin = 3;
+                r = search_radius(map, wgeo, CELL_LEVEL + 1);
+                stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
             }
-        } else {
-            for (uint32_t j = gl; j < map.m; j += S) scan_range(map.sorted, j, 1, qx, qy, qz, k);
-            merge_group<S>(k);
+            if (!done && !stop) { brute_attempt(map, wx, wy, wz, lane, kw); wbin = 4; }
+        } else {   // outside the voxel range (2^19 voxels from the map origin): no structure to lean on
+            if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
+            brute_attempt(map, wx, wy, wz, lane, kw);
+            wbin = 4;
+        }
+        if (lane / S == L / S) {   // (keys carry point ids: src stays -1)
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) k[j] = kw[j];
+            hist_bin = wbin;
             decided = true;
         }
     }
-    if (fell_back && gl == 0) atomicAdd(&kf->fallback_queries, 1);
-    if (DBG && hist && live && gl == 0) atomicAdd(&kf->level_hist[hist_bin >= 0 ? hist_bin : (level < map.n_levels ? 3 : 4)], 1);
+    if (DBG && hist && live && finite && gl == 0) atomicAdd(&kf->level_hist[hist_bin >= 0 ? hist_bin : 5], 1);
 }
 
 // Plane fit + gates + Jacobian row of ONE scan point (one lane): Plane.cpp:19-55, Utils.cpp:32-66,
@@ -656,9 +743,6 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
 //   slot  5    {world x, y, z, original scan index}
 //   slot  6    squared distances 0..3 (bits)      slot 7  {distance 4 (bits), found, -, -}
 constexpr int QREC_SLOTS = 8;
-#ifndef LV_COOP_FROM
-#define LV_COOP_FROM 2   // first bucket level searched by whole wavefronts (MAX_BUCKET_LEVELS: never)
-#endif
 #ifdef LV_SEARCH_WAVES
 #define LV_SEARCH_BOUNDS __launch_bounds__(256, LV_SEARCH_WAVES)
 #else
@@ -668,10 +752,12 @@ constexpr int QREC_SLOTS = 8;
 template <int S, bool DBG>
 __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
                                                      KfDev* __restrict__ kf, float4* __restrict__ qrec, uint32_t qstride,
-                                                     const uint32_t* __restrict__ tile_order, uint32_t n_tiles, DebugOut dbg) {
+                                                     const uint32_t* __restrict__ tile_order, uint32_t n_tiles, double max_dist_sq,
+                                                     DebugOut dbg) {
     constexpr int GS = 256 / S;
     constexpr int STAGE = S * 8;   // candidates of a lane group's first level-0 chunk, kept in LDS by position
     __shared__ Xyz s_stage[GS][STAGE];
+    __shared__ uint32_t s_pref[4][64], s_start[4][64];   // wavefront-cooperative levels: per-wave prefix sums / list starts
     if (kf->done) return;
     const int tid = threadIdx.x;
     const int gq = tid / S, gl = tid % S;
@@ -682,7 +768,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     long long* stamp_slot = (DBG && dbg.clk && tid == 0 && blockIdx.x < (uint32_t)dbg.clk_blocks) ? dbg.clk + (size_t)blockIdx.x * 8 : nullptr;
     if (DBG && stamp_slot) { stamp_slot[0] = clock64(); dbg.clk[(size_t)(dbg.clk_blocks + blockIdx.x) * 8 + 0] = wall_clock64(); }
     if (n == 0) return;
-    // no lane leaves early: the coarsest bucket levels are searched by whole wavefronts (knn_search COOP_FROM);
+    // no lane leaves early: the coarse levels are searched by whole wavefronts (knn_search);
     // padding lanes (q >= n) carry a copy of the last point, lend a hand and store nothing
     const bool live = q < n;
     kkey k[KNN];
@@ -694,11 +780,12 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     float qx, qy, qz;
     rt_apply(kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
     if (DBG && stamp_slot) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); stamp_slot[1] = clock64(); }
-    knn_search<S, DBG, LV_COOP_FROM>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk, live, s_stage[gq]);
+    knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk, live, s_stage[gq], max_dist_sq,
+                       s_pref[tid >> 6], s_start[tid >> 6]);
     if (DBG && stamp_slot) { asm volatile("" :: "v"(k[0]), "v"(k[4])); stamp_slot[3] = clock64(); }
     int found = 0;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) found += is_none(k[j]) ? 0 : 1;
+    for (int j = 0; j < KNN; ++j) found += key_real(k[j]) ? 1 : 0;
     if (live) {
 #pragma unroll
         for (int slot0 = 0; slot0 < QREC_SLOTS; slot0 += S) {
@@ -710,12 +797,12 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
 #pragma unroll
                 for (int j = 1; j < KNN; ++j) kk = (slot == j) ? k[j] : kk;
                 v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
-                if (!is_none(kk)) {
+                if (key_real(kk)) {
                     const uint32_t pos = key_lo(kk);
                     if (src == 0 && pos < (uint32_t)STAGE && !DBG) {
                         // decided at level 0 inside its first chunk (the common case): the point is still in LDS
-                        // (same wavefront wrote it, LDS operations of a wavefront execute in order); its original
-                        // index is only reported by capturing (DBG) launches
+                        // (same wavefront wrote it, LDS operations of a wavefront execute in order); its id is
+                        // only reported by capturing (DBG) launches
                         const Xyz w = s_stage[gq][pos];
                         v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
                     } else if (src >= 0) {
@@ -843,29 +930,31 @@ int fit_grid_size(uint32_t n, int max_blocks) {
 
 template <int S>
 static void launch_search(hipStream_t stream, bool dbg_on, const MapView& map, const float4* scan, uint32_t n, KfDev* kf,
-                          float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg) {
+                          float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq,
+                          const DebugOut& dbg) {
     constexpr uint32_t GS = 256 / S;
     uint32_t grid = (n + GS - 1) / GS;
     grid = (grid + 7u) & ~7u;
     if (grid == 0) grid = 8;
-    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, dbg);
-    else hipLaunchKernelGGL((search_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, dbg);
+    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg);
+    else hipLaunchKernelGGL((search_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg);
 }
 
 static bool debug_requested(const DebugOut& dbg) {
     return dbg.knn_idx || dbg.valid || dbg.p_world || dbg.abcd || dbg.dist || dbg.rows || dbg.clk;
 }
 
-// split form, kernel 1: exact 5-NN of every scan point -> qrec
+// split form, kernel 1: exact 5-NN of every scan point -> qrec (max_dist_sq: MAX_DIST_PLANE^2, the radius beyond
+// which a non-capturing launch may stop — see knn_search)
 int launch_search(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf, float4* qrec,
-                  uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, const DebugOut& dbg) {
+                  uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg) {
     const bool dbg_on = debug_requested(dbg);
     switch (S) {
-        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
-        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
-        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
-        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
-        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, dbg); break;
+        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
+        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
+        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
+        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
+        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
         default: set_error("lanes_per_query must be 1,2,4,8 or 16 (got %d)", S); return LV_EINVAL;
     }
     LV_HIP(hipGetLastError());

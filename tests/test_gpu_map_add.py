@@ -72,3 +72,135 @@ def test_first_add_on_empty_map_and_lattice_ties(capi, oracle):
         ctx.map_add(new, downsample=True)
         ref = oracle.map_add(ref, new, downsample=True)
         assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+
+
+def _knn_matches(ctx, oracle, ref, state, scan):
+    ctx.scan_set(scan)
+    g = ctx.iterate(state)
+    idx, d2 = ctx.fetch_knn()
+    oi, od, _, _ = oracle.knn_brute(ref, oracle.transform_scan(state, scan))
+    assert np.array_equal(idx, oi), f"kNN index mismatches at {(idx != oi).any(axis=1).sum()} points"
+    assert np.array_equal(_bits(d2), _bits(od))
+    o = oracle.iterate(state, ref, scan)
+    assert g["n_valid"] == o["n_valid"]
+    return g
+
+
+def test_fifty_incremental_adds_keep_map_and_search_exact(capi, oracle, lv):
+    """The mapping cycle of src/main.cpp:102 fifty times over: a 200k-point map takes fifty down-sampled scans (revisited
+    and new space), every one inserted IN PLACE (no rebuild: incremental_adds counts them).  After each add the map
+    equals the oracle's sequential lvo_map_add point for point and in order; the exact 5-NN (indices in the shifted
+    index space, distance bits) is re-checked along the way and at the end, through the capturing kernels and through
+    the timed ones."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(200_000, 4000)
+    rng = np.random.default_rng(5)
+    ref = sc["map_xyz"]
+    L = float(sc["L"])
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        for step in range(50):
+            # world points of a scan: noisy copies of map points in a drifting window (revisits: the box rule keeps or
+            # replaces occupants) plus fresh points beyond the mapped walls (new buckets, new voxels)
+            c = np.array([-0.6 * L + 0.02 * L * step, 0.3 * L - 0.01 * L * step, 0.0], np.float32)
+            near = ref[np.linalg.norm(ref - c, axis=1) < 25.0]
+            pick = near[rng.integers(0, len(near), 1500)] + rng.normal(0, 0.03, (1500, 3)).astype(np.float32)
+            fresh = (rng.uniform(-1, 1, (300, 3)) * [6, 6, 0.02] + [L + 4.0 + 0.1 * step, c[1], 0.5]).astype(np.float32)
+            batch = np.concatenate([pick, fresh]).astype(np.float32)
+            ctx.map_add(batch, downsample=True)
+            ref = oracle.map_add(ref, batch, downsample=True)
+            assert ctx.map_size() == len(ref), step
+            if step % 10 == 9 or step == 0:
+                assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref)), f"map differs after add {step}"
+                _knn_matches(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:1500])
+        st = ctx.map_stats()
+        assert st["incremental_adds"] == 50 and st["living"] == len(ref)
+        assert st["relinearisations"] <= 2, st          # in place, not rebuilt
+        assert st["tombstones"] > 0 or st["relinearisations"] > 0
+        # queries in the freshly mapped strip and in the revisited window
+        probe = np.concatenate([fresh[:200], pick[:300]])
+        ident = sc["x_true"].copy()
+        ident[:3] = 0
+        ident[3:7] = [0, 0, 0, 1]
+        _knn_matches(ctx, oracle, ref, ident, probe)
+        # the timed (non-capturing) kernels on the incrementally maintained structure: full update vs oracle on `ref`
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+        nbr, d2, pw, found = ctx.fetch_neighbors()
+        xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], ref, sc["scan_xyz"])
+        assert passes == po and [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+        assert np.abs(x - xo).max() < 1e-9
+        # a re-linearisation must not change anything observable
+        ctx.map_relinearise()
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        x2, P2, p2, _, _ = ctx.update(sc["x_init"], sc["P0"])
+        assert p2 == passes and np.abs(x2 - x).max() < 1e-12
+        _knn_matches(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:1000])
+
+
+def test_evictions_and_rolling_window(capi, oracle, scene_small):
+    sc = scene_small
+    ref = sc["map_xyz"]
+    rng = np.random.default_rng(8)
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        lo, hi = np.array([-12.0, -15.0, -1.0], np.float32), np.array([15.0, 11.0, 9.0], np.float32)
+        inside = np.all((ref >= lo) & (ref <= hi), axis=1)
+        assert ctx.map_evict_box(lo, hi, keep_inside=True) == int((~inside).sum())
+        ref = ref[inside]
+        assert ctx.map_size() == len(ref)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_matches(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:800])   # indices are ranks among the living
+        for step in range(3):
+            batch = (ref[rng.integers(0, len(ref), 3000)] + rng.normal(0, 0.05, (3000, 3))).astype(np.float32)
+            ctx.map_add(batch, downsample=True)
+            ref = oracle.map_add(ref, batch, downsample=True)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        k = len(ref) // 4
+        assert ctx.map_evict_oldest(k) == k
+        ref = ref[k:]
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_matches(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:800])
+        hole = np.all((ref >= -3.0) & (ref <= 3.0), axis=1)
+        assert ctx.map_evict_box([-3.0] * 3, [3.0] * 3, keep_inside=False) == int(hole.sum())
+        ref = ref[~hole]
+        _knn_matches(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:800])
+        # the whole update on the thinned map
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, passes, _, sums = ctx.update(sc["x_init"], sc["P0"])
+        xo, Po, po, _, so = oracle.update(sc["x_init"], sc["P0"], ref, sc["scan_xyz"])
+        assert passes == po and [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+        assert np.abs(x - xo).max() < 1e-9
+        # everything goes: no map (Localizator::correct returns, Localizator.cpp:24); the next add builds again
+        assert ctx.map_evict_box([-1e4] * 3, [1e4] * 3, keep_inside=False) == len(ref)
+        assert ctx.map_size() == 0
+        assert ctx.update(sc["x_init"], sc["P0"])[2] == 0
+        ctx.map_add(sc["map_xyz"][:5000], downsample=True)   # Add_Points(points, true) into an empty map: the rule among the new points
+        ref = oracle.map_add(np.zeros((0, 3), np.float32), sc["map_xyz"][:5000], downsample=True)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_matches(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:300])
+
+
+def test_map_add_scan_stays_on_the_device(capi, oracle, scene_small):
+    """lv_map_add_scan = `map.add(Xt2 * Xt2.I_Rt_L() * ds_compensated, t2, true)` (src/main.cpp:92,102) with the scan and
+    the state the device already holds: same map as transforming on the host with the oracle's f32 arithmetic."""
+    sc = scene_small
+    ref = sc["map_xyz"][:30000]
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        scan = sc["scan_xyz"].copy()
+        scan[7] = [np.nan, 0, 0]                      # a no-return point is skipped
+        ctx.scan_set(scan)
+        x, P, passes, _, _ = ctx.update(sc["x_init"], sc["P0"])
+        ctx.map_add_scan(downsample=True)             # state: the last update's result
+        world = oracle.transform_scan(x, np.delete(scan, 7, axis=0))
+        ref = oracle.map_add(ref, world, downsample=True)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        # resident filter as the state source
+        ctx.filter_set(sc["x_true"], sc["P0"])
+        ctx.scan_set(sc["scan_xyz"][:700])
+        ctx.map_add_scan(downsample=False)
+        ref = oracle.map_add(ref, oracle.transform_scan(sc["x_true"], sc["scan_xyz"][:700]), downsample=False)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        assert ctx.map_stats()["dropped"] == 1

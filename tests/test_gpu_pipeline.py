@@ -88,7 +88,8 @@ class HipPipe:
         return self.ctx.filter_get()[0]
 
     def map_add(self, pts):
-        self.ctx.map_add(pts, downsample=True)
+        # the device holds both the scan (de-skew output) and the posterior state: no host round trip (src/main.cpp:92,102)
+        self.ctx.map_add_scan(downsample=True)
 
     def map_size(self):
         return self.ctx.map_size()
