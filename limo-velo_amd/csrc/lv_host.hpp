@@ -60,8 +60,10 @@ struct MapStore {
     uint32_t* d_bidx[SORTED_LEVELS] = {}; // ids (ascending inside a bucket)
     float4* d_bucket4 = nullptr;          // level 2: unordered {x, y, z, id} records
     uint32_t* d_backptr = nullptr;        // [id * 27 + c]: position of a point in the level-2 bucket of its neighbour c
+    uint32_t* d_cellpos = nullptr;        // [id]: position of a point in its voxel's list (allocated with d_backptr)
     size_t backptr_cap = 0;               // ids it is allocated for
     size_t pool_cap[INC_LEVELS] = {};     // entries per pool ([CELL_SLOT]: d_cell4)
+    uint32_t pool_base[INC_LEVELS] = {};  // entries laid out by the last (re)build; the rest is split into arenas
     uint32_t n_bcells[REPL_LEVELS] = {};
     uint32_t* d_cell_slots = nullptr;  // scratch: table slots of the bucket voxels of the level being built
     uint32_t* d_bcount = nullptr;
@@ -78,8 +80,6 @@ struct MapStore {
     // ---- incremental maintenance (lv_mapinc.hpp)
     MapCounters* d_cnt = nullptr;
     MapCounters* h_cnt = nullptr;      // pinned mirror
-    uint32_t* d_work[INC_LEVELS] = {};
-    uint32_t work_cap = 0;
     float4* d_new = nullptr;           // staged batch
     uint64_t* d_nkeys = nullptr;
     uint64_t* d_nkeys_sorted = nullptr;
@@ -90,6 +90,16 @@ struct MapStore {
     uint32_t* d_rank = nullptr;
     void* d_ntmp = nullptr;
     size_t ntmp_bytes = 0, batch_cap = 0;
+    // voxel groups of a batch (lv_mapinc.hpp GroupRW)
+    uint4* d_gtab[REPL_LEVELS] = {};
+    uint32_t gtab_size = 0;
+    uint32_t* d_prank = nullptr;
+    uint32_t* d_pslot = nullptr;
+    uint32_t* d_gbase[REPL_LEVELS] = {};
+    uint32_t* d_gslot[REPL_LEVELS] = {};
+    uint32_t* d_gcnt = nullptr;        // [0] relocations of the batch
+    uint4* d_reloc = nullptr;
+    uint32_t reloc_cap = 0;
     float4* d_dead = nullptr;
     size_t dead_cap = 0;
     uint32_t* d_alive = nullptr;       // flags / ranks over all ids (eviction of the oldest, compaction)
@@ -108,7 +118,7 @@ struct MapStore {
     float cell = 0.5f;
     float bbox_min[3], bbox_max[3];    // of everything ever inserted since the origin was chosen
     bool built = false;                // the search structure describes d_orig[0 .. n_ids)
-    uint64_t relinearisations = 0, incremental_adds = 0, dropped_total = 0;
+    uint64_t relinearisations = 0, incremental_adds = 0, dropped_total = 0, tombstones = 0;
     MapView view{};
 
     int build_buckets(hipStream_t stream, int level, uint32_t n_occupied);

@@ -305,7 +305,8 @@ __global__ void cell_caps_kernel(const uint4* __restrict__ table, uint32_t size,
 }
 // sorted[i] goes to its level-2 voxel's list, at the rank it has inside the voxel's run of `sorted`
 __global__ void cell_fill_kernel(const uint64_t* __restrict__ keys_sorted, const float4* __restrict__ sorted, uint32_t m,
-                                 GridLevelW t2, const uint32_t* __restrict__ coff, float4* __restrict__ cell4) {
+                                 GridLevelW t2, const uint32_t* __restrict__ coff, float4* __restrict__ cell4,
+                                 uint32_t* __restrict__ cellpos) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const uint64_t k0 = keys_sorted[i];
@@ -315,7 +316,12 @@ __global__ void cell_fill_kernel(const uint64_t* __restrict__ keys_sorted, const
     for (;;) {
         const uint4 e = t2.table[slot];
         const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-        if (ek == key) { cell4[(size_t)coff[slot] + (i - e.z)] = sorted[i]; return; }
+        if (ek == key) {
+            const float4 p = sorted[i];
+            cell4[(size_t)coff[slot] + (i - e.z)] = p;
+            cellpos[__float_as_uint(p.w)] = i - e.z;
+            return;
+        }
         if (ek == EMPTY_KEY) return;   // cannot happen: every point's voxel was inserted
         slot = (slot + 1) & t2.mask;
     }
@@ -412,6 +418,11 @@ int MapStore::reserve(size_t cap) {
         if (n_ids) LV_HIP(hipMemcpy(nb, d_backptr, (size_t)n_ids * 27 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
         hipFree(d_backptr);
         d_backptr = nb;
+        uint32_t* nc = nullptr;
+        LV_HIP(hipMalloc(&nc, ncap * sizeof(uint32_t)));
+        if (n_ids) LV_HIP(hipMemcpy(nc, d_cellpos, (size_t)n_ids * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        hipFree(d_cellpos);
+        d_cellpos = nc;
         backptr_cap = ncap;
     }
     capacity = ncap;
@@ -438,15 +449,16 @@ void MapStore::release() {
     hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_bcap); hipFree(d_boff); hipFree(d_scan_tmp);
     for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_baux[l]); }
     for (int l = 0; l < SORTED_LEVELS; ++l) { hipFree(d_bxyz[l]); hipFree(d_bidx[l]); }
-    hipFree(d_bucket4); hipFree(d_backptr);
+    hipFree(d_bucket4); hipFree(d_backptr); hipFree(d_cellpos);
     hipFree(d_bucket_tmp); hipFree(d_caux); hipFree(d_cell4);
     for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
     hipFree(d_cnt);
     if (h_cnt) hipHostFree(h_cnt);
-    for (int l = 0; l < INC_LEVELS; ++l) hipFree(d_work[l]);
     hipFree(d_new); hipFree(d_nkeys); hipFree(d_nkeys_sorted); hipFree(d_nidx); hipFree(d_nidx_sorted); hipFree(d_nalive);
     hipFree(d_napos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_box); hipFree(d_box_next);
+    for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_gtab[l]); hipFree(d_gbase[l]); hipFree(d_gslot[l]); }
+    hipFree(d_prank); hipFree(d_pslot); hipFree(d_gcnt); hipFree(d_reloc);
     *this = MapStore();
 }
 
@@ -490,6 +502,7 @@ MapRW MapStore::rw() const {
     }
     M.bucket4 = d_bucket4;
     M.backptr = d_backptr;
+    M.cellpos = d_cellpos;
     M.lv[CELL_SLOT].table = d_tables[CELL_LEVEL];
     M.lv[CELL_SLOT].aux = d_caux;
     M.lv[CELL_SLOT].mask = table_size[CELL_LEVEL] - 1;
@@ -500,8 +513,6 @@ MapRW MapStore::rw() const {
     for (int a = 0; a < 3; ++a) M.origin[a] = origin[a];
     M.inv_cell = 1.0f / cell;
     M.cnt = d_cnt;
-    for (int l = 0; l < INC_LEVELS; ++l) M.work[l] = d_work[l];
-    M.work_cap = work_cap;
     return M;
 }
 
@@ -511,8 +522,17 @@ void MapStore::stats(MapStats* out) const {
     out->ids = n_ids;
     out->capacity = capacity;
     if (h_cnt && built) {
-        for (int l = 0; l < INC_LEVELS; ++l) { out->pool_used[l] = h_cnt->pool_used[l]; out->slots_used[l] = h_cnt->slots_used[l]; }
-        out->tombstones = h_cnt->tombstones;
+        for (int l = 0; l < INC_LEVELS; ++l) {
+            uint64_t used = pool_base[l];
+            for (int a = 0; a < N_ARENAS; ++a) {
+                const uint32_t start = pool_base[l] + (uint32_t)(((uint64_t)(pool_cap[l] - pool_base[l]) * a) / N_ARENAS);
+                const uint32_t cur = h_cnt->arena_cur[l][a] < h_cnt->arena_end[l][a] ? h_cnt->arena_cur[l][a] : h_cnt->arena_end[l][a];
+                used += cur - start;
+            }
+            out->pool_used[l] = used;
+            out->slots_used[l] = h_cnt->slots_used[l];
+        }
+        out->tombstones = tombstones;
     }
     for (int l = 0; l < INC_LEVELS; ++l) out->pool_cap[l] = pool_cap[l];
     for (int l = 0; l < REPL_LEVELS; ++l) out->slots_cap[l] = btable_size[l];
@@ -532,6 +552,7 @@ void MapStore::stats(MapStats* out) const {
 int MapStore::rebuild(hipStream_t stream) {
     built = false;
     have_boxes = false;
+    tombstones = 0;
     view = MapView();
     refresh_view();
     {
@@ -606,6 +627,14 @@ int MapStore::rebuild(hipStream_t stream) {
     }
     int rc = build_cells(stream, counts[CELL_LEVEL]);
     if (rc) return rc;
+    for (int l = 0; l < INC_LEVELS; ++l) {   // the free part of every pool, split into arenas
+        const uint64_t cap = pool_cap[l] > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : pool_cap[l];
+        const uint64_t free_entries = cap - pool_base[l];
+        for (int a = 0; a < N_ARENAS; ++a) {
+            h_cnt->arena_cur[l][a] = pool_base[l] + (uint32_t)((free_entries * a) / N_ARENAS);
+            h_cnt->arena_end[l][a] = pool_base[l] + (uint32_t)((free_entries * (a + 1)) / N_ARENAS);
+        }
+    }
     for (int l = 0; l < REPL_LEVELS; ++l) h_cnt->slots_used[l] = n_bcells[l];
     h_cnt->slots_used[CELL_SLOT] = counts[CELL_LEVEL];
     LV_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(MapCounters), hipMemcpyHostToDevice, stream));
@@ -693,13 +722,14 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
             }
             if (backptr_cap < capacity) {
                 LV_REALLOC(d_backptr, uint32_t, capacity * 27);
+                LV_REALLOC(d_cellpos, uint32_t, capacity);
                 backptr_cap = capacity;
             }
             hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb,
                                d_sorted, d_bcount, d_bcap, d_boff, d_bucket4, d_backptr);
         }
         LV_HIP(hipGetLastError());
-        h_cnt->pool_used[level] = (uint32_t)total;
+        pool_base[level] = (uint32_t)total;
         return LV_OK;
     }
 }
@@ -741,10 +771,10 @@ int MapStore::build_cells(hipStream_t stream, uint32_t n_occupied) {
         pool_cap[CELL_SLOT] = (size_t)want;
     }
     GridLevelW t2{d_tables[CELL_LEVEL], size - 1, (uint32_t)(64 - log2u(size))};
-    hipLaunchKernelGGL(cell_fill_kernel, dim3((m + B - 1) / B), dim3(B), 0, stream, d_keys_sorted, d_sorted, m, t2, d_boff, d_cell4);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3((m + B - 1) / B), dim3(B), 0, stream, d_keys_sorted, d_sorted, m, t2, d_boff, d_cell4, d_cellpos);
     hipLaunchKernelGGL(cell_commit_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[CELL_LEVEL], size, d_bcap, d_boff, d_caux);
     LV_HIP(hipGetLastError());
-    h_cnt->pool_used[CELL_SLOT] = (uint32_t)total;
+    pool_base[CELL_SLOT] = (uint32_t)total;
     return LV_OK;
 }
 
@@ -761,8 +791,17 @@ int MapStore::reserve_batch(size_t k) {
     LV_REALLOC(d_nalive, uint32_t, ncap);
     LV_REALLOC(d_napos, uint32_t, ncap);
     LV_REALLOC(d_rank, uint32_t, ncap * 27 * SORTED_LEVELS);
-    for (int l = 0; l < INC_LEVELS; ++l) LV_REALLOC(d_work[l], uint32_t, ncap * 27);
-    work_cap = (uint32_t)(ncap * 27 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ncap * 27);
+    gtab_size = next_pow2((uint64_t)ncap * 4);
+    for (int l = 0; l < REPL_LEVELS; ++l) {
+        LV_REALLOC(d_gtab[l], uint4, gtab_size);
+        LV_REALLOC(d_gbase[l], uint32_t, (size_t)gtab_size * GROUP_TARGETS);
+        LV_REALLOC(d_gslot[l], uint32_t, (size_t)gtab_size * GROUP_TARGETS);
+    }
+    LV_REALLOC(d_prank, uint32_t, ncap * REPL_LEVELS);
+    LV_REALLOC(d_pslot, uint32_t, ncap * REPL_LEVELS);
+    if (!d_gcnt) LV_HIP(hipMalloc(&d_gcnt, 4 * sizeof(uint32_t)));
+    reloc_cap = (uint32_t)(ncap * 27 > 0x0FFFFFF0ull ? 0x0FFFFFF0ull : ncap * 27);
+    LV_REALLOC(d_reloc, uint4, reloc_cap);
     if (d_ntmp) hipFree(d_ntmp);
     d_ntmp = nullptr;
     size_t a = 0, b = 0;
@@ -835,8 +874,8 @@ int MapStore::kill_dead_list(hipStream_t stream, uint32_t n_dead) {
 }
 
 static int reset_batch_counters(MapStore& S, hipStream_t stream) {
-    // work_n .. dropped are contiguous (MapCounters)
-    LV_HIP(hipMemsetAsync(&S.d_cnt->work_n[0], 0, offsetof(MapCounters, box_slots_used) - offsetof(MapCounters, work_n), stream));
+    // n_new .. dropped are contiguous (MapCounters)
+    LV_HIP(hipMemsetAsync(&S.d_cnt->n_new, 0, offsetof(MapCounters, box_slots_used) - offsetof(MapCounters, n_new), stream));
     return LV_OK;
 }
 
@@ -945,6 +984,22 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     }
     hipLaunchKernelGGL(inc_commit_points_kernel, dim3(gk), dim3(B), 0, stream, M, Bx, have_boxes ? 1 : 0, d_new, d_nalive, d_napos, k,
                        n_ids);
+    // voxel groups of the survivors on every level
+    GroupRW G{};
+    for (int l = 0; l < REPL_LEVELS; ++l) {
+        LV_HIP(hipMemsetAsync(d_gtab[l], 0xFF, (size_t)gtab_size * sizeof(uint4), stream));
+        G.table[l] = d_gtab[l];
+        G.gbase[l] = d_gbase[l];
+        G.gslot[l] = d_gslot[l];
+    }
+    G.mask = gtab_size - 1;
+    G.shift = (uint32_t)(64 - log2u(gtab_size));
+    G.size = gtab_size;
+    G.prank = d_prank;
+    G.pslot = d_pslot;
+    LV_HIP(hipMemsetAsync(d_gcnt, 0, 4 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(inc_group_kernel, dim3((uint32_t)(((uint64_t)k * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, M, G, d_new,
+                       d_nalive, k);
     if (downsample) {   // the occupants that lost: how many is only known on the device
         LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipStreamSynchronize(stream));
@@ -952,22 +1007,25 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         rc = kill_dead_list(stream, n_dead);
         if (rc) return rc;
     }
+    const uint64_t t_grp = (uint64_t)k * REPL_LEVELS * GROUP_TARGETS;
     const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
-    const uint32_t g_all = (uint32_t)((t_all + B - 1) / B), g_rep = (uint32_t)((t_rep + B - 1) / B);
-    const uint64_t w_max = t_all < work_cap ? t_all : work_cap;
-    const uint32_t g_work = (uint32_t)((w_max + B - 1) / B);
-    hipLaunchKernelGGL(inc_register_kernel, dim3(g_all), dim3(B), 0, stream, M, d_new, d_nalive, k);
-    hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_work), dim3(B), 0, stream, M);
-    hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, d_new, d_nalive, d_napos, k, n_ids);
-    hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, d_new, d_nalive, d_napos, k, n_ids, d_rank);
-    hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, d_new, d_nalive, d_napos, k, n_ids, d_rank);
-    hipLaunchKernelGGL(inc_commit_kernel, dim3(g_work), dim3(B), 0, stream, M);
+    const uint32_t g_grp = (uint32_t)((t_grp + B - 1) / B), g_all = (uint32_t)((t_all + B - 1) / B), g_rep = (uint32_t)((t_rep + B - 1) / B);
+    const uint64_t t_rel = (uint64_t)(reloc_cap < (1u << 18) ? reloc_cap : (1u << 18)) * RELOC_LANES;   // runs moved per batch (more: re-linearise)
+    hipLaunchKernelGGL(inc_register_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
+    hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+    hipLaunchKernelGGL(inc_relocate_kernel, dim3((uint32_t)((t_rel + B - 1) / B)), dim3(B), 0, stream, M, d_reloc,
+                       (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+    hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
+    hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
+    hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank);
+    hipLaunchKernelGGL(inc_commit_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     LV_HIP(hipGetLastError());
     LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
     n_ids += h_cnt->n_new;
     m += h_cnt->n_new;
     m -= n_dead;
+    tombstones += (uint64_t)n_dead * INC_SLOTS_PER_POINT;
     dropped_total += h_cnt->dropped;
     ++incremental_adds;
     refresh_view();
@@ -990,6 +1048,7 @@ int MapStore::evict_box(hipStream_t stream, const float lo[3], const float hi[3]
     LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
     m -= n_dead;
+    tombstones += (uint64_t)n_dead * INC_SLOTS_PER_POINT;
     if (n_evicted) *n_evicted = n_dead;
     refresh_view();
     if (m == 0) { n_ids = 0; return rebuild(stream); }
@@ -1018,6 +1077,7 @@ int MapStore::evict_oldest(hipStream_t stream, uint32_t n_oldest, uint32_t* n_ev
     LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
     m -= n_dead;
+    tombstones += (uint64_t)n_dead * INC_SLOTS_PER_POINT;
     if (n_evicted) *n_evicted = n_dead;
     refresh_view();
     if (m == 0) { n_ids = 0; return rebuild(stream); }

@@ -22,9 +22,9 @@
 //
 // An insert batch of k points (already staged on the device):
 //   box_keys -> stable sort by box -> box_rule (sequential replay per box, [UPSTREAM-RECALL ikd-Tree]) -> scan
-//   -> commit_points (ids, orig, box chains) -> kill (tombstones for the occupants that lost) -> register (find /
-//   create the 27 + 27 + 1 slots of every new point, count) -> reserve (room; relocation) -> fill (ids into the
-//   tails) -> rank (order of each tail) -> place -> commit (counts).  Any pool or table running full raises
+//   -> commit_points (ids, orig, box chains) -> group (new points by voxel, per level) -> kill (tombstones for the
+//   occupants that lost) -> register (per voxel group: find / create its 27 target slots, reserve tail shares) ->
+//   reserve + relocate (room) -> fill (ids into the tails) -> rank (order of each tail) -> place -> commit (counts).  Any pool or table running full raises
 //   `overflow`: the mutating kernels then do nothing and the host re-linearises (compaction + full rebuild).
 #pragma once
 
@@ -37,16 +37,19 @@ constexpr int INC_SLOTS_PER_POINT = 27 * REPL_LEVELS + 1;   // 27 buckets on eac
 constexpr int INC_LEVELS = REPL_LEVELS + 1;                 // tables: bt[0], bt[1], bt[2], voxel lists
 constexpr int CELL_SLOT = REPL_LEVELS;                      // index of the voxel-list table in the per-table arrays
 
+constexpr int N_ARENAS = 64;   // the free part of every pool is split into arenas with their own cursors: a run that
+                               // needs room bumps the cursor of arena (slot mod 64) — one shared cursor costs ~10 ns per
+                               // allocation (same-address atomics whose result is needed), 200 us when 20k buckets are new
 struct MapCounters {
-    uint32_t pool_used[INC_LEVELS];    // entries handed out in the level's pool (bucket runs incl. slack)
+    uint32_t arena_cur[INC_LEVELS][N_ARENAS];   // next free entry of each arena
+    uint32_t arena_end[INC_LEVELS][N_ARENAS];
     uint32_t slots_used[INC_LEVELS];   // occupied table slots
-    uint32_t work_n[INC_LEVELS];       // slots touched by the batch in flight
     uint32_t n_new;                    // surviving new points of the batch
     uint32_t n_dead;                   // length of the dead list
     uint32_t overflow;                 // a pool, a table or a work list ran full: re-linearise
     uint32_t dropped;                  // new points that were not finite or outside the voxel range
     uint32_t box_slots_used;
-    uint32_t tombstones;               // bucket / list entries turned into tombstones since the last rebuild
+    uint32_t tombstones;               // (unused on the device: the host counts INC_SLOTS_PER_POINT per deleted point)
     uint32_t pad_;
 };
 
@@ -66,12 +69,11 @@ struct MapRW {
     uint32_t* bidx[SORTED_LEVELS];
     float4* bucket4;                 // level-2 buckets
     uint32_t* backptr;               // [id * 27 + c]: position of point id inside the level-2 bucket of its neighbour c
+    uint32_t* cellpos;               // [id]: position of point id inside its voxel's list
     float4* cell4;
     float origin[3];
     float inv_cell;
     MapCounters* cnt;
-    uint32_t* work[INC_LEVELS];
-    uint32_t work_cap;
 };
 
 struct BoxRW {
@@ -101,26 +103,6 @@ __device__ __forceinline__ uint32_t table_find(const uint4* table, uint32_t mask
         if (ek == EMPTY_KEY) return ID_NONE;
         slot = (slot + 1) & mask;
     }
-    return ID_NONE;
-}
-
-// slot of `key`, inserting it (run {start 0, count 0}) if absent; ID_NONE if the table is full
-__device__ __forceinline__ uint32_t table_find_or_create(const LevelRW& L, uint64_t key, uint32_t* slots_used, uint32_t* overflow) {
-    uint32_t slot = hash_cell(key, L.shift) & L.mask;
-    for (uint32_t probes = 0; probes <= L.mask; ++probes) {
-        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&L.table[slot]);
-        const unsigned long long old = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-        if (old == (unsigned long long)EMPTY_KEY) {
-            L.table[slot].z = 0u;
-            L.table[slot].w = 0u;
-            const uint32_t n = atomicAdd(slots_used, 1u);
-            if (n + 1u > L.slot_limit) atomicExch(overflow, 1u);
-            return slot;
-        }
-        if (old == (unsigned long long)key) return slot;
-        slot = (slot + 1) & L.mask;
-    }
-    atomicExch(overflow, 1u);
     return ID_NONE;
 }
 
@@ -354,172 +336,292 @@ __global__ void inc_kill_kernel(MapRW M, const float4* __restrict__ dead, uint32
         }
         if (lo < e.w && ids[lo] == id) {
             M.bxyz[level][((size_t)e.z + lo) * 3] = pos_inf();
-            atomicAdd(&M.cnt->tombstones, 1u);
         }
     } else if (level < REPL_LEVELS) {
         const uint32_t pos = M.backptr[(size_t)id * 27 + (uint32_t)(w % 27)];
         if (pos < e.w && __float_as_uint(M.bucket4[(size_t)e.z + pos].w) == id) {
             M.bucket4[(size_t)e.z + pos].x = pos_inf();
-            atomicAdd(&M.cnt->tombstones, 1u);
         }
     } else {
-        float4* run = M.cell4 + e.z;
-        for (uint32_t i = 0; i < e.w; ++i)
-            if (__float_as_uint(run[i].w) == id) {
-                run[i].x = pos_inf();
-                atomicAdd(&M.cnt->tombstones, 1u);
-                break;
-            }
+        const uint32_t pos = M.cellpos[id];
+        if (pos < e.w && __float_as_uint(M.cell4[(size_t)e.z + pos].w) == id) M.cell4[(size_t)e.z + pos].x = pos_inf();
     }
 }
 
 // ---- appends ---------------------------------------------------------------------------------------------------
-// pass 1: find / create the slots a surviving new point goes into, count what each slot will receive, list the
-// slots touched
-__global__ void inc_register_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
+// The new points of a batch are grouped by their voxel on every level (a scratch hash table per level, no sort):
+// all points of a voxel go to the same 27 buckets, so ONE thread per (voxel, neighbour) finds / creates the bucket
+// slot and reserves the voxel's share of the bucket's tail with a single atomicAdd (point-by-point registration
+// cost 82 contended atomics per point: 4.3 ms of a 5.9 ms insert).  A point then knows its place without any
+// atomic: tail start + its voxel's offset in that bucket + its rank inside its voxel group.
+struct GroupRW {
+    uint4* table[REPL_LEVELS];     // scratch tables (0xFF-filled): {key lo, key hi, count - 1, -}; a group IS its slot
+    uint32_t mask, shift, size;    // same geometry on all levels
+    uint32_t* prank;               // [j * REPL_LEVELS + l]: rank of point j inside its level-l voxel group
+    uint32_t* pslot;               // [j * REPL_LEVELS + l]: scratch-table slot of that group
+    uint32_t* gbase[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: offset of the group's points in the batch tail of target c
+    uint32_t* gslot[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: table slot of target c (ID_NONE: outside the range)
+};
+constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + (level 2 only) the voxel's own list
+// (No global work lists or group counters: an atomic whose result is needed costs ~10 ns when every thread of a
+// launch hits the same address — 400 000 list appends were 4 ms of a 6 ms insert.  The group that reserves the
+// FIRST share of a target's tail (offset 0) owns that target for the rest of the batch: it makes room and commits.)
+
+// pass 1: every surviving new point joins its voxel group on each level
+__global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
-    const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
+    const uint32_t j = t / (uint32_t)REPL_LEVELS;
+    const int l = (int)(t % (uint32_t)REPL_LEVELS);
     if (j >= k || !alive[j]) return;
-    int level;
-    uint64_t key;
-    if (!inc_slot_key(M, newp[j], w, level, key)) return;
-    const LevelRW& L = M.lv[level];
-    const uint32_t slot = table_find_or_create(L, key, &M.cnt->slots_used[level], &M.cnt->overflow);
-    if (slot == ID_NONE) return;
-    if (atomicAdd(&L.aux[slot].pending, 1u) == 0u) {
-        const uint32_t wi = atomicAdd(&M.cnt->work_n[level], 1u);
-        if (wi < M.work_cap) M.work[level][wi] = slot;
-        else atomicExch(&M.cnt->overflow, 1u);
-    }
-}
-
-// pass 2: one thread per touched slot makes room: a run that cannot take its pending entries moves to fresh
-// space at the end of the pool (old contents copied, 1.5x the new size reserved)
-__global__ void inc_reserve_kernel(MapRW M) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-#pragma unroll
-    for (int level = 0; level < INC_LEVELS; ++level) {
-        if (t >= M.cnt->work_n[level] || t >= M.work_cap) continue;
-        const LevelRW& L = M.lv[level];
-        const uint32_t slot = M.work[level][t];
-        const uint4 e = L.table[slot];
-        SlotAux a = L.aux[slot];
-        const uint32_t need = e.w + a.pending;
-        if (need > a.cap) {
-            const uint32_t extra = need / 2u > 8u ? need / 2u : 8u;
-            const uint32_t ncap = need + extra;
-            const uint32_t ns = atomicAdd(&M.cnt->pool_used[level], ncap);
-            if ((uint64_t)ns + ncap > (uint64_t)L.pool_cap) {
-                atomicExch(&M.cnt->overflow, 1u);
-            } else {
-                if (level < SORTED_LEVELS) {
-                    float* xs = M.bxyz[level];
-                    uint32_t* is = M.bidx[level];
-                    for (uint32_t i = 0; i < e.w; ++i) {
-                        xs[((size_t)ns + i) * 3 + 0] = xs[((size_t)e.z + i) * 3 + 0];
-                        xs[((size_t)ns + i) * 3 + 1] = xs[((size_t)e.z + i) * 3 + 1];
-                        xs[((size_t)ns + i) * 3 + 2] = xs[((size_t)e.z + i) * 3 + 2];
-                        is[(size_t)ns + i] = is[(size_t)e.z + i];
-                    }
-                } else {
-                    float4* run = level < REPL_LEVELS ? M.bucket4 : M.cell4;
-                    for (uint32_t i = 0; i < e.w; ++i) run[(size_t)ns + i] = run[(size_t)e.z + i];
-                }
-                L.table[slot].z = ns;
-                L.aux[slot].cap = ncap;
-            }
+    const float4 p = newp[j];
+    const int cx = cell_coord(p.x, M.origin[0], M.inv_cell) >> l, cy = cell_coord(p.y, M.origin[1], M.inv_cell) >> l,
+              cz = cell_coord(p.z, M.origin[2], M.inv_cell) >> l;
+    const uint64_t key = pack_cell((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);
+    uint4* tab = G.table[l];
+    uint32_t slot = hash_cell(key, G.shift) & G.mask;
+    for (uint32_t probes = 0; probes <= G.mask; ++probes) {
+        uint64_t ek = entry_key(tab[slot]);
+        if (ek == EMPTY_KEY) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot]), (unsigned long long)EMPTY_KEY,
+                                                     (unsigned long long)key);
+            ek = old == (unsigned long long)EMPTY_KEY ? key : (uint64_t)old;
         }
-        L.aux[slot].tail0 = e.w;
+        if (ek == key) {
+            G.prank[(size_t)j * REPL_LEVELS + l] = atomicAdd(&tab[slot].z, 1u) + 1u;   // z starts at 0xFFFFFFFF: first rank 0
+            G.pslot[(size_t)j * REPL_LEVELS + l] = slot;
+            return;
+        }
+        slot = (slot + 1) & G.mask;
+    }
+    atomicExch(&M.cnt->overflow, 1u);
+}
+
+// slot of `key` in a bucket / list table, inserting it if absent (plain probe first: most slots exist)
+constexpr uint32_t MAX_PROBES = 256;   // a longer probe sequence means the table is too full: re-linearise
+__device__ __forceinline__ uint32_t table_get_slot(const LevelRW& L, uint64_t key, uint32_t* slots_used, uint32_t* overflow) {
+    uint32_t slot = hash_cell(key, L.shift) & L.mask;
+    for (uint32_t probes = 0; probes <= L.mask && probes < MAX_PROBES; ++probes) {
+        uint64_t ek = entry_key(L.table[slot]);
+        if (ek == EMPTY_KEY) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&L.table[slot]), (unsigned long long)EMPTY_KEY,
+                                                     (unsigned long long)key);
+            if (old == (unsigned long long)EMPTY_KEY) {
+                L.table[slot].z = 0u;
+                L.table[slot].w = 0u;
+                atomicAdd(slots_used, 1u);   // statistics only (result unused)
+                return slot;
+            }
+            ek = (uint64_t)old;
+        }
+        if (ek == key) return slot;
+        slot = (slot + 1) & L.mask;
+    }
+    atomicExch(overflow, 1u);
+    return ID_NONE;
+}
+
+// The passes that work per (voxel group, target) run one thread per (new point, level, target); only the group's
+// first point (rank 0) acts, the others leave at once.
+__device__ __forceinline__ bool inc_group_leader(const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint32_t t, int& l,
+                                                 int& c, uint32_t& gs) {
+    const uint32_t j = t / (uint32_t)(REPL_LEVELS * GROUP_TARGETS);
+    const uint32_t r = t % (uint32_t)(REPL_LEVELS * GROUP_TARGETS);
+    l = (int)(r / (uint32_t)GROUP_TARGETS);
+    c = (int)(r % (uint32_t)GROUP_TARGETS);
+    if (j >= k || !alive[j]) return false;
+    if (G.prank[(size_t)j * REPL_LEVELS + l] != 0u) return false;
+    gs = G.pslot[(size_t)j * REPL_LEVELS + l];
+    return true;
+}
+
+// pass 2: per (voxel group, target): find / create the target's slot and take the group's share of its batch tail
+__global__ void inc_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    int l, c;
+    uint32_t gs;
+    if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
+    const size_t r = (size_t)gs * GROUP_TARGETS + (size_t)c;
+    G.gslot[l][r] = ID_NONE;
+    G.gbase[l][r] = 0u;
+    const uint4 ge = G.table[l][gs];
+    const uint64_t vkey = entry_key(ge);
+    const uint32_t n_v = ge.z + 1u;
+    const uint32_t vx = (uint32_t)(vkey & 0x1fffff), vy = (uint32_t)((vkey >> 21) & 0x1fffff), vz = (uint32_t)((vkey >> 42) & 0x1fffff);
+    int tl;          // index of the target table
+    uint64_t key;
+    if (c < 27) {
+        const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+        const uint32_t nx = vx + (uint32_t)dx, ny = vy + (uint32_t)dy, nz = vz + (uint32_t)dz;
+        if (nx >= (1u << 21) || ny >= (1u << 21) || nz >= (1u << 21)) return;
+        tl = l;
+        key = pack_cell(nx, ny, nz);
+    } else {
+        if (l != CELL_LEVEL) return;
+        tl = CELL_SLOT;
+        key = vkey;
+    }
+    const LevelRW& L = M.lv[tl];
+    const uint32_t slot = table_get_slot(L, key, &M.cnt->slots_used[tl], &M.cnt->overflow);
+    if (slot == ID_NONE) return;
+    G.gbase[l][r] = atomicAdd(&L.aux[slot].pending, n_v);
+    G.gslot[l][r] = slot;
+}
+
+// pass 3: the group that took offset 0 of a target's tail makes room for the whole batch: a run that cannot take
+// its pending entries gets fresh space at the end of the pool (1.5x the new size); the move itself is listed for
+// inc_relocate_kernel
+__global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
+                                   uint32_t reloc_cap, uint32_t* __restrict__ n_reloc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    int l, c;
+    uint32_t gs;
+    if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
+    const size_t r = (size_t)gs * GROUP_TARGETS + (size_t)c;
+    const uint32_t slot = G.gslot[l][r];
+    if (slot == ID_NONE || G.gbase[l][r] != 0u) return;
+    const int level = c < 27 ? l : CELL_SLOT;
+    const LevelRW& L = M.lv[level];
+    const uint4 e = L.table[slot];
+    const SlotAux a = L.aux[slot];
+    const uint32_t need = e.w + a.pending;
+    if (need > a.cap) {
+        const uint32_t extra = need / 2u > 8u ? need / 2u : 8u;
+        const uint32_t ncap = need + extra;
+        uint32_t ns = 0;
+        bool got = false;
+        for (int tr = 0; tr < 4 && !got; ++tr) {   // (a failed try leaves its arena exhausted: the others still serve)
+            const uint32_t ar = (slot + (uint32_t)tr * 17u) & (uint32_t)(N_ARENAS - 1);
+            ns = atomicAdd(&M.cnt->arena_cur[level][ar], ncap);
+            got = (uint64_t)ns + ncap <= (uint64_t)M.cnt->arena_end[level][ar];
+        }
+        if (!got) {
+            atomicExch(&M.cnt->overflow, 1u);
+        } else {
+            if (e.w) {
+                const uint32_t ri = atomicAdd(n_reloc, 1u);
+                if (ri < reloc_cap) reloc[ri] = uint4{(uint32_t)level, e.z, ns, e.w};
+                else atomicExch(&M.cnt->overflow, 1u);
+            }
+            L.table[slot].z = ns;
+            L.aux[slot].cap = ncap;
+        }
+    }
+    L.aux[slot].tail0 = e.w;
+}
+
+// pass 3b: the listed runs move, 32 threads per run
+constexpr int RELOC_LANES = 32;
+__global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc) {
+    if (M.cnt->overflow) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = t / (uint32_t)RELOC_LANES, lane = t % (uint32_t)RELOC_LANES;
+    const uint32_t n = *n_reloc < reloc_cap ? *n_reloc : reloc_cap;
+    if (r >= n) return;
+    const uint4 m = reloc[r];   // {level, old start, new start, count}
+    if ((int)m.x < SORTED_LEVELS) {
+        float* xs = M.bxyz[m.x];
+        uint32_t* is = M.bidx[m.x];
+        for (uint32_t i = lane; i < m.w; i += RELOC_LANES) {
+            xs[((size_t)m.z + i) * 3 + 0] = xs[((size_t)m.y + i) * 3 + 0];
+            xs[((size_t)m.z + i) * 3 + 1] = xs[((size_t)m.y + i) * 3 + 1];
+            xs[((size_t)m.z + i) * 3 + 2] = xs[((size_t)m.y + i) * 3 + 2];
+            is[(size_t)m.z + i] = is[(size_t)m.y + i];
+        }
+    } else {
+        float4* run = (int)m.x < REPL_LEVELS ? M.bucket4 : M.cell4;
+        for (uint32_t i = lane; i < m.w; i += RELOC_LANES) run[(size_t)m.z + i] = run[(size_t)m.y + i];
     }
 }
 
-// pass 3: ids into the tails of the sorted levels (arbitrary order inside a tail); the unordered runs (level-2 buckets,
+// where new point j goes in target (l, c): its table slot and the position inside the run
+__device__ __forceinline__ bool inc_place_of(const MapRW& M, const GroupRW& G, uint32_t j, int w, int& tl, uint32_t& slot, uint32_t& pos) {
+    int l, c;
+    if (w < 27 * REPL_LEVELS) { l = w / 27; c = w % 27; tl = l; }
+    else { l = CELL_LEVEL; c = 27; tl = CELL_SLOT; }
+    const size_t r = (size_t)G.pslot[(size_t)j * REPL_LEVELS + l] * GROUP_TARGETS + (size_t)c;
+    slot = G.gslot[l][r];
+    if (slot == ID_NONE) return false;
+    pos = M.lv[tl].aux[slot].tail0 + G.gbase[l][r] + G.prank[(size_t)j * REPL_LEVELS + l];
+    return true;
+}
+
+// pass 4: ids into the tails of the sorted levels (arbitrary order inside a tail); the unordered runs (level-2 buckets,
 // voxel lists) take the whole record at once
-__global__ void inc_fill_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+__global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base) {
     if (M.cnt->overflow) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
     const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
     if (j >= k || !alive[j]) return;
+    int tl;
+    uint32_t slot, pos;
+    if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
     const float4 p = newp[j];
-    int level;
-    uint64_t key;
-    if (!inc_slot_key(M, p, w, level, key)) return;
-    const LevelRW& L = M.lv[level];
-    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
-    if (slot == ID_NONE) return;
     const uint32_t id = id_base + apos[j];
-    const uint32_t pos = L.aux[slot].tail0 + atomicAdd(&L.aux[slot].fill, 1u);
-    const size_t at = (size_t)L.table[slot].z + pos;
-    if (level < SORTED_LEVELS) {
-        M.bidx[level][at] = id;
-    } else if (level < REPL_LEVELS) {
+    const size_t at = (size_t)M.lv[tl].table[slot].z + pos;
+    if (tl < SORTED_LEVELS) {
+        M.bidx[tl][at] = id;
+    } else if (tl < REPL_LEVELS) {
         M.bucket4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
         M.backptr[(size_t)id * 27 + (uint32_t)(w % 27)] = pos;
     } else {
         M.cell4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+        M.cellpos[id] = pos;
     }
 }
 
-// pass 4: rank of every new bucket entry among the ids of its tail (levels 0, 1)
-__global__ void inc_rank_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
-                                const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, uint32_t* __restrict__ rank) {
+// pass 5: rank of every new bucket entry among the ids of its tail (levels 0, 1)
+__global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                uint32_t id_base, uint32_t* __restrict__ rank) {
     if (M.cnt->overflow) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
     if (j >= k || !alive[j]) return;
-    int level;
-    uint64_t key;
-    if (!inc_slot_key(M, newp[j], w, level, key)) return;
-    const LevelRW& L = M.lv[level];
-    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
-    if (slot == ID_NONE) return;
-    const SlotAux a = L.aux[slot];
-    const uint32_t* ids = M.bidx[level] + (size_t)L.table[slot].z + a.tail0;
+    int tl;
+    uint32_t slot, pos;
+    if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
+    const SlotAux a = M.lv[tl].aux[slot];
+    const uint32_t* ids = M.bidx[tl] + (size_t)M.lv[tl].table[slot].z + a.tail0;
     const uint32_t id = id_base + apos[j];
     uint32_t r = 0;
     for (uint32_t i = 0; i < a.pending; ++i) r += ids[i] < id ? 1u : 0u;
     rank[t] = r;
 }
 
-// pass 5: every new bucket entry goes to its ranked place (all reads of pass 4 are done: kernel boundary)
-__global__ void inc_place_kernel(MapRW M, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+// pass 6: every new bucket entry goes to its ranked place (all reads of pass 5 are done: kernel boundary)
+__global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                  const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {
     if (M.cnt->overflow) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
     if (j >= k || !alive[j]) return;
+    int tl;
+    uint32_t slot, pos;
+    if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
     const float4 p = newp[j];
-    int level;
-    uint64_t key;
-    if (!inc_slot_key(M, p, w, level, key)) return;
-    const LevelRW& L = M.lv[level];
-    const uint32_t slot = table_find(L.table, L.mask, L.shift, key);
-    if (slot == ID_NONE) return;
-    const size_t at = (size_t)L.table[slot].z + L.aux[slot].tail0 + rank[t];
-    M.bxyz[level][at * 3 + 0] = p.x;
-    M.bxyz[level][at * 3 + 1] = p.y;
-    M.bxyz[level][at * 3 + 2] = p.z;
-    M.bidx[level][at] = id_base + apos[j];
+    const size_t at = (size_t)M.lv[tl].table[slot].z + M.lv[tl].aux[slot].tail0 + rank[t];
+    M.bxyz[tl][at * 3 + 0] = p.x;
+    M.bxyz[tl][at * 3 + 1] = p.y;
+    M.bxyz[tl][at * 3 + 2] = p.z;
+    M.bidx[tl][at] = id_base + apos[j];
 }
 
-// pass 6: the touched slots take their tails in
-__global__ void inc_commit_kernel(MapRW M) {
+// pass 7: the owner of every touched target takes the batch tail in
+__global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ovf = M.cnt->overflow != 0u;
-#pragma unroll
-    for (int level = 0; level < INC_LEVELS; ++level) {
-        if (t >= M.cnt->work_n[level] || t >= M.work_cap) continue;
-        const LevelRW& L = M.lv[level];
-        const uint32_t slot = M.work[level][t];
-        if (!ovf) L.table[slot].w += L.aux[slot].pending;
-        L.aux[slot].pending = 0u;
-        L.aux[slot].fill = 0u;
-    }
+    int l, c;
+    uint32_t gs;
+    if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
+    const size_t r = (size_t)gs * GROUP_TARGETS + (size_t)c;
+    const uint32_t slot = G.gslot[l][r];
+    if (slot == ID_NONE || G.gbase[l][r] != 0u) return;
+    const LevelRW& L = M.lv[c < 27 ? l : CELL_SLOT];
+    if (M.cnt->overflow == 0u) L.table[slot].w += L.aux[slot].pending;
+    L.aux[slot].pending = 0u;
+    L.aux[slot].fill = 0u;
 }
 
 // ---- eviction --------------------------------------------------------------------------------------------------

@@ -68,15 +68,15 @@ struct Emu {
     std::vector<uint32_t> bidx[SORTED_LEVELS];
     std::vector<float4> bucket4;        // level-2 buckets
     std::vector<uint32_t> backptr;      // [id * 27 + c]
+    std::vector<uint32_t> cellpos;      // [id]
     std::vector<float4> cell4;
     uint32_t pool_cap[INC_LEVELS] = {0, 0, 0, 0};
     MapCounters cnt{};
-    std::vector<uint32_t> work[INC_LEVELS];
     std::vector<uint4> box;
     std::vector<uint32_t> box_next;
     bool have_boxes = false, built = false;
     uint32_t pool_reserve = 4096;       // small on purpose: relocation / overflow paths get exercised
-    uint64_t relinearisations = 0;
+    uint64_t relinearisations = 0, relocations = 0, n_killed = 0;
     std::string err;
 
     void cell_of(const float4& p, int c[3]) const {
@@ -91,6 +91,13 @@ struct Emu {
         t[slot] = uint4{(uint32_t)key, (uint32_t)(key >> 32), start, count};
         slot_out = slot;
     }
+    void set_arenas(int l, uint32_t used) {
+        const uint64_t free_entries = (uint64_t)pool_cap[l] - used;
+        for (int a = 0; a < N_ARENAS; ++a) {
+            cnt.arena_cur[l][a] = used + (uint32_t)((free_entries * a) / N_ARENAS);
+            cnt.arena_end[l][a] = used + (uint32_t)((free_entries * (a + 1)) / N_ARENAS);
+        }
+    }
     MapRW rw() {
         MapRW M{};
         M.orig = orig.data();
@@ -101,16 +108,15 @@ struct Emu {
             M.lv[l].shift = (uint32_t)(64 - log2u((uint32_t)table[l].size()));
             M.lv[l].slot_limit = (uint32_t)(table[l].size() * (l < REPL_LEVELS ? 7 : 6) / 10);
             M.lv[l].pool_cap = pool_cap[l];
-            M.work[l] = work[l].data();
         }
         for (int l = 0; l < SORTED_LEVELS; ++l) { M.bxyz[l] = bxyz[l].data(); M.bidx[l] = bidx[l].data(); }
         M.bucket4 = bucket4.data();
         M.backptr = backptr.data();
+        M.cellpos = cellpos.data();
         M.cell4 = cell4.data();
         for (int a = 0; a < 3; ++a) M.origin[a] = origin[a];
         M.inv_cell = 1.0f / cell;
         M.cnt = &cnt;
-        M.work_cap = (uint32_t)work[0].size();
         return M;
     }
     BoxRW bx() {
@@ -160,6 +166,7 @@ struct Emu {
             } else {
                 bucket4.assign(pool_cap[l], float4{0, 0, 0, 0});
                 backptr.assign(orig.size() * 27, 0xFFFFFFFFu);
+                cellpos.assign(orig.size(), 0xFFFFFFFFu);
             }
             uint32_t off = 0;
             for (auto& kv : buckets) {
@@ -184,7 +191,7 @@ struct Emu {
                 }
                 off += aux[l][slot].cap;
             }
-            cnt.pool_used[l] = off;
+            set_arenas(l, off);
             cnt.slots_used[l] = (uint32_t)buckets.size();
         }
         {
@@ -211,10 +218,11 @@ struct Emu {
                     const uint32_t id = kv.second[kv.second.size() - 1 - i];
                     const float4 p = orig[id];
                     cell4[off + i] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+                    cellpos[id] = (uint32_t)i;
                 }
                 off += aux[CELL_SLOT][slot].cap;
             }
-            cnt.pool_used[CELL_SLOT] = off;
+            set_arenas(CELL_SLOT, off);
             cnt.slots_used[CELL_SLOT] = (uint32_t)cells.size();
         }
         built = true;
@@ -236,6 +244,7 @@ struct Emu {
         while (n < cap) n *= 2;
         orig.resize(n, float4{0, 0, 0, 0});
         backptr.resize(n * 27, 0xFFFFFFFFu);
+        cellpos.resize(n, 0xFFFFFFFFu);
         if (have_boxes) box_next.resize(n, ID_NONE);
     }
 
@@ -249,7 +258,6 @@ struct Emu {
     }
 
     void reset_batch() {
-        for (int l = 0; l < INC_LEVELS; ++l) cnt.work_n[l] = 0;
         cnt.n_new = cnt.n_dead = cnt.overflow = cnt.dropped = 0;
     }
 
@@ -299,7 +307,6 @@ struct Emu {
         if (dead_ids > 64 && dead_ids > n_ids / 3) relinearise();
         reserve((size_t)n_ids + k);
         reset_batch();
-        for (int l = 0; l < INC_LEVELS; ++l) work[l].assign((size_t)k * 27, 0u);
         if (downsample) ensure_boxes();
         MapRW M = rw();
         BoxRW B = have_boxes ? bx() : BoxRW{};
@@ -321,19 +328,41 @@ struct Emu {
                (const uint32_t*)apos.data(), k, n_ids);
         const uint32_t n_dead = cnt.n_dead;
         if (n_dead) launch(inc_kill_kernel, (uint64_t)n_dead * INC_SLOTS_PER_POINT, M, (const float4*)dead.data(), n_dead);
+        // voxel groups (twin of the GroupRW set-up in MapStore::add_staged)
+        const uint32_t gsize = next_pow2((uint64_t)k * 4);
+        std::vector<uint4> gtab[REPL_LEVELS];
+        std::vector<uint32_t> gbase[REPL_LEVELS], gslot[REPL_LEVELS];
+        std::vector<uint32_t> prank((size_t)k * REPL_LEVELS, 0u), pslot((size_t)k * REPL_LEVELS, 0u), gcnt(4, 0u);
+        GroupRW G{};
+        for (int l = 0; l < REPL_LEVELS; ++l) {
+            gtab[l].assign(gsize, uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
+            gbase[l].assign((size_t)gsize * GROUP_TARGETS, 0xDEADBEEFu);
+            gslot[l].assign((size_t)gsize * GROUP_TARGETS, 0xDEADBEEFu);
+            G.table[l] = gtab[l].data(); G.gbase[l] = gbase[l].data(); G.gslot[l] = gslot[l].data();
+        }
+        G.mask = gsize - 1;
+        G.shift = (uint32_t)(64 - log2u(gsize));
+        G.size = gsize;
+        G.prank = prank.data();
+        G.pslot = pslot.data();
+        launch(inc_group_kernel, (uint64_t)k * REPL_LEVELS, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), k);
         std::vector<uint32_t> rank((size_t)k * 27 * SORTED_LEVELS, 0u);
+        std::vector<uint4> reloc((size_t)k * 27 + 64);
+        const uint64_t t_grp = (uint64_t)k * REPL_LEVELS * GROUP_TARGETS;
         const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
-        launch(inc_register_kernel, t_all, M, (const float4*)newp.data(), (const uint32_t*)alive.data(), k);
-        launch(inc_reserve_kernel, (uint64_t)k * 27, M);
-        launch(inc_fill_kernel, t_all, M, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids);
-        launch(inc_rank_kernel, t_rep, M, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
-               rank.data());
-        launch(inc_place_kernel, t_rep, M, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
+        launch(inc_register_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
+        launch(inc_reserve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k, reloc.data(), (uint32_t)reloc.size(), gcnt.data());
+        launch(inc_relocate_kernel, (uint64_t)reloc.size() * RELOC_LANES, M, (const uint4*)reloc.data(), (uint32_t)reloc.size(), (const uint32_t*)gcnt.data());
+        launch(inc_fill_kernel, t_all, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids);
+        launch(inc_rank_kernel, t_rep, M, G, (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids, rank.data());
+        launch(inc_place_kernel, t_rep, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
                (const uint32_t*)rank.data());
-        launch(inc_commit_kernel, (uint64_t)k * 27, M);
+        launch(inc_commit_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
+        relocations += gcnt[0];
         n_ids += cnt.n_new;
         m += cnt.n_new;
         m -= n_dead;
+        n_killed += n_dead;
         if (cnt.overflow) relinearise();
     }
 
@@ -444,10 +473,9 @@ struct Emu {
             if (used_slots != cnt.slots_used[l]) return fail("level %d: slots_used %u, table holds %u", l, cnt.slots_used[l], used_slots);
             std::sort(runs.begin(), runs.end());
             for (size_t i = 0; i < runs.size(); ++i) {
-                if ((uint64_t)runs[i].first + runs[i].second > cnt.pool_used[l]) return fail("level %d: run beyond pool_used", l);
+                if ((uint64_t)runs[i].first + runs[i].second > pool_cap[l]) return fail("level %d: run beyond the pool", l);
                 if (i && runs[i - 1].first + runs[i - 1].second > runs[i].first) return fail("level %d: runs overlap", l);
             }
-            if (cnt.pool_used[l] > pool_cap[l]) return fail("level %d: pool_used beyond pool_cap", l);
         }
         {
             std::vector<uint8_t> seen(n_ids, 0);
@@ -471,13 +499,14 @@ struct Emu {
                     cell_of(orig[id], c);
                     if (pack_cell((uint32_t)(c[0] >> 2), (uint32_t)(c[1] >> 2), (uint32_t)(c[2] >> 2)) != key) return fail("voxel list: id %u in the wrong voxel", id);
                     if (seen[id]++) return fail("voxel list: id %u listed twice", id);
+                    if (cellpos[id] != i) return fail("voxel list: position of id %u is stale", id);
                 }
             }
             for (uint32_t id = 0; id < n_ids; ++id)
                 if (pt_alive(orig[id]) && !seen[id]) return fail("voxel lists: living id %u missing", id);
             std::sort(runs.begin(), runs.end());
             for (size_t i = 0; i < runs.size(); ++i) {
-                if ((uint64_t)runs[i].first + runs[i].second > cnt.pool_used[CELL_SLOT]) return fail("voxel lists: run beyond pool_used");
+                if ((uint64_t)runs[i].first + runs[i].second > pool_cap[CELL_SLOT]) return fail("voxel lists: run beyond the pool");
                 if (i && runs[i - 1].first + runs[i - 1].second > runs[i].first) return fail("voxel lists: runs overlap");
             }
         }
@@ -513,7 +542,8 @@ void emu_relinearise(void* h) { static_cast<Emu*>(h)->relinearise(); }
 uint32_t emu_size(void* h) { return static_cast<Emu*>(h)->m; }
 uint32_t emu_ids(void* h) { return static_cast<Emu*>(h)->n_ids; }
 uint64_t emu_relinearisations(void* h) { return static_cast<Emu*>(h)->relinearisations; }
-uint32_t emu_tombstones(void* h) { return static_cast<Emu*>(h)->cnt.tombstones; }
+uint64_t emu_relocations(void* h) { return static_cast<Emu*>(h)->relocations; }
+uint32_t emu_tombstones(void* h) { return (uint32_t)static_cast<Emu*>(h)->n_killed; }
 uint32_t emu_fetch(void* h, float* out) {
     Emu* e = static_cast<Emu*>(h);
     uint32_t o = 0;

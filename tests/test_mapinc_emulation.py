@@ -43,6 +43,8 @@ def emu():
     lib.emu_ids.restype = C.c_uint32
     lib.emu_relinearisations.argtypes = [C.c_void_p]
     lib.emu_relinearisations.restype = C.c_uint64
+    lib.emu_relocations.argtypes = [C.c_void_p]
+    lib.emu_relocations.restype = C.c_uint64
     lib.emu_tombstones.argtypes = [C.c_void_p]
     lib.emu_tombstones.restype = C.c_uint32
     lib.emu_fetch.argtypes = [C.c_void_p, C.c_void_p]
@@ -134,6 +136,7 @@ def test_relocation_and_overflow_paths(emu, oracle):
         mp.check()
         assert np.array_equal(mp.fetch().view(np.uint32), ref.view(np.uint32)), f"step {step}"
     assert emu.emu_relinearisations(mp.h) >= 1
+    assert emu.emu_relocations(mp.h) >= 1
     mp.close()
 
 
