@@ -276,3 +276,86 @@ def make_extra_scan(m_points: int, n_points: int, k: int, *, sigma: float = 0.01
     dq = quat_from_rotvec(np.radians([0.5, -0.4, 0.8]))
     x_init = make_state(pos_true + np.array([0.10, -0.07, 0.05]), quat_mul(q_true, dq))
     return dict(scan_xyz=scan_xyz, x_true=x_true, x_init=x_init)
+
+
+# ---- BASELINE configs[4]: a LiDAR + IMU stream along a trajectory through the scene ----------------------------------
+STREAM_G = 9.809
+
+
+def stream_truth(t: float, v: float = 9.0, om: float = 0.3, yaw0: float = 0.5, p0=(-20.0, -25.0, 1.5)):
+    """Ground truth of the stream: a level arc (speed v, yaw rate om).  Returns pos, R (body -> world), vel, world
+    acceleration, quaternion (x, y, z, w)."""
+    yaw = yaw0 + om * t
+    pos = np.array([p0[0] + v / om * (math.sin(yaw) - math.sin(yaw0)), p0[1] - v / om * (math.cos(yaw) - math.cos(yaw0)), p0[2]])
+    R = np.array([[math.cos(yaw), -math.sin(yaw), 0], [math.sin(yaw), math.cos(yaw), 0], [0, 0, 1.0]])
+    vel = np.array([v * math.cos(yaw), v * math.sin(yaw), 0.0])
+    a_world = np.array([-v * om * math.sin(yaw), v * om * math.cos(yaw), 0.0])
+    q = np.array([0, 0, math.sin(yaw / 2), math.cos(yaw / 2)])
+    return pos, R, vel, a_world, q
+
+
+def stream_imu(t: float, om: float = 0.3, **kw):
+    """IMU reading in the reference's convention (State.cpp:104 `R a - g`, Localizator.cpp:138): a stationary IMU reads
+    (0, 0, -g)."""
+    _, R, _, a_world, _ = stream_truth(t, om=om, **kw)
+    return R.T @ (a_world - np.array([0, 0, STREAM_G])), np.array([0.0, 0.0, om])
+
+
+def make_stream(m_points: int, n_revs: int, *, n_rings: int = 64, n_az: int = 1024, rev_time: float = 0.1, fov_deg=(-24.8, 2.0),
+                sigma: float = 0.01, seed_map: int = SEED_MAP, seed_scan: int = SEED_SCAN, rmin: float = 4.0, rmax: float = 80.0,
+                map_radius: float | None = None, t0: float = 0.0):
+    """A spinning 64-ring LiDAR (HDL-64E-like vertical field of view) carried along stream_truth() through the scene of
+    make_scene(m_points, ...): every azimuth step fires all rings at its own time, from the pose the sensor has THEN
+    (so the raw points are skewed exactly as a moving sensor's are).  Returns dict(
+      map_xyz  [M', 3] f32  the scene's map points (only those within map_radius of the start, if given),
+      revs     list of n_revs dicts(xyz [n, 3] f32 LiDAR frame at firing time, t [n] f64 absolute stamps, stamp = end of the sweep),
+      L)."""
+    rng_m = _Rng(seed_map)
+    surf = _surfaces(rng_m, m_points)
+    map_xyz = _sample(rng_m, surf, m_points, sigma).astype(np.float32)
+    o, eu, ev, _, L = surf
+    if map_radius is not None:
+        p_start = stream_truth(t0)[0]
+        map_xyz = map_xyz[np.linalg.norm(map_xyz[:, :2] - p_start[:2].astype(np.float32), axis=1) < map_radius]
+    nrm = np.cross(eu, ev)
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    uu, vv = np.sum(eu * eu, axis=1), np.sum(ev * ev, axis=1)
+    el = np.radians(np.linspace(fov_deg[0], fov_deg[1], n_rings))
+    ce, se = np.cos(el), np.sin(el)
+    rng_s = _Rng(seed_scan)
+    revs = []
+    for r in range(n_revs):
+        t_az = t0 + (r + (np.arange(n_az) + 1.0) / n_az) * rev_time            # firing time of every azimuth step
+        az = 2.0 * math.pi * np.arange(n_az) / n_az
+        pos = np.empty((n_az, 3))
+        Rw = np.empty((n_az, 3, 3))
+        for i, t in enumerate(t_az):
+            p, R, _, _, _ = stream_truth(float(t))
+            pos[i], Rw[i] = p, R
+        dl = np.stack([ce[None, :] * np.cos(az)[:, None], ce[None, :] * np.sin(az)[:, None], se[None, :] * np.ones(n_az)[:, None]], axis=-1)
+        dw = np.einsum("aij,arj->ari", Rw, dl).reshape(-1, 3)                   # [n_az * n_rings, 3]
+        org = np.repeat(pos, n_rings, axis=0)
+        tt = np.repeat(t_az, n_rings)
+        best = np.full(len(dw), np.inf)
+        for c0 in range(0, len(dw), 16384):
+            d, og = dw[c0:c0 + 16384], org[c0:c0 + 16384]
+            den = d @ nrm.T
+            num = np.einsum("rk,rk->r", o, nrm)[None, :] - og @ nrm.T
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = num / den
+            t[~np.isfinite(t) | (t < rmin) | (t > rmax)] = np.inf
+            with np.errstate(invalid="ignore"):
+                hit = og[:, None, :] + t[:, :, None] * d[:, None, :]
+                rel = hit - o[None, :, :]
+                a = np.sum(rel * eu[None, :, :], axis=2) / uu[None, :]
+                b = np.sum(rel * ev[None, :, :], axis=2) / vv[None, :]
+            t[(a < 0) | (a > 1) | (b < 0) | (b > 1) | ~np.isfinite(a) | ~np.isfinite(b)] = np.inf
+            best[c0:c0 + 16384] = np.min(t, axis=1)
+        ok = np.isfinite(best)
+        pw = org[ok] + best[ok, None] * dw[ok]
+        pw = pw + (2.0 * rng_s.uniform(len(pw) * 3).reshape(-1, 3) - 1.0) * (sigma * math.sqrt(3.0))
+        # into the LiDAR frame of the firing instant (extrinsics = identity)
+        idx = np.nonzero(ok)[0] // n_rings
+        pl = np.einsum("nji,nj->ni", Rw[idx], pw - pos[idx])
+        revs.append(dict(xyz=pl.astype(np.float32), t=tt[ok].copy(), stamp=float(t0 + (r + 1) * rev_time)))
+    return dict(map_xyz=map_xyz, revs=revs, L=L)
