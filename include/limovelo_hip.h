@@ -53,10 +53,24 @@ typedef struct lv_params {
     int    estimate_extrinsics;  /* 0 */
     double LiDAR_noise;          /* 0.001 */
     double LIMITS[LV_STATE_DOF]; /* 23 x 0.001 */
-    double degeneracy_threshold; /* parsed, NOT applied: the fork-only degeneracy stage is unknown */
+    double degeneracy_threshold; /* 5.0 (config/params.yaml:52; kitti.yaml:46 = 400): used by degeneracy_mode 2 */
     /* ---- structure tuning (no reference counterpart) ---- */
     float  voxel_size;           /* level-0 cell edge of the voxel hash in metres (default 0.5) */
     int    lanes_per_query;      /* 1,2,4,8,16: lanes of a wavefront cooperating on one scan point (default 8) */
+    /* ---- degeneracy stage of the fork's update_iterated_dyn_share_modified(R, degeneracy_threshold, solve_time,
+     * print_degeneracy_values) (src/Modules/Localizator.cpp:132).  The fork's IKFoM source is absent, so
+     * the stage is a HOOK with an opt-in restatement, off by default:
+     *   0  off: esekf's plain iterated update (every parity and benchmark run); lv_create warns once on stderr if
+     *      degeneracy_threshold was changed from its default, because it then has no effect;
+     *   1  the eigenvalues of the 6x6 pose block of H^T H are computed every pass and kept for
+     *      lv_get_degeneracy_values ("print the degeneracy eigenvalues to guess what the threshold must be",
+     *      config/params.yaml:53); the update itself is unchanged;
+     *   2  [UNKNOWN-FORK, plausible restatement] solution remapping (Zhang, Kaess, Singh, ICRA 2016) in information
+     *      form: measurement information along pose eigen-directions whose eigenvalue is below degeneracy_threshold is
+     *      removed before the gain is formed; those directions keep their propagated value.
+     * print_degeneracy_values != 0 (with mode >= 1) also prints the eigenvalues of every pass to stderr. */
+    int    degeneracy_mode;
+    int    print_degeneracy_values;
 } lv_params;
 
 /* state_ikfom of the IKFoM fork (field order evidenced by src/Objects/State.cpp:53-61 and
@@ -165,6 +179,9 @@ typedef struct lv_motion_state {
  * result becomes the current scan exactly as if lv_scan_set had been called with it. */
 int lv_scan_deskew(lv_ctx* ctx, const void* points, size_t stride, size_t time_offset, size_t n,
                    const lv_motion_state* states, size_t n_states, const lv_motion_state* Xt2, float downsample_prec);
+/* Compensator::downsample(points) on its own (src/Modules/Compensator.cpp:104-107,148-163): the same voxel grid for
+ * points that are already compensated (downsample_prec <= 0: the points become the scan as they are, = lv_scan_set). */
+int lv_scan_downsample(lv_ctx* ctx, const void* points, size_t stride, size_t n, float downsample_prec);
 /* number of points of the current scan / copy them out (xyz packed, de-skew output order) */
 /* ---- row f-4: LiDAR wire formats (sensor_msgs/PointCloud2 -> the reference's time-stamped Points) -------------
  * lv_cloud_ingest = Accumulator::process (src/Modules/Accumulator.cpp:143-153): PointCloudProcessor::msg2points
@@ -234,6 +251,9 @@ int lv_filter_set(lv_ctx* ctx, const lv_state* x, const double* P);
 int lv_filter_get(lv_ctx* ctx, lv_state* x, double* P);
 int lv_predict(lv_ctx* ctx, double dt, const double* Q, const double acc[3], const double gyro[3]);
 int lv_correct(lv_ctx* ctx, int* passes);
+/* Eigenvalues of the pose block (pos, rot) of H^T H of every pass of the last update run with degeneracy_mode >= 1:
+ * eig receives n_passes x 6 doubles (capacity_passes rows available; Jacobi order, unsorted). */
+int lv_get_degeneracy_values(lv_ctx* ctx, double* eig, int capacity_passes, int* n_passes);
 
 /* Split form of lv_update for multi-GPU runs (scan points sharded across ranks, map replicated):
  *   lv_update_begin(x, P)

@@ -22,8 +22,8 @@ NS = 23
 ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_add_scan", "lv_map_evict_box", "lv_map_evict_oldest", "lv_map_relinearise", "lv_map_get_stats",
-    "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
-    "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
+    "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_downsample", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
+    "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
@@ -57,6 +57,8 @@ class Params(C.Structure):
         ("degeneracy_threshold", C.c_double),
         ("voxel_size", C.c_float),
         ("lanes_per_query", C.c_int),
+        ("degeneracy_mode", C.c_int),
+        ("print_degeneracy_values", C.c_int),
     ]
 
 
@@ -235,6 +237,11 @@ class Context:
                                             C.c_float(downsample_prec)))
         self._n = self.scan_size()
 
+    def scan_downsample(self, xyz, downsample_prec=0.5):
+        a, stride, n = _points(xyz)
+        self._check(self.lib.lv_scan_downsample(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(stride), C.c_size_t(n), C.c_float(downsample_prec)))
+        self._n = self.scan_size()
+
     # --- row f-4: LiDAR wire formats
     def cloud_format_preset(self, lidar_type: int) -> CloudFormat:
         f = CloudFormat()
@@ -328,6 +335,13 @@ class Context:
         p = C.c_int(0)
         self._check(self.lib.lv_correct(self.h, C.byref(p) if want_passes else None))
         return p.value
+
+    def degeneracy_values(self) -> np.ndarray:
+        """[passes, 6] eigenvalues of the pose block of H^T H of the last update (degeneracy_mode >= 1)."""
+        eig = np.zeros((16, 6))
+        n = C.c_int(0)
+        self._check(self.lib.lv_get_degeneracy_values(self.h, eig.ctypes.data_as(C.c_void_p), 16, C.byref(n)))
+        return eig[: n.value].copy()
 
     def update_begin(self, state, P):
         x = np.ascontiguousarray(state, np.float64)

@@ -247,6 +247,8 @@ int pass_solve(lv_ctx* c, bool from_groups) {
     sp.maximum_iter = c->prm.MAX_NUM_ITERS;
     sp.estimate_extrinsics = c->prm.estimate_extrinsics;
     sp.seq = c->update_seq;
+    sp.degeneracy_mode = c->prm.degeneracy_mode;
+    sp.degeneracy_threshold = c->prm.degeneracy_threshold;
     if (from_groups && c->fold_direct) return launch_solve(c->stream, c->d_kf, c->d_io, c->d_partials, c->grid, c->d_sums, sp);
     if (from_groups) return launch_solve(c->stream, c->d_kf, c->d_io, c->d_groups, c->ngroups, c->d_sums, sp);
     return launch_solve(c->stream, c->d_kf, c->d_io, c->d_sums, 1, nullptr, sp);
@@ -266,7 +268,9 @@ void lv_default_params(lv_params* p) {
     p->estimate_extrinsics = 0;     // :13
     p->LiDAR_noise = 0.001;         // :32
     for (int i = 0; i < LV_STATE_DOF; ++i) p->LIMITS[i] = 0.001;  // src/main.cpp:145
-    p->degeneracy_threshold = 5.0;  // :52 (not applied)
+    p->degeneracy_threshold = 5.0;  // :52 (applied by degeneracy_mode 2 only)
+    p->degeneracy_mode = 0;
+    p->print_degeneracy_values = 0; // :53
     p->voxel_size = 0.5f;
     p->lanes_per_query = 8;
 }
@@ -282,6 +286,17 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (!(params->voxel_size > 0.f)) { set_error("voxel_size must be > 0"); return LV_EINVAL; }
     const int S = params->lanes_per_query;
     if (!(S == 1 || S == 2 || S == 4 || S == 8 || S == 16)) { set_error("lanes_per_query must be 1,2,4,8,16"); return LV_EINVAL; }
+    if (params->degeneracy_mode < 0 || params->degeneracy_mode > 2) { set_error("degeneracy_mode must be 0, 1 or 2"); return LV_EINVAL; }
+    if (params->degeneracy_mode == 0 && params->degeneracy_threshold != 5.0) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "limovelo_hip: degeneracy_threshold = %g is set but has no effect: the degeneracy stage of the fork's "
+                            "update_iterated_dyn_share_modified is not part of the reference mount; degeneracy_mode = 2 enables a "
+                            "documented restatement, degeneracy_mode = 1 reports the eigenvalues (include/limovelo_hip.h)\n",
+                    params->degeneracy_threshold);
+        }
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { set_error("no HIP device available (%s)", hipGetErrorString(e)); return LV_ENODEV; }
@@ -563,6 +578,36 @@ int lv_scan_deskew(lv_ctx* c, const void* points, size_t stride, size_t time_off
     return c->scan.deskew_downsample(c->stream, (uint32_t)n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size);
 }
 
+// Compensator::downsample(points) on its own (Compensator.cpp:104-107, 148-163): the voxel grid of lv_scan_deskew
+// applied to points that are already compensated; the result becomes the current scan
+int lv_scan_downsample(lv_ctx* c, const void* points, size_t stride, size_t n, float downsample_prec) {
+    LV_CHECK_CTX(c);
+    if (n && (!points || stride < 12)) { set_error("bad point array (stride %zu)", stride); return LV_EINVAL; }
+    if (n > 0xFFFFFFF0ull) { set_error("scan too large"); return LV_EINVAL; }
+    c->dbg_valid = false;
+    c->qrec_valid = false;
+    c->scan.n = 0;
+    if (n == 0) return LV_OK;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    rc = c->scan.reserve_raw(n, 2);
+    if (rc) return rc;
+    rc = c->scan.reserve(n);
+    if (rc) return rc;
+    LV_HIP(hipStreamSynchronize(c->stream));  // staging buffer reuse
+    for (size_t i = 0; i < n; ++i) {
+        float x, y, z;
+        read_xyz(points, stride, i, x, y, z);
+        uint32_t ui = (uint32_t)i;
+        float w;
+        std::memcpy(&w, &ui, 4);
+        c->h_stage[i] = make_float4(x, y, z, w);
+    }
+    float4* dst = downsample_prec > 0.f ? c->scan.d_desk : c->scan.d_raw;
+    LV_HIP(hipMemcpyAsync(dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return c->scan.voxel_and_sort(c->stream, (uint32_t)n, downsample_prec, c->prm.voxel_size);
+}
+
 // ---- row f-4: LiDAR wire formats ----------------------------------------------------------------------------
 int lv_cloud_format_preset(int lidar_type, lv_cloud_format* out) {
     if (!out) { set_error("null argument"); return LV_EINVAL; }
@@ -821,6 +866,14 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
     if (passes) *passes = io->passes;
     c->h_kf->passes = io->passes;
     c->timing.last_passes = c->h_kf->passes;
+    if (c->prm.degeneracy_mode && c->prm.print_degeneracy_values) {   // print_degeneracy_values (config/params.yaml:53)
+        double eig[MAX_PASSES * 6];
+        int np = 0;
+        if (lv_get_degeneracy_values(c, eig, MAX_PASSES, &np) == LV_OK)
+            for (int i = 0; i < np; ++i)
+                fprintf(stderr, "degeneracy eigenvalues (pass %d): %.6g %.6g %.6g %.6g %.6g %.6g\n", i, eig[6 * i], eig[6 * i + 1],
+                        eig[6 * i + 2], eig[6 * i + 3], eig[6 * i + 4], eig[6 * i + 5]);
+    }
     return LV_OK;
 }
 
@@ -1033,6 +1086,21 @@ int lv_calculate_H(lv_ctx* c, const lv_state* x, const float* p_world, const flo
     hipFree(d_out);
     if (rc == LV_EHIP) set_error("lv_calculate_H: HIP error");
     return rc;
+}
+
+int lv_get_degeneracy_values(lv_ctx* c, double* eig, int capacity_passes, int* n_passes) {
+    LV_CHECK_CTX(c);
+    if (n_passes) *n_passes = 0;
+    if (!eig || capacity_passes < 0) { set_error("null argument"); return LV_EINVAL; }
+    if (c->prm.degeneracy_mode == 0) { set_error("degeneracy_mode is 0: no eigenvalues are computed"); return LV_ESTATE; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    int np = 0;
+    LV_HIP(hipMemcpy(&np, &c->d_kf->passes, sizeof(int), hipMemcpyDeviceToHost));
+    if (np > MAX_PASSES) np = MAX_PASSES;
+    if (np > capacity_passes) np = capacity_passes;
+    if (np > 0) LV_HIP(hipMemcpy(eig, c->d_kf->degen_eig, (size_t)np * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_passes) *n_passes = np;
+    return LV_OK;
 }
 
 int lv_get_level_histogram(lv_ctx* c, int out[8]) {

@@ -61,7 +61,8 @@ struct KfDev {
     double prep_dxnew[NS];
     double prep_P[NS * NS];
     double prep_A1[12 * 12];
-    int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / generic levels / brute force
+    int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / level-3 lists / every id / bounded stop
+    double degen_eig[MAX_PASSES * 6];  // degeneracy_mode >= 1: eigenvalues of the pose block of H^T H, per pass
 };
 
 // Pinned, host-mapped mailbox of one update: x_in / P_in stage the inputs (handed to kf_begin_kernel as kernel

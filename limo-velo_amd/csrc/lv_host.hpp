@@ -174,6 +174,8 @@ struct SolveParams {
     int maximum_iter;
     int estimate_extrinsics;
     int seq;   // written to the host mailbox by the pass that finishes the update
+    int degeneracy_mode;           // lv_params
+    double degeneracy_threshold;
 };
 int launch_solve(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
 // lv_predict.hip
@@ -216,6 +218,7 @@ struct ScanStore {
     int reserve(size_t cap);
     int reserve_raw(size_t cap, size_t n_states);
     int deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf, float sort_cell);
+    int voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell);
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
     int order_tiles(hipStream_t stream, uint32_t tile_points);
     void release();

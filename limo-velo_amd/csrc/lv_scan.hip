@@ -183,6 +183,15 @@ int ScanStore::deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_s
     if (rc) return rc;
     float4* desk = leaf > 0.f ? d_desk : d_raw;
     hipLaunchKernelGGL(deskew_kernel, dim3(grid), dim3(B), 0, stream, d_in, d_times, n_in, d_states, n_states, xt2, desk);
+    return voxel_and_sort(stream, n_in, leaf, sort_cell);
+}
+
+// the points (de-skewed, or uploaded as they are: Compensator::downsample on its own) wait in d_desk (leaf > 0) or
+// d_raw (leaf <= 0): voxel grid, then the Morton order the search kernel wants
+int ScanStore::voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell) {
+    const int B = 256;
+    const uint32_t grid = (n_in + B - 1) / B;
+    float4* desk = leaf > 0.f ? d_desk : d_raw;
     const unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
     LV_HIP(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(vg_bounds_kernel, dim3(grid), dim3(B), 0, stream, desk, n_in, d_bounds);

@@ -18,7 +18,7 @@
 // whose numerically safe form is  X_top = (Pr11^-1 + HTH)^-1,  X_bot = Pr21 Pr11^-1 X_top :
 // two 12x12 SPD inversions (unpivoted Gauss-Jordan) instead of two 23x23 ones, no cancellation
 // (the naive S = I + Pr11 HTH solve loses ~6 digits in the posterior covariance; measured in
-// tests/test_oracle_numerics.py).  Algebraically identical to upstream, rounding-level different.
+// tests/test_oracle.py::test_gain_form_numerics).  Algebraically identical to upstream, rounding-level different.
 #include <cstring>
 
 #include "lv_host.hpp"
@@ -226,6 +226,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 
     SV_STAMP(1);
     __syncthreads();   // sHTH / sHTh complete
+    if (prm.degeneracy_mode) {   // the fork's degeneracy stage (hook; off by default)
+        if (tid == 0) degeneracy_stage(sHTH, sHTh, prm.degeneracy_mode, prm.degeneracy_threshold, &kf->degen_eig[(pass < MAX_PASSES ? pass : 0) * 6]);
+        __syncthreads();
+    }
     // P_ (sP), dx_new and A1 = (P_/R)_ww^-1 (sG) come from solve_prep.  Pr = P_/R -> sA
     if (tid < NS * NS) sA[tid / NS][tid % NS] = sP[tid / NS][tid % NS] * prm.R_inv;
     // X = P_inv[:, 0:NW]:  X_top = (Pr_ww^-1 + HTH_ww)^-1 (unpivoted Gauss-Jordan inversion of an SPD NW x NW

@@ -199,6 +199,76 @@ __device__ inline void boxplus_block(int part, double* x, const double* d) {
     else d_s2_boxplus(x + 23, d + 21);
 }
 
+// Degeneracy stage of the fork's update_iterated_dyn_share_modified [UNKNOWN-FORK; see include/limovelo_hip.h
+// degeneracy_mode]: eigen-decomposition of the 6x6 pose block of H^T H by cyclic Jacobi (fixed 8 sweeps, one lane: a
+// serial f64 chain that only runs when the stage is switched on), eigenvalues to eig[6]; mode 2 projects the
+// measurement information onto the eigen-directions at or above the threshold:
+//   H^T H <- blockdiag(Pn, I) H^T H blockdiag(Pn, I),  H^T h <- blockdiag(Pn, I) H^T h,  Pn = sum_{lambda >= thr} v v^T.
+__device__ inline void degeneracy_stage(double (*HTH)[12], double* HTh, int mode, double threshold, double* eig) {
+    double A[6][6], V[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) { A[i][j] = HTH[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 8; ++sweep)
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    for (int i = 0; i < 6; ++i) eig[i] = A[i][i];
+    if (mode != 2) return;
+    double Pn[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int e = 0; e < 6; ++e)
+                if (A[e][e] >= threshold) s += V[i][e] * V[j][e];
+            Pn[i][j] = s;
+        }
+    double T[6][12];
+    for (int i = 0; i < 6; ++i)          // rows 0..5 of blockdiag(Pn, I) H
+        for (int j = 0; j < 12; ++j) {
+            double s = 0.0;
+            for (int e = 0; e < 6; ++e) s += Pn[i][e] * HTH[e][j];
+            T[i][j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 12; ++j) HTH[i][j] = T[i][j];
+    for (int i = 0; i < 12; ++i) {       // columns 0..5 of (.) blockdiag(Pn, I)
+        double r[6];
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int e = 0; e < 6; ++e) s += HTH[i][e] * Pn[e][j];
+            r[j] = s;
+        }
+        for (int j = 0; j < 6; ++j) HTH[i][j] = r[j];
+    }
+    double h6[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = 0.0;
+        for (int e = 0; e < 6; ++e) s += Pn[i][e] * HTh[e];
+        h6[i] = s;
+    }
+    for (int i = 0; i < 6; ++i) HTh[i] = h6[i];
+}
+
 // dof index -> offset in the 26-double state for the vect components
 __device__ __forceinline__ int vect_state_index(int dof) {  // dof in {0..2, 9..20}
     return dof < 3 ? dof : dof + 2;                         // 9..11 -> 11..13, 12..14 -> 14..16, ...

@@ -1,5 +1,5 @@
-// limovelo_shim.cpp — see limovelo_shim.hpp.  Data movement only; every number of the path is
-// produced by liblimovelo_hip.so.
+// limovelo_shim.cpp — see limovelo_shim.hpp.  Bulk computation is in liblimovelo_hip.so; the host keeps the
+// reference's bookkeeping (buffers, single-state motion model, single transforms).
 #include "limovelo_shim.hpp"
 
 struct Params Config;
@@ -62,10 +62,15 @@ State::State() {
     x.offset_R_L_I[3] = 1.0;
 }
 
-// State::State(const state_ikfom&, double) — reference src/Objects/State.cpp:51-62
+// State::State(const state_ikfom&, double) — reference src/Objects/State.cpp:41-62 (the controls come from the IMU that
+// follows t in the Accumulator, :46-49)
 State::State(const state_ikfom& s, double t) : State() {
     time = t;
     x = s;
+    {
+        const IMU imu = Accumulator::getInstance().get_next_imu(t);
+        for (int i = 0; i < 3; ++i) { a[i] = imu.a[i]; w[i] = imu.w[i]; }
+    }
     for (int i = 0; i < 3; ++i) { vel[i] = (float)s.vel[i]; bw[i] = (float)s.bg[i]; ba[i] = (float)s.ba[i]; }
     auto q2r = [](const double q[4], float R[9]) {  // Eigen Quaternion::toRotationMatrix, then cast<float>
         const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
@@ -150,7 +155,204 @@ lv_motion_state State::motion() const {
     return m;
 }
 
-// ---- Compensator (reference src/Modules/Compensator.cpp:123-163) -----------------------------------------
+// ---- RotTransl (reference src/Objects/RotTransl.cpp:19-54), f32, Eigen's 3-term order x0 + (x1 + x2) ----------
+RotTransl::RotTransl(const State& S) { std::memcpy(R, S.R, sizeof(R)); std::memcpy(t, S.pos, sizeof(t)); }
+RotTransl RotTransl::inv() const {
+    RotTransl o;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = R[j * 3 + i];
+    for (int i = 0; i < 3; ++i) o.t[i] = dot3(-o.R[i * 3], t[0], -o.R[i * 3 + 1], t[1], -o.R[i * 3 + 2], t[2]);
+    return o;
+}
+RotTransl operator*(const RotTransl& a, const RotTransl& b) {
+    RotTransl o;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = dot3(a.R[i * 3], b.R[j], a.R[i * 3 + 1], b.R[3 + j], a.R[i * 3 + 2], b.R[6 + j]);
+    for (int i = 0; i < 3; ++i) o.t[i] = dot3(a.R[i * 3], b.t[0], a.R[i * 3 + 1], b.t[1], a.R[i * 3 + 2], b.t[2]) + a.t[i];
+    return o;
+}
+Point operator*(const RotTransl& a, const Point& p) {
+    Point o = p;   // attributes copied (Point.cpp:32-35)
+    o.x = dot3(a.R[0], p.x, a.R[1], p.y, a.R[2], p.z) + a.t[0];
+    o.y = dot3(a.R[3], p.x, a.R[4], p.y, a.R[5], p.z) + a.t[1];
+    o.z = dot3(a.R[6], p.x, a.R[7], p.y, a.R[8], p.z) + a.t[2];
+    return o;
+}
+Points operator*(const RotTransl& a, const Points& pts) {
+    Points moved = pts;
+    for (Point& p : moved) p = a * p;
+    return moved;
+}
+
+// ---- Accumulator (reference src/Modules/Accumulator.cpp; include/Headers/Accumulator.hpp:62-118) ----------------
+namespace {
+// index of the newest content with time <= t in a new -> old deque (Algorithms::binary_search(content, t, true))
+template <typename T>
+int before_t(const std::deque<T>& c, double t) {
+    int lo = 0, hi = (int)c.size();
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (c[(size_t)mid].time > t) lo = mid + 1; else hi = mid;
+    }
+    return lo;   // == size() when every content is newer than t
+}
+template <typename T>
+std::deque<T> get_between(Buffer<T>& src, double t1, double t2) {   // Accumulator.hpp:62-74: t1 <= time <= t2, old -> new
+    std::deque<T> result;
+    for (int k = before_t(src.content, t2); k < (int)src.content.size(); ++k) {
+        const T& cnt = src.content[(size_t)k];
+        if (t1 > cnt.time) break;
+        if (t2 >= cnt.time) result.push_front(cnt);
+    }
+    return result;
+}
+}  // namespace
+
+void Accumulator::add(State cnt, double time) { if (time > 0) cnt.time = time; BUFFER_X.push(cnt); }
+void Accumulator::add(IMU cnt, double time) { if (time > 0) cnt.time = time; BUFFER_I.push(cnt); }
+size_t Accumulator::receive_lidar(const void* data, size_t n_points, const lv_cloud_format& format, uint64_t header_stamp_usec) {
+    return LidarBuffer::getInstance().process(data, n_points, format, header_stamp_usec);
+}
+void Accumulator::clear_buffers() { LidarBuffer::getInstance().clear_lidar(1e300); BUFFER_I.clear(); }
+void Accumulator::clear_buffers(TimeType t) { LidarBuffer::getInstance().clear_lidar(t); BUFFER_I.clear(t); }
+void Accumulator::clear_lidar(TimeType t) { LidarBuffer::getInstance().clear_lidar(t); }
+Points Accumulator::get_points(double t1, double t2) { return LidarBuffer::getInstance().get_points(t1, t2); }
+IMUs Accumulator::get_imus(double t1, double t2) { return get_between(BUFFER_I, t1, t2); }
+States Accumulator::get_states(double t1, double t2) { return get_between(BUFFER_X, t1, t2); }
+
+IMU Accumulator::get_next_imu(double t) {                               // Accumulator.hpp:76-92
+    const std::deque<IMU>& c = BUFFER_I.content;
+    if (c.empty()) return IMU();
+    if (c.back().time > t) return IMU();
+    if (t > c.front().time) return c.front();
+    const int k = before_t(c, t);                 // newest content with time <= t; the one before it in the deque follows t
+    return k > 0 ? c[(size_t)k - 1] : c.front();
+}
+State Accumulator::get_prev_state(double t) {                           // Accumulator.cpp:77-86, Accumulator.hpp:94-107
+    if (BUFFER_X.empty()) {
+        State X = Localizator::getInstance().latest_state();
+        add(X, t);
+        X.time = t;
+        return X;
+    }
+    for (const State& X : BUFFER_X.content)     // new -> old: the newest state strictly before t
+        if (t > X.time) return X;
+    return State();
+}
+bool Accumulator::enough_imus() { return BUFFER_I.size() > 2 * Config.real_time_delay * Config.imu_rate + 10; }   // :156-158
+void Accumulator::set_initial_time() {                                  // :160-165
+    if (BUFFER_I.size() < 1) return;
+    initial_time = BUFFER_I.front().time - Config.real_time_delay;
+}
+bool Accumulator::ready() {                                             // :102-114
+    if (is_ready) return true;
+    if (enough_imus()) {
+        set_initial_time();
+        Localizator::getInstance().initialize(initial_time);
+        return is_ready = true;
+    }
+    return is_ready = false;
+}
+double Accumulator::update_delta(const InitializationParams& ini, double t) {   // :123-126, 167-178
+    if (ini.times.empty()) return ini.deltas.back();
+    if (t - initial_time >= ini.times.back()) return ini.deltas.back();
+    for (size_t k = 0; k < ini.times.size(); ++k)
+        if (t - initial_time < ini.times[k]) return ini.deltas[k];
+    return ini.deltas.back();
+}
+double Accumulator::latest_time() { return BUFFER_I.front().time - Config.real_time_delay; }   // :128-134
+
+// ---- Compensator (reference src/Modules/Compensator.cpp) -----------------------------------------------------
+namespace {
+// Compensator::upsample (Compensator.cpp:63-95): every state, then the states integrated IMU by IMU up to the next one
+States upsample(const States& states, const IMUs& imus) {
+    size_t s = 0, u = 0;
+    States up;
+    State cur = states[0];
+    while (s + 1 < states.size()) {
+        up.push_back(states[s]);
+        while (u < imus.size() && imus[u].time < states[s + 1].time) {
+            cur += imus[u++];
+            up.push_back(cur);
+        }
+        cur = states[s++];
+    }
+    if (u >= imus.size()) u = imus.size() - 1;
+    up.push_back(states.back());
+    cur = states.back();
+    while (cur.time < imus.back().time && u < imus.size()) {
+        cur += imus[u++];
+        up.push_back(cur);
+    }
+    return up;
+}
+// Compensator::get_t2 (Compensator.cpp:52-61)
+State get_t2(const States& states, double t2) {
+    int s = (int)states.size() - 1;
+    while (s > 0 && t2 < states[(size_t)s].time) --s;
+    State Xt2 = states[(size_t)s];
+    Xt2 += IMU(Xt2.a, Xt2.w, t2);
+    return Xt2;
+}
+std::vector<lv_motion_state> motions(const States& states) {
+    std::vector<lv_motion_state> ms;
+    ms.reserve(states.size());
+    for (const State& st : states) ms.push_back(st.motion());
+    return ms;
+}
+Points fetch_scan(lv_ctx* c, double time) {
+    Points out;
+    const size_t n = lv_scan_size(c);
+    std::vector<float> xyz(3 * n);
+    check(lv_scan_fetch(c, xyz.data(), n), "lv_scan_fetch");
+    for (size_t i = 0; i < n; ++i) out.push_back(Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], time));
+    return out;
+}
+}  // namespace
+
+States Compensator::path(double t1, double t2) {                        // Compensator.cpp:37-50
+    Accumulator& accum = Accumulator::getInstance();
+    States states = accum.get_states(t1, t2);
+    states.push_front(accum.get_prev_state(t1));
+    IMUs imus = accum.get_imus(states.front().time, t2);
+    imus.push_back(accum.get_next_imu(t2));
+    return upsample(states, imus);
+}
+
+Points Compensator::compensate(double t1, double t2) {                  // Compensator.cpp:18-35
+    lv_ctx* c = HipRuntime::ctx();
+    States path_taken = path(t1, t2);
+    if (path_taken.size() < 2) return Points();
+    const State Xt2 = get_t2(path_taken, t2);
+    const std::vector<lv_motion_state> ms = motions(path_taken);
+    const lv_motion_state x2 = Xt2.motion();
+    size_t nw = 0;
+    check(lv_scan_deskew_window(c, t1, t2, ms.data(), ms.size(), &x2, 0.f, &nw), "lv_scan_deskew_window");
+    if (nw == 0) return Points();                                        // :24
+    return fetch_scan(c, t2);
+}
+
+size_t Compensator::compensate_downsample_on_device(double t1, double t2) {
+    lv_ctx* c = HipRuntime::ctx();
+    States path_taken = path(t1, t2);
+    if (path_taken.size() < 2) return 0;
+    const State Xt2 = get_t2(path_taken, t2);
+    const std::vector<lv_motion_state> ms = motions(path_taken);
+    const lv_motion_state x2 = Xt2.motion();
+    size_t nw = 0;
+    check(lv_scan_deskew_window(c, t1, t2, ms.data(), ms.size(), &x2, Config.downsample_prec, &nw), "lv_scan_deskew_window");
+    return nw == 0 ? 0 : lv_scan_size(c);
+}
+
+Points Compensator::downsample(const Points& points) {                  // Compensator.cpp:104-107, 148-163
+    if (points.empty()) return Points();
+    lv_ctx* c = HipRuntime::ctx();
+    PointVector v = as_vector(points);
+    check(lv_scan_downsample(c, v.data(), sizeof(Point), v.size(), Config.downsample_prec), "lv_scan_downsample");
+    return fetch_scan(c, points.back().time);
+}
+
+// ---- Compensator, explicit-path overloads (reference src/Modules/Compensator.cpp:123-163) ---------------------------
 Points Compensator::compensate(const States& states, const State& Xt2, const Points& points, float downsample_prec) {
     Points out;
     if (points.empty() || states.size() < 2) return out;
@@ -223,6 +425,11 @@ void Mapper::add(Points& points, double time, bool downsample) {         // :22-
     last_map_time = time;
 }
 
+void Mapper::add_current_scan(double time, bool downsample) {
+    check(lv_map_add_scan(HipRuntime::ctx(), downsample ? 1 : 0), "lv_map_add_scan");   // builds the map if there is none (Mapper.cpp:26)
+    last_map_time = time;
+}
+
 Matches Mapper::match(const State& X, const Points& points) {            // :40-56
     Matches matches;
     if (!exists()) return matches;
@@ -286,6 +493,52 @@ void Localizator::propagate(const IMU& imu) {                            // :159
     const double dt = imu.time - last_time_integrated;
     check(lv_predict(HipRuntime::ctx(), dt, Q, acc, gyro), "lv_predict");
     host_stale_ = true;
+}
+
+void Localizator::propagate_to(double t) {                               // :59-75
+    propagate_to(Accumulator::getInstance().get_imus(last_time_integrated, t), t);
+}
+
+void Localizator::initialize(double t) {                                 // :119-127 -> init_IKFoM_state :135-153
+    IMUs imus = Accumulator::getInstance().get_imus(-1, t);
+    if (imus.empty()) return;
+    const IMU& imu = imus.back();
+    state_ikfom x0;
+    std::memset(&x0, 0, sizeof(x0));
+    for (int i = 0; i < 4; ++i) x0.rot[i] = imu.q[i];                    // init_state.rot = imu.q
+    for (int i = 0; i < 3; ++i) x0.grav[i] = -(double)(i < (int)Config.initial_gravity.size() ? Config.initial_gravity[i] : 0.f);
+    // offset_R_L_I = SO3(Map<Matrix3f>(I_Rotation_L)) — column-major Map, no transpose: matrix -> quaternion
+    float M[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = Config.I_Rotation_L.size() == 9 ? Config.I_Rotation_L[(size_t)(j * 3 + i)] : (i == j);
+    {
+        const double tr = (double)M[0] + M[4] + M[8];
+        double q[4];
+        if (tr > 0) {
+            const double sq = std::sqrt(tr + 1.0) * 2.0;
+            q[3] = 0.25 * sq; q[0] = (M[7] - M[5]) / sq; q[1] = (M[2] - M[6]) / sq; q[2] = (M[3] - M[1]) / sq;
+        } else if (M[0] > M[4] && M[0] > M[8]) {
+            const double sq = std::sqrt(1.0 + M[0] - M[4] - M[8]) * 2.0;
+            q[3] = (M[7] - M[5]) / sq; q[0] = 0.25 * sq; q[1] = (M[1] + M[3]) / sq; q[2] = (M[2] + M[6]) / sq;
+        } else if (M[4] > M[8]) {
+            const double sq = std::sqrt(1.0 + M[4] - M[0] - M[8]) * 2.0;
+            q[3] = (M[2] - M[6]) / sq; q[0] = (M[1] + M[3]) / sq; q[1] = 0.25 * sq; q[2] = (M[5] + M[7]) / sq;
+        } else {
+            const double sq = std::sqrt(1.0 + M[8] - M[0] - M[4]) * 2.0;
+            q[3] = (M[3] - M[1]) / sq; q[0] = (M[2] + M[6]) / sq; q[1] = (M[5] + M[7]) / sq; q[2] = 0.25 * sq;
+        }
+        for (int i = 0; i < 4; ++i) x0.offset_R_L_I[i] = q[i];
+    }
+    for (int i = 0; i < 3; ++i) x0.offset_T_L_I[i] = i < (int)Config.I_Translation_L.size() ? Config.I_Translation_L[(size_t)i] : 0.f;
+    init_state(x0);
+}
+
+void Localizator::correct_current_scan(double time) {                    // :23-27 on the device-resident scan
+    if (!Mapper::getInstance().exists()) return;
+    if (!initialized) { push(); initialized = true; }
+    check(lv_correct(HipRuntime::ctx(), &last_passes), "lv_correct");
+    host_stale_ = true;
+    last_time_updated = time;
 }
 
 void Localizator::propagate_to(const IMUs& imus, double t) {             // :59-75

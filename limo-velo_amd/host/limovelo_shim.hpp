@@ -16,7 +16,10 @@
 //     compound manifold; IKFoM's esekf lives on the GPU (lv_update).
 //   * State(const state_ikfom&, double) no longer reaches into the Accumulator singleton
 //     (reference src/Objects/State.cpp:41-51): IMU-derived members are not on this path.
-// All arithmetic of the path runs in liblimovelo_hip.so; this file only moves data.
+// Every bulk computation of the path (matching, plane fits, Jacobians, the filter algebra, de-skew, voxel grid, map
+// maintenance) runs in liblimovelo_hip.so.  What stays on the host is the reference's own bookkeeping restated:
+// the IMU / state buffers of the Accumulator, the single-state f32 motion model State::operator+= that builds the
+// handful of states surrounding a window (Compensator::upsample), and RotTransl algebra on single transforms.
 #pragma once
 
 #include <cmath>
@@ -31,6 +34,11 @@
 #include "../../include/limovelo_hip.h"
 
 typedef double TimeType;
+
+struct InitializationParams {  // reference Common.hpp:51-54
+    std::vector<double> times;
+    std::vector<double> deltas = {0.1};
+};
 
 struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107), same names
     bool estimate_extrinsics = false;
@@ -51,6 +59,11 @@ struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107)
     std::vector<float> initial_gravity = {0.f, 0.f, -9.807f};
     std::vector<float> I_Rotation_L = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     std::vector<float> I_Translation_L = {0, 0, 0};
+    bool real_time = false, mapping_online = true;           // config/params.yaml:2-3
+    double real_time_delay = 0.1;                            // :24
+    int imu_rate = 400;                                      // :33
+    double empty_lidar_time = 0.2;                           // :23
+    InitializationParams Initialization;                     // :59-66
 };
 extern struct Params Config;  // the reference's global (src/main.cpp:14)
 
@@ -65,13 +78,29 @@ class Point {  // reference Objects.hpp:20-28 — 32 bytes, xyz at offset 0
 };
 static_assert(sizeof(Point) == 32, "Point must keep the reference's 32-byte layout");
 
-class IMU {  // reference Objects.hpp IMU (a, w, time); the ROS constructors are ingest-only
+class IMU {  // reference Objects.hpp IMU (a, w, q, time); the ROS constructors are ingest-only
   public:
     float a[3] = {0, 0, 0};
     float w[3] = {0, 0, 0};
+    float q[4] = {0, 0, 0, 1};   // orientation of the message (x, y, z, w): initial attitude, Localizator.cpp:137
     TimeType time = 0;
     IMU() = default;
     IMU(const float a_[3], const float w_[3], TimeType t) : time(t) { for (int i = 0; i < 3; ++i) { a[i] = a_[i]; w[i] = w_[i]; } }
+};
+
+template <typename ContentType>
+class Buffer {  // reference Objects.hpp:4-18, src/Objects/Buffer.cpp: newest content at the front
+  public:
+    std::deque<ContentType> content;
+    void push(const ContentType& cnt) { content.push_front(cnt); }
+    void pop_front() { content.pop_front(); }
+    void pop_back() { content.pop_back(); }
+    ContentType front() { return content.front(); }
+    ContentType back() { return content.back(); }
+    bool empty() { return content.empty(); }
+    int size() { return (int)content.size(); }
+    void clear() { content.clear(); }
+    void clear(TimeType t) { while (!content.empty() && t >= content.back().time) content.pop_back(); }
 };
 typedef std::deque<IMU> IMUs;
 
@@ -116,6 +145,19 @@ class Match {  // reference Objects.hpp:181-190
 };
 typedef std::vector<Match> Matches;
 
+class State;
+class RotTransl {  // reference Objects.hpp:139-151, src/Objects/RotTransl.cpp; row-major R
+  public:
+    float R[9], t[3];
+    RotTransl() : R{1, 0, 0, 0, 1, 0, 0, 0, 1}, t{0, 0, 0} {}
+    explicit RotTransl(const State& S);
+    RotTransl(const float dR[9], const float dt[3]) { std::memcpy(R, dR, sizeof(R)); std::memcpy(t, dt, sizeof(t)); }
+    RotTransl inv() const;
+    friend RotTransl operator*(const RotTransl&, const RotTransl&);
+    friend Point operator*(const RotTransl&, const Point&);
+    friend Points operator*(const RotTransl&, const Points&);
+};
+
 class State {  // f32 mirror of the filter state (reference Objects.hpp:97-137), row-major matrices
   public:
     float R[9], pos[3], vel[3], bw[3], ba[3], g[3];
@@ -127,11 +169,61 @@ class State {  // f32 mirror of the filter state (reference Objects.hpp:97-137),
     State(const state_ikfom& s, double t);
     void operator+=(const IMU& imu);  // State::update -> propagate_f (State.cpp:94-121); host math for single states
     lv_motion_state motion() const;   // the record lv_scan_deskew consumes
+    RotTransl I_Rt_L() const { return RotTransl(RLI, tLI); }           // State.cpp:64-69
+    RotTransl inv() const { return RotTransl(*this).inv(); }           // :71-73
+    friend Point operator*(const State& X, const Point& p) { return RotTransl(X) * p; }            // :79-81
+    friend RotTransl operator*(const State& X, const RotTransl& RT) { return RotTransl(X) * RT; } // :83-85
+    friend Points operator*(const State& X, const Points& pts) { return RotTransl(X) * pts; }      // :87-89
 };
 typedef std::deque<State> States;
 
-class Compensator {  // reference include/Headers/Compensator.hpp; the Accumulator-bound overloads are host plumbing
+// The reference's Accumulator (include/Headers/Accumulator.hpp, src/Modules/Accumulator.cpp) without ROS: the IMU
+// and state buffers live here on the host (a few hundred small records), the LiDAR buffer on the device
+// (LidarBuffer below).  Same method names and time-interval semantics (content sorted new -> old, closed intervals).
+class Accumulator {
   public:
+    Buffer<IMU> BUFFER_I;
+    Buffer<State> BUFFER_X;
+    double initial_time = 0;
+
+    void add(State cnt, double time = -1);
+    void add(IMU cnt, double time = -1);
+    void receive_imu(const IMU& imu) { add(imu); }                      // Accumulator.cpp:50-55 (the IMU_msg -> IMU step is ROS)
+    // Accumulator::receive_lidar (:38-48) for the payload of one sensor_msgs/PointCloud2: processed on the device
+    size_t receive_lidar(const void* data, size_t n_points, const lv_cloud_format& format, uint64_t header_stamp_usec);
+    void clear_buffers();
+    void clear_buffers(TimeType t);
+    void clear_lidar(TimeType t);
+    State get_prev_state(double t);
+    IMU get_next_imu(double t);
+    States get_states(double t1, double t2);
+    Points get_points(double t1, double t2);
+    IMUs get_imus(double t1, double t2);
+    bool ready();
+    double update_delta(const InitializationParams&, double t);
+    double latest_time();
+    static Accumulator& getInstance() {
+        static Accumulator* a = new Accumulator();
+        return *a;
+    }
+
+  private:
+    bool is_ready = false;
+    bool enough_imus();
+    void set_initial_time();
+};
+
+class Compensator {  // reference include/Headers/Compensator.hpp
+  public:
+    // Compensator::compensate(t1, t2) (Compensator.cpp:18-35): points of [t1, t2] from the (device) LiDAR buffer, states
+    // from the Accumulator (path -> upsample -> get_t2), de-skewed on the device; NOT down-sampled, as in the reference
+    Points compensate(double t1, double t2);
+    States path(double t1, double t2);                                  // :37-50
+    Points downsample(const Points& points);                            // :104-107 -> voxel grid with Config.downsample_prec, on the device
+    // compensate(t1, t2) + downsample in ONE device pass, the result staying on the device as the current scan
+    // (no fetch): what a maintainer calls instead of the two lines above to keep the cycle off the host; returns
+    // the number of down-sampled points
+    size_t compensate_downsample_on_device(double t1, double t2);
     // Compensator::compensate(states, Xt2, points) (Compensator.cpp:123-146) followed by
     // Compensator::downsample (:104-107,148-163) with leaf = downsample_prec; <= 0 skips the voxel grid
     Points compensate(const States& states, const State& Xt2, const Points& points, float downsample_prec);
@@ -170,6 +262,9 @@ class Mapper {
     bool exists();
     int size();
     void add(Points&, double time, bool downsample = false);
+    // map.add(Xt2 * Xt2.I_Rt_L() * ds_compensated, t2, true) (src/main.cpp:92,102) with the scan and the posterior the
+    // device already holds (lv_map_add_scan): the mapping step without a host round trip
+    void add_current_scan(double time, bool downsample = true);
     Matches match(const State&, const Points&);
     bool hasToMap(double t);
 
@@ -199,9 +294,11 @@ class Localizator {
     void change_x(const state_ikfom& x);
     void change_P(const double* P);
 
+    void initialize(double t);               // Localizator.cpp:119-127: initial IMU from the Accumulator -> init_IKFoM_state
     void correct(const Points&, double time);
-    // Localizator::propagate_to(t) (Localizator.cpp:59-75) with the IMU interval handed in by the caller (the
-    // reference pulls it from the Accumulator singleton): integrates every sample, then the last one up to t
+    void correct_current_scan(double time);  // the same update on the scan the device already holds (compensate_downsample_on_device)
+    void propagate_to(double t);             // Localizator.cpp:59-75: the IMUs of (last_time_integrated, t] from the Accumulator
+    // the same with the IMU interval handed in by the caller
     void propagate_to(const IMUs& imus, double t);
     void propagate(const IMU& imu);          // Localizator.cpp:159-173
     void calculate_H(const state_ikfom&, const Matches&, MatrixXd& H, VectorXd& h);

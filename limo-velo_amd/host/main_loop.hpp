@@ -1,0 +1,54 @@
+// main_loop.hpp — the body of the reference's processing loop (src/main.cpp:52-128) written against the shim, to show
+// (and compile-check) that the lines a maintainer keeps are the reference's own: only the ROS publishers are gone.
+//   ref:  while (accum.ready()) { ... loc.propagate_to(t2); comp.compensate(t1, t2); comp.downsample(...);
+//          loc.correct(ds_compensated, t2); State Xt2 = loc.latest_state(); accum.add(Xt2, t2);
+//          Points global_ds_compensated = Xt2 * Xt2.I_Rt_L() * ds_compensated; map.add(global_ds_compensated, t2, true);
+//          accum.clear_lidar(t2 - Config.empty_lidar_time); break; }
+// run_cycle() is one turn of that inner loop; `on_device` selects the three calls that keep the scan on the GPU
+// between the stages (same results, no host round trips) instead of the reference's by-value hand-overs.
+#pragma once
+
+#include "limovelo_shim.hpp"
+
+struct LoopClock {      // the time variables of main.cpp:44-49
+    double t1 = 0, t2 = 1e300, delta = 0;
+};
+
+// returns true if a localisation happened in this turn
+inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, Mapper& map, LoopClock& clk, bool on_device,
+                      State* Xt2_out = nullptr, size_t* n_points = nullptr) {
+    if (!accum.ready()) return false;
+    // Step 0. TIME MANAGEMENT (main.cpp:58-73)
+    if (Config.real_time) clk.t2 = accum.latest_time();
+    else clk.t2 = std::min(clk.t2 + clk.delta, accum.latest_time());
+    clk.delta = accum.update_delta(Config.Initialization, clk.t2);
+    clk.t1 = std::max(clk.t2 - clk.delta, loc.last_time_updated);
+    if (clk.t2 - clk.t1 < clk.delta - 1e-6) return false;
+    // Step 1. LOCALIZATION (:75-93)
+    loc.propagate_to(clk.t2);
+    State Xt2;
+    if (!on_device) {
+        Points compensated = comp.compensate(clk.t1, clk.t2);
+        Points ds_compensated = comp.downsample(compensated);
+        if ((int)ds_compensated.size() < Config.MAX_POINTS2MATCH) return false;
+        loc.correct(ds_compensated, clk.t2);
+        Xt2 = loc.latest_state();
+        accum.add(Xt2, clk.t2);
+        Points global_ds_compensated = Xt2 * Xt2.I_Rt_L() * ds_compensated;
+        // Step 2. MAPPING (:98-103)
+        if (Config.mapping_online) map.add(global_ds_compensated, clk.t2, true);
+        if (n_points) *n_points = ds_compensated.size();
+    } else {
+        const size_t n_ds = comp.compensate_downsample_on_device(clk.t1, clk.t2);
+        if ((int)n_ds < Config.MAX_POINTS2MATCH) return false;
+        loc.correct_current_scan(clk.t2);
+        Xt2 = loc.latest_state();
+        accum.add(Xt2, clk.t2);
+        if (Config.mapping_online) map.add_current_scan(clk.t2, true);
+        if (n_points) *n_points = n_ds;
+    }
+    // Step 3. ERASE OLD DATA (:116-118)
+    accum.clear_lidar(clk.t2 - Config.empty_lidar_time);
+    if (Xt2_out) *Xt2_out = Xt2;
+    return true;
+}

@@ -1,0 +1,124 @@
+// stream_demo.cpp — drives main_loop.hpp (the reference's loop, src/main.cpp:52-128) through the C++ shim on a
+// recorded stream, so that tests/test_gpu_shim.py can check the trajectory against the ground truth and against the
+// Python-driven pipeline.  Input: a binary file written by the test (little endian):
+//   u32 magic 'LVST', u32 on_device, f64 delta, u32 n_map, f32 map[n_map*3],
+//   u32 n_imu, { f64 t, f32 a[3], f32 w[3], f32 q[4] } * n_imu,
+//   u32 n_msgs, { f64 arrival, u64 stamp_usec, u32 n_points, u8 payload[n_points * 48] } * n_msgs   (hesai layout)
+// IMU samples and LiDAR messages are fed in time order; after every IMU sample the loop body runs as often as it can.
+// Output: u32 n_updates, { f64 t2, f64 x[26], u32 n_points } * n_updates.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "main_loop.hpp"
+
+template <typename T>
+static T rd(std::ifstream& f) {
+    T v;
+    f.read(reinterpret_cast<char*>(&v), sizeof(T));
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) { std::cerr << "usage: stream_demo in.bin out.bin\n"; return 2; }
+    try {
+        std::ifstream f(argv[1], std::ios::binary);
+        if (!f || rd<uint32_t>(f) != 0x5453564Cu) throw std::runtime_error("bad input file");
+        const bool on_device = rd<uint32_t>(f) != 0;
+        const double delta = rd<double>(f);
+        const uint32_t n_map = rd<uint32_t>(f);
+        std::vector<float> mapv((size_t)n_map * 3);
+        f.read(reinterpret_cast<char*>(mapv.data()), (std::streamsize)(mapv.size() * 4));
+        struct ImuRec { double t; float a[3], w[3], q[4]; };
+        std::vector<ImuRec> imus(rd<uint32_t>(f));
+        for (auto& r : imus) { r.t = rd<double>(f); f.read(reinterpret_cast<char*>(r.a), 12); f.read(reinterpret_cast<char*>(r.w), 12); f.read(reinterpret_cast<char*>(r.q), 16); }
+        struct Msg { double arrival; uint64_t stamp; uint32_t n; std::vector<unsigned char> data; };
+        std::vector<Msg> msgs(rd<uint32_t>(f));
+        for (auto& m : msgs) {
+            m.arrival = rd<double>(f); m.stamp = rd<uint64_t>(f); m.n = rd<uint32_t>(f);
+            m.data.resize((size_t)m.n * 48);
+            f.read(reinterpret_cast<char*>(m.data.data()), (std::streamsize)m.data.size());
+        }
+        Config.Initialization.times = {};
+        Config.Initialization.deltas = {delta};
+        Config.real_time = false;
+        Config.real_time_delay = 0.1;
+        Config.imu_rate = 100;
+        Config.empty_lidar_time = 1.0;
+        Config.mapping_online = true;
+        Config.initial_gravity = {0.f, 0.f, -9.809f};
+
+        Accumulator& accum = Accumulator::getInstance();
+        Compensator comp;
+        Localizator& loc = Localizator::getInstance();
+        Mapper& map = Mapper::getInstance();
+        Points map_pts;
+        for (uint32_t i = 0; i < n_map; ++i) map_pts.push_back(Point(mapv[3 * i], mapv[3 * i + 1], mapv[3 * i + 2], 0.0));
+        map.add(map_pts, 0.0, false);                       // a prior map (the reference starts empty; either is Mapper::add)
+
+        lv_cloud_format fmt;
+        lv_cloud_format_preset(LV_LIDAR_HESAI, &fmt);
+        LoopClock clk;
+        clk.delta = delta;
+        std::vector<double> out_t;
+        std::vector<state_ikfom> out_x;
+        std::vector<uint32_t> out_n;
+        size_t mi = 0;
+        bool positioned = false;
+        for (const ImuRec& r : imus) {
+            while (mi < msgs.size() && msgs[mi].arrival <= r.t) {
+                accum.receive_lidar(msgs[mi].data.data(), msgs[mi].n, fmt, msgs[mi].stamp);
+                ++mi;
+            }
+            IMU imu(r.a, r.w, r.t);
+            std::memcpy(imu.q, r.q, sizeof(imu.q));
+            accum.receive_imu(imu);
+            if (accum.ready() && !positioned) {
+                // the test's trajectory does not start at the origin: place the filter (the reference starts at pos = 0
+                // in its own map frame; with a prior map the start pose has to be given)
+                state_ikfom x0 = loc.get_x();
+                std::ifstream pf(std::string(argv[1]) + ".x0", std::ios::binary);
+                if (pf) pf.read(reinterpret_cast<char*>(&x0), sizeof(x0));
+                loc.change_x(x0);
+                // the given state IS the state at the initial time: without this the first propagate_to would integrate
+                // every buffered IMU sample of [-1, t] (Localizator.cpp:61-62) — harmless for a sensor at rest, as the
+                // reference assumes at start-up, a 0.2 m kick for one that is already moving at 9 m/s
+                loc.last_time_integrated = accum.initial_time;
+                // ... and the first state of the path: the reference's start-up stamps its latest state with t1 when the
+                // state buffer is empty (Accumulator.cpp:77-83), which is the same thing for a sensor at rest only
+                loc.last_time_updated = accum.initial_time;
+                accum.add(loc.latest_state(), accum.initial_time);
+                clk.t2 = accum.initial_time;               // main.cpp:45 starts from DBL_MAX and lets min() pick latest_time()
+                positioned = true;
+            }
+            for (int guard = 0; guard < 64; ++guard) {
+                State Xt2;
+                size_t np = 0;
+                if (!run_cycle(accum, comp, loc, map, clk, on_device, &Xt2, &np)) break;
+                if (getenv("LV_DEMO_VERBOSE") && out_t.size() < 6)
+                    fprintf(stderr, "update %zu: t1 %.4f t2 %.4f points %zu pos %.4f %.4f %.4f vel %.3f %.3f passes %d states %d\n", out_t.size(),
+                            clk.t1, clk.t2, np, loc.get_x().pos[0], loc.get_x().pos[1], loc.get_x().pos[2], loc.get_x().vel[0], loc.get_x().vel[1],
+                            loc.last_passes, accum.BUFFER_X.size());
+                out_t.push_back(clk.t2);
+                out_x.push_back(loc.get_x());
+                out_n.push_back((uint32_t)np);
+            }
+        }
+        std::ofstream o(argv[2], std::ios::binary);
+        const uint32_t n = (uint32_t)out_t.size();
+        o.write(reinterpret_cast<const char*>(&n), 4);
+        for (uint32_t i = 0; i < n; ++i) {
+            o.write(reinterpret_cast<const char*>(&out_t[i]), 8);
+            o.write(reinterpret_cast<const char*>(&out_x[i]), sizeof(state_ikfom));
+            o.write(reinterpret_cast<const char*>(&out_n[i]), 4);
+        }
+        std::cout << "stream_demo: " << n << " updates, map " << map.size() << " points\n";
+        HipRuntime::shutdown();
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << "stream_demo: " << e.what() << "\n";
+        return 1;
+    }
+}

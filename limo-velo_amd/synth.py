@@ -96,9 +96,13 @@ def default_P0() -> np.ndarray:
     return P
 
 
-def _surfaces(rng: _Rng, m_points: int, density: float = 25.0, wall_h: float = 8.0):
-    """Rectangles (origin, edge u, edge v) of the scene; total area ~ m_points / density."""
-    n_boxes = int(max(4, min(64, m_points // 15625)))
+def _surfaces(rng: _Rng, m_points: int, density: float = 25.0, wall_h: float = 8.0, max_boxes: int | None = 64):
+    """Rectangles (origin, edge u, edge v) of the scene; total area ~ m_points / density.  max_boxes = None: one box per
+    ~15 600 map points at any size (a 10M-point scene then keeps the box density of the 1M one — with the default cap
+    of 64 a large scene is mostly bare ground, x / y / yaw hardly observable)."""
+    n_boxes = int(max(4, m_points // 15625))
+    if max_boxes is not None:
+        n_boxes = min(n_boxes, max_boxes)
     u = rng.uniform(n_boxes * 5)
     side_x = 2.0 + 4.0 * u[0::5]
     side_y = 2.0 + 4.0 * u[1::5]
@@ -311,20 +315,26 @@ def make_stream(m_points: int, n_revs: int, *, n_rings: int = 64, n_az: int = 10
       revs     list of n_revs dicts(xyz [n, 3] f32 LiDAR frame at firing time, t [n] f64 absolute stamps, stamp = end of the sweep),
       L)."""
     rng_m = _Rng(seed_map)
-    surf = _surfaces(rng_m, m_points)
+    surf = _surfaces(rng_m, m_points, max_boxes=64 if m_points <= 1_048_576 else None)
     map_xyz = _sample(rng_m, surf, m_points, sigma).astype(np.float32)
-    o, eu, ev, _, L = surf
+    o_all, eu_all, ev_all, _, L = surf
     if map_radius is not None:
         p_start = stream_truth(t0)[0]
         map_xyz = map_xyz[np.linalg.norm(map_xyz[:, :2] - p_start[:2].astype(np.float32), axis=1) < map_radius]
-    nrm = np.cross(eu, ev)
-    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
-    uu, vv = np.sum(eu * eu, axis=1), np.sum(ev * ev, axis=1)
     el = np.radians(np.linspace(fov_deg[0], fov_deg[1], n_rings))
     ce, se = np.cos(el), np.sin(el)
     rng_s = _Rng(seed_scan)
     revs = []
+    ctr_all = o_all + 0.5 * (eu_all + ev_all)
+    half_all = 0.5 * (np.linalg.norm(eu_all, axis=1) + np.linalg.norm(ev_all, axis=1))
     for r in range(n_revs):
+        # only the rectangles a ray of this sweep can reach (a 10M-point scene has thousands)
+        p_mid = stream_truth(t0 + (r + 0.5) * rev_time)[0]
+        near = np.linalg.norm(ctr_all - p_mid, axis=1) < rmax + half_all + 5.0
+        o, eu, ev = o_all[near], eu_all[near], ev_all[near]
+        nrm = np.cross(eu, ev)
+        nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+        uu, vv = np.sum(eu * eu, axis=1), np.sum(ev * ev, axis=1)
         t_az = t0 + (r + (np.arange(n_az) + 1.0) / n_az) * rev_time            # firing time of every azimuth step
         az = 2.0 * math.pi * np.arange(n_az) / n_az
         pos = np.empty((n_az, 3))

@@ -32,6 +32,13 @@ typedef struct lvo_params {
     int    estimate_extrinsics;  /* estimate_extrinsics (false) */
     double lidar_noise;          /* LiDAR_noise (1e-3) -> R */
     double limits[23];           /* LIMITS (23 x 1e-3) */
+    /* degeneracy stage of the fork's 4-argument update_iterated_dyn_share_modified (Localizator.cpp:132;
+     * config/params.yaml:51-53).  The fork's source is absent: [UNKNOWN-FORK].  mode 0 = off (every
+     * parity / benchmark run), 1 = eigenvalues of the pose block of H^T H reported only ("print_degeneracy_values"),
+     * 2 = a plausible restatement (solution remapping, Zhang/Kaess/Singh 2016, in information form): measurement
+     * information along eigen-directions of the 6x6 pose block whose eigenvalue is below the threshold is removed. */
+    int    degeneracy_mode;
+    double degeneracy_threshold;
 } lvo_params;
 
 /* state_ikfom (IKFoM fork; field order confirmed by reference src/Objects/State.cpp:53-61 and
@@ -119,6 +126,9 @@ int lvo_update(lvo_state* x, double* P, const lvo_params* prm, const void* tree,
  * `finalize` it also writes the posterior P.  Returns 1 if |dx_| <= limits for all 23 dof. */
 int lvo_kf_step(lvo_state* x, const lvo_state* x_prop, const double* P_prop, const lvo_params* prm,
                 const lvo_iter_out* sums, double dx_out[23], int finalize, double* P_out);
+/* The degeneracy stage alone: eigenvalues (cyclic Jacobi, 8 sweeps, unsorted) of the 6x6 pose block of sums->HTH into
+ * eig[6]; with prm->degeneracy_mode == 2 the sums are modified in place (see lvo_params). */
+void lvo_degeneracy(lvo_iter_out* sums, const lvo_params* prm, double eig[6]);
 
 /* Manifold helpers exposed for tests. */
 void lvo_boxplus(lvo_state* x, const double dx[23]);

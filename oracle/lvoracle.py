@@ -35,6 +35,8 @@ class Params(C.Structure):
         ("estimate_extrinsics", C.c_int),
         ("lidar_noise", C.c_double),
         ("limits", C.c_double * 23),
+        ("degeneracy_mode", C.c_int),
+        ("degeneracy_threshold", C.c_double),
     ]
 
 
@@ -226,6 +228,22 @@ def kf_step(x, x_prop, P_prop, sums: dict, params=None, finalize=True):
     conv = lib().lvo_kf_step(_p(xs, C.c_double), _p(xp, C.c_double), _p(Pp, C.c_double), C.byref(prm), C.byref(io),
                              _p(dx, C.c_double), int(finalize), _p(Pout, C.c_double))
     return xs, dx, bool(conv), Pout
+
+
+def degeneracy(sums: dict, params=None):
+    """The degeneracy stage alone: returns (eigenvalues[6] of the pose block, possibly modified sums)."""
+    prm = params or default_params()
+    io = IterOut()
+    HTH = _f64(sums["HTH"]).ravel()
+    for i in range(144):
+        io.HTH[i] = HTH[i]
+    for i in range(12):
+        io.HTh[i] = float(sums["HTh"][i])
+    io.sum_h2 = float(sums.get("sum_h2", 0.0))
+    io.n_valid = int(sums.get("n_valid", 1))
+    eig = np.zeros(6)
+    lib().lvo_degeneracy(C.byref(io), C.byref(prm), _p(eig, C.c_double))
+    return eig, io.as_dict()
 
 
 def boxplus(x, dx):

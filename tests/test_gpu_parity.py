@@ -454,3 +454,41 @@ def test_timed_build_is_pinned_per_pass(capi, oracle, lv, m, n):
         assert np.array_equal(_bits(nbr[near]), _bits(exp[near])), f"pass {k}: neighbour coordinates differ at {(nbr[near] != exp[near]).any(axis=(1, 2)).sum()} points"
         assert np.array_equal(_bits(d2[near]), _bits(o["knn_d2"][near])), f"pass {k}"
         assert np.array_equal(_bits(pw), _bits(oracle.transform_scan(states[k], sc["scan_xyz"]))), f"pass {k}"
+
+
+def test_degeneracy_hook(capi, oracle, lv):
+    """The degeneracy stage of the fork's update_iterated_dyn_share_modified (Localizator.cpp:132) as a hook:
+    mode 1 reports the eigenvalues of the pose block of H^T H per pass and leaves the update bit-identical to mode 0;
+    mode 2 (the documented restatement) matches the oracle's same restatement on a scan that only sees near-horizontal
+    planes (x / y degenerate)."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 4_000)
+    full = oracle.iterate(sc["x_true"], sc["map_xyz"], sc["scan_xyz"])
+    ground = sc["scan_xyz"][(full["valid"] == 1) & (np.abs(full["abcd"][:, 2]) > 0.99)]
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(ground)
+        x0, P0, p0, tr0, s0 = ctx.update(sc["x_init"], sc["P0"])
+    with capi.Context(capi.default_params(degeneracy_mode=1)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(ground)
+        x1, P1, p1, tr1, s1 = ctx.update(sc["x_init"], sc["P0"])
+        eig = ctx.degeneracy_values()
+    assert p1 == p0 and np.array_equal(x1, x0) and np.array_equal(P1, P0)
+    assert eig.shape == (p1, 6)
+    for i in range(p1):
+        ref = np.linalg.eigvalsh(s1[i]["HTH"][:6, :6])
+        assert np.allclose(np.sort(eig[i]), ref, rtol=1e-9, atol=1e-9 * ref.max()), i
+    es = np.sort(eig[0])
+    thr = float(np.sqrt(es[1] * es[2]))
+    prm_o = oracle.default_params(degeneracy_mode=2, degeneracy_threshold=thr)
+    xo, Po, po, tro, _ = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], ground, params=prm_o)
+    with capi.Context(capi.default_params(degeneracy_mode=2, degeneracy_threshold=thr)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(ground)
+        x2, P2, p2, tr2, _ = ctx.update(sc["x_init"], sc["P0"])
+    assert p2 == po
+    assert np.abs(tr2 - tro).max() < 1e-8 and np.abs(x2 - xo).max() < 1e-8
+    assert np.abs(P2 - Po).max() < 1e-8 * max(1.0, np.abs(Po).max())
+    assert np.abs(x2[:2] - sc["x_init"][:2]).max() < 2e-3 < np.abs(x0[:2] - sc["x_init"][:2]).max()

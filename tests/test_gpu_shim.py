@@ -47,3 +47,78 @@ def test_cpp_shim_demo_matches_oracle(oracle, scene_small, tmp_path):
     xo, Po, po, _, _ = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], scan, tree=tree)
     assert passes == po
     assert np.abs(x - xo).max() < 1e-9 and np.abs(P - Po).max() < 1e-10
+
+
+def _write_stream_input(path, on_device, delta, stream, n_revs, x0):
+    """The binary input of limo-velo_amd/host/stream_demo.cpp."""
+    import struct
+
+    from limo_velo_amd import synth
+
+    import test_gpu_stream as T
+
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IId", 0x5453564C, int(on_device), delta))
+        f.write(struct.pack("<I", len(stream["map_xyz"])))
+        f.write(np.ascontiguousarray(stream["map_xyz"], np.float32).tobytes())
+        t_imu = np.arange(0, int(round(n_revs * 0.1 / 0.01)) + 12) * 0.01
+        f.write(struct.pack("<I", len(t_imu)))
+        for t in t_imu:
+            a, w = synth.stream_imu(float(t))
+            q = synth.stream_truth(float(t))[4]
+            f.write(struct.pack("<d", float(t)) + np.asarray(a, np.float32).tobytes() + np.asarray(w, np.float32).tobytes()
+                    + np.asarray(q, np.float32).tobytes())
+        f.write(struct.pack("<I", n_revs))
+        for r in range(n_revs):
+            raw, n, fmt, stamp = T.hesai_message(stream["revs"][r])
+            assert fmt["point_step"] == 48
+            f.write(struct.pack("<dQI", stream["revs"][r]["stamp"], stamp, n))
+            f.write(raw)
+    np.ascontiguousarray(x0, np.float64).tofile(str(path) + ".x0")
+
+
+def _read_stream_output(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(raw[:4].view(np.uint32)[0])
+    rec = raw[4:4 + n * (8 + 208 + 4)].reshape(n, 220)
+    t = rec[:, :8].copy().view(np.float64)[:, 0]
+    x = rec[:, 8:216].copy().view(np.float64).reshape(n, 26)
+    npts = rec[:, 216:220].copy().view(np.uint32)[:, 0]
+    return t, x, npts
+
+
+def test_reference_main_loop_through_the_shim(lv, tmp_path):
+    """src/main.cpp:52-128 (main_loop.hpp: the reference's own lines minus the ROS publishers) run by a C++ program over
+    the shim's Accumulator / Compensator / Localizator / Mapper on a 100 Hz stream: once with the reference's by-value
+    hand-overs (compensate -> downsample -> correct -> Xt2 * Xt2.I_Rt_L() * ds -> map.add), once with the three calls
+    that keep the scan on the device.  Both track the ground truth and agree with each other."""
+    from limo_velo_amd import synth
+
+    host = os.path.join(ROOT, "limo-velo_amd", "host")
+    exe = os.path.join(host, "stream_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", host])
+    n_revs, delta = 9, 0.01
+    stream = synth.make_stream(1_048_576, n_revs, n_az=512, map_radius=62.0)
+    t_init = 0.30 - 0.1        # Accumulator::ready at the 31st IMU sample; initial_time = its stamp - real_time_delay
+    pos0, _, vel0, _, q0 = synth.stream_truth(t_init)
+    x0 = synth.make_state(pos0 + [0.02, -0.015, 0.01], synth.quat_mul(q0, synth.quat_from_rotvec([0.002, -0.001, 0.003])), vel=vel0,
+                          grav=(0, 0, synth.STREAM_G))
+    res = {}
+    for on_device in (0, 1):
+        inp, out = tmp_path / f"in{on_device}.bin", tmp_path / f"out{on_device}.bin"
+        _write_stream_input(inp, on_device, delta, stream, n_revs, x0)
+        r = subprocess.run([exe, str(inp), str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        if os.environ.get("LV_DEMO_VERBOSE"):
+            print(r.stderr)
+        res[on_device] = _read_stream_output(out)
+    t0, xa, na = res[0]
+    t1, xb, nb = res[1]
+    assert len(t0) >= 50 and np.array_equal(t0, t1) and np.array_equal(na, nb)
+    assert np.allclose(np.diff(t0), delta, atol=1e-9)                      # one localisation per 10 ms field of view
+    truth = np.array([synth.stream_truth(t)[0] for t in t0])
+    for x in (xa, xb):
+        err = np.linalg.norm(x[:, :3] - truth, axis=1)
+        assert np.sqrt(np.mean(err ** 2)) < 0.03, err
+    assert np.abs(xa - xb).max() < 1e-6                                     # the device-resident hand-overs change nothing

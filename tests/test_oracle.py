@@ -328,3 +328,34 @@ def test_rows_golden_is_current(oracle):
     assert mg.digest(oracle.voxelgrid(desk, 0.5)) == str(g["voxelgrid_sha256"])
     merged = oracle.map_add(sc["map_xyz"], (sc["map_xyz"][:3000] + np.float32(0.013)).astype(np.float32), downsample=True)
     assert mg.digest(merged) == str(g["map_add_sha256"])
+
+
+def test_degeneracy_stage_restatement(oracle, lv):
+    """The fork's degeneracy stage is a hook with a documented restatement (the source is absent).  On a
+    scan that only sees the ground, three pose directions (x, y, yaw) carry no information: their eigenvalues are
+    ~0 while the others are large; mode 1 only reports, mode 2 leaves those directions at their propagated value."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 4_000)
+    full = oracle.iterate(sc["x_true"], sc["map_xyz"], sc["scan_xyz"])
+    ground = sc["scan_xyz"][(full["valid"] == 1) & (np.abs(full["abcd"][:, 2]) > 0.99)]   # matched to (near-)horizontal planes only
+    assert len(ground) > 500
+    o = oracle.iterate(sc["x_init"], sc["map_xyz"], ground, details=False)
+    eig, same = oracle.degeneracy(o, oracle.default_params(degeneracy_mode=1))
+    ref = np.linalg.eigvalsh(o["HTH"][:6, :6])
+    assert np.allclose(np.sort(eig), ref, rtol=1e-9, atol=1e-6 * ref.max())
+    assert np.array_equal(same["HTH"], o["HTH"]) and np.array_equal(same["HTh"], o["HTh"])   # mode 1 only reports
+    es = np.sort(eig)
+    assert es[1] < 0.05 * es[2]                                 # two directions (x, y: only noise in the normals) are degenerate
+    thr = float(np.sqrt(es[1] * es[2]))
+    prm2 = oracle.default_params(degeneracy_mode=2, degeneracy_threshold=thr)
+    eig2, mod = oracle.degeneracy(o, prm2)
+    w = np.linalg.eigvalsh(mod["HTH"][:6, :6])
+    assert (np.abs(w[:2]) < 1e-9 * w[-1]).all() and np.allclose(w[2:], ref[2:], rtol=1e-9)    # information removed, rest kept
+    x0, P0 = sc["x_init"], sc["P0"]
+    x_off, _, p_off, _, _ = oracle.update(x0, P0, sc["map_xyz"], ground)
+    x_on, _, p_on, _, _ = oracle.update(x0, P0, sc["map_xyz"], ground, params=prm2)
+    assert np.abs(x_on[:2] - x0[:2]).max() < 2e-3             # x, y: (almost) no measurement information -> stay near the prior
+    assert np.abs(x_off[:2] - x0[:2]).max() > 5 * np.abs(x_on[:2] - x0[:2]).max()   # ... which the plain update does not
+    assert abs(x_on[2] - sc["x_true"][2]) < 5e-3              # z is observed and corrected as without the stage
+    assert abs(x_on[2] - x_off[2]) < 1e-3
