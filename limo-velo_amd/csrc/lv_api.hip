@@ -69,6 +69,10 @@ struct lv_ctx {
     bool dbg_valid = false;
     bool qrec_valid = false;       // d_qrec holds the records of a pass over the CURRENT scan (lv_fetch_neighbors)
 
+    bool begin_pending = false;    // the update's state waits in h_begin for the first search launch (no begin kernel)
+    BeginArg h_begin;
+    int fallback_base = 0;         // device counter value before the update in flight (the device never resets it)
+
     bool in_update = false;
     bool want_log = false;         // download trace / per-pass sums at lv_update_end
     int passes_issued = 0;
@@ -156,9 +160,19 @@ void unpack_sums(const double* rec, lv_sums* out) {
 
 // from_host: x / P_prop wait in the pinned mailbox (lv_update_begin), otherwise they are in d_kf already (copied
 // from the resident filter): take them over, derive the pass constants
-int begin_device(lv_ctx* c, const double* x_host) {
-    int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, x_host);
-    if (rc) return rc;
+int begin_device(lv_ctx* c, const double* x_host, bool defer) {
+    c->begin_pending = false;
+    if (c->capture) LV_HIP(hipMemsetAsync(c->d_kf->level_hist, 0, sizeof(int) * 8, c->stream));   // instrumentation of capturing passes
+    if (defer && x_host && c->scan.n > 0 && c->map.view.m > 0) {
+        // the first search launch installs everything (x_host: x followed by P_prop, KfHostIO layout)
+        std::memcpy(c->h_begin.x, x_host, sizeof(c->h_begin.x));
+        std::memcpy(c->h_begin.P, x_host + NX, sizeof(c->h_begin.P));
+        compute_pose_consts(c->h_begin.x, &c->h_begin.pose);
+        c->begin_pending = true;
+    } else {
+        int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, x_host);
+        if (rc) return rc;
+    }
     c->grid = fit_grid_size(c->scan.n, c->max_blocks);
     if ((uint32_t)c->scan.n > c->qstride) {
         uint32_t cap = c->qstride ? c->qstride : 4096;
@@ -173,7 +187,7 @@ int begin_device(lv_ctx* c, const double* x_host) {
     return LV_OK;
 }
 
-int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
+int begin_common(lv_ctx* c, const lv_state* x, const double* P, bool defer = true) {
     KfHostIO* io = c->h_io;
     std::memcpy(io->x_in, x, sizeof(double) * NX);
     if (P) {
@@ -182,7 +196,7 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P) {
         for (int i = 0; i < NS * NS; ++i) io->P_in[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;
-    return begin_device(c, io->x_in);   // x_in and P_in (contiguous) ride in the kernel arguments
+    return begin_device(c, io->x_in, defer);   // x_in and P_in (contiguous) ride in the kernel arguments
 }
 
 int pass_solve(lv_ctx* c, bool from_groups);
@@ -207,9 +221,12 @@ int pass_reduce(lv_ctx* c, bool finalize) {
     }
     int rc = LV_OK;
     c->qrec_valid = c->scan.n > 0;
-    if (c->scan.n > 0)
+    if (c->scan.n > 0) {
         rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
-                           c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, mp.max_dist_plane_sq, dbg);
+                           c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, mp.max_dist_plane_sq, dbg,
+                           c->begin_pending ? &c->h_begin : nullptr, c->d_io);
+        c->begin_pending = false;
+    }
     if (rc) return rc;
     if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
     rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
@@ -755,18 +772,18 @@ int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
     if (!x || !out) { set_error("null argument"); return LV_EINVAL; }
     std::memset(out, 0, sizeof(*out));
     if (c->map.view.m == 0 || c->scan.n == 0) { c->dbg_valid = false; return LV_OK; }  // Mapper.cpp:42 — empty Matches
-    int rc = begin_common(c, x, nullptr);
-    if (rc) return rc;
     const bool cap = c->capture;
     c->capture = true;  // lv_iterate is the API-parity path: always captures per-point outputs
-    rc = pass_reduce(c, true);
+    int rc = begin_common(c, x, nullptr);
+    if (!rc) rc = pass_reduce(c, true);
     c->capture = cap;
     if (rc) return rc;
     LV_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, SUMS_LEN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipMemcpyAsync(&c->h_kf->fallback_queries, &c->d_kf->fallback_queries, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
     unpack_sums(c->h_sums, out);
-    c->timing.fallback_queries = c->h_kf->fallback_queries;
+    c->timing.fallback_queries = c->h_kf->fallback_queries - c->fallback_base;
+    c->fallback_base = c->h_kf->fallback_queries;
     return LV_OK;
 }
 
@@ -860,7 +877,8 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
         if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
     }
     const KfHostIO* io = c->h_io;
-    c->timing.fallback_queries = io->fallback_queries;
+    c->timing.fallback_queries = io->fallback_queries - c->fallback_base;
+    c->fallback_base = io->fallback_queries;
     if (x) std::memcpy(x, io->x, sizeof(double) * NX);
     if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
     if (passes) *passes = io->passes;
@@ -959,7 +977,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
     if (rc) return rc;
-    rc = begin_device(c, nullptr);
+    rc = begin_device(c, nullptr, false);
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
@@ -1065,7 +1083,7 @@ int lv_calculate_H(lv_ctx* c, const lv_state* x, const float* p_world, const flo
     if (!x || (n && (!p_world || !abcd || !dist || !H || !h))) { set_error("null argument"); return LV_EINVAL; }
     if (n == 0) return LV_OK;
     if (c->in_update) { set_error("lv_calculate_H inside an update"); return LV_ESTATE; }
-    int rc = begin_common(c, x, nullptr);  // derives the pass constants from x on the device
+    int rc = begin_common(c, x, nullptr, false);  // derives the pass constants from x on the device (begin kernel)
     if (rc) return rc;
     float *d_in = nullptr;
     double* d_out = nullptr;

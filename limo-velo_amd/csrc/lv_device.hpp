@@ -65,6 +65,16 @@ struct KfDev {
     double degen_eig[MAX_PASSES * 6];  // degeneracy_mode >= 1: eigenvalues of the pose block of H^T H, per pass
 };
 
+// What an update starts from, handed to the FIRST search launch of the update as kernel arguments (lv_update /
+// lv_iterate: the state comes from the host anyway, so no begin kernel runs): the state, its covariance and the
+// pass constants the host derived from the state (compute_pose_consts is the same code on both sides, f64 -> f32
+// casts and f32 sums in the same order => same bits).
+struct BeginArg {
+    double x[NX];
+    double P[NS * NS];
+    PoseConsts pose;
+};
+
 // Pinned, host-mapped mailbox of one update: x_in / P_in stage the inputs (handed to kf_begin_kernel as kernel
 // arguments), the results are stored by solve_kernel straight across PCIe, so an update needs no copy kernels.
 struct KfHostIO {
@@ -149,19 +159,19 @@ struct DebugOut {  // all optional (nullptr = skip); indexed by ORIGINAL scan in
 // ---------------------------------------------------------------------------------------------
 // f32 / f64 3-vector algebra in Eigen 3.3 fixed-size evaluation order: x0 + (x1 + x2).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dot3f(float a0, float b0, float a1, float b1, float a2, float b2) {
+__host__ __device__ __forceinline__ float dot3f(float a0, float b0, float a1, float b1, float a2, float b2) {
     float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
     float t = p1 + p2;
     return p0 + t;
 }
-__device__ __forceinline__ double dot3d(double a0, double b0, double a1, double b1, double a2, double b2) {
+__host__ __device__ __forceinline__ double dot3d(double a0, double b0, double a1, double b1, double a2, double b2) {
     double p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
     double t = p1 + p2;
     return p0 + t;
 }
 
 // RotTransl operator*(RT1, RT2) — reference src/Objects/RotTransl.cpp:36-41
-__device__ inline RT32 rt_compose(const RT32& a, const RT32& b) {
+__host__ __device__ inline RT32 rt_compose(const RT32& a, const RT32& b) {
     RT32 o;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -180,7 +190,7 @@ __device__ __forceinline__ void rt_apply(const RT32& a, float px, float py, floa
     oz = dot3f(a.R[6], px, a.R[7], py, a.R[8], pz) + a.t[2];
 }
 // RotTransl::inv() — reference src/Objects/RotTransl.cpp:29-34
-__device__ inline RT32 rt_inv(const RT32& a) {
+__host__ __device__ inline RT32 rt_inv(const RT32& a) {
     RT32 o;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -193,7 +203,7 @@ __device__ inline RT32 rt_inv(const RT32& a) {
 }
 
 // [UPSTREAM-RECALL Eigen Quaternion::toRotationMatrix]; q = (x,y,z,w)
-__device__ inline void quat_to_rot(const double q[4], double R[9]) {
+__host__ __device__ inline void quat_to_rot(const double q[4], double R[9]) {
     const double x = q[0], y = q[1], z = q[2], w = q[3];
     const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
     const double twx = tx * w, twy = ty * w, twz = tz * w;
@@ -206,7 +216,7 @@ __device__ inline void quat_to_rot(const double q[4], double R[9]) {
 
 // State(const state_ikfom&, double) (reference src/Objects/State.cpp:51-62) followed by the
 // per-pass transforms.  x = lv_state as 26 doubles.
-__device__ inline void compute_pose_consts(const double* x, PoseConsts* out) {
+__host__ __device__ inline void compute_pose_consts(const double* x, PoseConsts* out) {
     double R[9], RLI[9];
     quat_to_rot(x + 3, R);
     quat_to_rot(x + 7, RLI);

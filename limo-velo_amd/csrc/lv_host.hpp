@@ -156,8 +156,11 @@ int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
 // lv_match.hip
 // search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries);
 // fit_reduce_kernel turns them into `grid` block partials (and one extra workgroup runs solve_prep)
+// begin != nullptr: the first launch of an update (no begin kernel ran): the state / covariance / pass constants
+// travel as kernel arguments and one extra workgroup installs them in kf and the mailbox io
 int launch_search(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
-                  float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg);
+                  float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg,
+                  const BeginArg* begin, KfHostIO* io);
 int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
                       double* partials, int grid, const DebugOut& dbg);
 int fit_grid_size(uint32_t n, int max_blocks);

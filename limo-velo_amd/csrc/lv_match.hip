@@ -749,16 +749,46 @@ constexpr int QREC_SLOTS = 8;
 #define LV_SEARCH_BOUNDS __launch_bounds__(256)
 #endif
 
-template <int S, bool DBG>
+// FIRST: the update starts here (no begin kernel): the pass constants come with the kernel arguments, and one extra
+// workgroup (the last) installs the state, covariance, constants and loop counters in kf / the mailbox for the kernels
+// that follow.
+template <int S, bool DBG, bool FIRST>
 __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
                                                      KfDev* __restrict__ kf, float4* __restrict__ qrec, uint32_t qstride,
                                                      const uint32_t* __restrict__ tile_order, uint32_t n_tiles, double max_dist_sq,
-                                                     DebugOut dbg) {
+                                                     DebugOut dbg, BeginArg begin, KfHostIO* io) {
     constexpr int GS = 256 / S;
     constexpr int STAGE = S * 8;   // candidates of a lane group's first level-0 chunk, kept in LDS by position
     __shared__ Xyz s_stage[GS][STAGE];
     __shared__ uint32_t s_pref[4][64], s_start[4][64];   // wavefront-cooperative levels: per-wave prefix sums / list starts
-    if (kf->done) return;
+    if (FIRST) {
+        if (blockIdx.x == gridDim.x - 1u) {   // the installing workgroup
+            for (int i = threadIdx.x; i < NS * NS; i += 256) {
+                const double p = begin.P[i];
+                kf->P_prop[i] = p;
+                kf->P_post[i] = p;
+                io->P_post[i] = p;   // an update without a terminal pass returns the propagated covariance
+            }
+            if (threadIdx.x < NX) {
+                const double v = begin.x[threadIdx.x];
+                kf->x[threadIdx.x] = v;
+                kf->x_prop[threadIdx.x] = v;
+                io->x[threadIdx.x] = v;
+            }
+            constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
+            if (threadIdx.x < NW32) reinterpret_cast<uint32_t*>(&kf->pose)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&begin.pose)[threadIdx.x];
+            if (threadIdx.x == 0) {
+                io->passes = 0;
+                kf->t = 0;
+                kf->iter = -1;  // upstream loop starts at i = -1
+                kf->done = 0;
+                kf->passes = 0;
+            }
+            return;
+        }
+    } else {
+        if (kf->done) return;
+    }
     const int tid = threadIdx.x;
     const int gq = tid / S, gl = tid % S;
     // tile order: farthest-from-sensor tiles first (ScanStore::order_tiles).  An XCD-aware order (contiguous
@@ -778,7 +808,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     int src = -1;
     const float4 sp = scan[live ? q : n - 1];
     float qx, qy, qz;
-    rt_apply(kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
+    rt_apply(FIRST ? begin.pose.Tc : kf->pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
     if (DBG && stamp_slot) { asm volatile("" :: "v"(qx), "v"(qy), "v"(qz)); stamp_slot[1] = clock64(); }
     knn_search<S, DBG>(map, kf, qx, qy, qz, gl, k, bstart, src, stamp_slot, DBG && !dbg.clk, live, s_stage[gq], max_dist_sq,
                        s_pref[tid >> 6], s_start[tid >> 6]);
@@ -931,13 +961,19 @@ int fit_grid_size(uint32_t n, int max_blocks) {
 template <int S>
 static void launch_search(hipStream_t stream, bool dbg_on, const MapView& map, const float4* scan, uint32_t n, KfDev* kf,
                           float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq,
-                          const DebugOut& dbg) {
+                          const DebugOut& dbg, const BeginArg* begin, KfHostIO* io) {
     constexpr uint32_t GS = 256 / S;
     uint32_t grid = (n + GS - 1) / GS;
     grid = (grid + 7u) & ~7u;
     if (grid == 0) grid = 8;
-    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg);
-    else hipLaunchKernelGGL((search_kernel<S, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg);
+    if (begin) {   // first launch of an update: one more workgroup installs the state
+        if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true, true>), dim3(grid + 1), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, *begin, io);
+        else hipLaunchKernelGGL((search_kernel<S, false, true>), dim3(grid + 1), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, *begin, io);
+        return;
+    }
+    static const BeginArg none{};
+    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, none, io);
+    else hipLaunchKernelGGL((search_kernel<S, false, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, none, io);
 }
 
 static bool debug_requested(const DebugOut& dbg) {
@@ -947,14 +983,15 @@ static bool debug_requested(const DebugOut& dbg) {
 // split form, kernel 1: exact 5-NN of every scan point -> qrec (max_dist_sq: MAX_DIST_PLANE^2, the radius beyond
 // which a non-capturing launch may stop — see knn_search)
 int launch_search(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf, float4* qrec,
-                  uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg) {
+                  uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg,
+                  const BeginArg* begin, KfHostIO* io) {
     const bool dbg_on = debug_requested(dbg);
     switch (S) {
-        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
-        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
-        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
-        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
-        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg); break;
+        case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
+        case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
+        case 4: launch_search<4>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
+        case 8: launch_search<8>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
+        case 16: launch_search<16>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
         default: set_error("lanes_per_query must be 1,2,4,8 or 16 (got %d)", S); return LV_EINVAL;
     }
     LV_HIP(hipGetLastError());

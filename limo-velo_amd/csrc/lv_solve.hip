@@ -52,13 +52,12 @@ __global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, 
     }
     if (tid == 0) {
         io->passes = 0;
-        io->fallback_queries = 0;
         kf->t = 0;
         kf->iter = -1;  // upstream loop starts at i = -1
         kf->done = 0;
         kf->passes = 0;
-        kf->fallback_queries = 0;
-        for (int i = 0; i < 8; ++i) kf->level_hist[i] = 0;
+        // (fallback_queries only ever grows on the device: the host reports differences — an update that starts in its
+        // first search launch has no kernel before it that could reset the counter)
     }
     __syncthreads();
     // compute_pose_consts (lv_device.hpp) spread over lanes: four quaternion -> matrix conversions, then the
@@ -212,11 +211,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
                 for (int i = 0; i < NX; ++i) kf->trace[pass * 49 + NS + i] = kf->x[i];
             }
             kf->passes = pass + 1;
-            IO_STORE(&io->passes, pass + 1);
-            IO_STORE(&io->fallback_queries, kf_fallback);
             kf->iter = kf_iter + 1;
             if (kf_iter + 1 >= prm.maximum_iter) {
                 kf->done = 1;
+                // the update ends on a pass without matches: the mailbox gets the state the earlier passes left
+                // (the passes in between store nothing across PCIe)
+                IO_STORE(&io->passes, pass + 1);
+                IO_STORE(&io->fallback_queries, kf_fallback);
+                for (int i = 0; i < NX; ++i) IO_STORE(&io->x[i], kf->x[i]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through mailbox stores above have retired
                 __hip_atomic_store(&io->seq, prm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // final: the host may stop waiting
             }
@@ -294,12 +296,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     }
     __syncthreads();
     SV_STAMP(7);
-    if (tid < NX) { kf->x[tid] = sx[tid]; IO_STORE(&io->x[tid], sx[tid]); }
+    const int last = s_last;
+    if (tid < NX) {
+        kf->x[tid] = sx[tid];
+        if (last) IO_STORE(&io->x[tid], sx[tid]);   // the mailbox (write-through across PCIe) only hears from the pass that ends the update
+    }
     if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
         const int e = tid - 64;
         kf->trace[pass * 49 + e] = e < NS ? sdxo[e] : sx[e - NS];
     }
-    const int last = s_last;
     if (!last && tid >= 320 && tid < 324) {  // the four rotation matrices of the next pass, one lane each
         const int w = tid - 320;               // 0: rot, 1: offset_R_L_I, 2: conj(rot), 3: conj(offset_R_L_I)
         const int q = (w & 1) ? 7 : 3;
@@ -310,10 +315,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __syncthreads();
     if (tid == 0) {
         kf->passes = pass + 1;
-        IO_STORE(&io->passes, pass + 1);
-        IO_STORE(&io->fallback_queries, kf_fallback);
         kf->iter = kf_iter + 1;
-        if (last) kf->done = 1;
+        if (last) {
+            kf->done = 1;
+            IO_STORE(&io->passes, pass + 1);
+            IO_STORE(&io->fallback_queries, kf_fallback);
+        }
     }
     if (!last) {  // the next pass' constants: finish_pose_consts spread over one wavefront, then coalesced stores
         if (tid >= 64 && tid < 128) pose_consts_stage_a(tid - 64, sx, sRot, &s_pose, s_ptmp);

@@ -3,7 +3,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lvamd
 
 lvamd.load()
