@@ -359,3 +359,76 @@ def test_degeneracy_stage_restatement(oracle, lv):
     assert np.abs(x_off[:2] - x0[:2]).max() > 5 * np.abs(x_on[:2] - x0[:2]).max()   # ... which the plain update does not
     assert abs(x_on[2] - sc["x_true"][2]) < 5e-3              # z is observed and corrected as without the stage
     assert abs(x_on[2] - x_off[2]) < 1e-3
+
+
+def test_gain_branches_and_cholesky_pass_through(oracle, lv):
+    """esekf's two gain branches [UPSTREAM-RECALL esekfom.hpp]:
+        n > dof_Measurement (fewer than 23 rows):  K = P H^T (H P H^T + R)^-1
+        otherwise:                                 K = (H^T H + (P/R)^-1)^-1 H^T     (what the oracle and the device use)
+    are the same estimator.  Checked numerically on real data, conditioning included, for
+      (a) a scan with fewer than 23 matches (dense H, the branch the oracle does not take), and
+      (b) INTEGRATION.md's pass-through for an unmodified esekf: the 12-row pseudo measurement h_x = U (U^T U = H^T H),
+          h = U^-T H^T h fed to EITHER branch gives the gain products K h and K H of the true measurement."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 2_000, extrinsics="xaloc")
+    prm = oracle.default_params(estimate_extrinsics=1)
+    R = prm.lidar_noise
+    x, P = sc["x_init"].copy(), sc["P0"].copy()
+    Q = np.diag([1e-4] * 3 + [1e-2] * 3 + [1e-5] * 3 + [1e-4] * 3)
+    for _ in range(10):
+        x, P = oracle.predict(x, P, 0.01, Q, [0.1, -0.05, 9.81], [0.01, 0.02, -0.01])
+
+    def gains(H, h):
+        """K h and K H (23 x 12 non-zero columns) through both branches; H is m x 12 (state columns 0..11)."""
+        m = len(h)
+        Hf = np.zeros((m, 23))
+        Hf[:, :12] = H
+        K1 = P @ Hf.T @ np.linalg.inv(Hf @ P @ Hf.T + R * np.eye(m))
+        K2 = np.linalg.inv(Hf.T @ Hf + np.linalg.inv(P / R)) @ Hf.T
+        return (K1 @ h, K1 @ Hf), (K2 @ h, K2 @ Hf)
+
+    o = oracle.iterate(x, sc["map_xyz"], sc["scan_xyz"], params=prm)
+    sel = np.nonzero(o["valid"])[0]
+    # (a) 20 matches: the n > dof_Measurement branch vs the normal-equation form
+    few = sel[:20]
+    (kh1, kx1), (kh2, kx2) = gains(o["Hrows"][few], o["h"][few])
+    assert np.abs(kh1 - kh2).max() < 1e-9 * max(1.0, np.abs(kh2).max())
+    assert np.abs(kx1 - kx2).max() < 1e-9
+    # (b) pass-through of the whole scan's H^T H / H^T h as a 12-row pseudo measurement
+    # With estimate_extrinsics the 12x12 H^T H is only SEMI-definite (the columns of `pos` and of `offset_T_L_I` are
+    # the same normal seen in two frames: rank <= 9), so the factor has to be rank revealing: H^T H = V L V^T,
+    # U = sqrt(L+) V^T, h = L+^(-1/2) V^T H^T h (H^T h lies in the range of H^T H).  A plain Cholesky is enough for
+    # the 6x6 block of the default configuration (checked below).
+    HTH, HTh = o["HTH"], o["HTh"]
+    lam, V = np.linalg.eigh(HTH)
+    keep = lam > 1e-12 * lam.max()
+    assert keep.sum() < 12
+    U = np.sqrt(lam[keep])[:, None] * V[:, keep].T
+    hp = (V[:, keep].T @ HTh) / np.sqrt(lam[keep])
+    assert np.abs(U.T @ U - HTH).max() < 1e-9 * np.abs(HTH).max() and np.abs(U.T @ hp - HTh).max() < 1e-9 * np.abs(HTh).max()
+    (ph1, px1), (ph2, px2) = gains(U, hp)
+    H_all, h_all = o["Hrows"][sel], o["h"][sel]
+    Hf = np.zeros((len(sel), 23))
+    Hf[:, :12] = H_all
+    K = np.linalg.inv(Hf.T @ Hf + np.linalg.inv(P / R)) @ Hf.T          # the true measurement, normal-equation branch
+    want_h, want_x = K @ h_all, K @ Hf
+    for got_h, got_x in ((ph1, px1), (ph2, px2)):
+        assert np.abs(got_h - want_h).max() < 1e-8 * max(1.0, np.abs(want_h).max())
+        assert np.abs(got_x - want_x).max() < 1e-8
+    # and the oracle's own step (normal-equation form on H^T H / H^T h) lands where the dense K-form does in the linear
+    # part: dx_ = K h + (K H - I) dx_new with dx_new = 0 on the first pass (x == x_prop)
+    xs, dx, _, _ = oracle.kf_step(x, x, P, dict(HTH=HTH, HTh=HTh, n_valid=len(sel)), params=prm)
+    assert np.abs(dx - want_h).max() < 1e-8 * max(1.0, np.abs(want_h).max())
+    # default configuration (no extrinsic estimation): the leading 6x6 block is positive definite -> Cholesky, padded
+    o6 = oracle.iterate(x, sc["map_xyz"], sc["scan_xyz"])
+    U6 = np.zeros((6, 12))
+    U6[:, :6] = np.linalg.cholesky(o6["HTH"][:6, :6]).T
+    h6 = np.linalg.solve(U6[:, :6].T, o6["HTh"][:6])
+    (qh1, qx1), (qh2, qx2) = gains(U6, h6)
+    s6 = np.nonzero(o6["valid"])[0]
+    Hf6 = np.zeros((len(s6), 23))
+    Hf6[:, :12] = o6["Hrows"][s6]
+    K6 = np.linalg.inv(Hf6.T @ Hf6 + np.linalg.inv(P / R)) @ Hf6.T
+    for got_h, got_x in ((qh1, qx1), (qh2, qx2)):
+        assert np.abs(got_h - K6 @ o6["h"][s6]).max() < 1e-8 and np.abs(got_x - K6 @ Hf6).max() < 1e-8
