@@ -326,6 +326,8 @@ typedef struct lv_timing {
     int   fallback_queries;    /* scan points that left the bucketed voxel levels (generic search) in the last update */
     float pass_match_ms[8];    /* device time of search_kernel per pass of the last profiled lv_update */
     float pass_solve_ms[8];    /* device time of fit_reduce_kernel + solve_kernel per pass */
+    int   mailbox_resyncs;     /* updates (since lv_create) whose result mailbox failed its checksum at first sight: the host
+                                  then waited with hipStreamSynchronize instead (expected: 0) */
 } lv_timing;
 int lv_get_timing(lv_ctx* ctx, lv_timing* out);
 /* 0 = off; 1 = per-kernel HIP-event timing inside lv_update (adds event records to the stream);

@@ -73,7 +73,7 @@ class Sums(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("last_update_ms", C.c_float), ("last_reduce_ms", C.c_float), ("last_solve_ms", C.c_float),
                 ("last_passes", C.c_int), ("fallback_queries", C.c_int), ("pass_match_ms", C.c_float * 8),
-                ("pass_solve_ms", C.c_float * 8)]
+                ("pass_solve_ms", C.c_float * 8), ("mailbox_resyncs", C.c_int)]
 
 
 class MapStats(C.Structure):  # lv_map_stats

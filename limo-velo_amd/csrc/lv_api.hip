@@ -72,6 +72,7 @@ struct lv_ctx {
     bool begin_pending = false;    // the update's state waits in h_begin for the first search launch (no begin kernel)
     BeginArg h_begin;
     int fallback_base = 0;         // device counter value before the update in flight (the device never resets it)
+    long mailbox_resyncs = 0;      // updates whose mailbox checksum did not match at first sight (stream synchronised instead)
 
     bool in_update = false;
     bool want_log = false;         // download trace / per-pass sums at lv_update_end
@@ -866,13 +867,26 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
         // anything unusual (errors, very long updates) still ends in hipStreamSynchronize.
         bool seen = false;
         if (c->spin_wait && !c->profiling && !c->phase_clocks && !c->capture) {
-            volatile const int* seq = &c->h_io->seq;
+            volatile const unsigned long long* sc = &c->h_io->seqcheck;
             const auto t0 = std::chrono::steady_clock::now();
+            unsigned long long word = 0;
             for (int it = 0;; ++it) {
-                if (*seq == c->update_seq) { seen = true; break; }
+                word = *sc;
+                if ((uint32_t)word == (uint32_t)c->update_seq) { seen = true; break; }
                 if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
             }
             std::atomic_thread_fence(std::memory_order_acquire);
+            if (seen) {
+                // the results were stored before the word, but only the checksum proves that they have all ARRIVED
+                const uint32_t want = (uint32_t)(word >> 32);
+                const KfHostIO* io = c->h_io;
+                uint32_t chk = 0;
+                for (int i = 0; i < NS * NS; ++i) chk ^= mailbox_mix(io->P_post[i], (uint32_t)i);
+                for (int i = 0; i < NX; ++i) chk ^= mailbox_mix(io->x[i], 1000u + (uint32_t)i);
+                chk ^= mailbox_mix((double)io->passes, 2000u);
+                if (chk == MAILBOX_UNCHECKED) chk = 0u;
+                if (want == MAILBOX_UNCHECKED || chk != want) { seen = false; ++c->mailbox_resyncs; }
+            }
         }
         if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
     }
@@ -1140,6 +1154,7 @@ int lv_get_solve_clocks(lv_ctx* c, long long* out, int capacity) {
 int lv_get_timing(lv_ctx* c, lv_timing* out) {
     if (!c || !out) { set_error("null argument"); return LV_EINVAL; }
     *out = c->timing;
+    out->mailbox_resyncs = (int)c->mailbox_resyncs;
     return LV_OK;
 }
 

@@ -84,9 +84,22 @@ struct KfHostIO {
     double P_post[NS * NS];
     int passes;
     int fallback_queries;
-    int seq;   // sequence number of the last FINISHED update (stored after all results, system-scope fence)
-    int pad_;
+    // {sequence number of the last FINISHED update (low word), checksum of x / P_post / passes as stored (high word)},
+    // written with ONE 64-bit store after all results.  The results are write-through stores that have retired
+    // (s_waitcnt) before this word is stored, but nothing in the memory model orders them across PCIe: the host
+    // verifies the checksum and falls back to hipStreamSynchronize on a mismatch (MAILBOX_UNCHECKED: always).
+    unsigned long long seqcheck;
 };
+constexpr uint32_t MAILBOX_UNCHECKED = 0xFFFFFFFFu;
+__host__ __device__ __forceinline__ uint32_t mailbox_mix(double v, uint32_t idx) {
+    unsigned long long b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (unsigned long long)__double_as_longlong(v);
+#else
+    __builtin_memcpy(&b, &v, 8);
+#endif
+    return ((uint32_t)b * 31u + (uint32_t)(b >> 32)) ^ (idx * 0x9E3779B9u + 0x7F4A7C15u);
+}
 
 // Filter state resident on the device between lv_predict / lv_correct calls (row f-3).
 struct FilterDev {

@@ -21,8 +21,10 @@
 // within (2^l * cell) of the query up to rounding of the voxel coordinates; a level is accepted only
 // if 5 candidates were found and d5 < r_l^2 with r_l shrunk by a 1e-3 relative margin plus the f32
 // rounding bound of the coordinates involved.  Otherwise the next (coarser) level is searched from
-// scratch, and after the last level a brute-force scan of all M points decides.  Hence the result
-// equals exhaustive search under the (d, index) order for every query.
+// scratch: bucket levels 0 and 1 per lane group, level 2 by whole wavefronts, the level-3 block as the 216
+// level-2 voxel lists that tile it, finally every id.  Hence the result equals exhaustive search under the
+// (d, index) order for every query.  Non-capturing launches may stop once a rejected level proves
+// d5 >= MAX_DIST_PLANE^2 (knn_search): the reference drops such a match whatever its neighbours are.
 #include "lv_host.hpp"
 #include "lv_solve_dev.hpp"   // solve_prep (restores -ffp-contract=off for everything below)
 

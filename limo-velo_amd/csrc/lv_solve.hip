@@ -164,6 +164,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     __shared__ PoseConsts s_pose;
     __shared__ float s_ptmp[8];
     __shared__ int s_last, s_conv;
+    __shared__ uint32_t s_chk;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // every global read of this kernel is issued up front (one memory round trip): the records, x, x_prop and
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         if (sums_out) sums_out[tid] = s;
         if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = s;
     }
-    if (tid == 200) s_conv = 1;
+    if (tid == 200) { s_conv = 1; s_chk = 0u; }
     __syncthreads();
     if (tid < 144) {
         const int a = tid / 12, b = tid % 12;
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
                 IO_STORE(&io->fallback_queries, kf_fallback);
                 for (int i = 0; i < NX; ++i) IO_STORE(&io->x[i], kf->x[i]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through mailbox stores above have retired
-                __hip_atomic_store(&io->seq, prm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // final: the host may stop waiting
+                // final: the host may stop waiting (no checksum on this rare path: the host synchronises the stream)
+                __hip_atomic_store(&io->seqcheck, ((unsigned long long)MAILBOX_UNCHECKED << 32) | (unsigned long long)(uint32_t)prm.seq,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         return;
@@ -365,7 +368,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         const double pv = sB[i][j] - s;
         kf->P_post[tid] = pv;
         IO_STORE(&io->P_post[tid], pv);
+        atomicXor(&s_chk, mailbox_mix(pv, (uint32_t)tid));
     }
+    if (tid < NX) atomicXor(&s_chk, mailbox_mix(sx[tid], 1000u + (uint32_t)tid));
+    if (tid == 0) atomicXor(&s_chk, mailbox_mix((double)(pass + 1), 2000u));
     SV_STAMP(9);
     // the update is final (kf->done was set above): every result store is ordered before the sequence number
     // the host waits on
@@ -374,7 +380,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
     // L2, ~4 us — and plain stores without it were observed to arrive after the sequence number)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&io->seq, prm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+        uint32_t chk = s_chk;
+        if (chk == MAILBOX_UNCHECKED) chk = 0u;   // (the value that means "unchecked" is not used as a checksum; the host maps it likewise)
+        __hip_atomic_store(&io->seqcheck, ((unsigned long long)chk << 32) | (unsigned long long)(uint32_t)prm.seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #undef SV_STAMP
 }
 
