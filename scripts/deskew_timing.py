@@ -1,6 +1,7 @@
 """Row f-2 / f-4 timing: PointCloud2 ingest, windowed de-skew + voxel grid of one sweep (GPU only)."""
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
 import numpy as np
 import torch  # noqa: F401
 import lvamd; lvamd.load()

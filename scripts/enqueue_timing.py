@@ -1,6 +1,7 @@
 """Host-side cost of enqueuing one update (13 kernel launches) vs its device time: is the loop launch-bound?"""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth

@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth
 sc = synth.make_scene(1_048_576, 65_536)

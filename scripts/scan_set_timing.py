@@ -1,6 +1,7 @@
 """PCIe-inclusive timing: lv_scan_set (host scan in: repack + H2D + Morton sort) + lv_update (state out)."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401  (torch runtime first)
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth

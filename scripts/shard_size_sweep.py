@@ -1,7 +1,8 @@
 """What one rank of an N-GPU run sees: the 64k-point scan cut to 64k / N points against the full 1M-point map
 (no collective: an upper bound for the strong-scaling run), plus larger scans."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth

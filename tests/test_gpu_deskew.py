@@ -75,3 +75,18 @@ def test_points_outside_the_state_window_are_dropped(lv, oracle):
         ctx.scan_deskew(xyz, times, states, xt2, downsample_prec=0.5)
         got = ctx.scan_fetch()
     assert np.array_equal(_bits(got), _bits(ref))
+
+
+def test_downsample_alone_is_the_voxel_grid(lv, oracle, scene_small):
+    """lv_scan_downsample = Compensator::downsample (Compensator.cpp:104-107,148-163) on already compensated points."""
+    from limo_velo_amd import capi
+
+    pts = scene_small["scan_xyz"]
+    with capi.Context() as ctx:
+        for leaf in (0.5, 0.2):
+            ctx.scan_downsample(pts, leaf)
+            got = ctx.scan_fetch()
+            want = oracle.voxelgrid(pts, leaf)
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), leaf
+        ctx.scan_downsample(pts, 0.0)      # no voxel grid: the points become the scan as they are
+        assert np.array_equal(ctx.scan_fetch().view(np.uint32), pts.view(np.uint32))

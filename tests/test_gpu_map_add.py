@@ -204,3 +204,25 @@ def test_map_add_scan_stays_on_the_device(capi, oracle, scene_small):
         ref = oracle.map_add(ref, oracle.transform_scan(sc["x_true"], sc["scan_xyz"][:700]), downsample=False)
         assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
         assert ctx.map_stats()["dropped"] == 1
+
+
+def test_map_add_scan_builds_an_empty_map(capi, oracle, scene_small):
+    """Mapper::add on an empty map BUILDS it from the cloud as it is (Mapper.cpp:22-27: no down-sampling, whatever the
+    flag says) — lv_map_add_scan follows Mapper::add; lv_map_add follows KD_TREE::Add_Points (the box rule applies)."""
+    sc = scene_small
+    scan = sc["scan_xyz"][:1500].copy()
+    scan[3] = [np.inf, 0, 0]
+    with capi.Context() as ctx:
+        ctx.filter_set(sc["x_true"], sc["P0"])
+        ctx.scan_set(scan)
+        assert ctx.map_size() == 0
+        ctx.map_add_scan(downsample=True)
+        want = oracle.transform_scan(sc["x_true"], np.delete(scan, 3, axis=0))
+        assert ctx.map_size() == len(want)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(want))
+        _knn_matches(ctx, oracle, want, sc["x_true"], sc["scan_xyz"][:200])
+        # the next one is an insert with the box rule
+        ctx.scan_set(sc["scan_xyz"][1500:])
+        ctx.map_add_scan(downsample=True)
+        want = oracle.map_add(want, oracle.transform_scan(sc["x_true"], sc["scan_xyz"][1500:]), downsample=True)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(want))
