@@ -2,7 +2,8 @@
 """bench.py — KF-update iterations/s of the MI355X-native LIMO-Velo hot path.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run,
-one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+one rank per GPU, RCCL; a plain `python bench.py --gpus N` without WORLD_SIZE in the environment
+re-launches itself that way on 127.0.0.1).  Prints ONE JSON line on rank 0.
 
 Workload (BASELINE.json metric): 65 536-point scan vs 1 048 576-point map, k = 5, MAX_NUM_ITERS = 3
 (4 measurement passes per update), synthetic planar scene (limo-velo_amd/synth.py).

@@ -46,18 +46,21 @@ def test_struct_layouts_match_c(capi, tmp_path):
     src = tmp_path / "layout.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "limovelo_hip.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(lv_params), offsetof(lv_params, LIMITS),"
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(lv_params), offsetof(lv_params, LIMITS),"
         " offsetof(lv_params, voxel_size), offsetof(lv_params, lanes_per_query), sizeof(lv_state), sizeof(lv_sums),"
         " offsetof(lv_sums, n_valid), sizeof(lv_timing), sizeof(lv_cloud_format), offsetof(lv_cloud_format, relative_time),"
         " sizeof(lv_ingest_params), offsetof(lv_ingest_params, full_rotation_time), offsetof(lv_ingest_params, min_dist),"
-        " sizeof(lv_motion_state));return 0;}\n")
+        " sizeof(lv_motion_state), offsetof(lv_params, degeneracy_mode), offsetof(lv_params, print_degeneracy_values),"
+        " offsetof(lv_timing, mailbox_resyncs), sizeof(lv_map_stats), offsetof(lv_map_stats, bytes));return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(capi.Params), capi.Params.LIMITS.offset, capi.Params.voxel_size.offset,
             capi.Params.lanes_per_query.offset, 26 * 8, C.sizeof(capi.Sums), capi.Sums.n_valid.offset,
             C.sizeof(capi.Timing), C.sizeof(capi.CloudFormat), capi.CloudFormat.relative_time.offset,
-            C.sizeof(capi.IngestParams), capi.IngestParams.full_rotation_time.offset, capi.IngestParams.min_dist.offset, 184]
+            C.sizeof(capi.IngestParams), capi.IngestParams.full_rotation_time.offset, capi.IngestParams.min_dist.offset, 184,
+            capi.Params.degeneracy_mode.offset, capi.Params.print_degeneracy_values.offset,
+            capi.Timing.mailbox_resyncs.offset, C.sizeof(capi.MapStats), capi.MapStats.bytes.offset]
     assert got == want
 
 
