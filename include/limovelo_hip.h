@@ -304,6 +304,18 @@ int lv_fetch_knn(lv_ctx* ctx, uint32_t* idx, float* d2);
  * NULL.  Tests compare these with the oracle's neighbours to pin the fast build (the index-carrying lv_fetch_knn
  * needs a capturing launch). */
 int lv_fetch_neighbors(lv_ctx* ctx, float* nbr_xyz, float* d2, float* p_world, int32_t* found);
+/* The single-GPU lv_update / lv_correct run ONE launch per pass (pass_kernel: the solve of the previous pass in every
+ * workgroup, the search, the plane fits; no capture, no communicator, degeneracy_mode 0, lanes_per_query 8) and keep the
+ * hand-over records in LDS.  lv_set_record_dump(ctx, 1) makes that same kernel also store them to memory so that
+ * lv_fetch_neighbors can pin it (one uniform branch; off by default).  lv_last_update_fused: 1 if the most recent
+ * lv_update / lv_correct took the one-launch-per-pass route, 0 if the three-kernel pass (search / fit / solve). */
+int lv_set_record_dump(lv_ctx* ctx, int enabled);
+int lv_last_update_fused(lv_ctx* ctx);
+/* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
+int lv_set_fused_pass(lv_ctx* ctx, int enabled);
+/* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): per search workgroup of the last
+ * pass_kernel launch, 8 shader-clock stamps followed by 8 wall-clock stamps (100 MHz) at its phase boundaries. */
+int lv_get_pass_clocks(lv_ctx* ctx, long long* out, int capacity_wg, int* n_wg);
 /* Mapper::match outputs: valid N (Match::is_chosen), p_world N x 3, abcd N x 4 (Normal A,B,C,D),
  * dist N (Match::distance).  Any pointer may be NULL. */
 int lv_fetch_matches(lv_ctx* ctx, uint8_t* valid, float* p_world, float* abcd, float* dist);
@@ -320,8 +332,9 @@ int lv_calculate_H(lv_ctx* ctx, const lv_state* x, const float* p_world, const f
 /* ---- instrumentation ------------------------------------------------------------------------- */
 typedef struct lv_timing {
     float last_update_ms;      /* device time of the last lv_update (HIP events on the ctx stream) */
-    float last_reduce_ms;      /* average device time of search_kernel (the dominant kernel) in the last lv_update */
-    float last_solve_ms;       /* average device time of fit_reduce_kernel + solve_kernel in the last lv_update */
+    float last_reduce_ms;      /* average device time of the dominant kernel in the last lv_update: pass_kernel (one launch
+                                  per pass) or search_kernel (three-kernel pass) */
+    float last_solve_ms;       /* average device time of fit_reduce_kernel + solve_kernel in the last lv_update (three-kernel pass; else 0) */
     int   last_passes;
     int   fallback_queries;    /* scan points that left the bucketed voxel levels (generic search) in the last update */
     float pass_match_ms[8];    /* device time of search_kernel per pass of the last profiled lv_update */

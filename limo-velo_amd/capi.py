@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_add_scan", "lv_map_evict_box", "lv_map_evict_oldest", "lv_map_relinearise", "lv_map_get_stats",
     "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_downsample", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
-    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_set_fused_pass", "lv_get_pass_clocks", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
 ]
@@ -432,6 +432,22 @@ class Context:
         d2 = np.empty((n, 5), np.float32)
         self._check(self.lib.lv_fetch_knn(self.h, idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p)))
         return idx, d2
+
+    def set_record_dump(self, on=True):
+        """pass_kernel (one launch per pass) also stores its hand-over records to memory (for fetch_neighbors)."""
+        self._check(self.lib.lv_set_record_dump(self.h, int(on)))
+
+    def set_fused_pass(self, on=True):
+        self._check(self.lib.lv_set_fused_pass(self.h, int(on)))
+
+    def pass_clocks(self, capacity=1024):
+        buf = np.zeros((capacity, 16), np.int64)
+        n = C.c_int(0)
+        self._check(self.lib.lv_get_pass_clocks(self.h, buf.ctypes.data_as(C.c_void_p), capacity, C.byref(n)))
+        return buf[: n.value]
+
+    def last_update_fused(self) -> bool:
+        return bool(self.lib.lv_last_update_fused(self.h))
 
     def fetch_neighbors(self):
         """Neighbour coordinates / squared distances / world points / found counts out of the hand-over records of

@@ -61,6 +61,16 @@ struct lv_ctx {
     bool tile_lpt = true;          // dispatch the search tiles farthest-first (LV_TILE_LPT=0: plain order, A/B knob)
     float4* d_qrec = nullptr;      // search -> fit hand-over: 8 float4 planes of qstride entries (one record per scan point)
     uint32_t qstride = 0;
+    // one launch per pass (pass_kernel, lv_pass_dev.hpp): compact workgroup partials, ping-pong by pass parity
+    double* d_cpart[2] = {nullptr, nullptr};
+    int pass_max_wg = 512;         // search workgroups of pass_kernel: all resident at once (2 per CU)
+    bool fused_pass = true;        // LV_FUSED_PASS=0: the three-kernel pass (search / fit / solve) also where pass_kernel applies
+    int fit_sel = 1;               // LV_FIT_SEL: which wavefronts of a workgroup fit planes (speed heuristic)
+    bool record_dump = false;      // lv_set_record_dump: pass_kernel also writes its hand-over records to d_qrec (lv_fetch_neighbors)
+    bool last_update_fused = false;
+    long long* d_pclk = nullptr;   // LV_PASS_CLK=1: phase stamps of pass_kernel's workgroups (lv_get_pass_clocks)
+    int pclk_wg = 0;
+    bool fused_ext = false;        // LV_FUSED_EXT=1: pass_kernel also with estimate_extrinsics (12-column rows: 3 waves per SIMD only)
 
     // capture (debug / API-parity) buffers, sized for the current scan
     bool capture = false;
@@ -272,6 +282,67 @@ int pass_solve(lv_ctx* c, bool from_groups) {
     return launch_solve(c->stream, c->d_kf, c->d_io, c->d_sums, 1, nullptr, sp);
 }
 
+// One launch per pass (pass_kernel) applies to the plain single-GPU update: no capture / phase clocks, no
+// communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
+bool pass_fused_applies(const lv_ctx* c) {
+    return c->fused_pass && !c->capture && !c->phase_clocks && c->comm == nullptr && c->prm.degeneracy_mode == 0 &&
+           c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->scan.n > 0 && c->map.view.m > 0;
+}
+
+// The whole iterated update as npass + 1 launches: launch i = [solve of pass i-1 in every workgroup] + pass i, the
+// closing launch (one workgroup) = the solve of the last pass.  begin_device() ran before: either the state waits in
+// h_begin (begin_pending: it rides in the first launch's kernel arguments) or a begin kernel installed it in d_kf.
+int update_fused(lv_ctx* c) {
+    const int npass = c->prm.MAX_NUM_ITERS + 1;
+    PassLaunch pl{};
+    pl.map = &c->map.view;
+    pl.scan = c->scan.d_sorted;
+    pl.tile_order = (c->tile_lpt && c->scan.tile_points == 32u && c->scan.n_tiles == (c->scan.n + 31u) / 32u) ? c->scan.d_tile_order : nullptr;
+    pl.n = c->scan.n;
+    pl.kf = c->d_kf;
+    pl.io = c->d_io;
+    pl.sums_out = c->d_sums;
+    pl.fit_sel = c->fit_sel;
+    pl.mp.R_inv = 1.0 / c->prm.LiDAR_noise;
+    pl.mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
+    pl.mp.planes_threshold = c->prm.PLANES_THRESHOLD;
+    pl.mp.estimate_extrinsics = c->prm.estimate_extrinsics;
+    pl.sp.R = c->prm.LiDAR_noise;
+    pl.sp.R_inv = 1.0 / c->prm.LiDAR_noise;
+    for (int i = 0; i < NS; ++i) pl.sp.limits[i] = c->prm.LIMITS[i];
+    pl.sp.maximum_iter = c->prm.MAX_NUM_ITERS;
+    pl.sp.estimate_extrinsics = c->prm.estimate_extrinsics;
+    pl.sp.seq = c->update_seq;
+    pl.sp.degeneracy_mode = 0;
+    pl.sp.degeneracy_threshold = c->prm.degeneracy_threshold;
+    int nwg = 0, rounds = 0;
+    pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &rounds);
+    pl.qrec = c->record_dump ? c->d_qrec : nullptr;
+    pl.clk = c->d_pclk;
+    c->pclk_wg = nwg;
+    pl.qstride = c->qstride;
+    c->qrec_valid = c->record_dump;
+    c->last_update_fused = true;
+    for (int i = 0; i <= npass; ++i) {
+        const bool closing = i == npass;
+        pl.mode = i == 0 ? (c->begin_pending ? 0 : 2) : 1;
+        pl.recs_in = c->d_cpart[(i + 1) & 1];
+        pl.part_out = c->d_cpart[i & 1];
+        pl.nrec = nwg;
+        pl.nwg = closing ? 0 : nwg;
+        pl.rounds = closing ? 0 : rounds;
+        if (c->profiling && !closing) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
+        int rc = launch_pass(c->stream, pl, (i == 0 && c->begin_pending) ? &c->h_begin : nullptr);
+        c->begin_pending = false;
+        if (rc) return rc;
+        if (c->profiling && !closing) {
+            LV_HIP(hipEventRecord(c->ev_pass[3 * i + 1], c->stream));
+            LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
+        }
+    }
+    return LV_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -332,6 +403,17 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;  // tuning knob
     if (const char* e = getenv("LV_TILE_LPT")) c->tile_lpt = atoi(e) != 0;
     if (const char* e = getenv("LV_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
+    if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
+    if (const char* e = getenv("LV_FIT_SEL")) c->fit_sel = atoi(e);
+    if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
+    if (const char* e = getenv("LV_PASS_CLK")) {
+        if (atoi(e) != 0) {
+            LV_HIP(hipMalloc(&c->d_pclk, (size_t)(c->pass_max_wg + 1) * 16 * sizeof(long long)));
+            LV_HIP(hipMemset(c->d_pclk, 0, (size_t)(c->pass_max_wg + 1) * 16 * sizeof(long long)));
+        }
+    }
+    c->pass_max_wg = prop.multiProcessorCount * 2;
+    if (const char* e = getenv("LV_PASS_WG")) c->pass_max_wg = atoi(e) > 0 ? atoi(e) : c->pass_max_wg;
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -348,6 +430,10 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipHostGetDevicePointer((void**)&c->d_io, c->h_io, 0));
     LV_HIP(hipMalloc(&c->d_partials, (size_t)(c->max_blocks + 8) * SUMS_LEN * sizeof(double)));
     LV_HIP(hipMalloc(&c->d_groups, (size_t)(c->max_blocks / 32 + 2) * SUMS_LEN * sizeof(double)));
+    for (int i = 0; i < 2; ++i) {
+        LV_HIP(hipMalloc(&c->d_cpart[i], (size_t)(c->pass_max_wg + 8) * SUMS_LEN * sizeof(double)));
+        LV_HIP(hipMemset(c->d_cpart[i], 0, (size_t)(c->pass_max_wg + 8) * SUMS_LEN * sizeof(double)));
+    }
     LV_HIP(hipMalloc(&c->d_sums_own, SUMS_LEN * sizeof(double)));
     LV_HIP(hipMemset(c->d_sums_own, 0, SUMS_LEN * sizeof(double)));
     c->d_sums = c->d_sums_own;
@@ -375,6 +461,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_filter) hipHostFree(c->h_filter);
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
+    hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk);
     hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
@@ -768,6 +855,30 @@ int lv_set_capture(lv_ctx* c, int enabled) {
     return LV_OK;
 }
 
+int lv_set_record_dump(lv_ctx* c, int enabled) {
+    LV_CHECK_CTX(c);
+    c->record_dump = enabled != 0;
+    return LV_OK;
+}
+
+int lv_last_update_fused(lv_ctx* c) { return (c && c->last_update_fused) ? 1 : 0; }
+
+int lv_set_fused_pass(lv_ctx* c, int enabled) {
+    LV_CHECK_CTX(c);
+    c->fused_pass = enabled != 0;
+    return LV_OK;
+}
+
+int lv_get_pass_clocks(lv_ctx* c, long long* out, int capacity_wg, int* n_wg) {
+    LV_CHECK_CTX(c);
+    if (!c->d_pclk) { set_error("no pass clocks: create the context with LV_PASS_CLK=1 in the environment"); return LV_ESTATE; }
+    const int nb = c->pclk_wg < capacity_wg ? c->pclk_wg : capacity_wg;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(out, c->d_pclk, (size_t)nb * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (n_wg) *n_wg = nb;
+    return LV_OK;
+}
+
 int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
     LV_CHECK_CTX(c);
     if (!x || !out) { set_error("null argument"); return LV_EINVAL; }
@@ -918,13 +1029,19 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     int rc = lv_update_begin(c, x, P);
     if (rc) return rc;
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_begin, c->stream));
-    for (int i = 0; i < npass; ++i) {
-        if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
-        c->ev_mid = c->profiling ? c->ev_pass[3 * i + 1] : nullptr;
-        rc = pass_full(c);
-        c->ev_mid = nullptr;
+    c->last_update_fused = false;
+    if (pass_fused_applies(c)) {
+        rc = update_fused(c);
         if (rc) { c->in_update = false; return rc; }
-        if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
+    } else {
+        for (int i = 0; i < npass; ++i) {
+            if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
+            c->ev_mid = c->profiling ? c->ev_pass[3 * i + 1] : nullptr;
+            rc = pass_full(c);
+            c->ev_mid = nullptr;
+            if (rc) { c->in_update = false; return rc; }
+            if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
+        }
     }
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_end, c->stream));
     int np = 0;
@@ -995,9 +1112,15 @@ int lv_correct(lv_ctx* c, int* passes) {
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
-    for (int i = 0; i < npass; ++i) {
-        rc = pass_full(c);
+    c->last_update_fused = false;
+    if (pass_fused_applies(c)) {
+        rc = update_fused(c);
         if (rc) { c->in_update = false; return rc; }
+    } else {
+        for (int i = 0; i < npass; ++i) {
+            rc = pass_full(c);
+            if (rc) { c->in_update = false; return rc; }
+        }
     }
     c->in_update = false;
     rc = launch_kf_to_filter(c->stream, c->d_kf, c->d_filter);

@@ -181,6 +181,29 @@ struct SolveParams {
     double degeneracy_threshold;
 };
 int launch_solve(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* recs, int nrec, double* sums_out, const SolveParams& prm);
+// lv_match.hip — one launch per pass (pass_kernel): prologue solve of the previous pass in every workgroup + search +
+// plane fits + one compact partial per workgroup (lv_pass_dev.hpp)
+struct PassLaunch {
+    const MapView* map;
+    const float4* scan;
+    const uint32_t* tile_order;   // 32-point tiles (ScanStore::order_tiles(32)) or nullptr
+    uint32_t n;
+    KfDev* kf;
+    KfHostIO* io;
+    const double* recs_in;        // compact partials of the previous launch (mode 1), nrec of them
+    double* part_out;
+    double* sums_out;
+    float4* qrec;                 // optional (debug): the hand-over records also go to memory, 8 planes of qstride entries
+    long long* clk;               // optional (instrumentation): 16 stamps per search workgroup
+    uint32_t qstride;
+    int nrec;
+    int mode;                     // 0: the update starts here (state in the BeginArg); 1: solve the previous pass first; 2: state already in kf
+    int rounds, fit_sel, nwg;     // nwg search workgroups (+ 1 designated); nwg = 0: closing launch
+    MatchParams mp;
+    SolveParams sp;
+};
+void pass_grid_size(uint32_t n, int max_wg, int* nwg, int* rounds);
+int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin);
 // lv_predict.hip
 int launch_predict(hipStream_t stream, FilterDev* f, double dt, const double* Q, const double* acc, const double* gyro);
 int launch_filter_to_kf(hipStream_t stream, const FilterDev* f, KfDev* kf);

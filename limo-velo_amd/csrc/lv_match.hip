@@ -26,7 +26,7 @@
 // (d, index) order for every query.  Non-capturing launches may stop once a rejected level proves
 // d5 >= MAX_DIST_PLANE^2 (knn_search): the reference drops such a match whatever its neighbours are.
 #include "lv_host.hpp"
-#include "lv_solve_dev.hpp"   // solve_prep (restores -ffp-contract=off for everything below)
+#include "lv_pass_dev.hpp"    // solve_prep / solve_core / out_pair (restores -ffp-contract=off for everything below)
 
 namespace lv {
 
@@ -263,33 +263,6 @@ __device__ inline void plane_qr_solve(float (&A)[KNN][3], float (&x)[3]) {
             for (int a = 0; a < 3; ++a)
                 if (perm[i] == a) x[a] = c[i];
         }
-    }
-}
-
-// reduction outputs: thread t owns the product column pair (a, b) of the staged row and its slot
-// `rec` in the 96-double record ([0..77] upper triangle of the 12x12 H^T H, [78..89] H^T h, 90 n_valid,
-// 91 sum h^2).  W = number of Jacobian columns that can be non-zero (6 without extrinsics, else 12).
-template <int W>
-__device__ __forceinline__ void out_pair(int t, int& a, int& b, int& rec) {
-    constexpr int NTRI = W * (W + 1) / 2;
-    if (t < NTRI) {
-        int i = 0, rem = t;
-        while (rem >= W - i) { rem -= W - i; ++i; }
-        a = i;
-        b = i + rem;
-        rec = a * 12 - a * (a - 1) / 2 + (b - a);
-    } else if (t < NTRI + W) {
-        a = t - NTRI;
-        b = W;          // h
-        rec = 78 + a;
-    } else if (t == NTRI + W) {
-        a = W + 1;      // valid * valid
-        b = W + 1;
-        rec = 90;
-    } else {
-        a = W;          // h * h
-        b = W;
-        rec = 91;
     }
 }
 
@@ -1010,6 +983,311 @@ int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, 
     if (ext) { if (dbg_on) LV_LAUNCH(true, true); else LV_LAUNCH(true, false); }
     else { if (dbg_on) LV_LAUNCH(false, true); else LV_LAUNCH(false, false); }
 #undef LV_LAUNCH
+    LV_HIP(hipGetLastError());
+    return LV_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// ONE launch per measurement pass (lv_pass_dev.hpp): every workgroup of 512 threads
+//   1. prologue: re-derives the state and the f32 constants of this pass — the solve of the PREVIOUS pass from the
+//      workgroup partials that launch left behind (mode 1), or takes them from the kernel arguments (mode 0: the update
+//      starts here) / from kf (mode 2: a begin kernel installed a device-resident state);
+//   2. per round searches 4 tiles of 32 scan points (two steps of its two 256-thread halves; S = 8 lanes per point,
+//      the same knn_search as search_kernel) and keeps the 128-byte hand-over records in LDS instead of HBM;
+//   3. two of its wavefronts (one per step, 64 points each, one lane per point) run the plane fits, rows and the
+//      contraction of fit_reduce_kernel on those records;
+//   4. writes one compact partial (PassDims::OW doubles) for the next launch's prologue.
+// The grid is sized so that every workgroup is resident at once (<= 2 per CU): there are no residency rounds whose
+// workgroups would each pay the prologue, and nothing in the kernel waits for another workgroup.
+// The last workgroup of the grid is the designated one (bookkeeping / prepare_next / terminal pass); a launch with a
+// grid of one workgroup is the closing launch of an update (the solve of its last pass, nothing to search).
+struct PassArgs {
+    MapView map;
+    const float4* scan;
+    const uint32_t* tile_order;   // 32-point tiles, farthest first (or nullptr)
+    uint32_t n, n_tiles32;
+    KfDev* kf;
+    KfHostIO* io;
+    const double* recs_in;        // compact partials of the previous launch (mode 1)
+    double* part_out;             // compact partials of this launch
+    double* sums_out;             // optional: the folded 96-double record of the previous pass
+    float4* qrec;                 // optional (lv_set_record_dump): the hand-over records also go to memory (lv_fetch_neighbors)
+    long long* clk;               // optional (instrumentation): 8 shader-clock + 8 wall-clock stamps per workgroup
+    uint32_t qstride;
+    int nrec, mode, rounds, fit_sel;
+    MatchParams mp;
+    SolveParams sp;
+};
+constexpr int PK_GROUPS = PK_THREADS / 8;         // lane groups (= scan points in flight) per workgroup: 64
+constexpr int PK_STAGE = 64;                      // candidates of a lane group's first level-0 chunk kept in LDS
+constexpr int PK_STEPS = 2;                       // search steps per round; one fit wavefront per step
+constexpr size_t PK_REGION0 = sizeof(Xyz) * PK_GROUPS * PK_STAGE;                       // 49152: stage | solve scratch | rows
+constexpr size_t PK_OFF_REC = PK_REGION0;                                             // float4 [steps][8 slots][64]
+constexpr size_t PK_OFF_PREF = PK_OFF_REC + sizeof(float4) * PK_STEPS * QREC_SLOTS * 64;
+constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS / 64) * 64;
+constexpr size_t PK_OFF_OUT = PK_OFF_POSE + ((sizeof(PoseConsts) + 15) / 16) * 16;
+constexpr size_t PK_LDS_BYTES = PK_OFF_OUT + sizeof(double) * PK_STEPS * 2 * SUMS_LEN;
+static_assert(sizeof(SolveLds) % 8 == 0 && sizeof(SolveLds) + sizeof(BookLds) <= PK_REGION0, "solve scratch must fit under the stage");
+static_assert(sizeof(double) * PK_STEPS * 64 * 14 <= PK_REGION0, "staged rows must fit under the stage");
+static_assert(PK_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+
+template <bool EXT>
+__global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
+    constexpr int S = 8;
+    constexpr int W = EXT ? 12 : 6;
+    constexpr int ROW_W = W + 2;
+    constexpr int NOUT = PassDims<W>::NOUT, OW = PassDims<W>::OW;
+    constexpr int NACC = (NOUT + 63) / 64;
+    constexpr bool HALVES = NOUT <= 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PK_LDS_BYTES];
+    SolveLds& L = *reinterpret_cast<SolveLds*>(smem);
+    BookLds& Bk = *reinterpret_cast<BookLds*>(smem + sizeof(SolveLds));
+    Xyz (*s_stage)[PK_STAGE] = reinterpret_cast<Xyz (*)[PK_STAGE]>(smem);
+    double (*s_rows)[64][ROW_W] = reinterpret_cast<double (*)[64][ROW_W]>(smem);
+    float4* s_rec = reinterpret_cast<float4*>(smem + PK_OFF_REC);
+    uint32_t (*s_pref)[64] = reinterpret_cast<uint32_t (*)[64]>(smem + PK_OFF_PREF);
+    uint32_t (*s_start)[64] = s_pref + PK_THREADS / 64;
+    PoseConsts& s_pose = *reinterpret_cast<PoseConsts*>(smem + PK_OFF_POSE);
+    double (*s_out)[2][SUMS_LEN] = reinterpret_cast<double (*)[2][SUMS_LEN]>(smem + PK_OFF_OUT);
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint32_t nwg = gridDim.x - 1u, bid = blockIdx.x;
+    const bool designated = bid == nwg;
+    KfDev* __restrict__ kf = a.kf;
+    if (a.mode != 0 && kf->done) return;   // the update ended in an earlier launch
+    constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
+    long long* clk = (a.clk && !designated) ? a.clk + (size_t)bid * 16 : nullptr;
+#define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[8 + (i)] = wall_clock64(); } } while (0)
+    PK_STAMP(0, tid == 0);
+
+    // ---- 1. prologue ------------------------------------------------------------------------------------
+    if (a.mode == 1) {
+        solve_core<W>(L, kf, a.recs_in, a.nrec, a.sp, &s_pose, tid);   // (ends with a barrier)
+        if (designated) {
+            bookkeeping<W>(L, Bk, kf, a.io, a.sums_out, a.sp, &s_pose, tid);
+            return;
+        }
+        const int ended = L.last;
+        __syncthreads();      // (region 0 is about to become the candidate stage)
+        if (ended) return;    // that solve ended the update: nothing to search
+    } else {
+        if (tid < NW32)
+            reinterpret_cast<uint32_t*>(&s_pose)[tid] =
+                a.mode == 0 ? reinterpret_cast<const uint32_t*>(&begin.pose)[tid] : reinterpret_cast<const uint32_t*>(&kf->pose)[tid];
+        if (designated) {
+            // the update starts here: install the state (mode 0; mode 2: a begin kernel did) and prepare the first solve
+            for (int i = tid; i < NS * NS; i += PK_THREADS) {
+                double p;
+                if (a.mode == 0) {
+                    p = begin.P[i];
+                    kf->P_prop[i] = p;
+                    kf->P_post[i] = p;
+                    a.io->P_post[i] = p;   // an update without a terminal pass returns the propagated covariance
+                } else {
+                    p = kf->P_prop[i];
+                }
+                Bk.B[i / NS][i % NS] = p;
+            }
+            if (tid < NX) {
+                double v;
+                if (a.mode == 0) {
+                    v = begin.x[tid];
+                    kf->x[tid] = v;
+                    kf->x_prop[tid] = v;
+                    a.io->x[tid] = v;
+                } else {
+                    v = kf->x[tid];
+                }
+                L.x[tid] = v;
+                Bk.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
+            }
+            if (a.mode == 0) {
+                if (tid >= 128 && tid < 128 + NW32) reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(&begin.pose)[tid - 128];
+                if (tid == 0) {
+                    a.io->passes = 0;
+                    kf->t = 0;
+                    kf->iter = -1;  // upstream loop starts at i = -1
+                    kf->done = 0;
+                    kf->passes = 0;
+                }
+            }
+            prepare_next<W>(L, Bk, kf, L.x, a.sp.R_inv, tid);   // (its first barrier publishes L.x / Bk.B / Bk.xp)
+            return;
+        }
+        __syncthreads();
+    }
+    // (from here on region 0 is the candidate stage / the staged rows; s_pose stays)
+    PK_STAMP(1, tid == 0);
+
+    // ---- 2. / 3. search and fit rounds ------------------------------------------------------------------
+    const int gq = tid / S, gl = tid % S;           // lane group (0..63) and lane in group
+    const int half = tid >> 8;                      // 256-thread half: one 32-point tile per step
+    const int pidx = gq;                            // position of the point among the 64 of a step (= half * 32 + group in half)
+    // fit wavefronts: one per step.  Two workgroups share a CU; fit_sel = 1 moves the second one's fit wavefronts
+    // to the other two SIMDs (wave w sits on SIMD w % 4; co-resident workgroups are observed to differ in bit 8 of their
+    // index — a speed heuristic only)
+    const int fw0 = (a.fit_sel == 1 && ((bid >> 8) & 1u)) ? 2 : 0;
+    const int my_step = wave - fw0;                 // 0 / 1 for the two fit wavefronts
+    const bool fitter = my_step >= 0 && my_step < PK_STEPS;
+    int oa[NACC], ob[NACC];
+    double acc[NACC];
+    const int olane = HALVES ? (lane & 31) : lane;       // output owned by this lane
+    const int prow0 = HALVES ? (lane >> 5) * 32 : 0;     // first row of its share
+#pragma unroll
+    for (int c = 0; c < NACC; ++c) {
+        int orec_unused = 0;
+        oa[c] = ob[c] = 0;
+        acc[c] = 0.0;
+        if (olane + c * 64 < NOUT) out_pair<W>(olane + c * 64, oa[c], ob[c], orec_unused);
+    }
+    for (int t = tid; t < PK_STEPS * 2 * SUMS_LEN; t += PK_THREADS) (&s_out[0][0][0])[t] = 0.0;
+    const DebugOut nodbg{};
+    for (int round = 0; round < a.rounds; ++round) {
+#pragma unroll 1
+        for (int step = 0; step < PK_STEPS; ++step) {
+            const uint32_t vbi = (uint32_t)((round * PK_STEPS + step) * 2 + half) * nwg + bid;   // strided: every workgroup gets far and near tiles
+            const bool tile_ok = vbi < a.n_tiles32;
+            float4* rec = s_rec + (size_t)step * QREC_SLOTS * 64;
+            if (!tile_ok) {   // (whole 256-thread half: uniform per wavefront)
+                if (gl == 7) rec[7 * 64 + pidx] = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
+                continue;
+            }
+            const uint32_t tile = a.tile_order ? a.tile_order[vbi] : vbi;
+            const uint32_t q = tile * 32u + (uint32_t)(gq & 31);
+            const bool live = q < a.n;
+            kkey k[KNN];
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) k[j] = none_key();
+            uint32_t bstart = 0;
+            int src = -1;
+            const float4 sp = a.scan[live ? q : a.n - 1];
+            float qx, qy, qz;
+            rt_apply(s_pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
+            knn_search<S, false>(a.map, kf, qx, qy, qz, gl, k, bstart, src, nullptr, false, live, s_stage[gq], a.mp.max_dist_plane_sq,
+                                 s_pref[wave], s_start[wave]);
+            int found = 0;
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) found += key_real(k[j]) ? 1 : 0;
+            {
+                const int slot = gl;
+                float4 v;
+                if (slot < KNN) {
+                    kkey kk = k[0];
+#pragma unroll
+                    for (int j = 1; j < KNN; ++j) kk = (slot == j) ? k[j] : kk;
+                    v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+                    if (live && key_real(kk)) {
+                        const uint32_t pos = key_lo(kk);
+                        if (src == 0 && pos < (uint32_t)PK_STAGE) {
+                            const Xyz w = s_stage[gq][pos];   // still in LDS (same wavefront wrote it)
+                            v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
+                        } else if (src >= 0) {
+                            const Xyz w = reinterpret_cast<const Xyz*>(a.map.bxyz[src])[(size_t)bstart + pos];
+                            v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
+                        } else {
+                            v = a.map.orig[pos];
+                            v.w = __uint_as_float(pos);
+                        }
+                    }
+                } else if (slot == 5) {
+                    v = make_float4(qx, qy, qz, sp.w);
+                } else if (slot == 6) {
+                    v = make_float4(__uint_as_float(key_hi(k[0])), __uint_as_float(key_hi(k[1])), __uint_as_float(key_hi(k[2])),
+                                    __uint_as_float(key_hi(k[3])));
+                } else {
+                    v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(live ? found : -1), 0.f, 0.f);
+                }
+                rec[slot * 64 + pidx] = v;
+                if (a.qrec && live) a.qrec[(size_t)slot * a.qstride + q] = v;
+            }
+            if (round == 0) PK_STAMP(2 + step, tid == 0);
+        }
+        __syncthreads();   // the records of both steps are complete; nobody reads the candidate stage any more
+        if (round == 0) PK_STAMP(4, tid == 0);
+        if (fitter) {
+            const float4* rec = s_rec + (size_t)my_step * QREC_SLOTS * 64;
+            float4 r[QREC_SLOTS];
+#pragma unroll
+            for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = rec[sl * 64 + lane];
+            float P[KNN][3];
+            uint32_t nidx[KNN], dbits[KNN];
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) { P[j][0] = r[j].x; P[j][1] = r[j].y; P[j][2] = r[j].z; nidx[j] = __float_as_uint(r[j].w); }
+            dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
+            dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
+            const int found = __float_as_int(r[7].y);
+            double* srow = &s_rows[my_step][lane][0];
+            fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
+            wave_lds_fence();   // this wavefront's 64 rows are staged
+            if (round == 0) PK_STAMP(5, my_step == 0 && lane == 0);
+            const double (*rows)[ROW_W] = s_rows[my_step];
+#pragma unroll
+            for (int c = 0; c < NACC; ++c) {
+                if (olane + c * 64 < NOUT) {
+                    double sacc = acc[c];
+#pragma unroll 8
+                    for (int p = 0; p < (HALVES ? 32 : 64); ++p) sacc += rows[prow0 + p][oa[c]] * rows[prow0 + p][ob[c]];
+                    acc[c] = sacc;
+                }
+            }
+        }
+        if (round == 0) PK_STAMP(6, fitter && my_step == 0 && lane == 0);
+        __syncthreads();   // the next round reuses the stage (under the rows) and the records
+    }
+    // ---- 4. the workgroup partial, compact layout, fixed order
+    if (fitter) {
+#pragma unroll
+        for (int c = 0; c < NACC; ++c)
+            if (olane + c * 64 < NOUT) s_out[my_step][HALVES ? (lane >> 5) : 0][olane + c * 64] = acc[c];
+    }
+    __syncthreads();
+    if (tid < OW) {
+        double s = 0.0;
+        if (tid < NOUT) s = (s_out[0][0][tid] + s_out[0][1][tid]) + (s_out[1][0][tid] + s_out[1][1][tid]);
+        a.part_out[(size_t)bid * OW + tid] = s;
+    }
+    PK_STAMP(7, tid == 0);
+#undef PK_STAMP
+}
+
+// search workgroups and rounds of pass_kernel for an n-point scan (32-point tiles, 4 per workgroup and round)
+void pass_grid_size(uint32_t n, int max_wg, int* nwg, int* rounds) {
+    const uint32_t nt = (n + 31u) / 32u;
+    uint32_t g = (nt + 3u) / 4u;
+    if (g > (uint32_t)max_wg) g = (uint32_t)max_wg;
+    if (g < 1) g = 1;
+    *nwg = (int)g;
+    *rounds = (int)((nt + 4u * g - 1u) / (4u * g));
+}
+
+int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin) {
+    PassArgs a;
+    a.map = *pl.map;
+    a.scan = pl.scan;
+    a.tile_order = pl.tile_order;
+    a.n = pl.n;
+    a.n_tiles32 = (pl.n + 31u) / 32u;
+    a.kf = pl.kf;
+    a.io = pl.io;
+    a.recs_in = pl.recs_in;
+    a.part_out = pl.part_out;
+    a.sums_out = pl.sums_out;
+    a.qrec = pl.qrec;
+    a.clk = pl.clk;
+    a.qstride = pl.qstride;
+    a.nrec = pl.nrec;
+    a.mode = pl.mode;
+    a.rounds = pl.rounds;
+    a.fit_sel = pl.fit_sel;
+    a.mp = pl.mp;
+    a.sp = pl.sp;
+    static const BeginArg none{};
+    const BeginArg& b = begin ? *begin : none;
+    const dim3 grid((unsigned)pl.nwg + 1u), block(PK_THREADS);
+    if (pl.mp.estimate_extrinsics) hipLaunchKernelGGL((pass_kernel<true>), grid, block, 0, stream, a, b);
+    else hipLaunchKernelGGL((pass_kernel<false>), grid, block, 0, stream, a, b);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }

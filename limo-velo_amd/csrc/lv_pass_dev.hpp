@@ -1,0 +1,357 @@
+// lv_pass_dev.hpp — the filter algebra of one pass as device functions over caller-provided LDS, for
+// pass_kernel (lv_match.hip): ONE launch per measurement pass instead of search / fit / solve.
+//
+// pass_kernel(p) = [prologue: the solve of pass p-1, computed REDUNDANTLY by every workgroup from the
+// workgroup partials that pass_kernel(p-1) left in memory] -> [search + plane fits of pass p] -> [one
+// partial per workgroup].  The redundant solve removes two dependent kernel boundaries per pass (fit ->
+// solve -> search) and the single-workgroup solve kernel's launch ramp; it costs every workgroup the
+// solve's ~5 us latency chain once, at a time when the GPU would otherwise idle behind that chain anyway.
+// All workgroups execute the same instructions on the same inputs, so they derive bit-identical states and
+// pass constants (no broadcast, no inter-workgroup wait).  One extra ("designated") workgroup keeps the
+// books: state / trace / sums log in KfDev, the record-independent half of the NEXT solve (prepare), and on
+// the pass that ends the update the posterior covariance and the host mailbox.
+//
+// Same algebra as solve_kernel / solve_prep (lv_solve.hip, lv_solve_dev.hpp):
+// esekf::update_iterated_dyn_share_modified [IKFoM absent from the reference mount; UPSTREAM-RECALL of
+// hku-mars/IKFoM esekfom.hpp; call site reference src/Modules/Localizator.cpp:132].
+#pragma once
+
+#include "lv_host.hpp"
+#include "lv_solve_dev.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace lv {
+
+// reduction outputs: output t owns the product column pair (a, b) of a staged Jacobian row and its slot
+// `rec` in the 96-double record ([0..77] upper triangle of the 12x12 H^T H, [78..89] H^T h, 90 n_valid,
+// 91 sum h^2).  W = number of Jacobian columns that can be non-zero (6 without extrinsics, else 12).
+template <int W>
+__device__ __forceinline__ void out_pair(int t, int& a, int& b, int& rec) {
+    constexpr int NTRI = W * (W + 1) / 2;
+    if (t < NTRI) {
+        int i = 0, rem = t;
+        while (rem >= W - i) { rem -= W - i; ++i; }
+        a = i;
+        b = i + rem;
+        rec = a * 12 - a * (a - 1) / 2 + (b - a);
+    } else if (t < NTRI + W) {
+        a = t - NTRI;
+        b = W;          // h
+        rec = 78 + a;
+    } else if (t == NTRI + W) {
+        a = W + 1;      // valid * valid
+        b = W + 1;
+        rec = 90;
+    } else {
+        a = W;          // h * h
+        b = W;
+        rec = 91;
+    }
+}
+
+// Workgroup partials of pass_kernel are COMPACT: OW doubles per workgroup, entry t = output t of out_pair<W>
+// (t < NOUT), so that the prologue's fold reads whole cache lines of live data.
+template <int NW> struct PassDims {
+    static constexpr int NOUT = NW * (NW + 1) / 2 + NW + 2;   // 29 / 92
+    static constexpr int OW = NW == 6 ? 32 : 96;              // record stride in doubles
+};
+
+constexpr int PK_THREADS = 512;
+
+// LDS of the prologue solve (every workgroup)
+struct SolveLds {
+    double part[PK_THREADS];   // [parts][OW]
+    double rec[SUMS_LEN];      // the folded record in the 96-double layout of the C-ABI (lv_sums)
+    double HTH[12][12];
+    double HTh[12];
+    double G[12][12];          // A1 = (P_/R)_ww^-1   (prepare)
+    double A[NS][12];          // (P_/R)[:, 0:NW]
+    double W[2][12][13];
+    double T[12][12];
+    double X[NS][12];
+    double v[12];
+    double dxnew[NS];
+    double dxo[NS];
+    double x[NX];
+    double Rot[4][9];
+    float ptmp[8];
+    int last, conv, n_valid0, t_new;
+    int kf_t, kf_iter, pass, pad_;
+};
+// LDS of the designated workgroup's extra work (prepare / terminal pass); follows SolveLds
+struct BookLds {
+    double P[NS][LD], A[NS][LD], B[NS][LD], J[NS][LD];
+    double Kx[NS][12];
+    double xp[NX], dx[NS];
+    uint32_t chk;
+};
+
+// The solve of one pass from `nrec` compact workgroup partials: x <- x [+] dx_, convergence bookkeeping, the f32
+// constants of the next pass.  T = PK_THREADS threads, all must call.  On return (after its final barrier):
+// L.x (new state), L.dxo, L.X, L.HTH, L.rec, L.last, L.t_new, L.n_valid0, *pose.
+template <int NW>
+__device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, const double* __restrict__ recs, int nrec,
+                                  const SolveParams& prm, PoseConsts* pose, int tid) {
+    constexpr int T = PK_THREADS;
+    constexpr int OW = PassDims<NW>::OW, NOUT = PassDims<NW>::NOUT;
+    constexpr int PARTS = T / OW;                 // 16 / 5
+    constexpr int DEPTH = NW == 6 ? 32 : 24;      // records per thread issued in one memory round trip
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fo = tid % OW, fpart = tid / OW;
+    // ---- every global read up front (one memory round trip)
+    double fv[DEPTH];
+    const bool folder = fpart < PARTS && fo < NOUT;
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+        const int r = fpart + PARTS * i;
+        fv[i] = (folder && r < nrec) ? recs[(size_t)r * OW + fo] : 0.0;
+    }
+    if (tid < NX) L.x[tid] = kf->x[tid];
+    for (int e = tid; e < NS * NW; e += T) L.A[e / NW][e % NW] = kf->prep_P[(e / NW) * NS + (e % NW)] * prm.R_inv;
+    if (tid >= 64 && tid < 64 + NS) L.dxnew[tid - 64] = kf->prep_dxnew[tid - 64];
+    if (tid >= 128 && tid < 128 + NW * NW) L.G[(tid - 128) / NW][(tid - 128) % NW] = kf->prep_A1[tid - 128];
+    if (tid < SUMS_LEN) L.rec[tid] = 0.0;
+    if (tid == 448) { L.kf_t = kf->t; L.kf_iter = kf->iter; L.pass = kf->passes; L.conv = 1; L.last = 0; L.n_valid0 = 0; }
+    // ---- fold, fixed order: thread (fo, fpart) sums records fpart, fpart + PARTS, ... (four interleaved running sums),
+    // the PARTS part sums are then added left to right
+    {
+        double a0 = fv[0], a1 = fv[1], a2 = fv[2], a3 = fv[3];
+#pragma unroll
+        for (int i = 4; i + 3 < DEPTH; i += 4) { a0 += fv[i]; a1 += fv[i + 1]; a2 += fv[i + 2]; a3 += fv[i + 3]; }
+        static_assert(DEPTH % 4 == 0, "fold assumes a multiple of four");
+        double s = (a0 + a1) + (a2 + a3);
+        for (int r = fpart + PARTS * DEPTH; folder && r < nrec; r += PARTS) s += recs[(size_t)r * OW + fo];   // (larger grids)
+        if (fpart < PARTS) L.part[fpart * OW + fo] = s;
+    }
+    __syncthreads();
+    if (tid < NOUT) {
+        double s = L.part[tid];
+#pragma unroll
+        for (int p = 1; p < PARTS; ++p) s += L.part[p * OW + tid];
+        int a, b, rec;
+        out_pair<NW>(tid, a, b, rec);
+        L.rec[rec] = s;
+        if (b < NW) { L.HTH[a][b] = s; L.HTH[b][a] = s; }
+        else if (b == NW && a < NW) L.HTh[a] = s;
+    }
+    __syncthreads();
+    const double n_valid = L.rec[90];
+    const int kf_t = L.kf_t, kf_iter = L.kf_iter;
+    if (n_valid == 0.0) {   // h_share_model: dyn_share.valid = false -> `continue`: the state does not move
+        if (tid == 0) {
+            L.n_valid0 = 1;
+            L.t_new = kf_t;
+            L.last = (kf_iter + 1 >= prm.maximum_iter) ? 1 : 0;
+        }
+        if (tid < NS) L.dxo[tid] = 0.0;
+    } else {
+        // X = P_inv[:, 0:NW]:  X_top = (Pr_ww^-1 + HTH_ww)^-1,  X_bot = Pr[NW:, 0:NW] Pr_ww^-1 X_top   (lv_solve.hip)
+        int cur = 0;
+        if (tid < NW * NW) {
+            const int i = tid / NW, j = tid % NW;
+            L.W[cur][i][j] = L.G[i][j] + L.HTH[i][j];
+        }
+        if (tid >= 64 && tid < 64 + NW) {   // v = HTh + HTH dx_new[:NW]
+            const int i = tid - 64;
+            double s = L.HTh[i];
+            for (int j = 0; j < NW; ++j) s += L.HTH[i][j] * L.dxnew[j];
+            L.v[i] = s;
+        }
+        __syncthreads();
+        gj_spd<NW>(L.W, cur, tid);               // L.W[cur] = X_top
+        if (tid < NW * NW) {                     // T = A1 X_top
+            const int i = tid / NW, c = tid % NW;
+            double s = 0.0;
+            for (int j = 0; j < NW; ++j) s += L.G[i][j] * L.W[cur][j][c];
+            L.T[i][c] = s;
+        }
+        __syncthreads();
+        if (tid < NS * NW) {                     // X = [X_top ; Pr[NW:, :NW] T]
+            const int i = tid / NW, c = tid % NW;
+            double v;
+            if (i < NW) {
+                v = L.W[cur][i][c];
+            } else {
+                double s = 0.0;
+                for (int j = 0; j < NW; ++j) s += L.A[i][j] * L.T[j][c];
+                v = s;
+            }
+            L.X[i][c] = v;
+        }
+        __syncthreads();
+        if (tid < NS) {  // dx_ = X v - dx_new
+            double s = 0.0;
+            for (int j = 0; j < NW; ++j) s += L.X[tid][j] * L.v[j];
+            const double d = s - L.dxnew[tid];
+            L.dxo[tid] = d;
+            if (fabs(d) > prm.limits[tid]) L.conv = 0;  // dyn_share.converge
+        }
+        __syncthreads();
+        // x_.boxplus(dx_)
+        if (wave < 3 && lane == 0) boxplus_block(wave, L.x, L.dxo);
+        if (wave == 3 && lane < 15) {
+            const int dof = lane < 3 ? lane : lane + 6;
+            L.x[vect_state_index(dof)] += L.dxo[dof];
+        }
+        if (tid == 256) {
+            int t = kf_t;
+            if (L.conv) t++;
+            L.t_new = t;
+            L.last = (t > 1 || kf_iter == prm.maximum_iter - 1) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // the constants of the coming pass: four rotation matrices, one lane each, then the composed transforms spread over
+    // one wavefront (same operations, same order as compute_pose_consts => same bits)
+    if (tid >= 320 && tid < 324) {
+        const int w = tid - 320;               // 0: rot, 1: offset_R_L_I, 2: conj(rot), 3: conj(offset_R_L_I)
+        const int q = (w & 1) ? 7 : 3;
+        const double sg = (w & 2) ? -1.0 : 1.0;
+        const double qq[4] = {sg * L.x[q], sg * L.x[q + 1], sg * L.x[q + 2], L.x[q + 3]};
+        quat_to_rot(qq, &L.Rot[w][0]);
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < 128) pose_consts_stage_a(tid - 64, L.x, L.Rot, pose, L.ptmp);
+    __syncthreads();
+    if (tid >= 64 && tid < 128) pose_consts_stage_b(tid - 64, L.Rot, pose, L.ptmp);
+    __syncthreads();
+}
+
+// The record-independent half of the NEXT solve (solve_prep of lv_solve_dev.hpp over caller-provided LDS): dx = x [-] x_prop
+// with its projection J, dx_new = J dx, P_ = J P_prop J^T and A1 = (P_/R)_ww^-1 -> kf->prep_*.  x: the state the coming
+// pass is evaluated at (LDS).  The caller's threads have stored the propagated covariance in Bk.B and the propagated
+// state in Bk.xp (no barrier needed in between).
+template <int NW>
+__device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev* __restrict__ kf, const double* x, double R_inv, int tid) {
+    constexpr int T = PK_THREADS;
+    const int wave = tid >> 6, lane = tid & 63;
+    set_identity<T>(Bk.J, tid);
+    __syncthreads();
+    if (wave < 3 && lane == 0) manifold_block(wave, 0, x, Bk.xp, nullptr, Bk.dx, Bk.J);
+    if (wave == 3 && lane < 15) {
+        const int dof = lane < 3 ? lane : lane + 6;  // 0..2, 9..20
+        const int si = vect_state_index(dof);
+        Bk.dx[dof] = x[si] - Bk.xp[si];
+    }
+    __syncthreads();
+    if (tid < NS) {  // dx_new = J dx (identity outside the blocks)
+        double s = 0.0;
+        const int b = (tid >= 3 && tid < 6) ? 3 : (tid >= 6 && tid < 9) ? 6 : (tid >= 21) ? 21 : -1;
+        if (b < 0) s = Bk.dx[tid];
+        else if (b == 21) s = Bk.J[tid][21] * Bk.dx[21] + Bk.J[tid][22] * Bk.dx[22];
+        else s = dot3d(Bk.J[tid][b], Bk.dx[b], Bk.J[tid][b + 1], Bk.dx[b + 1], Bk.J[tid][b + 2], Bk.dx[b + 2]);
+        kf->prep_dxnew[tid] = s;
+    }
+    congruence<T>(Bk.P, Bk.J, Bk.B, tid);  // P_ = J P_prop J^T
+    __syncthreads();
+    for (int e = tid; e < NS * NS; e += T) kf->prep_P[e] = Bk.P[e / NS][e % NS];
+    if (tid < NW * NW) L.W[0][tid / NW][tid % NW] = Bk.P[tid / NW][tid % NW] * R_inv;
+    __syncthreads();
+    int cur = 0;
+    gj_spd<NW>(L.W, cur, tid);
+    if (tid < NW * NW) kf->prep_A1[tid] = L.W[cur][tid / NW][tid % NW];
+}
+
+#define LV_IO_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+
+// The designated workgroup after solve_core: the books of the pass just solved; on the pass that ends the update the
+// posterior covariance and the host mailbox (as solve_kernel's terminal part), otherwise prepare_next.
+template <int NW>
+__device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__ kf, KfHostIO* io, double* __restrict__ sums_out,
+                                   const SolveParams& prm, const PoseConsts* pose, int tid) {
+    constexpr int T = PK_THREADS;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int pass = L.pass, last = L.last, kf_iter = L.kf_iter;
+    const int kf_fallback = kf->fallback_queries;
+    if (tid < SUMS_LEN) {
+        if (sums_out) sums_out[tid] = L.rec[tid];
+        if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = L.rec[tid];
+    }
+    if (tid < NX) kf->x[tid] = L.x[tid];
+    if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
+        const int e = tid - 64;
+        kf->trace[pass * 49 + e] = e < NS ? L.dxo[e] : L.x[e - NS];
+    }
+    {
+        constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
+        if (tid >= 128 && tid < 128 + NW32) reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(pose)[tid - 128];
+    }
+    if (tid == 0) {
+        kf->t = L.t_new;
+        kf->passes = pass + 1;
+        kf->iter = kf_iter + 1;
+        if (last) {
+            kf->done = 1;
+            LV_IO_STORE(&io->passes, pass + 1);
+            LV_IO_STORE(&io->fallback_queries, kf_fallback);
+        }
+    }
+    if (!last) {
+        for (int e = tid; e < NS * NS; e += T) Bk.B[e / NS][e % NS] = kf->P_prop[e];
+        if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
+        prepare_next<NW>(L, Bk, kf, L.x, prm.R_inv, tid);
+        return;
+    }
+    if (tid < NX) LV_IO_STORE(&io->x[tid], L.x[tid]);
+    if (L.n_valid0) {
+        // the update ends on a pass without matches: the mailbox keeps the covariance the install stored (propagated);
+        // no checksum on this rare path: the host synchronises the stream
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(&io->seqcheck, ((unsigned long long)MAILBOX_UNCHECKED << 32) | (unsigned long long)(uint32_t)prm.seq,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // terminal pass: L_ = J2 P_ J2^T, K_x rows projected, P_ <- P_ J2^T, P = L_ - K_x[:, :NW] P_[0:NW, :]
+    for (int e = tid; e < NS * NS; e += T) Bk.P[e / NS][e % NS] = kf->prep_P[e];
+    if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
+    if (tid == 0) Bk.chk = 0u;
+    set_identity<T>(Bk.J, tid);
+    __syncthreads();
+    if (wave < 3 && lane == 0) manifold_block(wave, 1, L.x, Bk.xp, L.dxo, nullptr, Bk.J);
+    __syncthreads();
+    congruence<T>(Bk.B, Bk.J, Bk.P, tid);  // B = L_ = J2 P_ J2^T
+    mm<T>(Bk.A, Bk.P, Bk.J, true, tid);    // A = P_ J2^T
+    if (tid < NS * NW) {                    // K_x[:, :NW] = X HTH (columns >= NW are zero)
+        const int i = tid / NW, c = tid % NW;
+        double t = 0.0;
+        for (int j = 0; j < NW; ++j) t += L.X[i][j] * L.HTH[j][c];
+        Bk.Kx[i][c] = t;
+    }
+    __syncthreads();
+    if (tid < NS * NW) {                    // K_x <- J2 K_x (rows)  -> L.A (free by now)
+        const int i = tid / NW, c = tid % NW;
+        double s = 0;
+        for (int r = 0; r < NS; ++r) s += Bk.J[i][r] * Bk.Kx[r][c];
+        L.A[i][c] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < NS * NS; e += T) {
+        const int i = e / NS, j = e % NS;
+        double s = 0;
+        for (int c = 0; c < NW; ++c) s += L.A[i][c] * Bk.A[c][j];
+        const double pv = Bk.B[i][j] - s;
+        kf->P_post[e] = pv;
+        LV_IO_STORE(&io->P_post[e], pv);
+        atomicXor(&Bk.chk, mailbox_mix(pv, (uint32_t)e));
+    }
+    if (tid < NX) atomicXor(&Bk.chk, mailbox_mix(L.x[tid], 1000u + (uint32_t)tid));
+    if (tid == 0) atomicXor(&Bk.chk, mailbox_mix((double)(pass + 1), 2000u));
+    // every mailbox store is a system-scope write-through store: once a lane's stores have retired they are visible to
+    // the host; the host verifies the checksum (lv_update_end)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t chk = Bk.chk;
+        if (chk == MAILBOX_UNCHECKED) chk = 0u;
+        __hip_atomic_store(&io->seqcheck, ((unsigned long long)chk << 32) | (unsigned long long)(uint32_t)prm.seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace lv
+
+// back to the build default for the includer's own code (the f32 path is bit-exact against FMA-free arithmetic)
+#pragma clang fp contract(off)

@@ -162,7 +162,7 @@ __device__ inline void pose_consts_stage_b(int lane, const double (*rot)[9], Pos
 // on different SIMDs.  part 0: rot (dof 3), 1: offset_R_L_I (dof 6), 2: grav (dof 21).
 // mode 0: seg = x [-] x_prop for this block (written to dx), then the projection block from seg
 // mode 1: projection block from the given tangent `seg_in`
-__device__ inline void manifold_block(int part, int mode, const double* x, const double* xp, const double* seg_in, double* dx,
+__device__ __forceinline__ void manifold_block(int part, int mode, const double* x, const double* xp, const double* seg_in, double* dx,
                                       double (*J)[LD]) {
     if (part < 2) {
         const int idx = part == 0 ? 3 : 6, q = part == 0 ? 3 : 7;

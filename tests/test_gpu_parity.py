@@ -438,7 +438,9 @@ def test_timed_build_is_pinned_per_pass(capi, oracle, lv, m, n):
         with capi.Context(capi.default_params(MAX_NUM_ITERS=k)) as ctx:
             ctx.map_build(sc["map_xyz"])
             ctx.scan_set(sc["scan_xyz"])
+            ctx.set_record_dump(True)   # pass_kernel keeps its records in LDS: the same kernel also stores them for this check
             xk, _, pk, trk, _ = ctx.update(sc["x_init"], sc["P0"])
+            assert ctx.last_update_fused()
             assert pk == k + 1
             if k:
                 assert np.array_equal(trk[k - 1][23:49], states[k])   # deterministic: same state before pass k
