@@ -313,8 +313,10 @@ int lv_set_record_dump(lv_ctx* ctx, int enabled);
 int lv_last_update_fused(lv_ctx* ctx);
 /* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);
-/* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): per search workgroup of the last
- * pass_kernel launch, 8 shader-clock stamps followed by 8 wall-clock stamps (100 MHz) at its phase boundaries. */
+/* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): for every launch of the last update
+ * (MAX_NUM_ITERS + 2 of them) and every workgroup slot (capacity_wg >= CUs + 1 of them per launch; slot *n_wg is the
+ * launch's designated workgroup), 16 shader-clock stamps followed by 16 wall-clock stamps (100 MHz) at its phase
+ * boundaries: out holds (MAX_NUM_ITERS + 2) x capacity_wg... see scripts/pass_clocks.py for the layout. */
 int lv_get_pass_clocks(lv_ctx* ctx, long long* out, int capacity_wg, int* n_wg);
 /* Mapper::match outputs: valid N (Match::is_chosen), p_world N x 3, abcd N x 4 (Normal A,B,C,D),
  * dist N (Match::distance).  Any pointer may be NULL. */

@@ -440,11 +440,14 @@ class Context:
     def set_fused_pass(self, on=True):
         self._check(self.lib.lv_set_fused_pass(self.h, int(on)))
 
-    def pass_clocks(self, capacity=1024):
-        buf = np.zeros((capacity, 16), np.int64)
+    def pass_clocks(self, slots=257):
+        """[launch][workgroup slot][32] stamps of the last update's pass_kernel launches, and the number of search
+        workgroups n (slot n - 1 of a launch = its bookkeeping workgroup, stamp 10 = books done).  slots = CUs + 1."""
+        nl = self.params.MAX_NUM_ITERS + 2
+        buf = np.zeros((nl, slots, 32), np.int64)
         n = C.c_int(0)
-        self._check(self.lib.lv_get_pass_clocks(self.h, buf.ctypes.data_as(C.c_void_p), capacity, C.byref(n)))
-        return buf[: n.value]
+        self._check(self.lib.lv_get_pass_clocks(self.h, buf.ctypes.data_as(C.c_void_p), slots, C.byref(n)))
+        return buf, n.value
 
     def last_update_fused(self) -> bool:
         return bool(self.lib.lv_last_update_fused(self.h))

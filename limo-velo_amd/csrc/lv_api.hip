@@ -63,9 +63,8 @@ struct lv_ctx {
     uint32_t qstride = 0;
     // one launch per pass (pass_kernel, lv_pass_dev.hpp): compact workgroup partials, ping-pong by pass parity
     double* d_cpart[2] = {nullptr, nullptr};
-    int pass_max_wg = 512;         // search workgroups of pass_kernel: all resident at once (2 per CU)
+    int pass_max_wg = 256;         // search workgroups of pass_kernel: all resident at once (one 1024-thread workgroup per CU)
     bool fused_pass = true;        // LV_FUSED_PASS=0: the three-kernel pass (search / fit / solve) also where pass_kernel applies
-    int fit_sel = 1;               // LV_FIT_SEL: which wavefronts of a workgroup fit planes (speed heuristic)
     bool record_dump = false;      // lv_set_record_dump: pass_kernel also writes its hand-over records to d_qrec (lv_fetch_neighbors)
     bool last_update_fused = false;
     long long* d_pclk = nullptr;   // LV_PASS_CLK=1: phase stamps of pass_kernel's workgroups (lv_get_pass_clocks)
@@ -302,7 +301,6 @@ int update_fused(lv_ctx* c) {
     pl.kf = c->d_kf;
     pl.io = c->d_io;
     pl.sums_out = c->d_sums;
-    pl.fit_sel = c->fit_sel;
     pl.mp.R_inv = 1.0 / c->prm.LiDAR_noise;
     pl.mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
     pl.mp.planes_threshold = c->prm.PLANES_THRESHOLD;
@@ -318,7 +316,6 @@ int update_fused(lv_ctx* c) {
     int nwg = 0, rounds = 0;
     pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &rounds);
     pl.qrec = c->record_dump ? c->d_qrec : nullptr;
-    pl.clk = c->d_pclk;
     c->pclk_wg = nwg;
     pl.qstride = c->qstride;
     c->qrec_valid = c->record_dump;
@@ -331,6 +328,8 @@ int update_fused(lv_ctx* c) {
         pl.nrec = nwg;
         pl.nwg = closing ? 0 : nwg;
         pl.rounds = closing ? 0 : rounds;
+        pl.launch = i;
+        pl.clk = c->d_pclk ? c->d_pclk + (size_t)i * (c->pass_max_wg + 1) * pass_clock_words() : nullptr;
         if (c->profiling && !closing) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
         int rc = launch_pass(c->stream, pl, (i == 0 && c->begin_pending) ? &c->h_begin : nullptr);
         c->begin_pending = false;
@@ -404,15 +403,15 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_TILE_LPT")) c->tile_lpt = atoi(e) != 0;
     if (const char* e = getenv("LV_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
-    if (const char* e = getenv("LV_FIT_SEL")) c->fit_sel = atoi(e);
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_PASS_CLK")) {
         if (atoi(e) != 0) {
-            LV_HIP(hipMalloc(&c->d_pclk, (size_t)(c->pass_max_wg + 1) * 16 * sizeof(long long)));
-            LV_HIP(hipMemset(c->d_pclk, 0, (size_t)(c->pass_max_wg + 1) * 16 * sizeof(long long)));
+            const size_t words = (size_t)(MAX_PASSES + 1) * (c->pass_max_wg + 1) * pass_clock_words();   // per launch of an update
+            LV_HIP(hipMalloc(&c->d_pclk, words * sizeof(long long)));
+            LV_HIP(hipMemset(c->d_pclk, 0, words * sizeof(long long)));
         }
     }
-    c->pass_max_wg = prop.multiProcessorCount * 2;
+    c->pass_max_wg = prop.multiProcessorCount;
     if (const char* e = getenv("LV_PASS_WG")) c->pass_max_wg = atoi(e) > 0 ? atoi(e) : c->pass_max_wg;
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
@@ -872,10 +871,13 @@ int lv_set_fused_pass(lv_ctx* c, int enabled) {
 int lv_get_pass_clocks(lv_ctx* c, long long* out, int capacity_wg, int* n_wg) {
     LV_CHECK_CTX(c);
     if (!c->d_pclk) { set_error("no pass clocks: create the context with LV_PASS_CLK=1 in the environment"); return LV_ESTATE; }
-    const int nb = c->pclk_wg < capacity_wg ? c->pclk_wg : capacity_wg;
+    // layout: [launch 0 .. MAX_NUM_ITERS + 1][pass_max_wg + 1 workgroup slots][pass_clock_words()]; slot n_wg - 1 of a launch is
+    // its bookkeeping workgroup (stamp 10 = books done); the closing launch has one workgroup (slot 0)
+    const int slots = c->pass_max_wg + 1;
+    if (capacity_wg < slots) { set_error("lv_get_pass_clocks: capacity %d < %d workgroup slots per launch", capacity_wg, slots); return LV_EINVAL; }
     LV_HIP(hipStreamSynchronize(c->stream));
-    LV_HIP(hipMemcpy(out, c->d_pclk, (size_t)nb * 16 * sizeof(long long), hipMemcpyDeviceToHost));
-    if (n_wg) *n_wg = nb;
+    LV_HIP(hipMemcpy(out, c->d_pclk, (size_t)(c->prm.MAX_NUM_ITERS + 2) * slots * pass_clock_words() * sizeof(long long), hipMemcpyDeviceToHost));
+    if (n_wg) *n_wg = c->pclk_wg;
     return LV_OK;
 }
 

@@ -63,6 +63,16 @@ struct KfDev {
     double prep_A1[12 * 12];
     int level_hist[8];  // captured passes only: scan points decided at bucket level 0,1,2 / level-3 lists / every id / bounded stop
     double degen_eig[MAX_PASSES * 6];  // degeneracy_mode >= 1: eigenvalues of the pose block of H^T H, per pass
+    // pass_kernel (one launch per pass): what launch i hands to launch i + 1, double-buffered by launch parity — the
+    // bookkeeping workgroup of launch i writes ps[(i + 1) & 1] while workgroups of the same launch may still be reading
+    // ps[i & 1] (dispatch order and timing are not a contract)
+    struct PassState {
+        double x[NX];
+        double prep_dxnew[NS];
+        double prep_P[NS * NS];
+        double prep_A1[12 * 12];
+        int t, iter, passes, pad_;
+    } ps[2];
 };
 
 // What an update starts from, handed to the FIRST search launch of the update as kernel arguments (lv_update /

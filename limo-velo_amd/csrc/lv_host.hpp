@@ -198,11 +198,13 @@ struct PassLaunch {
     uint32_t qstride;
     int nrec;
     int mode;                     // 0: the update starts here (state in the BeginArg); 1: solve the previous pass first; 2: state already in kf
-    int rounds, fit_sel, nwg;     // nwg search workgroups (+ 1 designated); nwg = 0: closing launch
+    int rounds, launch, nwg;      // nwg workgroups (the last one keeps the books); nwg = 0: closing launch (one workgroup, no search);
+                                  // launch = index of the launch in the update
     MatchParams mp;
     SolveParams sp;
 };
 void pass_grid_size(uint32_t n, int max_wg, int* nwg, int* rounds);
+int pass_clock_words();   // stamp words per workgroup (PassLaunch::clk)
 int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin);
 // lv_predict.hip
 int launch_predict(hipStream_t stream, FilterDev* f, double dt, const double* Q, const double* acc, const double* gyro);

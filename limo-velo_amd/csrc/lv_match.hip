@@ -989,19 +989,21 @@ int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, 
 
 
 // ------------------------------------------------------------------------------------------------------
-// ONE launch per measurement pass (lv_pass_dev.hpp): every workgroup of 512 threads
+// ONE launch per measurement pass (lv_pass_dev.hpp): every workgroup of 1024 threads (one per CU)
 //   1. prologue: re-derives the state and the f32 constants of this pass — the solve of the PREVIOUS pass from the
 //      workgroup partials that launch left behind (mode 1), or takes them from the kernel arguments (mode 0: the update
 //      starts here) / from kf (mode 2: a begin kernel installed a device-resident state);
-//   2. per round searches 4 tiles of 32 scan points (two steps of its two 256-thread halves; S = 8 lanes per point,
+//   2. per round searches 8 tiles of 32 scan points (two steps of its four 256-thread units; S = 8 lanes per point,
 //      the same knn_search as search_kernel) and keeps the 128-byte hand-over records in LDS instead of HBM;
-//   3. two of its wavefronts (one per step, 64 points each, one lane per point) run the plane fits, rows and the
-//      contraction of fit_reduce_kernel on those records;
+//   3. four of its wavefronts (64 points each, one lane per point) run the plane fits, rows and the contraction of
+//      fit_reduce_kernel on those records;
 //   4. writes one compact partial (PassDims::OW doubles) for the next launch's prologue.
-// The grid is sized so that every workgroup is resident at once (<= 2 per CU): there are no residency rounds whose
+// The grid is sized so that every workgroup is resident at once (one per CU): there are no residency rounds whose
 // workgroups would each pay the prologue, and nothing in the kernel waits for another workgroup.
-// The last workgroup of the grid is the designated one (bookkeeping / prepare_next / terminal pass); a launch with a
-// grid of one workgroup is the closing launch of an update (the solve of its last pass, nothing to search).
+// The last workgroup of the grid (its tiles are the nearest ones = the lightest search share) also keeps the books
+// after its own search and fits (bookkeeping / prepare_next / terminal pass): that work hides behind the heavier
+// workgroups' searches.  A launch with rounds = 0 and one workgroup is the closing launch of an update (the solve of
+// its last pass, nothing to search).
 struct PassArgs {
     MapView map;
     const float4* scan;
@@ -1013,24 +1015,28 @@ struct PassArgs {
     double* part_out;             // compact partials of this launch
     double* sums_out;             // optional: the folded 96-double record of the previous pass
     float4* qrec;                 // optional (lv_set_record_dump): the hand-over records also go to memory (lv_fetch_neighbors)
-    long long* clk;               // optional (instrumentation): 8 shader-clock + 8 wall-clock stamps per workgroup
+    long long* clk;               // optional (instrumentation): 16 shader-clock + 16 wall-clock stamps per workgroup
     uint32_t qstride;
-    int nrec, mode, rounds, fit_sel;
+    int nrec, mode, rounds, launch;   // launch: index of this launch in the update (parity selects KfDev::ps)
     MatchParams mp;
     SolveParams sp;
 };
-constexpr int PK_GROUPS = PK_THREADS / 8;         // lane groups (= scan points in flight) per workgroup: 64
+constexpr int PK_UNITS = PK_THREADS / 256;        // 256-thread units: one 32-point tile each per step
+constexpr int PK_GROUPS = PK_THREADS / 8;         // lane groups (= scan points in flight) per workgroup: 128
 constexpr int PK_STAGE = 64;                      // candidates of a lane group's first level-0 chunk kept in LDS
-constexpr int PK_STEPS = 2;                       // search steps per round; one fit wavefront per step
-constexpr size_t PK_REGION0 = sizeof(Xyz) * PK_GROUPS * PK_STAGE;                       // 49152: stage | solve scratch | rows
-constexpr size_t PK_OFF_REC = PK_REGION0;                                             // float4 [steps][8 slots][64]
-constexpr size_t PK_OFF_PREF = PK_OFF_REC + sizeof(float4) * PK_STEPS * QREC_SLOTS * 64;
+constexpr int PK_STEPS = 2;                       // search steps per round
+constexpr int PK_FITW = PK_STEPS * PK_GROUPS / 64;   // fit wavefronts: one per 64 points of a round (4)
+constexpr int PK_CLK = 32;                        // stamp words per workgroup
+constexpr size_t PK_REGION0 = sizeof(Xyz) * PK_GROUPS * PK_STAGE;                     // 98304: stage | solve scratch | rows
+constexpr size_t PK_OFF_REC = PK_REGION0;                                             // float4 [steps][8 slots][128]
+constexpr size_t PK_OFF_PREF = PK_OFF_REC + sizeof(float4) * PK_STEPS * QREC_SLOTS * PK_GROUPS;
 constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS / 64) * 64;
 constexpr size_t PK_OFF_OUT = PK_OFF_POSE + ((sizeof(PoseConsts) + 15) / 16) * 16;
-constexpr size_t PK_LDS_BYTES = PK_OFF_OUT + sizeof(double) * PK_STEPS * 2 * SUMS_LEN;
+constexpr size_t PK_OFF_KEEP = PK_OFF_OUT + sizeof(double) * PK_FITW * 2 * SUMS_LEN;
+constexpr size_t PK_LDS_BYTES = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
 static_assert(sizeof(SolveLds) % 8 == 0 && sizeof(SolveLds) + sizeof(BookLds) <= PK_REGION0, "solve scratch must fit under the stage");
-static_assert(sizeof(double) * PK_STEPS * 64 * 14 <= PK_REGION0, "staged rows must fit under the stage");
-static_assert(PK_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(double) * PK_FITW * 64 * 14 <= PK_REGION0, "staged rows must fit under the stage");
+static_assert(PK_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 template <bool EXT>
 __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
@@ -1053,84 +1059,53 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const uint32_t nwg = gridDim.x - 1u, bid = blockIdx.x;
-    const bool designated = bid == nwg;
+    const uint32_t nwg = gridDim.x, bid = blockIdx.x;
+    const bool keeper = bid == nwg - 1u;   // the bookkeeping workgroup
     KfDev* __restrict__ kf = a.kf;
-    if (a.mode != 0 && kf->done) return;   // the update ended in an earlier launch
+    const KfDev::PassState* __restrict__ ps_in = &kf->ps[a.launch & 1];
+    KfDev::PassState* __restrict__ ps_out = &kf->ps[(a.launch + 1) & 1];
+    KeepLds& K = *reinterpret_cast<KeepLds*>(smem + PK_OFF_KEEP);
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
-    long long* clk = (a.clk && !designated) ? a.clk + (size_t)bid * 16 : nullptr;
-#define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[8 + (i)] = wall_clock64(); } } while (0)
+    long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
+#define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[16 + (i)] = wall_clock64(); } } while (0)
     PK_STAMP(0, tid == 0);
 
     // ---- 1. prologue ------------------------------------------------------------------------------------
+    bool searching = a.rounds > 0;
     if (a.mode == 1) {
-        solve_core<W>(L, kf, a.recs_in, a.nrec, a.sp, &s_pose, tid);   // (ends with a barrier)
-        if (designated) {
-            bookkeeping<W>(L, Bk, kf, a.io, a.sums_out, a.sp, &s_pose, tid);
-            return;
+        if (!solve_core<W>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk)) return;   // the update ended in an earlier launch
+        if (keeper) {   // region 0 is about to become the candidate stage: remember what the books need
+            for (int e = tid; e < SUMS_LEN; e += PK_THREADS) K.rec[e] = L.rec[e];
+            for (int e = tid; e < 144; e += PK_THREADS) K.HTH[e / 12][e % 12] = L.HTH[e / 12][e % 12];
+            for (int e = tid; e < NS * 12; e += PK_THREADS) K.X[e / 12][e % 12] = L.X[e / 12][e % 12];
+            if (tid < NS) K.dxo[tid] = L.dxo[tid];
+            if (tid < NX) K.x[tid] = L.x[tid];
+            if (tid == 0) { K.last = L.last; K.n_valid0 = L.n_valid0; K.t_new = L.t_new; K.kf_iter = L.kf_iter; K.pass = L.pass; }
         }
         const int ended = L.last;
-        __syncthreads();      // (region 0 is about to become the candidate stage)
-        if (ended) return;    // that solve ended the update: nothing to search
+        __syncthreads();
+        if (ended) {          // that solve ended the update: nothing to search
+            if (!keeper) return;
+            searching = false;
+        }
     } else {
+        if (a.mode == 2 && kf->done) return;
         if (tid < NW32)
             reinterpret_cast<uint32_t*>(&s_pose)[tid] =
                 a.mode == 0 ? reinterpret_cast<const uint32_t*>(&begin.pose)[tid] : reinterpret_cast<const uint32_t*>(&kf->pose)[tid];
-        if (designated) {
-            // the update starts here: install the state (mode 0; mode 2: a begin kernel did) and prepare the first solve
-            for (int i = tid; i < NS * NS; i += PK_THREADS) {
-                double p;
-                if (a.mode == 0) {
-                    p = begin.P[i];
-                    kf->P_prop[i] = p;
-                    kf->P_post[i] = p;
-                    a.io->P_post[i] = p;   // an update without a terminal pass returns the propagated covariance
-                } else {
-                    p = kf->P_prop[i];
-                }
-                Bk.B[i / NS][i % NS] = p;
-            }
-            if (tid < NX) {
-                double v;
-                if (a.mode == 0) {
-                    v = begin.x[tid];
-                    kf->x[tid] = v;
-                    kf->x_prop[tid] = v;
-                    a.io->x[tid] = v;
-                } else {
-                    v = kf->x[tid];
-                }
-                L.x[tid] = v;
-                Bk.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
-            }
-            if (a.mode == 0) {
-                if (tid >= 128 && tid < 128 + NW32) reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(&begin.pose)[tid - 128];
-                if (tid == 0) {
-                    a.io->passes = 0;
-                    kf->t = 0;
-                    kf->iter = -1;  // upstream loop starts at i = -1
-                    kf->done = 0;
-                    kf->passes = 0;
-                }
-            }
-            prepare_next<W>(L, Bk, kf, L.x, a.sp.R_inv, tid);   // (its first barrier publishes L.x / Bk.B / Bk.xp)
-            return;
-        }
         __syncthreads();
     }
-    // (from here on region 0 is the candidate stage / the staged rows; s_pose stays)
-    PK_STAMP(1, tid == 0);
+    // (from here on region 0 is the candidate stage / the staged rows; s_pose and K stay)
+    PK_STAMP(3, tid == 0);
 
+    if (searching) {
     // ---- 2. / 3. search and fit rounds ------------------------------------------------------------------
-    const int gq = tid / S, gl = tid % S;           // lane group (0..63) and lane in group
-    const int half = tid >> 8;                      // 256-thread half: one 32-point tile per step
-    const int pidx = gq;                            // position of the point among the 64 of a step (= half * 32 + group in half)
-    // fit wavefronts: one per step.  Two workgroups share a CU; fit_sel = 1 moves the second one's fit wavefronts
-    // to the other two SIMDs (wave w sits on SIMD w % 4; co-resident workgroups are observed to differ in bit 8 of their
-    // index — a speed heuristic only)
-    const int fw0 = (a.fit_sel == 1 && ((bid >> 8) & 1u)) ? 2 : 0;
-    const int my_step = wave - fw0;                 // 0 / 1 for the two fit wavefronts
-    const bool fitter = my_step >= 0 && my_step < PK_STEPS;
+    const int gq = tid / S, gl = tid % S;           // lane group (0..127) = position of its point among the 128 of a step; lane in group
+    const int unit = tid >> 8;                      // 256-thread unit: one 32-point tile per step
+    // fit wavefronts: wavefront f < PK_FITW takes the 64 points [fbase, fbase + 64) of step fstep (wavefronts 0..3 of a
+    // workgroup sit on the four SIMDs of the CU)
+    const bool fitter = wave < PK_FITW;
+    const int fstep = wave / (PK_GROUPS / 64), fbase = (wave % (PK_GROUPS / 64)) * 64;
     int oa[NACC], ob[NACC];
     double acc[NACC];
     const int olane = HALVES ? (lane & 31) : lane;       // output owned by this lane
@@ -1142,16 +1117,17 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         acc[c] = 0.0;
         if (olane + c * 64 < NOUT) out_pair<W>(olane + c * 64, oa[c], ob[c], orec_unused);
     }
-    for (int t = tid; t < PK_STEPS * 2 * SUMS_LEN; t += PK_THREADS) (&s_out[0][0][0])[t] = 0.0;
+    for (int t = tid; t < PK_FITW * 2 * SUMS_LEN; t += PK_THREADS) (&s_out[0][0][0])[t] = 0.0;
     const DebugOut nodbg{};
     for (int round = 0; round < a.rounds; ++round) {
 #pragma unroll 1
         for (int step = 0; step < PK_STEPS; ++step) {
-            const uint32_t vbi = (uint32_t)((round * PK_STEPS + step) * 2 + half) * nwg + bid;   // strided: every workgroup gets far and near tiles
+            // strided assignment: every workgroup gets far and near tiles (tile_order is farthest first)
+            const uint32_t vbi = (uint32_t)((round * PK_STEPS + step) * PK_UNITS + unit) * nwg + bid;
             const bool tile_ok = vbi < a.n_tiles32;
-            float4* rec = s_rec + (size_t)step * QREC_SLOTS * 64;
-            if (!tile_ok) {   // (whole 256-thread half: uniform per wavefront)
-                if (gl == 7) rec[7 * 64 + pidx] = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
+            float4* rec = s_rec + (size_t)step * QREC_SLOTS * PK_GROUPS;
+            if (!tile_ok) {   // (whole 256-thread unit: uniform per wavefront)
+                if (gl == 7) rec[7 * PK_GROUPS + gq] = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
                 continue;
             }
             const uint32_t tile = a.tile_order ? a.tile_order[vbi] : vbi;
@@ -1199,18 +1175,18 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
                 } else {
                     v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(live ? found : -1), 0.f, 0.f);
                 }
-                rec[slot * 64 + pidx] = v;
+                rec[slot * PK_GROUPS + gq] = v;
                 if (a.qrec && live) a.qrec[(size_t)slot * a.qstride + q] = v;
             }
-            if (round == 0) PK_STAMP(2 + step, tid == 0);
+            if (round == 0) PK_STAMP(4 + step, tid == 0);
         }
         __syncthreads();   // the records of both steps are complete; nobody reads the candidate stage any more
-        if (round == 0) PK_STAMP(4, tid == 0);
+        if (round == 0) PK_STAMP(6, tid == 0);
         if (fitter) {
-            const float4* rec = s_rec + (size_t)my_step * QREC_SLOTS * 64;
+            const float4* rec = s_rec + (size_t)fstep * QREC_SLOTS * PK_GROUPS + fbase;
             float4 r[QREC_SLOTS];
 #pragma unroll
-            for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = rec[sl * 64 + lane];
+            for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = rec[sl * PK_GROUPS + lane];
             float P[KNN][3];
             uint32_t nidx[KNN], dbits[KNN];
 #pragma unroll
@@ -1218,11 +1194,11 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
             dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
             const int found = __float_as_int(r[7].y);
-            double* srow = &s_rows[my_step][lane][0];
+            double* srow = &s_rows[wave][lane][0];
             fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
             wave_lds_fence();   // this wavefront's 64 rows are staged
-            if (round == 0) PK_STAMP(5, my_step == 0 && lane == 0);
-            const double (*rows)[ROW_W] = s_rows[my_step];
+            if (round == 0) PK_STAMP(7, tid == 0);
+            const double (*rows)[ROW_W] = s_rows[wave];
 #pragma unroll
             for (int c = 0; c < NACC; ++c) {
                 if (olane + c * 64 < NOUT) {
@@ -1233,34 +1209,99 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
                 }
             }
         }
-        if (round == 0) PK_STAMP(6, fitter && my_step == 0 && lane == 0);
+        if (round == 0) PK_STAMP(8, tid == 0);
         __syncthreads();   // the next round reuses the stage (under the rows) and the records
     }
     // ---- 4. the workgroup partial, compact layout, fixed order
     if (fitter) {
 #pragma unroll
         for (int c = 0; c < NACC; ++c)
-            if (olane + c * 64 < NOUT) s_out[my_step][HALVES ? (lane >> 5) : 0][olane + c * 64] = acc[c];
+            if (olane + c * 64 < NOUT) s_out[wave][HALVES ? (lane >> 5) : 0][olane + c * 64] = acc[c];
     }
     __syncthreads();
     if (tid < OW) {
         double s = 0.0;
-        if (tid < NOUT) s = (s_out[0][0][tid] + s_out[0][1][tid]) + (s_out[1][0][tid] + s_out[1][1][tid]);
+        if (tid < NOUT) {
+            s = s_out[0][0][tid] + s_out[0][1][tid];
+#pragma unroll
+            for (int f = 1; f < PK_FITW; ++f) s += s_out[f][0][tid] + s_out[f][1][tid];
+        }
         a.part_out[(size_t)bid * OW + tid] = s;
     }
-    PK_STAMP(7, tid == 0);
+    }   // searching
+    PK_STAMP(9, tid == 0);
+    if (!keeper) return;
+
+    // ---- 5. the books (one workgroup) ---------------------------------------------------------------------
+    __syncthreads();   // region 0 is scratch again
+    if (a.mode == 1) {
+        for (int e = tid; e < SUMS_LEN; e += PK_THREADS) L.rec[e] = K.rec[e];
+        for (int e = tid; e < 144; e += PK_THREADS) L.HTH[e / 12][e % 12] = K.HTH[e / 12][e % 12];
+        for (int e = tid; e < NS * 12; e += PK_THREADS) L.X[e / 12][e % 12] = K.X[e / 12][e % 12];
+        if (tid < NS) L.dxo[tid] = K.dxo[tid];
+        if (tid < NX) L.x[tid] = K.x[tid];
+        if (tid == 0) { L.last = K.last; L.n_valid0 = K.n_valid0; L.t_new = K.t_new; L.kf_iter = K.kf_iter; L.pass = K.pass; }
+        __syncthreads();
+        bookkeeping<W>(L, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp, &s_pose, tid);
+    } else {
+        // the update starts here: install the state (mode 0; mode 2: a begin kernel did) and prepare the first solve
+        for (int i = tid; i < NS * NS; i += PK_THREADS) {
+            double p;
+            if (a.mode == 0) {
+                p = begin.P[i];
+                kf->P_prop[i] = p;
+                kf->P_post[i] = p;
+                a.io->P_post[i] = p;   // an update without a terminal pass returns the propagated covariance
+            } else {
+                p = kf->P_prop[i];
+            }
+            Bk.B[i / NS][i % NS] = p;
+        }
+        if (tid < NX) {
+            double v;
+            if (a.mode == 0) {
+                v = begin.x[tid];
+                kf->x[tid] = v;
+                kf->x_prop[tid] = v;
+                a.io->x[tid] = v;
+            } else {
+                v = kf->x[tid];
+            }
+            ps_out->x[tid] = v;
+            L.x[tid] = v;
+            Bk.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
+        }
+        if (a.mode == 0 && tid >= 128 && tid < 128 + NW32)
+            reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(&begin.pose)[tid - 128];
+        if (tid == 0) {
+            if (a.mode == 0) {
+                a.io->passes = 0;
+                kf->t = 0;
+                kf->iter = -1;  // upstream loop starts at i = -1
+                kf->done = 0;
+                kf->passes = 0;
+            }
+            ps_out->t = 0;
+            ps_out->iter = -1;
+            ps_out->passes = 0;
+        }
+        prepare_next<W>(L, Bk, ps_out, L.x, a.sp.R_inv, tid);   // (its first barrier publishes L.x / Bk.B / Bk.xp)
+    }
+    PK_STAMP(10, tid == 0);
 #undef PK_STAMP
 }
 
-// search workgroups and rounds of pass_kernel for an n-point scan (32-point tiles, 4 per workgroup and round)
+// search workgroups and rounds of pass_kernel for an n-point scan (32-point tiles, PK_STEPS * PK_UNITS per workgroup and round)
 void pass_grid_size(uint32_t n, int max_wg, int* nwg, int* rounds) {
+    constexpr uint32_t per = (uint32_t)(PK_STEPS * PK_UNITS);
     const uint32_t nt = (n + 31u) / 32u;
-    uint32_t g = (nt + 3u) / 4u;
+    uint32_t g = (nt + per - 1u) / per;
     if (g > (uint32_t)max_wg) g = (uint32_t)max_wg;
     if (g < 1) g = 1;
     *nwg = (int)g;
-    *rounds = (int)((nt + 4u * g - 1u) / (4u * g));
+    *rounds = (int)((nt + per * g - 1u) / (per * g));
 }
+int pass_clock_words() { return PK_CLK; }
 
 int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin) {
     PassArgs a;
@@ -1280,12 +1321,12 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
     a.nrec = pl.nrec;
     a.mode = pl.mode;
     a.rounds = pl.rounds;
-    a.fit_sel = pl.fit_sel;
+    a.launch = pl.launch;
     a.mp = pl.mp;
     a.sp = pl.sp;
     static const BeginArg none{};
     const BeginArg& b = begin ? *begin : none;
-    const dim3 grid((unsigned)pl.nwg + 1u), block(PK_THREADS);
+    const dim3 grid((unsigned)(pl.nwg > 0 ? pl.nwg : 1)), block(PK_THREADS);
     if (pl.mp.estimate_extrinsics) hipLaunchKernelGGL((pass_kernel<true>), grid, block, 0, stream, a, b);
     else hipLaunchKernelGGL((pass_kernel<false>), grid, block, 0, stream, a, b);
     LV_HIP(hipGetLastError());

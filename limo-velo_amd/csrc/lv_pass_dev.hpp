@@ -7,9 +7,10 @@
 // solve -> search) and the single-workgroup solve kernel's launch ramp; it costs every workgroup the
 // solve's ~5 us latency chain once, at a time when the GPU would otherwise idle behind that chain anyway.
 // All workgroups execute the same instructions on the same inputs, so they derive bit-identical states and
-// pass constants (no broadcast, no inter-workgroup wait).  One extra ("designated") workgroup keeps the
-// books: state / trace / sums log in KfDev, the record-independent half of the NEXT solve (prepare), and on
-// the pass that ends the update the posterior covariance and the host mailbox.
+// pass constants (no broadcast, no inter-workgroup wait).  One workgroup (the one with the lightest search
+// share) also keeps the books AFTER its own search and fits: state / trace / sums log in KfDev, the
+// record-independent half of the NEXT solve (prepare), and on the pass that ends the update the posterior
+// covariance and the host mailbox.  What a launch hands to the next one lives in KfDev::ps[launch parity].
 //
 // Same algebra as solve_kernel / solve_prep (lv_solve.hip, lv_solve_dev.hpp):
 // esekf::update_iterated_dyn_share_modified [IKFoM absent from the reference mount; UPSTREAM-RECALL of
@@ -57,7 +58,7 @@ template <int NW> struct PassDims {
     static constexpr int OW = NW == 6 ? 32 : 96;              // record stride in doubles
 };
 
-constexpr int PK_THREADS = 512;
+constexpr int PK_THREADS = 1024;   // one workgroup per CU: 16 wavefronts
 
 // LDS of the prologue solve (every workgroup)
 struct SolveLds {
@@ -77,9 +78,18 @@ struct SolveLds {
     double Rot[4][9];
     float ptmp[8];
     int last, conv, n_valid0, t_new;
-    int kf_t, kf_iter, pass, pad_;
+    int kf_t, kf_iter, pass, done;
 };
-// LDS of the designated workgroup's extra work (prepare / terminal pass); follows SolveLds
+// What the bookkeeping workgroup must remember of its prologue solve while region 0 of its LDS serves the search
+struct KeepLds {
+    double rec[SUMS_LEN];
+    double HTH[12][12];
+    double X[NS][12];
+    double dxo[NS];
+    double x[NX];
+    int last, n_valid0, t_new, kf_iter, pass, pad_;
+};
+// LDS of the bookkeeping workgroup's extra work (prepare / terminal pass); follows SolveLds
 struct BookLds {
     double P[NS][LD], A[NS][LD], B[NS][LD], J[NS][LD];
     double Kx[NS][12];
@@ -90,13 +100,16 @@ struct BookLds {
 // The solve of one pass from `nrec` compact workgroup partials: x <- x [+] dx_, convergence bookkeeping, the f32
 // constants of the next pass.  T = PK_THREADS threads, all must call.  On return (after its final barrier):
 // L.x (new state), L.dxo, L.X, L.HTH, L.rec, L.last, L.t_new, L.n_valid0, *pose.
+// Returns false (to every thread) if the update had already ended in an earlier launch (kf->done): nothing was computed.
+// clk: optional stamp slot of this workgroup (instrumentation).
 template <int NW>
-__device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, const double* __restrict__ recs, int nrec,
-                                  const SolveParams& prm, PoseConsts* pose, int tid) {
+__device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
+                                  const double* __restrict__ recs, int nrec, const SolveParams& prm, PoseConsts* pose, int tid,
+                                  long long* clk) {
     constexpr int T = PK_THREADS;
     constexpr int OW = PassDims<NW>::OW, NOUT = PassDims<NW>::NOUT;
-    constexpr int PARTS = T / OW;                 // 16 / 5
-    constexpr int DEPTH = NW == 6 ? 32 : 24;      // records per thread issued in one memory round trip
+    constexpr int PARTS = T / OW;                 // 32 / 10
+    constexpr int DEPTH = NW == 6 ? 8 : 28;       // records per thread issued in one memory round trip (x PARTS >= 256 workgroups)
     const int wave = tid >> 6, lane = tid & 63;
     const int fo = tid % OW, fpart = tid / OW;
     // ---- every global read up front (one memory round trip)
@@ -107,12 +120,12 @@ __device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
         const int r = fpart + PARTS * i;
         fv[i] = (folder && r < nrec) ? recs[(size_t)r * OW + fo] : 0.0;
     }
-    if (tid < NX) L.x[tid] = kf->x[tid];
-    for (int e = tid; e < NS * NW; e += T) L.A[e / NW][e % NW] = kf->prep_P[(e / NW) * NS + (e % NW)] * prm.R_inv;
-    if (tid >= 64 && tid < 64 + NS) L.dxnew[tid - 64] = kf->prep_dxnew[tid - 64];
-    if (tid >= 128 && tid < 128 + NW * NW) L.G[(tid - 128) / NW][(tid - 128) % NW] = kf->prep_A1[tid - 128];
+    if (tid < NX) L.x[tid] = in->x[tid];
+    for (int e = tid; e < NS * NW; e += T) L.A[e / NW][e % NW] = in->prep_P[(e / NW) * NS + (e % NW)] * prm.R_inv;
+    if (tid >= 64 && tid < 64 + NS) L.dxnew[tid - 64] = in->prep_dxnew[tid - 64];
+    if (tid >= 128 && tid < 128 + NW * NW) L.G[(tid - 128) / NW][(tid - 128) % NW] = in->prep_A1[tid - 128];
     if (tid < SUMS_LEN) L.rec[tid] = 0.0;
-    if (tid == 448) { L.kf_t = kf->t; L.kf_iter = kf->iter; L.pass = kf->passes; L.conv = 1; L.last = 0; L.n_valid0 = 0; }
+    if (tid == 448) { L.kf_t = in->t; L.kf_iter = in->iter; L.pass = in->passes; L.done = kf->done; L.conv = 1; L.last = 0; L.n_valid0 = 0; }
     // ---- fold, fixed order: thread (fo, fpart) sums records fpart, fpart + PARTS, ... (four interleaved running sums),
     // the PARTS part sums are then added left to right
     {
@@ -125,6 +138,8 @@ __device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
         if (fpart < PARTS) L.part[fpart * OW + fo] = s;
     }
     __syncthreads();
+    if (L.done) return false;   // (the loads above were issued before this word was known: one round trip, not two)
+    if (clk && tid == 0) { clk[1] = clock64(); clk[17] = wall_clock64(); }
     if (tid < NOUT) {
         double s = L.part[tid];
 #pragma unroll
@@ -160,6 +175,7 @@ __device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
         }
         __syncthreads();
         gj_spd<NW>(L.W, cur, tid);               // L.W[cur] = X_top
+        if (clk && tid == 0) { clk[2] = clock64(); clk[18] = wall_clock64(); }
         if (tid < NW * NW) {                     // T = A1 X_top
             const int i = tid / NW, c = tid % NW;
             double s = 0.0;
@@ -216,6 +232,7 @@ __device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     __syncthreads();
     if (tid >= 64 && tid < 128) pose_consts_stage_b(tid - 64, L.Rot, pose, L.ptmp);
     __syncthreads();
+    return true;
 }
 
 // The record-independent half of the NEXT solve (solve_prep of lv_solve_dev.hpp over caller-provided LDS): dx = x [-] x_prop
@@ -223,7 +240,7 @@ __device__ inline void solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
 // pass is evaluated at (LDS).  The caller's threads have stored the propagated covariance in Bk.B and the propagated
 // state in Bk.xp (no barrier needed in between).
 template <int NW>
-__device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev* __restrict__ kf, const double* x, double R_inv, int tid) {
+__device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev::PassState* __restrict__ out, const double* x, double R_inv, int tid) {
     constexpr int T = PK_THREADS;
     const int wave = tid >> 6, lane = tid & 63;
     set_identity<T>(Bk.J, tid);
@@ -241,16 +258,16 @@ __device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev* __restrict_
         if (b < 0) s = Bk.dx[tid];
         else if (b == 21) s = Bk.J[tid][21] * Bk.dx[21] + Bk.J[tid][22] * Bk.dx[22];
         else s = dot3d(Bk.J[tid][b], Bk.dx[b], Bk.J[tid][b + 1], Bk.dx[b + 1], Bk.J[tid][b + 2], Bk.dx[b + 2]);
-        kf->prep_dxnew[tid] = s;
+        out->prep_dxnew[tid] = s;
     }
     congruence<T>(Bk.P, Bk.J, Bk.B, tid);  // P_ = J P_prop J^T
     __syncthreads();
-    for (int e = tid; e < NS * NS; e += T) kf->prep_P[e] = Bk.P[e / NS][e % NS];
+    for (int e = tid; e < NS * NS; e += T) out->prep_P[e] = Bk.P[e / NS][e % NS];
     if (tid < NW * NW) L.W[0][tid / NW][tid % NW] = Bk.P[tid / NW][tid % NW] * R_inv;
     __syncthreads();
     int cur = 0;
     gj_spd<NW>(L.W, cur, tid);
-    if (tid < NW * NW) kf->prep_A1[tid] = L.W[cur][tid / NW][tid % NW];
+    if (tid < NW * NW) out->prep_A1[tid] = L.W[cur][tid / NW][tid % NW];
 }
 
 #define LV_IO_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
@@ -258,7 +275,8 @@ __device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev* __restrict_
 // The designated workgroup after solve_core: the books of the pass just solved; on the pass that ends the update the
 // posterior covariance and the host mailbox (as solve_kernel's terminal part), otherwise prepare_next.
 template <int NW>
-__device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__ kf, KfHostIO* io, double* __restrict__ sums_out,
+__device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
+                                   KfDev::PassState* __restrict__ out, KfHostIO* io, double* __restrict__ sums_out,
                                    const SolveParams& prm, const PoseConsts* pose, int tid) {
     constexpr int T = PK_THREADS;
     const int wave = tid >> 6, lane = tid & 63;
@@ -268,7 +286,7 @@ __device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__
         if (sums_out) sums_out[tid] = L.rec[tid];
         if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = L.rec[tid];
     }
-    if (tid < NX) kf->x[tid] = L.x[tid];
+    if (tid < NX) { kf->x[tid] = L.x[tid]; out->x[tid] = L.x[tid]; }
     if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
         const int e = tid - 64;
         kf->trace[pass * 49 + e] = e < NS ? L.dxo[e] : L.x[e - NS];
@@ -281,6 +299,9 @@ __device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__
         kf->t = L.t_new;
         kf->passes = pass + 1;
         kf->iter = kf_iter + 1;
+        out->t = L.t_new;
+        out->passes = pass + 1;
+        out->iter = kf_iter + 1;
         if (last) {
             kf->done = 1;
             LV_IO_STORE(&io->passes, pass + 1);
@@ -290,7 +311,7 @@ __device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__
     if (!last) {
         for (int e = tid; e < NS * NS; e += T) Bk.B[e / NS][e % NS] = kf->P_prop[e];
         if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
-        prepare_next<NW>(L, Bk, kf, L.x, prm.R_inv, tid);
+        prepare_next<NW>(L, Bk, out, L.x, prm.R_inv, tid);
         return;
     }
     if (tid < NX) LV_IO_STORE(&io->x[tid], L.x[tid]);
@@ -305,7 +326,7 @@ __device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__
         return;
     }
     // terminal pass: L_ = J2 P_ J2^T, K_x rows projected, P_ <- P_ J2^T, P = L_ - K_x[:, :NW] P_[0:NW, :]
-    for (int e = tid; e < NS * NS; e += T) Bk.P[e / NS][e % NS] = kf->prep_P[e];
+    for (int e = tid; e < NS * NS; e += T) Bk.P[e / NS][e % NS] = in->prep_P[e];
     if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
     if (tid == 0) Bk.chk = 0u;
     set_identity<T>(Bk.J, tid);

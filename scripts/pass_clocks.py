@@ -1,6 +1,6 @@
-"""Phase stamps of pass_kernel (one launch per pass): LV_PASS_CLK=1 python scripts/pass_clocks.py [MAX_NUM_ITERS ...]
-Prints, for the LAST searching launch of an update, the median / p90 / max duration of every phase over the search
-workgroups, in shader cycles and in wall-clock microseconds, plus the launch-wide picture (first start, last end)."""
+"""Phase stamps of pass_kernel (one launch per pass): LV_PASS_CLK=1 python scripts/pass_clocks.py
+Prints the launch-level timeline of one update (wall clock: first workgroup start, last workgroup end, gap to the
+previous launch) and, per launch, the median / p90 / max duration of every phase over the workgroups."""
 import os, sys
 os.environ.setdefault("LV_PASS_CLK", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,22 +10,36 @@ lvamd.load()
 from limo_velo_amd import capi, synth
 
 sc = synth.make_scene(1_048_576, 65_536)
-names = ["prologue", "search step 0", "search step 1", "barrier", "fit rows", "contraction", "tail"]
-for npass in (int(a) for a in (sys.argv[1:] or ["3"])):
-    prm = capi.default_params(MAX_NUM_ITERS=npass)
-    with capi.Context(prm) as c2:
-        c2.map_build(sc["map_xyz"])
-        c2.scan_set(sc["scan_xyz"])
-        c2.set_fused_pass(True)
-        for _ in range(5):
-            c2.update(sc["x_init"], sc["P0"])
-        assert c2.last_update_fused()
-        clk = c2.pass_clocks()
-    sh, wl = clk[:, :8], clk[:, 8:]
-    print(f"== MAX_NUM_ITERS={npass}: last searching launch, {len(clk)} workgroups")
-    t0 = wl[:, 0].min()
-    print(f"   launch: first start 0, last start {(wl[:,0].max()-t0)/100:.2f} us, first end {(wl[:,7].min()-t0)/100:.2f} us, last end {(wl[:,7].max()-t0)/100:.2f} us")
-    for i, nm in enumerate(names):
+names = ["fold", "W + gauss-jordan", "gain, [+], consts", "search step 0", "search step 1", "barrier", "fit rows", "contraction", "tail"]
+with capi.Context() as ctx:
+    ctx.map_build(sc["map_xyz"])
+    ctx.scan_set(sc["scan_xyz"])
+    ctx.set_fused_pass(True)
+    for _ in range(5):
+        ctx.update(sc["x_init"], sc["P0"])
+    assert ctx.last_update_fused()
+    clk, n = ctx.pass_clocks()
+W = 16
+t0 = clk[0, :n, W].min()
+prev_end = None
+for li in range(clk.shape[0]):
+    closing = li == clk.shape[0] - 1
+    nw = 1 if closing else n
+    sl = clk[li, :nw]
+    start = sl[:, W]
+    s0 = start.min()
+    keeper_end = sl[nw - 1, W + 10]
+    e1 = max(keeper_end, 0 if closing else sl[:, W + 9].max())
+    gap = "" if prev_end is None else f"gap to previous launch's last end {(s0 - prev_end) / 100:.2f} us"
+    print(f"launch {li}: first start {(s0 - t0) / 100:8.2f} us, last end {(e1 - t0) / 100:8.2f} us, span {(e1 - s0) / 100:6.2f} us  {gap}")
+    prev_end = e1
+    if closing:
+        continue
+    se = sl[:, W + 9]
+    print(f"      workgroups: start 0 .. {(start.max() - s0) / 100:.2f} us; search+fit end {(se.min() - s0) / 100:.2f} .. {(se.max() - s0) / 100:.2f}; "
+          f"bookkeeper: search+fit end {(sl[nw - 1, W + 9] - s0) / 100:.2f}, books done {(keeper_end - s0) / 100:.2f}")
+    sh = sl[:, :W]
+    first = 3 if li == 0 else 0
+    for i in range(first, 9):
         d = (sh[:, i + 1] - sh[:, i]).astype(np.float64)
-        w = (wl[:, i + 1] - wl[:, i]).astype(np.float64) / 100.0
-        print(f"   {nm:14s} cycles med {np.median(d):8.0f} p90 {np.percentile(d,90):8.0f} max {d.max():8.0f} | us med {np.median(w):6.2f} p90 {np.percentile(w,90):6.2f} max {w.max():6.2f}")
+        print(f"      {names[i]:18s} cycles med {np.median(d):8.0f} p90 {np.percentile(d, 90):8.0f} max {d.max():8.0f}")

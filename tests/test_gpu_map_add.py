@@ -126,8 +126,10 @@ def test_fifty_incremental_adds_keep_map_and_search_exact(capi, oracle, lv):
         _knn_matches(ctx, oracle, ref, ident, probe)
         # the timed (non-capturing) kernels on the incrementally maintained structure: full update vs oracle on `ref`
         ctx.scan_set(sc["scan_xyz"])
+        ctx.set_record_dump(True)   # pass_kernel keeps its hand-over records in LDS; the same kernel also stores them for the fetch
         x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
         nbr, d2, pw, found = ctx.fetch_neighbors()
+        ctx.set_record_dump(False)
         xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], ref, sc["scan_xyz"])
         assert passes == po and [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
         assert np.abs(x - xo).max() < 1e-9

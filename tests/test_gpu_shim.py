@@ -121,4 +121,6 @@ def test_reference_main_loop_through_the_shim(lv, tmp_path):
     for x in (xa, xb):
         err = np.linalg.norm(x[:, :3] - truth, axis=1)
         assert np.sqrt(np.mean(err ** 2)) < 0.03, err
-    assert np.abs(xa - xb).max() < 1e-6                                     # the device-resident hand-overs change nothing
+    # the device-resident hand-overs change nothing beyond rounding: the two free-running runs see world points that differ
+    # in the last f32 bit now and then (one ulp = 4e-6 m at 60 m), which 70 mapping updates amplify to the 1e-5 m level
+    assert np.abs(xa - xb).max() < 3e-5

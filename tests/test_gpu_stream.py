@@ -231,7 +231,11 @@ def test_cfg4_stream_300_updates(lv, oracle):
         assert int(g["n_map0"]) == len(stream["map_xyz"]) and float(g["map_checksum"]) == float(stream["map_xyz"].astype(np.float64).sum())
         to, so, sko = g["traj"], [tuple(int(v) for v in r) for r in g["sizes"]], int(g["skipped"])
     assert skg == sko == 0 and len(tg) == len(to) == n_updates
-    assert [s[0] for s in sg] == [s[0] for s in so]              # same scan size at every update
+    # scan sizes (voxel-grid leaves of the de-skewed window): the very same early on; free-running, a state that differs at
+    # the 1e-5 m level (below) now and then moves one point across a leaf boundary
+    nsg, nso = np.array([s[0] for s in sg]), np.array([s[0] for s in so])
+    assert np.array_equal(nsg[:100], nso[:100])
+    assert np.abs(nsg - nso).max() <= 2 and np.count_nonzero(nsg != nso) <= n_updates // 20, (nsg - nso)[nsg != nso]
     # Free-running, the two pipelines cannot stay bitwise together: map points are f32 (one ulp = 4e-6 m at 60 m), so a
     # 1e-10 difference in the state rounds a few inserted points differently, the next scans are matched against maps
     # that differ by micrometres, and the difference grows to the 1e-5 m level over a hundred mapping updates (the
