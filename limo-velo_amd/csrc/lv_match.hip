@@ -1033,10 +1033,69 @@ constexpr size_t PK_OFF_PREF = PK_OFF_REC + sizeof(float4) * PK_STEPS * QREC_SLO
 constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS / 64) * 64;
 constexpr size_t PK_OFF_OUT = PK_OFF_POSE + ((sizeof(PoseConsts) + 15) / 16) * 16;
 constexpr size_t PK_OFF_KEEP = PK_OFF_OUT + sizeof(double) * PK_FITW * 2 * SUMS_LEN;
-constexpr size_t PK_LDS_BYTES = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
-static_assert(sizeof(SolveLds) % 8 == 0 && sizeof(SolveLds) + sizeof(BookLds) <= PK_REGION0, "solve scratch must fit under the stage");
-static_assert(sizeof(double) * PK_FITW * 64 * 14 <= PK_REGION0, "staged rows must fit under the stage");
+constexpr size_t PK_OFF_SUBBAR = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
+constexpr size_t PK_LDS_BYTES = PK_OFF_SUBBAR + 16;
+constexpr size_t PK_OFF_BOOK = 32 * 1024;   // the books' scratch inside region 0: above the solve scratch and above the staged rows
+static_assert(sizeof(SolveLds) <= PK_OFF_BOOK && PK_OFF_BOOK + sizeof(BookLds) <= PK_REGION0, "solve / books scratch must fit under the stage");
+static_assert(sizeof(double) * PK_FITW * 64 * 14 <= PK_OFF_BOOK, "staged rows must stay below the books' scratch");
+constexpr int PK_BOOK_THREADS = PK_THREADS - PK_FITW * 64;   // the wavefronts that do not fit planes keep the books meanwhile
 static_assert(PK_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+// The bookkeeping workgroup's extra work in a searching launch, by T threads that synchronise through bar (tid = 0 .. T - 1):
+// mode 1: the books of the pass the prologue solved (K) and the preparation of the next solve; mode 0 / 2: the update
+// starts in this launch: install the state (mode 0: from the kernel arguments; mode 2: a begin kernel did) and prepare
+// the first solve.
+template <int W, int T, class Bar>
+__device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& begin, KeepLds& K, BookLds& Bk, KfDev* __restrict__ kf,
+                                             const KfDev::PassState* __restrict__ ps_in, KfDev::PassState* __restrict__ ps_out,
+                                             const PoseConsts* pose, int tid, Bar& bar, long long* clk) {
+    if (a.mode == 1) {
+        bookkeeping<W, T>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp, pose, K.Pprop, K.xp, false, tid, bar, clk);
+        return;
+    }
+    constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
+    for (int i = tid; i < NS * NS; i += T) {
+        double p;
+        if (a.mode == 0) {
+            p = begin.P[i];
+            kf->P_prop[i] = p;
+            kf->P_post[i] = p;
+            a.io->P_post[i] = p;   // an update without a terminal pass returns the propagated covariance
+        } else {
+            p = kf->P_prop[i];
+        }
+        Bk.B[i / NS][i % NS] = p;
+    }
+    if (tid < NX) {
+        double v;
+        if (a.mode == 0) {
+            v = begin.x[tid];
+            kf->x[tid] = v;
+            kf->x_prop[tid] = v;
+            a.io->x[tid] = v;
+        } else {
+            v = kf->x[tid];
+        }
+        ps_out->x[tid] = v;
+        K.x[tid] = v;
+        Bk.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
+    }
+    if (a.mode == 0 && tid >= 128 && tid < 128 + NW32)
+        reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(&begin.pose)[tid - 128];
+    if (tid == 0) {
+        if (a.mode == 0) {
+            a.io->passes = 0;
+            kf->t = 0;
+            kf->iter = -1;  // upstream loop starts at i = -1
+            kf->done = 0;
+            kf->passes = 0;
+        }
+        ps_out->t = 0;
+        ps_out->iter = -1;
+        ps_out->passes = 0;
+    }
+    prepare_next<W, T>(Bk, ps_out, K.x, a.sp.R_inv, tid, bar, clk);   // (its first barrier publishes K.x / Bk.B / Bk.xp)
+}
 
 template <bool EXT>
 __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
@@ -1048,7 +1107,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     constexpr bool HALVES = NOUT <= 32;
     __shared__ __attribute__((aligned(16))) unsigned char smem[PK_LDS_BYTES];
     SolveLds& L = *reinterpret_cast<SolveLds*>(smem);
-    BookLds& Bk = *reinterpret_cast<BookLds*>(smem + sizeof(SolveLds));
+    BookLds& Bk = *reinterpret_cast<BookLds*>(smem + PK_OFF_BOOK);
     Xyz (*s_stage)[PK_STAGE] = reinterpret_cast<Xyz (*)[PK_STAGE]>(smem);
     double (*s_rows)[64][ROW_W] = reinterpret_cast<double (*)[64][ROW_W]>(smem);
     float4* s_rec = reinterpret_cast<float4*>(smem + PK_OFF_REC);
@@ -1065,6 +1124,8 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     const KfDev::PassState* __restrict__ ps_in = &kf->ps[a.launch & 1];
     KfDev::PassState* __restrict__ ps_out = &kf->ps[(a.launch + 1) & 1];
     KeepLds& K = *reinterpret_cast<KeepLds*>(smem + PK_OFF_KEEP);
+    int* s_subbar = reinterpret_cast<int*>(smem + PK_OFF_SUBBAR);
+    if (threadIdx.x == 0) *s_subbar = 0;   // (the prologue's barriers publish it)
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
     long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
 #define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[16 + (i)] = wall_clock64(); } } while (0)
@@ -1073,20 +1134,29 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     // ---- 1. prologue ------------------------------------------------------------------------------------
     bool searching = a.rounds > 0;
     if (a.mode == 1) {
-        if (!solve_core<W>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk)) return;   // the update ended in an earlier launch
-        if (keeper) {   // region 0 is about to become the candidate stage: remember what the books need
-            for (int e = tid; e < SUMS_LEN; e += PK_THREADS) K.rec[e] = L.rec[e];
-            for (int e = tid; e < 144; e += PK_THREADS) K.HTH[e / 12][e % 12] = L.HTH[e / 12][e % 12];
-            for (int e = tid; e < NS * 12; e += PK_THREADS) K.X[e / 12][e % 12] = L.X[e / 12][e % 12];
-            if (tid < NS) K.dxo[tid] = L.dxo[tid];
-            if (tid < NX) K.x[tid] = L.x[tid];
-            if (tid == 0) { K.last = L.last; K.n_valid0 = L.n_valid0; K.t_new = L.t_new; K.kf_iter = L.kf_iter; K.pass = L.pass; }
+        if (keeper) {
+            // what the books will need besides the solve: fetched now, while the prologue's own loads are in flight
+            if (searching) {
+                for (int e = tid; e < NS * NS; e += PK_THREADS) K.Pprop[e] = kf->P_prop[e];
+                if (tid < NX) K.xp[tid] = kf->x_prop[tid];
+            } else {   // closing launch: the terminal pass (region 0 is not reused: straight into the books' scratch)
+                for (int e = tid; e < NS * NS; e += PK_THREADS) Bk.P[e / NS][e % NS] = ps_in->prep_P[e];
+                if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
+            }
         }
+        if (!solve_core<W>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk)) return;   // the update ended in an earlier launch
+        if (keeper) keep_solve(K, L, tid);   // region 0 is about to become the candidate stage: remember what the books need
         const int ended = L.last;
         __syncthreads();
-        if (ended) {          // that solve ended the update: nothing to search
+        if (ended || !searching) {   // that solve ended the update (or this is the closing launch): nothing to search
             if (!keeper) return;
-            searching = false;
+            // the books by the whole workgroup
+            WgBar bar;
+            const bool closing = a.rounds == 0;
+            bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp, &s_pose, closing ? kf->P_prop : K.Pprop,
+                                       closing ? kf->x_prop : K.xp, closing, tid, bar, clk);
+            PK_STAMP(10, tid == 0);
+            return;
         }
     } else {
         if (a.mode == 2 && kf->done) return;
@@ -1231,61 +1301,12 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     }   // searching
     PK_STAMP(9, tid == 0);
     if (!keeper) return;
-
-    // ---- 5. the books (one workgroup) ---------------------------------------------------------------------
-    __syncthreads();   // region 0 is scratch again
-    if (a.mode == 1) {
-        for (int e = tid; e < SUMS_LEN; e += PK_THREADS) L.rec[e] = K.rec[e];
-        for (int e = tid; e < 144; e += PK_THREADS) L.HTH[e / 12][e % 12] = K.HTH[e / 12][e % 12];
-        for (int e = tid; e < NS * 12; e += PK_THREADS) L.X[e / 12][e % 12] = K.X[e / 12][e % 12];
-        if (tid < NS) L.dxo[tid] = K.dxo[tid];
-        if (tid < NX) L.x[tid] = K.x[tid];
-        if (tid == 0) { L.last = K.last; L.n_valid0 = K.n_valid0; L.t_new = K.t_new; L.kf_iter = K.kf_iter; L.pass = K.pass; }
-        __syncthreads();
-        bookkeeping<W>(L, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp, &s_pose, tid);
-    } else {
-        // the update starts here: install the state (mode 0; mode 2: a begin kernel did) and prepare the first solve
-        for (int i = tid; i < NS * NS; i += PK_THREADS) {
-            double p;
-            if (a.mode == 0) {
-                p = begin.P[i];
-                kf->P_prop[i] = p;
-                kf->P_post[i] = p;
-                a.io->P_post[i] = p;   // an update without a terminal pass returns the propagated covariance
-            } else {
-                p = kf->P_prop[i];
-            }
-            Bk.B[i / NS][i % NS] = p;
-        }
-        if (tid < NX) {
-            double v;
-            if (a.mode == 0) {
-                v = begin.x[tid];
-                kf->x[tid] = v;
-                kf->x_prop[tid] = v;
-                a.io->x[tid] = v;
-            } else {
-                v = kf->x[tid];
-            }
-            ps_out->x[tid] = v;
-            L.x[tid] = v;
-            Bk.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
-        }
-        if (a.mode == 0 && tid >= 128 && tid < 128 + NW32)
-            reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(&begin.pose)[tid - 128];
-        if (tid == 0) {
-            if (a.mode == 0) {
-                a.io->passes = 0;
-                kf->t = 0;
-                kf->iter = -1;  // upstream loop starts at i = -1
-                kf->done = 0;
-                kf->passes = 0;
-            }
-            ps_out->t = 0;
-            ps_out->iter = -1;
-            ps_out->passes = 0;
-        }
-        prepare_next<W>(L, Bk, ps_out, L.x, a.sp.R_inv, tid);   // (its first barrier publishes L.x / Bk.B / Bk.xp)
+    // ---- 5. the books (one workgroup, after its own search and fits; its scratch lies above the staged rows) ---------
+    // (Running them on the twelve wavefronts that do not fit planes, beside the fits, was tried — SubBar, lv_pass_dev.hpp:
+    // inlined into the round loop the books' register appetite spilled the search, the whole kernel ran 60 % longer.)
+    {
+        WgBar bar;
+        keeper_books<W, PK_THREADS>(a, begin, K, Bk, kf, ps_in, ps_out, &s_pose, tid, bar, clk);
     }
     PK_STAMP(10, tid == 0);
 #undef PK_STAMP

@@ -87,14 +87,17 @@ struct KeepLds {
     double X[NS][12];
     double dxo[NS];
     double x[NX];
+    double Pprop[NS * NS];   // propagated covariance and state: constant during an update, fetched while the prologue's loads fly
+    double xp[NX];
     int last, n_valid0, t_new, kf_iter, pass, pad_;
 };
 // LDS of the bookkeeping workgroup's extra work (prepare / terminal pass); follows SolveLds
 struct BookLds {
     double P[NS][LD], A[NS][LD], B[NS][LD], J[NS][LD];
-    double Kx[NS][12];
+    double Kx[NS][12], XA[NS][12];
+    double W[2][12][13];
     double xp[NX], dx[NS];
-    uint32_t chk;
+    uint32_t chk, pad_;
 };
 
 // The solve of one pass from `nrec` compact workgroup partials: x <- x [+] dx_, convergence bookkeeping, the f32
@@ -235,23 +238,96 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     return true;
 }
 
+// ---- the books --------------------------------------------------------------------------------------------------
+// Run by T threads (tid = 0 .. T - 1) that synchronise through `bar`: either the whole workgroup (WgBar: closing launch,
+// or an update that ended in this launch's prologue) or the twelve wavefronts of the bookkeeping workgroup that do not
+// fit planes (SubBar) — the books then hide behind that workgroup's own plane fits.
+struct WgBar {
+    __device__ __forceinline__ void operator()() { __syncthreads(); }
+};
+// barrier among `nwaves` wavefronts of a workgroup through an LDS counter (zeroed before first use; monotonic)
+struct SubBar {
+    int* cnt;
+    int expected, nwaves;
+    __device__ __forceinline__ void operator()() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        expected += nwaves;
+        if ((threadIdx.x & 63u) == 0u) {
+            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expected) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+// in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix as gj_spd (lv_solve_dev.hpp), synchronising through bar
+template <int NW, class Bar>
+__device__ inline void gj_spd_bar(double (*W)[12][13], int& cur, int tid, Bar& bar) {
+    if (NW * NW <= 64) {
+        if (tid < 64) {   // the whole matrix lives in one wavefront: its LDS operations execute in order
+            int c = cur;
+            for (int k = 0; k < NW; ++k) {
+                if (tid < NW * NW) {
+                    const int i = tid / NW, j = tid % NW;
+                    const double rp = ddiv(1.0, W[c][k][k]);
+                    double v;
+                    if (i == k) {
+                        v = (j == k) ? rp : W[c][k][j] * rp;
+                    } else {
+                        const double f = W[c][i][k];
+                        v = (j == k) ? -(f * rp) : W[c][i][j] - f * (W[c][k][j] * rp);
+                    }
+                    W[c ^ 1][i][j] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                c ^= 1;
+            }
+        }
+        cur ^= (NW & 1);
+        bar();
+        return;
+    }
+    for (int k = 0; k < NW; ++k) {
+        if (tid < NW * NW) {
+            const int i = tid / NW, j = tid % NW;
+            const double rp = ddiv(1.0, W[cur][k][k]);
+            double v;
+            if (i == k) {
+                v = (j == k) ? rp : W[cur][k][j] * rp;
+            } else {
+                const double f = W[cur][i][k];
+                v = (j == k) ? -(f * rp) : W[cur][i][j] - f * (W[cur][k][j] * rp);
+            }
+            W[cur ^ 1][i][j] = v;
+        }
+        bar();
+        cur ^= 1;
+    }
+}
+
 // The record-independent half of the NEXT solve (solve_prep of lv_solve_dev.hpp over caller-provided LDS): dx = x [-] x_prop
-// with its projection J, dx_new = J dx, P_ = J P_prop J^T and A1 = (P_/R)_ww^-1 -> kf->prep_*.  x: the state the coming
+// with its projection J, dx_new = J dx, P_ = J P_prop J^T and A1 = (P_/R)_ww^-1 -> out->prep_*.  x: the state the coming
 // pass is evaluated at (LDS).  The caller's threads have stored the propagated covariance in Bk.B and the propagated
 // state in Bk.xp (no barrier needed in between).
-template <int NW>
-__device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev::PassState* __restrict__ out, const double* x, double R_inv, int tid) {
-    constexpr int T = PK_THREADS;
+template <int NW, int T, class Bar>
+__device__ inline void prepare_next(BookLds& Bk, KfDev::PassState* __restrict__ out, const double* x, double R_inv, int tid, Bar& bar,
+                                    long long* clk) {
     const int wave = tid >> 6, lane = tid & 63;
     set_identity<T>(Bk.J, tid);
-    __syncthreads();
+    bar();
+    if (clk && tid == 0) { clk[11] = clock64(); clk[27] = wall_clock64(); }
     if (wave < 3 && lane == 0) manifold_block(wave, 0, x, Bk.xp, nullptr, Bk.dx, Bk.J);
     if (wave == 3 && lane < 15) {
         const int dof = lane < 3 ? lane : lane + 6;  // 0..2, 9..20
         const int si = vect_state_index(dof);
         Bk.dx[dof] = x[si] - Bk.xp[si];
     }
-    __syncthreads();
+    bar();
+    if (clk && tid == 0) { clk[12] = clock64(); clk[28] = wall_clock64(); }
     if (tid < NS) {  // dx_new = J dx (identity outside the blocks)
         double s = 0.0;
         const int b = (tid >= 3 && tid < 6) ? 3 : (tid >= 6 && tid < 9) ? 6 : (tid >= 21) ? 21 : -1;
@@ -261,115 +337,130 @@ __device__ inline void prepare_next(SolveLds& L, BookLds& Bk, KfDev::PassState* 
         out->prep_dxnew[tid] = s;
     }
     congruence<T>(Bk.P, Bk.J, Bk.B, tid);  // P_ = J P_prop J^T
-    __syncthreads();
+    bar();
     for (int e = tid; e < NS * NS; e += T) out->prep_P[e] = Bk.P[e / NS][e % NS];
-    if (tid < NW * NW) L.W[0][tid / NW][tid % NW] = Bk.P[tid / NW][tid % NW] * R_inv;
-    __syncthreads();
+    if (tid < NW * NW) Bk.W[0][tid / NW][tid % NW] = Bk.P[tid / NW][tid % NW] * R_inv;
+    bar();
+    if (clk && tid == 0) { clk[13] = clock64(); clk[29] = wall_clock64(); }
     int cur = 0;
-    gj_spd<NW>(L.W, cur, tid);
-    if (tid < NW * NW) out->prep_A1[tid] = L.W[cur][tid / NW][tid % NW];
+    gj_spd_bar<NW>(Bk.W, cur, tid, bar);
+    if (tid < NW * NW) out->prep_A1[tid] = Bk.W[cur][tid / NW][tid % NW];
 }
 
 #define LV_IO_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
-// The designated workgroup after solve_core: the books of the pass just solved; on the pass that ends the update the
-// posterior covariance and the host mailbox (as solve_kernel's terminal part), otherwise prepare_next.
-template <int NW>
-__device__ inline void bookkeeping(SolveLds& L, BookLds& Bk, KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
+// The books of the pass just solved (what solve_core left, saved in K): state / trace / sums log, the hand-over to the next
+// launch (out); on the pass that ends the update the posterior covariance and the host mailbox (as solve_kernel's terminal
+// part), otherwise prepare_next.  Pprop / xprop: the propagated covariance / state (K's early-fetched copies, or kf's);
+// prep_preloaded: Bk.P already holds in->prep_P and Bk.xp the propagated state (closing launch).
+template <int NW, int T, class Bar>
+__device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
                                    KfDev::PassState* __restrict__ out, KfHostIO* io, double* __restrict__ sums_out,
-                                   const SolveParams& prm, const PoseConsts* pose, int tid) {
-    constexpr int T = PK_THREADS;
+                                   const SolveParams& prm, const PoseConsts* pose, const double* Pprop, const double* xprop,
+                                   bool prep_preloaded, int tid, Bar& bar, long long* clk) {
     const int wave = tid >> 6, lane = tid & 63;
-    const int pass = L.pass, last = L.last, kf_iter = L.kf_iter;
-    const int kf_fallback = kf->fallback_queries;
+    const int pass = K.pass, last = K.last, kf_iter = K.kf_iter;
     if (tid < SUMS_LEN) {
-        if (sums_out) sums_out[tid] = L.rec[tid];
-        if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = L.rec[tid];
+        if (sums_out) sums_out[tid] = K.rec[tid];
+        if (pass < MAX_PASSES) kf->sums_log[pass * SUMS_LEN + tid] = K.rec[tid];
     }
-    if (tid < NX) { kf->x[tid] = L.x[tid]; out->x[tid] = L.x[tid]; }
+    if (tid < NX) { kf->x[tid] = K.x[tid]; out->x[tid] = K.x[tid]; }
     if (tid >= 64 && tid < 64 + 49 && pass < MAX_PASSES) {
         const int e = tid - 64;
-        kf->trace[pass * 49 + e] = e < NS ? L.dxo[e] : L.x[e - NS];
+        kf->trace[pass * 49 + e] = e < NS ? K.dxo[e] : K.x[e - NS];
     }
     {
         constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
         if (tid >= 128 && tid < 128 + NW32) reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(pose)[tid - 128];
     }
     if (tid == 0) {
-        kf->t = L.t_new;
+        kf->t = K.t_new;
         kf->passes = pass + 1;
         kf->iter = kf_iter + 1;
-        out->t = L.t_new;
+        out->t = K.t_new;
         out->passes = pass + 1;
         out->iter = kf_iter + 1;
         if (last) {
             kf->done = 1;
             LV_IO_STORE(&io->passes, pass + 1);
-            LV_IO_STORE(&io->fallback_queries, kf_fallback);
+            LV_IO_STORE(&io->fallback_queries, kf->fallback_queries);
         }
     }
     if (!last) {
-        for (int e = tid; e < NS * NS; e += T) Bk.B[e / NS][e % NS] = kf->P_prop[e];
-        if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
-        prepare_next<NW>(L, Bk, out, L.x, prm.R_inv, tid);
+        for (int e = tid; e < NS * NS; e += T) Bk.B[e / NS][e % NS] = Pprop[e];
+        if (tid < NX) Bk.xp[tid] = xprop[tid];
+        prepare_next<NW, T>(Bk, out, K.x, prm.R_inv, tid, bar, clk);
         return;
     }
-    if (tid < NX) LV_IO_STORE(&io->x[tid], L.x[tid]);
-    if (L.n_valid0) {
+    if (tid < NX) LV_IO_STORE(&io->x[tid], K.x[tid]);
+    if (K.n_valid0) {
         // the update ends on a pass without matches: the mailbox keeps the covariance the install stored (propagated);
         // no checksum on this rare path: the host synchronises the stream
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        bar();
         if (tid == 0)
             __hip_atomic_store(&io->seqcheck, ((unsigned long long)MAILBOX_UNCHECKED << 32) | (unsigned long long)(uint32_t)prm.seq,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     // terminal pass: L_ = J2 P_ J2^T, K_x rows projected, P_ <- P_ J2^T, P = L_ - K_x[:, :NW] P_[0:NW, :]
-    for (int e = tid; e < NS * NS; e += T) Bk.P[e / NS][e % NS] = in->prep_P[e];
-    if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
+    if (!prep_preloaded) {
+        for (int e = tid; e < NS * NS; e += T) Bk.P[e / NS][e % NS] = in->prep_P[e];
+        if (tid < NX) Bk.xp[tid] = xprop[tid];
+    }
     if (tid == 0) Bk.chk = 0u;
     set_identity<T>(Bk.J, tid);
-    __syncthreads();
-    if (wave < 3 && lane == 0) manifold_block(wave, 1, L.x, Bk.xp, L.dxo, nullptr, Bk.J);
-    __syncthreads();
+    bar();
+    if (wave < 3 && lane == 0) manifold_block(wave, 1, K.x, Bk.xp, K.dxo, nullptr, Bk.J);
+    bar();
     congruence<T>(Bk.B, Bk.J, Bk.P, tid);  // B = L_ = J2 P_ J2^T
     mm<T>(Bk.A, Bk.P, Bk.J, true, tid);    // A = P_ J2^T
     if (tid < NS * NW) {                    // K_x[:, :NW] = X HTH (columns >= NW are zero)
         const int i = tid / NW, c = tid % NW;
         double t = 0.0;
-        for (int j = 0; j < NW; ++j) t += L.X[i][j] * L.HTH[j][c];
+        for (int j = 0; j < NW; ++j) t += K.X[i][j] * K.HTH[j][c];
         Bk.Kx[i][c] = t;
     }
-    __syncthreads();
-    if (tid < NS * NW) {                    // K_x <- J2 K_x (rows)  -> L.A (free by now)
+    bar();
+    if (tid < NS * NW) {                    // K_x <- J2 K_x (rows)
         const int i = tid / NW, c = tid % NW;
         double s = 0;
         for (int r = 0; r < NS; ++r) s += Bk.J[i][r] * Bk.Kx[r][c];
-        L.A[i][c] = s;
+        Bk.XA[i][c] = s;
     }
-    __syncthreads();
+    bar();
     for (int e = tid; e < NS * NS; e += T) {
         const int i = e / NS, j = e % NS;
         double s = 0;
-        for (int c = 0; c < NW; ++c) s += L.A[i][c] * Bk.A[c][j];
+        for (int c = 0; c < NW; ++c) s += Bk.XA[i][c] * Bk.A[c][j];
         const double pv = Bk.B[i][j] - s;
         kf->P_post[e] = pv;
         LV_IO_STORE(&io->P_post[e], pv);
         atomicXor(&Bk.chk, mailbox_mix(pv, (uint32_t)e));
     }
-    if (tid < NX) atomicXor(&Bk.chk, mailbox_mix(L.x[tid], 1000u + (uint32_t)tid));
+    if (tid < NX) atomicXor(&Bk.chk, mailbox_mix(K.x[tid], 1000u + (uint32_t)tid));
     if (tid == 0) atomicXor(&Bk.chk, mailbox_mix((double)(pass + 1), 2000u));
     // every mailbox store is a system-scope write-through store: once a lane's stores have retired they are visible to
     // the host; the host verifies the checksum (lv_update_end)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    bar();
     if (tid == 0) {
         uint32_t chk = Bk.chk;
         if (chk == MAILBOX_UNCHECKED) chk = 0u;
         __hip_atomic_store(&io->seqcheck, ((unsigned long long)chk << 32) | (unsigned long long)(uint32_t)prm.seq, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// What the books need of the prologue solve, copied out of the solve scratch (all threads of the workgroup call; the caller
+// provides the barrier that follows)
+__device__ inline void keep_solve(KeepLds& K, const SolveLds& L, int tid) {
+    for (int e = tid; e < SUMS_LEN; e += PK_THREADS) K.rec[e] = L.rec[e];
+    for (int e = tid; e < 144; e += PK_THREADS) K.HTH[e / 12][e % 12] = L.HTH[e / 12][e % 12];
+    for (int e = tid; e < NS * 12; e += PK_THREADS) K.X[e / 12][e % 12] = L.X[e / 12][e % 12];
+    if (tid < NS) K.dxo[tid] = L.dxo[tid];
+    if (tid < NX) K.x[tid] = L.x[tid];
+    if (tid == 0) { K.last = L.last; K.n_valid0 = L.n_valid0; K.t_new = L.t_new; K.kf_iter = L.kf_iter; K.pass = L.pass; }
 }
 
 }  // namespace lv
