@@ -265,29 +265,12 @@ struct SubBar {
 // in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix as gj_spd (lv_solve_dev.hpp), synchronising through bar
 template <int NW, class Bar>
 __device__ inline void gj_spd_bar(double (*W)[12][13], int& cur, int tid, Bar& bar) {
-    if (NW * NW <= 64) {
-        if (tid < 64) {   // the whole matrix lives in one wavefront: its LDS operations execute in order
-            int c = cur;
-            for (int k = 0; k < NW; ++k) {
-                if (tid < NW * NW) {
-                    const int i = tid / NW, j = tid % NW;
-                    const double rp = ddiv(1.0, W[c][k][k]);
-                    double v;
-                    if (i == k) {
-                        v = (j == k) ? rp : W[c][k][j] * rp;
-                    } else {
-                        const double f = W[c][i][k];
-                        v = (j == k) ? -(f * rp) : W[c][i][j] - f * (W[c][k][j] * rp);
-                    }
-                    W[c ^ 1][i][j] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                c ^= 1;
-            }
+    if (NW == 6) {
+        if (tid < 64) {   // the whole matrix lives in the registers of one wavefront (gj6_in_lanes, lv_solve_dev.hpp)
+            const int l = tid < 36 ? tid : 35;
+            const double w = gj6_in_lanes(W[cur][l / 6][l % 6], tid);
+            if (tid < 36) W[cur][tid / 6][tid % 6] = w;
         }
-        cur ^= (NW & 1);
         bar();
         return;
     }

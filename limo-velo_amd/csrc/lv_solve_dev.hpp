@@ -21,35 +21,48 @@ __device__ inline void mm(double (*out)[LD], const double (*a)[LD], const double
         out[i][j] = s;
     }
 }
+// Gauss-Jordan inverse of an SPD 6 x 6 matrix held one element per lane (lane = 6 i + j, lanes 0..35 of one wavefront;
+// every lane of the wavefront must call): the pivot of step k is a lane broadcast, the pivot row / column elements
+// come through two cross-lane permutes, so the six elimination steps need no LDS round trip in between.  Same
+// operations in the same order as the ping-pong form below (one reciprocal per step).
+__device__ __forceinline__ double lane_bcast_f64(double v, int src_lane) {   // src_lane uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_gather_f64(double v, int src_lane) {  // src_lane per lane
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double gj6_in_lanes(double w, int lane) {
+    const int l = lane < 36 ? lane : 35;     // (idle lanes mirror a valid element: every permute source stays inside the matrix)
+    const int i = l / 6, j = l % 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double rp = ddiv(1.0, lane_bcast_f64(w, k * 6 + k));
+        const double wkj = lane_gather_f64(w, k * 6 + j);   // pivot row, my column
+        const double wik = lane_gather_f64(w, i * 6 + k);   // my row, pivot column
+        double v;
+        if (i == k) {
+            v = (j == k) ? rp : wkj * rp;
+        } else {
+            v = (j == k) ? -(wik * rp) : w - wik * (wkj * rp);
+        }
+        w = v;
+    }
+    return w;
+}
+
 // in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix (NW = 6 or 12); all threads call,
 // tid < NW*NW work; one reciprocal per step
 template <int NW>
 __device__ inline void gj_spd(double (*W)[12][13], int& cur, int tid) {
-    if (NW * NW <= 64) {
-        // the whole matrix lives in wavefront 0: its LDS operations execute in order, so the NW elimination steps
-        // need no workgroup barrier in between (the other wavefronts just wait at the one barrier below)
+    if (NW == 6) {
+        // the whole matrix lives in the registers of wavefront 0 (the other wavefronts just wait at the one barrier below)
         if (tid < 64) {
-            int c = cur;
-            for (int k = 0; k < NW; ++k) {
-                if (tid < NW * NW) {
-                    const int i = tid / NW, j = tid % NW;
-                    const double rp = ddiv(1.0, W[c][k][k]);
-                    double v;
-                    if (i == k) {
-                        v = (j == k) ? rp : W[c][k][j] * rp;
-                    } else {
-                        const double f = W[c][i][k];
-                        v = (j == k) ? -(f * rp) : W[c][i][j] - f * (W[c][k][j] * rp);
-                    }
-                    W[c ^ 1][i][j] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                c ^= 1;
-            }
+            const int l = tid < 36 ? tid : 35;
+            const double w = gj6_in_lanes(W[cur][l / 6][l % 6], tid);
+            if (tid < 36) W[cur][tid / 6][tid % 6] = w;
         }
-        cur ^= (NW & 1);
         __syncthreads();
         return;
     }
