@@ -69,6 +69,7 @@ struct lv_ctx {
     bool last_update_fused = false;
     long long* d_pclk = nullptr;   // LV_PASS_CLK=1: phase stamps of pass_kernel's workgroups (lv_get_pass_clocks)
     int pclk_wg = 0;
+    bool fused_multi_round = false;   // LV_FUSED_MULTI=1: pass_kernel also for scans that need several rounds per workgroup
     bool fused_ext = false;        // LV_FUSED_EXT=1: pass_kernel also with estimate_extrinsics (12-column rows: 3 waves per SIMD only)
 
     // capture (debug / API-parity) buffers, sized for the current scan
@@ -284,6 +285,11 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 // One launch per pass (pass_kernel) applies to the plain single-GPU update: no capture / phase clocks, no
 // communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
 bool pass_fused_applies(const lv_ctx* c) {
+    // (scans of more than one round per workgroup — beyond 64 points per wavefront slot of the chip — stay with the
+    // three-kernel pass: pass_kernel would idle twelve of sixteen wavefronts during every round's plane fits)
+    int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
+    pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
+    if (rounds > 1 && !c->fused_multi_round) return false;
     return c->fused_pass && !c->capture && !c->phase_clocks && c->comm == nullptr && c->prm.degeneracy_mode == 0 &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->scan.n > 0 && c->map.view.m > 0;
 }
@@ -313,10 +319,10 @@ int update_fused(lv_ctx* c) {
     pl.sp.seq = c->update_seq;
     pl.sp.degeneracy_mode = 0;
     pl.sp.degeneracy_threshold = c->prm.degeneracy_threshold;
-    int nwg = 0, rounds = 0;
-    pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &rounds);
+    int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
+    pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     pl.qrec = c->record_dump ? c->d_qrec : nullptr;
-    c->pclk_wg = nwg;
+    c->pclk_wg = nwg + dedicated;   // (the last slot is the bookkeeping workgroup either way)
     pl.qstride = c->qstride;
     c->qrec_valid = c->record_dump;
     c->last_update_fused = true;
@@ -326,8 +332,10 @@ int update_fused(lv_ctx* c) {
         pl.recs_in = c->d_cpart[(i + 1) & 1];
         pl.part_out = c->d_cpart[i & 1];
         pl.nrec = nwg;
-        pl.nwg = closing ? 0 : nwg;
+        pl.nwg = nwg;
         pl.rounds = closing ? 0 : rounds;
+        pl.steps = steps;
+        pl.dedicated = dedicated;
         pl.launch = i;
         pl.clk = c->d_pclk ? c->d_pclk + (size_t)i * (c->pass_max_wg + 1) * pass_clock_words() : nullptr;
         if (c->profiling && !closing) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
@@ -404,6 +412,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
+    if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0;
     if (const char* e = getenv("LV_PASS_CLK")) {
         if (atoi(e) != 0) {
             const size_t words = (size_t)(MAX_PASSES + 1) * (c->pass_max_wg + 1) * pass_clock_words();   // per launch of an update

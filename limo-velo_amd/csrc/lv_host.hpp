@@ -198,12 +198,14 @@ struct PassLaunch {
     uint32_t qstride;
     int nrec;
     int mode;                     // 0: the update starts here (state in the BeginArg); 1: solve the previous pass first; 2: state already in kf
-    int rounds, launch, nwg;      // nwg workgroups (the last one keeps the books); nwg = 0: closing launch (one workgroup, no search);
+    int rounds, launch, nwg;      // nwg searching workgroups; rounds = 0: closing launch (one workgroup, no search);
                                   // launch = index of the launch in the update
+    int steps, dedicated;         // search steps per round (1 or 2); dedicated != 0: one more workgroup only keeps the books
+                                  // (otherwise the last searching workgroup does, after its own fits)
     MatchParams mp;
     SolveParams sp;
 };
-void pass_grid_size(uint32_t n, int max_wg, int* nwg, int* rounds);
+void pass_grid_size(uint32_t n, int max_wg, int* nsearch, int* steps, int* rounds, int* dedicated);
 int pass_clock_words();   // stamp words per workgroup (PassLaunch::clk)
 int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin);
 // lv_predict.hip

@@ -1018,6 +1018,8 @@ struct PassArgs {
     long long* clk;               // optional (instrumentation): 16 shader-clock + 16 wall-clock stamps per workgroup
     uint32_t qstride;
     int nrec, mode, rounds, launch;   // launch: index of this launch in the update (parity selects KfDev::ps)
+    int steps;                        // search steps per round: 2, or 1 for scans small enough to spread over the CUs in one step
+    uint32_t nsearch;                 // searching workgroups: the grid, or the grid minus a dedicated bookkeeping workgroup
     MatchParams mp;
     SolveParams sp;
 };
@@ -1118,8 +1120,9 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const uint32_t nwg = gridDim.x, bid = blockIdx.x;
-    const bool keeper = bid == nwg - 1u;   // the bookkeeping workgroup
+    const uint32_t nwg = a.nsearch, bid = blockIdx.x;
+    const bool keeper = bid == gridDim.x - 1u;   // the bookkeeping workgroup: the last searching one, or (scans that leave a CU
+                                                 // free) a dedicated one whose books run beside the others' searches
     KfDev* __restrict__ kf = a.kf;
     const KfDev::PassState* __restrict__ ps_in = &kf->ps[a.launch & 1];
     KfDev::PassState* __restrict__ ps_out = &kf->ps[(a.launch + 1) & 1];
@@ -1132,11 +1135,11 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     PK_STAMP(0, tid == 0);
 
     // ---- 1. prologue ------------------------------------------------------------------------------------
-    bool searching = a.rounds > 0;
+    const bool searching = a.rounds > 0 && bid < nwg;
     if (a.mode == 1) {
         if (keeper) {
             // what the books will need besides the solve: fetched now, while the prologue's own loads are in flight
-            if (searching) {
+            if (a.rounds > 0) {
                 for (int e = tid; e < NS * NS; e += PK_THREADS) K.Pprop[e] = kf->P_prop[e];
                 if (tid < NX) K.xp[tid] = kf->x_prop[tid];
             } else {   // closing launch: the terminal pass (region 0 is not reused: straight into the books' scratch)
@@ -1174,8 +1177,8 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     const int unit = tid >> 8;                      // 256-thread unit: one 32-point tile per step
     // fit wavefronts: wavefront f < PK_FITW takes the 64 points [fbase, fbase + 64) of step fstep (wavefronts 0..3 of a
     // workgroup sit on the four SIMDs of the CU)
-    const bool fitter = wave < PK_FITW;
     const int fstep = wave / (PK_GROUPS / 64), fbase = (wave % (PK_GROUPS / 64)) * 64;
+    const bool fitter = wave < PK_FITW && fstep < a.steps;
     int oa[NACC], ob[NACC];
     double acc[NACC];
     const int olane = HALVES ? (lane & 31) : lane;       // output owned by this lane
@@ -1191,9 +1194,9 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     const DebugOut nodbg{};
     for (int round = 0; round < a.rounds; ++round) {
 #pragma unroll 1
-        for (int step = 0; step < PK_STEPS; ++step) {
+        for (int step = 0; step < a.steps; ++step) {
             // strided assignment: every workgroup gets far and near tiles (tile_order is farthest first)
-            const uint32_t vbi = (uint32_t)((round * PK_STEPS + step) * PK_UNITS + unit) * nwg + bid;
+            const uint32_t vbi = (uint32_t)((round * a.steps + step) * PK_UNITS + unit) * nwg + bid;
             const bool tile_ok = vbi < a.n_tiles32;
             float4* rec = s_rec + (size_t)step * QREC_SLOTS * PK_GROUPS;
             if (!tile_ok) {   // (whole 256-thread unit: uniform per wavefront)
@@ -1312,15 +1315,21 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
 #undef PK_STAMP
 }
 
-// search workgroups and rounds of pass_kernel for an n-point scan (32-point tiles, PK_STEPS * PK_UNITS per workgroup and round)
-void pass_grid_size(uint32_t n, int max_wg, int* nwg, int* rounds) {
-    constexpr uint32_t per = (uint32_t)(PK_STEPS * PK_UNITS);
-    const uint32_t nt = (n + 31u) / 32u;
-    uint32_t g = (nt + per - 1u) / per;
-    if (g > (uint32_t)max_wg) g = (uint32_t)max_wg;
+// Geometry of pass_kernel for an n-point scan (32-point tiles; a workgroup takes PK_UNITS tiles per step): the searching
+// workgroups, search steps per round (1 when one step per workgroup covers the scan), rounds, and whether a CU is left over
+// for a dedicated bookkeeping workgroup (its books then run beside the others' searches instead of after its own).
+void pass_grid_size(uint32_t n, int max_wg, int* nsearch, int* steps, int* rounds, int* dedicated) {
+    const uint32_t nt = (n + 31u) / 32u, U = (uint32_t)PK_UNITS, M = (uint32_t)(max_wg > 1 ? max_wg : 2);
+    uint32_t st, g;
+    if (nt <= U * M) { st = 1; g = (nt + U - 1u) / U; }
+    else { st = (uint32_t)PK_STEPS; g = (nt + st * U - 1u) / (st * U); }
+    const bool ded = g <= M - 1u;
+    if (g > M) g = M;
     if (g < 1) g = 1;
-    *nwg = (int)g;
-    *rounds = (int)((nt + per * g - 1u) / (per * g));
+    *nsearch = (int)g;
+    *steps = (int)st;
+    *rounds = (int)((nt + st * U * g - 1u) / (st * U * g));
+    *dedicated = ded ? 1 : 0;
 }
 int pass_clock_words() { return PK_CLK; }
 
@@ -1343,11 +1352,13 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
     a.mode = pl.mode;
     a.rounds = pl.rounds;
     a.launch = pl.launch;
+    a.steps = pl.steps;
+    a.nsearch = (uint32_t)pl.nwg;
     a.mp = pl.mp;
     a.sp = pl.sp;
     static const BeginArg none{};
     const BeginArg& b = begin ? *begin : none;
-    const dim3 grid((unsigned)(pl.nwg > 0 ? pl.nwg : 1)), block(PK_THREADS);
+    const dim3 grid((unsigned)(pl.rounds > 0 ? pl.nwg + (pl.dedicated ? 1 : 0) : 1)), block(PK_THREADS);
     if (pl.mp.estimate_extrinsics) hipLaunchKernelGGL((pass_kernel<true>), grid, block, 0, stream, a, b);
     else hipLaunchKernelGGL((pass_kernel<false>), grid, block, 0, stream, a, b);
     LV_HIP(hipGetLastError());

@@ -8,7 +8,9 @@ import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth
 sc = synth.make_scene(1_048_576, 262_144)
 ctx = capi.Context(); ctx.map_build(sc["map_xyz"])
-for n in (8192, 16384, 32768, 65536, 131072, 262144):
+if len(sys.argv) > 1:
+    ctx.set_fused_pass(int(sys.argv[1]) != 0)   # 0: the three-kernel pass, 1: one launch per pass (the default)
+for n in (512, 2048, 8192, 16384, 32768, 65536, 131072, 262144):
     ctx.scan_set(sc["scan_xyz"][:n])
     for _ in range(10):
         ctx.update(sc["x_init"], sc["P0"], want_trace=False)
