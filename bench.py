@@ -38,8 +38,9 @@ def b_alg(m: int) -> int:
     return 16 + 16 * math.ceil(math.log2(m / 32)) + 2 * 32 * 16
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel (lv::search_kernel) from the committed rocprofv3 PMC pass
+def pmc_traffic_bytes(kernel="search"):
+    """HBM bytes per launch of the dominant kernel (kernel = "pass": lv::pass_kernel, one launch per pass — the single-GPU
+    default; "search": lv::search_kernel of the three-kernel pass) from the committed rocprofv3 PMC pass
     of this same command (profiles/pmc_search_*.json, produced by scripts/gpu_profile.sh).  Per
     MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE reports half of
     the bytes of wide coalesced reads, so it is doubled.  The factor is calibrated on known byte counts
@@ -50,7 +51,7 @@ def pmc_traffic_bytes():
     committed."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_search_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"pmc_{kernel}_*.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -259,6 +260,10 @@ def main() -> None:
 
     if rank == 0:
         value = total_passes / dt
+        # which kernel ran the passes: one launch per pass (pass_kernel: the solve of the previous pass in every workgroup +
+        # search + plane fits; the single-GPU default) or the three-kernel pass (search / fit / solve; with a communicator)
+        fused = bool(ctx.last_update_fused())
+        kname = "pass" if fused else "search"
         avg_kernel_s = (kern_ms / max(kern_cnt, 1)) * 1e-3
         alg_bytes = b_alg(M_POINTS) * n_local
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
@@ -288,13 +293,14 @@ def main() -> None:
             "knn_mpts_per_s": n_local * world / avg_kernel_s / 1e6 if avg_kernel_s > 0 else None,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "lv::search_kernel",
+                "kernel": "lv::pass_kernel (one launch per pass: solve of the previous pass + search + plane fits)" if fused else "lv::search_kernel",
+                "launches_per_update": (int(round(total_passes / args.steps)) + 1) if fused else 3 * int(round(total_passes / args.steps)),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes()[0] if world == 1 else None,
-                "traffic_source": pmc_traffic_bytes()[1],
+                "traffic": pmc_traffic_bytes(kname)[0] if world == 1 else None,
+                "traffic_source": pmc_traffic_bytes(kname)[1],
                 "alg_bytes_per_launch": alg_bytes,
                 "alg_bytes_per_point_pass": b_alg(M_POINTS),
                 "avg_kernel_us": avg_kernel_s * 1e6,
@@ -304,7 +310,7 @@ def main() -> None:
                 # SURVEY 8(d) metric 3: algorithmic bytes of ALL passes of a step over the step's wall time
                 "whole_update_frac": alg_bytes * (total_passes / args.steps) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                 # the same kernel priced with the PMC-measured bytes instead of the algorithmic ones
-                "measured_traffic_gbs": (pmc_traffic_bytes()[0] / avg_kernel_s / 1e9) if (world == 1 and pmc_traffic_bytes()[0] and avg_kernel_s > 0) else None,
+                "measured_traffic_gbs": (pmc_traffic_bytes(kname)[0] / avg_kernel_s / 1e9) if (world == 1 and pmc_traffic_bytes(kname)[0] and avg_kernel_s > 0) else None,
                 "cold": cold,
             },
             "fallback": ctx.timing()["fallback_queries"],

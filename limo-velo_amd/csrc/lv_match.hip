@@ -1099,7 +1099,9 @@ __device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& 
     prepare_next<W, T>(Bk, ps_out, K.x, a.sp.R_inv, tid, bar, clk);   // (its first barrier publishes K.x / Bk.B / Bk.xp)
 }
 
-template <bool EXT>
+// CLOSING: the closing launch of an update as its own (search-free) kernel: the solve of the last pass and the terminal
+// books by one workgroup.
+template <bool EXT, bool CLOSING>
 __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
     constexpr int S = 8;
     constexpr int W = EXT ? 12 : 6;
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     PK_STAMP(0, tid == 0);
 
     // ---- 1. prologue ------------------------------------------------------------------------------------
-    const bool searching = a.rounds > 0 && bid < nwg;
+    const bool searching = !CLOSING && a.rounds > 0 && bid < nwg;
     if (a.mode == 1) {
         if (keeper) {
             // what the books will need besides the solve: fetched now, while the prologue's own loads are in flight
@@ -1171,6 +1173,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     // (from here on region 0 is the candidate stage / the staged rows; s_pose and K stay)
     PK_STAMP(3, tid == 0);
 
+    if constexpr (!CLOSING) {
     if (searching) {
     // ---- 2. / 3. search and fit rounds ------------------------------------------------------------------
     const int gq = tid / S, gl = tid % S;           // lane group (0..127) = position of its point among the 128 of a step; lane in group
@@ -1302,6 +1305,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         a.part_out[(size_t)bid * OW + tid] = s;
     }
     }   // searching
+    }   // !CLOSING
     PK_STAMP(9, tid == 0);
     if (!keeper) return;
     // ---- 5. the books (one workgroup, after its own search and fits; its scratch lies above the staged rows) ---------
@@ -1359,8 +1363,14 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
     static const BeginArg none{};
     const BeginArg& b = begin ? *begin : none;
     const dim3 grid((unsigned)(pl.rounds > 0 ? pl.nwg + (pl.dedicated ? 1 : 0) : 1)), block(PK_THREADS);
-    if (pl.mp.estimate_extrinsics) hipLaunchKernelGGL((pass_kernel<true>), grid, block, 0, stream, a, b);
-    else hipLaunchKernelGGL((pass_kernel<false>), grid, block, 0, stream, a, b);
+    const bool closing = pl.rounds == 0;
+    if (pl.mp.estimate_extrinsics) {
+        if (closing) hipLaunchKernelGGL((pass_kernel<true, true>), grid, block, 0, stream, a, b);
+        else hipLaunchKernelGGL((pass_kernel<true, false>), grid, block, 0, stream, a, b);
+    } else {
+        if (closing) hipLaunchKernelGGL((pass_kernel<false, true>), grid, block, 0, stream, a, b);
+        else hipLaunchKernelGGL((pass_kernel<false, false>), grid, block, 0, stream, a, b);
+    }
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
