@@ -63,12 +63,14 @@ struct lv_ctx {
     uint32_t qstride = 0;
     // one launch per pass (pass_kernel, lv_pass_dev.hpp): compact workgroup partials, ping-pong by pass parity
     double* d_cpart[2] = {nullptr, nullptr};
+    uint32_t* d_wgcost[2] = {nullptr, nullptr};   // per searching workgroup: how long its search + fits took (picks the next bookkeeper)
     int pass_max_wg = 256;         // search workgroups of pass_kernel: all resident at once (one 1024-thread workgroup per CU)
     bool fused_pass = true;        // LV_FUSED_PASS=0: the three-kernel pass (search / fit / solve) also where pass_kernel applies
     bool record_dump = false;      // lv_set_record_dump: pass_kernel also writes its hand-over records to d_qrec (lv_fetch_neighbors)
     bool last_update_fused = false;
     long long* d_pclk = nullptr;   // LV_PASS_CLK=1: phase stamps of pass_kernel's workgroups (lv_get_pass_clocks)
     int pclk_wg = 0;
+    bool keeper_by_cost = true;       // LV_KEEPER_BY_COST=0: the last searching workgroup always keeps the books (A/B knob)
     bool fused_multi_round = false;   // LV_FUSED_MULTI=1: pass_kernel also for scans that need several rounds per workgroup
     bool fused_ext = false;        // LV_FUSED_EXT=1: pass_kernel also with estimate_extrinsics (12-column rows: 3 waves per SIMD only)
 
@@ -332,6 +334,8 @@ int update_fused(lv_ctx* c) {
         pl.recs_in = c->d_cpart[(i + 1) & 1];
         pl.part_out = c->d_cpart[i & 1];
         pl.nrec = nwg;
+        pl.cost_in = (i > 0 && c->keeper_by_cost) ? c->d_wgcost[(i + 1) & 1] : nullptr;
+        pl.cost_out = c->d_wgcost[i & 1];
         pl.nwg = nwg;
         pl.rounds = closing ? 0 : rounds;
         pl.steps = steps;
@@ -413,6 +417,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0;
+    if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_PASS_CLK")) {
         if (atoi(e) != 0) {
             const size_t words = (size_t)(MAX_PASSES + 1) * (c->pass_max_wg + 1) * pass_clock_words();   // per launch of an update
@@ -441,6 +446,8 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     for (int i = 0; i < 2; ++i) {
         LV_HIP(hipMalloc(&c->d_cpart[i], (size_t)(c->pass_max_wg + 8) * SUMS_LEN * sizeof(double)));
         LV_HIP(hipMemset(c->d_cpart[i], 0, (size_t)(c->pass_max_wg + 8) * SUMS_LEN * sizeof(double)));
+        LV_HIP(hipMalloc(&c->d_wgcost[i], (size_t)(c->pass_max_wg + 8) * sizeof(uint32_t)));
+        LV_HIP(hipMemset(c->d_wgcost[i], 0, (size_t)(c->pass_max_wg + 8) * sizeof(uint32_t)));
     }
     LV_HIP(hipMalloc(&c->d_sums_own, SUMS_LEN * sizeof(double)));
     LV_HIP(hipMemset(c->d_sums_own, 0, SUMS_LEN * sizeof(double)));
@@ -469,7 +476,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_filter) hipHostFree(c->h_filter);
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
-    hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk);
+    hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk); hipFree(c->d_wgcost[0]); hipFree(c->d_wgcost[1]);
     hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);

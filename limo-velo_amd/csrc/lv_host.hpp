@@ -200,6 +200,8 @@ struct PassLaunch {
     int mode;                     // 0: the update starts here (state in the BeginArg); 1: solve the previous pass first; 2: state already in kf
     int rounds, launch, nwg;      // nwg searching workgroups; rounds = 0: closing launch (one workgroup, no search);
                                   // launch = index of the launch in the update
+    const uint32_t* cost_in;      // per searching workgroup: time of its search + fits in the previous launch (nullptr: none) ...
+    uint32_t* cost_out;           // ... and where this launch leaves its own
     int steps, dedicated;         // search steps per round (1 or 2); dedicated != 0: one more workgroup only keeps the books
                                   // (otherwise the last searching workgroup does, after its own fits)
     MatchParams mp;

@@ -1018,6 +1018,8 @@ struct PassArgs {
     long long* clk;               // optional (instrumentation): 16 shader-clock + 16 wall-clock stamps per workgroup
     uint32_t qstride;
     int nrec, mode, rounds, launch;   // launch: index of this launch in the update (parity selects KfDev::ps)
+    const uint32_t* cost_in;          // per searching workgroup: wall-clock ticks its search + fits took in the previous launch (or nullptr)
+    uint32_t* cost_out;               // ... in this launch
     int steps;                        // search steps per round: 2, or 1 for scans small enough to spread over the CUs in one step
     uint32_t nsearch;                 // searching workgroups: the grid, or the grid minus a dedicated bookkeeping workgroup
     MatchParams mp;
@@ -1123,8 +1125,12 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t nwg = a.nsearch, bid = blockIdx.x;
-    const bool keeper = bid == gridDim.x - 1u;   // the bookkeeping workgroup: the last searching one, or (scans that leave a CU
-                                                 // free) a dedicated one whose books run beside the others' searches
+    // the bookkeeping workgroup: a dedicated one (scans that leave a CU free: its books run beside the others' searches);
+    // otherwise a searching one, after its own fits: the one that was quickest in the previous launch (its books then
+    // hide behind the slower workgroups' searches), without a history the last one (nearest = cheapest tiles)
+    const bool dedicated = gridDim.x > nwg;
+    bool keeper = bid == gridDim.x - 1u;
+    const long long t_begin = wall_clock64();
     KfDev* __restrict__ kf = a.kf;
     const KfDev::PassState* __restrict__ ps_in = &kf->ps[a.launch & 1];
     KfDev::PassState* __restrict__ ps_out = &kf->ps[(a.launch + 1) & 1];
@@ -1135,22 +1141,26 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
 #define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[16 + (i)] = wall_clock64(); } } while (0)
     PK_STAMP(0, tid == 0);
+    if (clk && tid == 0) clk[16 + 10] = 0;   // (stamp 10 marks the launch's bookkeeping workgroup)
 
     // ---- 1. prologue ------------------------------------------------------------------------------------
     const bool searching = !CLOSING && a.rounds > 0 && bid < nwg;
     if (a.mode == 1) {
-        if (keeper) {
-            // what the books will need besides the solve: fetched now, while the prologue's own loads are in flight
-            if (a.rounds > 0) {
+        if (CLOSING) {   // the terminal pass: what it needs besides the solve, fetched while the prologue's own loads are in flight
+            for (int e = tid; e < NS * NS; e += PK_THREADS) Bk.P[e / NS][e % NS] = ps_in->prep_P[e];
+            if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
+        }
+        const bool choose = !CLOSING && !dedicated && a.cost_in != nullptr;
+        if (!solve_core<W>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk, choose ? a.cost_in : nullptr, choose ? (int)nwg : 0))
+            return;   // the update ended in an earlier launch
+        if (choose && L.cheapest >= 0) keeper = (int)bid == L.cheapest;
+        if (keeper) {   // region 0 is about to become the candidate stage: remember what the books need
+            keep_solve(K, L, tid);
+            if (!CLOSING) {   // (the propagated covariance / state arrive while this workgroup searches)
                 for (int e = tid; e < NS * NS; e += PK_THREADS) K.Pprop[e] = kf->P_prop[e];
                 if (tid < NX) K.xp[tid] = kf->x_prop[tid];
-            } else {   // closing launch: the terminal pass (region 0 is not reused: straight into the books' scratch)
-                for (int e = tid; e < NS * NS; e += PK_THREADS) Bk.P[e / NS][e % NS] = ps_in->prep_P[e];
-                if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
             }
         }
-        if (!solve_core<W>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk)) return;   // the update ended in an earlier launch
-        if (keeper) keep_solve(K, L, tid);   // region 0 is about to become the candidate stage: remember what the books need
         const int ended = L.last;
         __syncthreads();
         if (ended || !searching) {   // that solve ended the update (or this is the closing launch): nothing to search
@@ -1305,6 +1315,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         a.part_out[(size_t)bid * OW + tid] = s;
     }
     }   // searching
+    if (a.cost_out && tid == 0 && bid < nwg) a.cost_out[bid] = (uint32_t)(wall_clock64() - t_begin);
     }   // !CLOSING
     PK_STAMP(9, tid == 0);
     if (!keeper) return;
@@ -1357,6 +1368,8 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
     a.rounds = pl.rounds;
     a.launch = pl.launch;
     a.steps = pl.steps;
+    a.cost_in = pl.cost_in;
+    a.cost_out = pl.cost_out;
     a.nsearch = (uint32_t)pl.nwg;
     a.mp = pl.mp;
     a.sp = pl.sp;

@@ -79,6 +79,7 @@ struct SolveLds {
     float ptmp[8];
     int last, conv, n_valid0, t_new;
     int kf_t, kf_iter, pass, done;
+    int cheapest, pad_[3];     // the workgroup whose search + fits took least time in the previous launch (keeps the books now)
 };
 // What the bookkeeping workgroup must remember of its prologue solve while region 0 of its LDS serves the search
 struct KeepLds {
@@ -108,7 +109,9 @@ struct BookLds {
 template <int NW>
 __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
                                   const double* __restrict__ recs, int nrec, const SolveParams& prm, PoseConsts* pose, int tid,
-                                  long long* clk) {
+                                  long long* clk, const uint32_t* __restrict__ cost_in = nullptr, int ncost = 0) {
+    // cost_in (optional): how long each of the ncost searching workgroups of the PREVIOUS launch took; L.cheapest = the
+    // quickest one (ties: the highest index), -1 without a history
     constexpr int T = PK_THREADS;
     constexpr int OW = PassDims<NW>::OW, NOUT = PassDims<NW>::NOUT;
     constexpr int PARTS = T / OW;                 // 32 / 10
@@ -129,6 +132,20 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     if (tid >= 128 && tid < 128 + NW * NW) L.G[(tid - 128) / NW][(tid - 128) % NW] = in->prep_A1[tid - 128];
     if (tid < SUMS_LEN) L.rec[tid] = 0.0;
     if (tid == 448) { L.kf_t = in->t; L.kf_iter = in->iter; L.pass = in->passes; L.done = kf->done; L.conv = 1; L.last = 0; L.n_valid0 = 0; }
+    if (tid >= 960) {   // the last wavefront: argmin of the previous launch's workgroup times (key = time << 10 | 1023 - index)
+        const int ln = tid - 960;
+        unsigned long long best = ~0ull;
+        for (int w = ln; w < ncost; w += 64) {
+            const unsigned long long key = ((unsigned long long)cost_in[w] << 16) | (unsigned long long)(65535 - w);
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_xor((long long)best, m);
+            best = o < best ? o : best;
+        }
+        if (ln == 0) L.cheapest = (cost_in && ncost > 0) ? 65535 - (int)(best & 0xFFFFull) : -1;
+    }
     // ---- fold, fixed order: thread (fo, fpart) sums records fpart, fpart + PARTS, ... (four interleaved running sums),
     // the PARTS part sums are then added left to right
     {

@@ -39,18 +39,19 @@ for li in range(nl):
     for clk in runs:
         sl = clk[li, :nw]
         s0 = sl[:, W].min()
-        kend = sl[nw - 1, W + 10]
+        ki = int(np.argmax(sl[:, W + 10]))     # the launch's bookkeeping workgroup (the only one with stamp 10)
+        kend = sl[ki, W + 10]
         e1 = max(kend, 0 if closing else sl[:, W + 9].max())
         spans.append((e1 - s0) / 100)
         if li:
             pl = clk[li - 1, :(n if li - 1 < nl - 1 else 1)]
-            pe = max(pl[-1, W + 10], pl[:, W + 9].max())
+            pe = max(pl[:, W + 10].max(), pl[:, W + 9].max())
             gaps.append((s0 - pe) / 100)
         if not closing:
             se = sl[:, W + 9]
             ends_min.append((se.min() - s0) / 100); ends_max.append((se.max() - s0) / 100)
-            keep_end.append((sl[nw - 1, W + 9] - s0) / 100)
-            kk = sl[nw - 1]
+            keep_end.append((sl[ki, W + 9] - s0) / 100)
+            kk = sl[ki]
             books.append((kend - kk[W + 9]) / 100)     # the books follow the bookkeeper's own search and fits
             fits.append((kk[W + 8] - kk[W + 6]) / 100)
             if kk[W + 11] > 0:
