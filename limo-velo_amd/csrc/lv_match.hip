@@ -539,6 +539,40 @@ __device__ __forceinline__ void brute_attempt(const MapView& map, float qx, floa
     merge_team<64>(k);
 }
 
+// One scan point that the per-lane-group bucket levels left undecided, searched by a WHOLE wavefront: level-2 bucket, the
+// level-3 block as 216 voxel lists, finally every id (see knn_search).  On return every lane holds the sorted result in kw
+// (keys carry point ids); returns what decided (2, 3 voxel levels; 4 every id; 5 bounded stop: no neighbours reported).
+template <bool DBG>
+__device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict__ kf, float wx, float wy, float wz, int lane, kkey (&kw)[KNN],
+                                          double max_dist_sq, uint32_t* s_pref, uint32_t* s_start) {
+    const QGeom wgeo = make_geom(map, wx, wy, wz);
+    const bool w_in_range = wgeo.amax < CELL_FAR;
+#pragma unroll
+    for (int j = 0; j < KNN; ++j) kw[j] = none_key();
+    int wbin = 5;
+    bool done = false;
+    if (w_in_range) {
+        done = bucket_attempt_by_id<64>(map, 2, wgeo, wx, wy, wz, lane, kw);
+        if (done) wbin = 2;
+        // not accepted: d5 >= r^2 (f32).  The reference's gate is (double)d5 < MAX_DIST_PLANE^2 (Plane.cpp:42)
+        float r = search_radius(map, wgeo, 2);
+        bool stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
+        if (!done && !stop) {
+            if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
+            done = cells_attempt<CELL_LEVEL + 1>(map, wgeo, wx, wy, wz, lane, kw, s_pref, s_start);
+            if (done) wbin = 3;
+            r = search_radius(map, wgeo, CELL_LEVEL + 1);
+            stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
+        }
+        if (!done && !stop) { brute_attempt(map, wx, wy, wz, lane, kw); wbin = 4; }
+    } else {   // outside the voxel range (2^19 voxels from the map origin): no structure to lean on
+        if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
+        brute_attempt(map, wx, wy, wz, lane, kw);
+        wbin = 4;
+    }
+    return wbin;
+}
+
 // Exact 5-NN of the world point (qx, qy, qz): executed by the S lanes of a lane group (gl = lane in group); all 64
 // lanes of the wavefront must be active (`live` = false marks padding lanes that only lend a hand).
 // On return every lane of the group holds the same sorted keys k[]; src >= 0: bucket level the winners came
@@ -554,7 +588,11 @@ __device__ __forceinline__ void brute_attempt(const MapView& map, float qx, floa
 template <int S, bool DBG>
 __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
                                            kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist,
-                                           bool live, Xyz* stage0, double max_dist_sq, uint32_t* s_pref, uint32_t* s_start) {
+                                           bool live, Xyz* stage0, double max_dist_sq, uint32_t* s_pref, uint32_t* s_start,
+                                           bool* undecided = nullptr) {
+    // undecided != nullptr: stop after the bucket levels 0 / 1 and report whether the point is still open (the caller
+    // then runs knn_coarse on it)
+    if (undecided) *undecided = false;
     if (map.m == 0) return;
     const QGeom geo = make_geom(map, qx, qy, qz);
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
@@ -573,38 +611,18 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
             }
         }
     }
+    if (undecided) {   // the caller shares the coarse levels out among the wavefronts of its workgroup (pass_kernel)
+        *undecided = !decided;
+        return;
+    }
     const int lane = (int)(threadIdx.x & 63u);
     unsigned long long pending = __ballot(!decided && gl == 0);
     while (pending) {
         const int L = __ffsll((long long)pending) - 1;   // leader lane of the scan point served now
         pending &= pending - 1;
         const float wx = __shfl(qx, L), wy = __shfl(qy, L), wz = __shfl(qz, L);
-        const QGeom wgeo = make_geom(map, wx, wy, wz);
-        const bool w_in_range = wgeo.amax < CELL_FAR;
         kkey kw[KNN];
-#pragma unroll
-        for (int j = 0; j < KNN; ++j) kw[j] = none_key();
-        int wbin = 5;
-        bool done = false;
-        if (w_in_range) {
-            done = bucket_attempt_by_id<64>(map, 2, wgeo, wx, wy, wz, lane, kw);
-            if (done) wbin = 2;
-            // not accepted: d5 >= r^2 (f32).  The reference's gate is (double)d5 < MAX_DIST_PLANE^2 (Plane.cpp:42)
-            float r = search_radius(map, wgeo, 2);
-            bool stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
-            if (!done && !stop) {
-                if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
-                done = cells_attempt<CELL_LEVEL + 1>(map, wgeo, wx, wy, wz, lane, kw, s_pref, s_start);
-                if (done) wbin = 3;
-                r = search_radius(map, wgeo, CELL_LEVEL + 1);
-                stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
-            }
-            if (!done && !stop) { brute_attempt(map, wx, wy, wz, lane, kw); wbin = 4; }
-        } else {   // outside the voxel range (2^19 voxels from the map origin): no structure to lean on
-            if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
-            brute_attempt(map, wx, wy, wz, lane, kw);
-            wbin = 4;
-        }
+        const int wbin = knn_coarse<DBG>(map, kf, wx, wy, wz, lane, kw, max_dist_sq, s_pref, s_start);
         if (lane / S == L / S) {   // (keys carry point ids: src stays -1)
 #pragma unroll
             for (int j = 0; j < KNN; ++j) k[j] = kw[j];
@@ -1030,6 +1048,7 @@ constexpr int PK_GROUPS = PK_THREADS / 8;         // lane groups (= scan points 
 constexpr int PK_STAGE = 64;                      // candidates of a lane group's first level-0 chunk kept in LDS
 constexpr int PK_STEPS = 2;                       // search steps per round
 constexpr int PK_FITW = PK_STEPS * PK_GROUPS / 64;   // fit wavefronts: one per 64 points of a round (4)
+constexpr int PK_RPTS_MAX = PK_STEPS * PK_GROUPS;    // scan points per workgroup and round (256)
 constexpr int PK_CLK = 32;                        // stamp words per workgroup
 constexpr size_t PK_REGION0 = sizeof(Xyz) * PK_GROUPS * PK_STAGE;                     // 98304: stage | solve scratch | rows
 constexpr size_t PK_OFF_REC = PK_REGION0;                                             // float4 [steps][8 slots][128]
@@ -1038,7 +1057,9 @@ constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS 
 constexpr size_t PK_OFF_OUT = PK_OFF_POSE + ((sizeof(PoseConsts) + 15) / 16) * 16;
 constexpr size_t PK_OFF_KEEP = PK_OFF_OUT + sizeof(double) * PK_FITW * 2 * SUMS_LEN;
 constexpr size_t PK_OFF_SUBBAR = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
-constexpr size_t PK_LDS_BYTES = PK_OFF_SUBBAR + 16;
+constexpr size_t PK_OFF_QUEUE = PK_OFF_SUBBAR + 16;                              // float4 [256] + uint32 [256]: points left to the coarse levels
+constexpr size_t PK_OFF_QUEUEQ = PK_OFF_QUEUE + sizeof(float4) * PK_RPTS_MAX;
+constexpr size_t PK_LDS_BYTES = PK_OFF_QUEUEQ + sizeof(uint32_t) * PK_RPTS_MAX;
 constexpr size_t PK_OFF_BOOK = 32 * 1024;   // the books' scratch inside region 0: above the solve scratch and above the staged rows
 static_assert(sizeof(SolveLds) <= PK_OFF_BOOK && PK_OFF_BOOK + sizeof(BookLds) <= PK_REGION0, "solve / books scratch must fit under the stage");
 static_assert(sizeof(double) * PK_FITW * 64 * 14 <= PK_OFF_BOOK, "staged rows must stay below the books' scratch");
@@ -1136,7 +1157,10 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     KfDev::PassState* __restrict__ ps_out = &kf->ps[(a.launch + 1) & 1];
     KeepLds& K = *reinterpret_cast<KeepLds*>(smem + PK_OFF_KEEP);
     int* s_subbar = reinterpret_cast<int*>(smem + PK_OFF_SUBBAR);
-    if (threadIdx.x == 0) *s_subbar = 0;   // (the prologue's barriers publish it)
+    int* s_qn = s_subbar + 1;              // entries in the queue of points left to the coarse levels
+    float4* s_queue = reinterpret_cast<float4*>(smem + PK_OFF_QUEUE);
+    uint32_t* s_queueq = reinterpret_cast<uint32_t*>(smem + PK_OFF_QUEUEQ);
+    if (threadIdx.x == 0) { *s_subbar = 0; *s_qn = 0; }   // (the prologue's barriers publish them)
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
     long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
 #define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[16 + (i)] = wall_clock64(); } } while (0)
@@ -1227,8 +1251,17 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             const float4 sp = a.scan[live ? q : a.n - 1];
             float qx, qy, qz;
             rt_apply(s_pose.Tc, sp.x, sp.y, sp.z, qx, qy, qz);  // Mapper.cpp:51
+            // bucket levels 0 / 1 here; a point they leave open (a handful per scan once the pose is close, a few per cent of the
+            // far tiles while it is off) goes to the workgroup's queue: the coarse levels take a whole wavefront per point,
+            // and sixteen wavefronts share them out after the barrier instead of one wavefront serving its own in turn
+            bool open_pt = false;
             knn_search<S, false>(a.map, kf, qx, qy, qz, gl, k, bstart, src, nullptr, false, live, s_stage[gq], a.mp.max_dist_plane_sq,
-                                 s_pref[wave], s_start[wave]);
+                                 s_pref[wave], s_start[wave], &open_pt);
+            if (open_pt && gl == 0) {
+                const int qi = atomicAdd(s_qn, 1);
+                s_queue[qi] = make_float4(qx, qy, qz, __int_as_float(step * PK_GROUPS + gq));
+                s_queueq[qi] = q;
+            }
             int found = 0;
 #pragma unroll
             for (int j = 0; j < KNN; ++j) found += key_real(k[j]) ? 1 : 0;
@@ -1268,6 +1301,43 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         }
         __syncthreads();   // the records of both steps are complete; nobody reads the candidate stage any more
         if (round == 0) PK_STAMP(6, tid == 0);
+        const int nq = *s_qn;
+        if (nq > 0) {   // (uniform) the open points, one per wavefront at a time: level-2 bucket / level-3 lists / every id
+            for (int i = wave; i < nq; i += PK_THREADS / 64) {
+                const float4 e = s_queue[i];
+                const int p = __float_as_int(e.w);
+                const uint32_t q = s_queueq[i];
+                kkey kw[KNN];
+                knn_coarse<false>(a.map, kf, e.x, e.y, e.z, lane, kw, a.mp.max_dist_plane_sq, s_pref[wave], s_start[wave]);
+                int found = 0;
+#pragma unroll
+                for (int j = 0; j < KNN; ++j) found += key_real(kw[j]) ? 1 : 0;
+                if (lane < QREC_SLOTS && lane != 5) {   // (slot 5, the world point, is in the record already)
+                    const int slot = lane;
+                    float4 v;
+                    if (slot < KNN) {
+                        kkey kk = kw[0];
+#pragma unroll
+                        for (int j = 1; j < KNN; ++j) kk = (slot == j) ? kw[j] : kk;
+                        v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+                        if (key_real(kk)) {   // (keys carry point ids)
+                            const uint32_t pos = key_lo(kk);
+                            v = a.map.orig[pos];
+                            v.w = __uint_as_float(pos);
+                        }
+                    } else if (slot == 6) {
+                        v = make_float4(__uint_as_float(key_hi(kw[0])), __uint_as_float(key_hi(kw[1])), __uint_as_float(key_hi(kw[2])),
+                                        __uint_as_float(key_hi(kw[3])));
+                    } else {
+                        v = make_float4(__uint_as_float(key_hi(kw[4])), __int_as_float(found), 0.f, 0.f);
+                    }
+                    s_rec[((p / PK_GROUPS) * QREC_SLOTS + slot) * PK_GROUPS + (p % PK_GROUPS)] = v;
+                    if (a.qrec) a.qrec[(size_t)slot * a.qstride + q] = v;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) *s_qn = 0;   // (next round; the barrier after the fits publishes it)
+        }
         if (fitter) {
             const float4* rec = s_rec + (size_t)fstep * QREC_SLOTS * PK_GROUPS + fbase;
             float4 r[QREC_SLOTS];
