@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
         }
         const bool choose = !CLOSING && !dedicated && a.cost_in != nullptr;
-        if (!solve_core<W>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk, choose ? a.cost_in : nullptr, choose ? (int)nwg : 0))
+        if (!solve_core<W, !CLOSING>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk, choose ? a.cost_in : nullptr, choose ? (int)nwg : 0))
             return;   // the update ended in an earlier launch
         if (choose && L.cheapest >= 0) keeper = (int)bid == L.cheapest;
         if (keeper) {   // region 0 is about to become the candidate stage: remember what the books need

@@ -106,7 +106,7 @@ struct BookLds {
 // L.x (new state), L.dxo, L.X, L.HTH, L.rec, L.last, L.t_new, L.n_valid0, *pose.
 // Returns false (to every thread) if the update had already ended in an earlier launch (kf->done): nothing was computed.
 // clk: optional stamp slot of this workgroup (instrumentation).
-template <int NW>
+template <int NW, bool WITH_POSE = true>
 __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
                                   const double* __restrict__ recs, int nrec, const SolveParams& prm, PoseConsts* pose, int tid,
                                   long long* clk, const uint32_t* __restrict__ cost_in = nullptr, int ncost = 0) {
@@ -238,6 +238,7 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
         }
     }
     __syncthreads();
+    if (!WITH_POSE) return true;   // (closing launch: no pass follows)
     // the constants of the coming pass: four rotation matrices, one lane each, then the composed transforms spread over
     // one wavefront (same operations, same order as compute_pose_consts => same bits)
     if (tid >= 320 && tid < 324) {
@@ -371,7 +372,8 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
     }
     {
         constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
-        if (tid >= 128 && tid < 128 + NW32) reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(pose)[tid - 128];
+        // (as solve_kernel: the constants of the next pass; none follows the pass that ends the update)
+        if (!last && tid >= 128 && tid < 128 + NW32) reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(pose)[tid - 128];
     }
     if (tid == 0) {
         kf->t = K.t_new;
