@@ -1056,14 +1056,13 @@ constexpr size_t PK_OFF_PREF = PK_OFF_REC + sizeof(float4) * PK_STEPS * QREC_SLO
 constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS / 64) * 64;
 constexpr size_t PK_OFF_OUT = PK_OFF_POSE + ((sizeof(PoseConsts) + 15) / 16) * 16;
 constexpr size_t PK_OFF_KEEP = PK_OFF_OUT + sizeof(double) * PK_FITW * 2 * SUMS_LEN;
-constexpr size_t PK_OFF_SUBBAR = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
-constexpr size_t PK_OFF_QUEUE = PK_OFF_SUBBAR + 16;                              // float4 [256] + uint32 [256]: points left to the coarse levels
+constexpr size_t PK_OFF_QN = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
+constexpr size_t PK_OFF_QUEUE = PK_OFF_QN + 16;                              // float4 [256] + uint32 [256]: points left to the coarse levels
 constexpr size_t PK_OFF_QUEUEQ = PK_OFF_QUEUE + sizeof(float4) * PK_RPTS_MAX;
 constexpr size_t PK_LDS_BYTES = PK_OFF_QUEUEQ + sizeof(uint32_t) * PK_RPTS_MAX;
 constexpr size_t PK_OFF_BOOK = 32 * 1024;   // the books' scratch inside region 0: above the solve scratch and above the staged rows
 static_assert(sizeof(SolveLds) <= PK_OFF_BOOK && PK_OFF_BOOK + sizeof(BookLds) <= PK_REGION0, "solve / books scratch must fit under the stage");
 static_assert(sizeof(double) * PK_FITW * 64 * 14 <= PK_OFF_BOOK, "staged rows must stay below the books' scratch");
-constexpr int PK_BOOK_THREADS = PK_THREADS - PK_FITW * 64;   // the wavefronts that do not fit planes keep the books meanwhile
 static_assert(PK_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // The bookkeeping workgroup's extra work in a searching launch, by T threads that synchronise through bar (tid = 0 .. T - 1):
@@ -1156,11 +1155,10 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     const KfDev::PassState* __restrict__ ps_in = &kf->ps[a.launch & 1];
     KfDev::PassState* __restrict__ ps_out = &kf->ps[(a.launch + 1) & 1];
     KeepLds& K = *reinterpret_cast<KeepLds*>(smem + PK_OFF_KEEP);
-    int* s_subbar = reinterpret_cast<int*>(smem + PK_OFF_SUBBAR);
-    int* s_qn = s_subbar + 1;              // entries in the queue of points left to the coarse levels
+    int* s_qn = reinterpret_cast<int*>(smem + PK_OFF_QN);   // entries in the queue of points left to the coarse levels
     float4* s_queue = reinterpret_cast<float4*>(smem + PK_OFF_QUEUE);
     uint32_t* s_queueq = reinterpret_cast<uint32_t*>(smem + PK_OFF_QUEUEQ);
-    if (threadIdx.x == 0) { *s_subbar = 0; *s_qn = 0; }   // (the prologue's barriers publish them)
+    if (threadIdx.x == 0) *s_qn = 0;   // (the prologue's barriers publish it)
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
     long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
 #define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[16 + (i)] = wall_clock64(); } } while (0)
@@ -1390,7 +1388,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     PK_STAMP(9, tid == 0);
     if (!keeper) return;
     // ---- 5. the books (one workgroup, after its own search and fits; its scratch lies above the staged rows) ---------
-    // (Running them on the twelve wavefronts that do not fit planes, beside the fits, was tried — SubBar, lv_pass_dev.hpp:
+    // (Running them on the twelve wavefronts that do not fit planes, beside the fits, over an LDS-counter barrier was tried:
     // inlined into the round loop the books' register appetite spilled the search, the whole kernel ran 60 % longer.)
     {
         WgBar bar;

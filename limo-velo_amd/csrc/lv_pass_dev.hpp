@@ -257,29 +257,12 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
 }
 
 // ---- the books --------------------------------------------------------------------------------------------------
-// Run by T threads (tid = 0 .. T - 1) that synchronise through `bar`: either the whole workgroup (WgBar: closing launch,
-// or an update that ended in this launch's prologue) or the twelve wavefronts of the bookkeeping workgroup that do not
-// fit planes (SubBar) — the books then hide behind that workgroup's own plane fits.
+// Run by T threads (tid = 0 .. T - 1) that synchronise through `bar` (today always the whole workgroup, WgBar; the
+// functions are written against a barrier object because a sub-group of wavefronts running them beside the plane fits
+// was measured — DESIGN §3 — and may return once the books fit a smaller register budget).
 struct WgBar {
     __device__ __forceinline__ void operator()() { __syncthreads(); }
 };
-// barrier among `nwaves` wavefronts of a workgroup through an LDS counter (zeroed before first use; monotonic)
-struct SubBar {
-    int* cnt;
-    int expected, nwaves;
-    __device__ __forceinline__ void operator()() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        expected += nwaves;
-        if ((threadIdx.x & 63u) == 0u) {
-            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expected) __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-};
-
 // in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix as gj_spd (lv_solve_dev.hpp), synchronising through bar
 template <int NW, class Bar>
 __device__ inline void gj_spd_bar(double (*W)[12][13], int& cur, int tid, Bar& bar) {

@@ -1,0 +1,154 @@
+"""pass_kernel (one launch per measurement pass: the solve of the previous pass in every workgroup + search + plane fits,
+limo-velo_amd/csrc/lv_pass_dev.hpp) against the three-kernel pass (search / fit / solve) and the oracle: the two routes run the
+same device functions and differ only in the (fixed) order the workgroup partials are summed in, so states agree to ~1e-13;
+every geometry of pass_grid_size is crossed (one / two search steps, dedicated / searching bookkeeping workgroup), every way
+an update can end (all passes, early convergence, a pass without matches), both entries (lv_update, lv_correct)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_X, TOL_P_REL = 1e-12, 1e-9
+
+
+@pytest.fixture(scope="module")
+def capi(lv):
+    from limo_velo_amd import capi as c
+
+    return c
+
+
+def _both(ctx, sc, x0, P0, scan=None):
+    if scan is not None:
+        ctx.scan_set(scan)
+    ctx.set_fused_pass(True)
+    xf, Pf, pf, trf, sf = ctx.update(x0, P0)
+    fused = ctx.last_update_fused()
+    ctx.set_fused_pass(False)
+    xt, Pt, pt, trt, st = ctx.update(x0, P0)
+    assert not ctx.last_update_fused()
+    ctx.set_fused_pass(True)
+    return (xf, Pf, pf, trf, sf, fused), (xt, Pt, pt, trt, st)
+
+
+def _agree(a, b):
+    xf, Pf, pf, trf, sf, _ = a
+    xt, Pt, pt, trt, st = b
+    assert pf == pt
+    np.testing.assert_allclose(xf, xt, rtol=0, atol=TOL_X)
+    np.testing.assert_allclose(Pf, Pt, rtol=TOL_P_REL, atol=1e-13)   # (small entries are differences of larger ones)
+    assert [s["n_valid"] for s in sf] == [s["n_valid"] for s in st]
+    for u, v in zip(sf, st):
+        scale = max(np.abs(v["HTH"]).max(), 1.0)
+        assert np.abs(u["HTH"] - v["HTH"]).max() <= 1e-12 * scale
+    np.testing.assert_allclose(np.asarray(trf), np.asarray(trt), rtol=0, atol=1e-11)   # dx_ and the state after every pass
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 1000, 4096, 8192, 32_640, 32_768, 32_769, 65_280, 65_281, 65_536])
+def test_geometries_match_the_three_kernel_pass(capi, lv, n):
+    """n crosses pass_grid_size's cases on a 256-CU part: <= 1024 tiles of 32 points: one search step (32 768 points fill
+    every CU: the bookkeeper searches too; below that a dedicated one); up to 2040 tiles: two steps + dedicated bookkeeper;
+    2041..2048 tiles: every CU searches, the books follow the bookkeeper's fits."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(300_000, 65_536)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        a, b = _both(ctx, sc, sc["x_init"], sc["P0"], sc["scan_xyz"][:n])
+        assert a[5]                      # the one-launch route really ran
+        _agree(a, b)
+
+
+def test_larger_scans_take_the_three_kernel_pass(capi, lv):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(300_000, 70_000)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        ctx.update(sc["x_init"], sc["P0"])
+        assert not ctx.last_update_fused()   # several rounds per workgroup: pass_kernel would idle during every round's fits
+
+
+@pytest.mark.parametrize("iters", [0, 1, 2, 3])
+def test_pass_counts_and_oracle(capi, oracle, scene_small, iters):
+    sc = scene_small
+    prm = capi.default_params(MAX_NUM_ITERS=iters)
+    with capi.Context(prm) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        a, b = _both(ctx, sc, sc["x_init"], sc["P0"], sc["scan_xyz"])
+        _agree(a, b)
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=oracle.default_params(max_num_iters=iters))
+    assert a[2] == po == iters + 1
+    assert np.abs(a[0] - xo).max() < 1e-9 and np.abs(a[1] - Po).max() < 1e-9
+    assert [s["n_valid"] for s in a[4]] == [s["n_valid"] for s in so]
+
+
+def test_early_convergence_ends_the_update_inside_a_prologue(capi, oracle, scene_small):
+    """From the true pose dx falls under LIMITS twice in a row before MAX_NUM_ITERS + 1 passes: the launch whose prologue
+    finds that out searches nothing, its bookkeeping workgroup writes the terminal results, the launches behind it exit."""
+    sc = scene_small
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        a, b = _both(ctx, sc, sc["x_true"], sc["P0"], sc["scan_xyz"])
+        _agree(a, b)
+        assert a[5] and a[2] < ctx.params.MAX_NUM_ITERS + 1
+        # the next update on the same context starts clean
+        a2, b2 = _both(ctx, sc, sc["x_init"], sc["P0"])
+        _agree(a2, b2)
+        assert a2[2] == ctx.params.MAX_NUM_ITERS + 1
+    xo, Po, po, _, _ = oracle.update(sc["x_true"], sc["P0"], sc["map_xyz"], sc["scan_xyz"])
+    assert a[2] == po and np.abs(a[0] - xo).max() < 1e-9
+
+
+def test_passes_without_matches(capi, scene_small):
+    """A scan 500 m from the map: every pass has n_valid = 0 (h_share_model: valid = false -> continue): the state does not
+    move, the covariance returned is the propagated one, all MAX_NUM_ITERS + 1 passes are counted — on both routes."""
+    sc = scene_small
+    far = sc["scan_xyz"][:3000] + np.float32([500.0, 0.0, 0.0])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        a, b = _both(ctx, sc, sc["x_init"], sc["P0"], far)
+        assert a[5]
+    for x, P, p, tr, sums in (a[:5], b):
+        assert p == 4 and [s["n_valid"] for s in sums] == [0] * 4
+        assert np.array_equal(x, sc["x_init"]) and np.array_equal(P, sc["P0"])
+
+
+def test_correlated_covariance_and_resident_filter(capi, scene_small):
+    sc = scene_small
+    rng = np.random.default_rng(3)
+    A = rng.normal(0, 1, (23, 23))
+    P0 = sc["P0"] + 1e-3 * (A @ A.T)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        a, b = _both(ctx, sc, sc["x_init"], P0, sc["scan_xyz"])
+        _agree(a, b)
+        # lv_correct (state resident on the device: a begin kernel installs it, the first launch is "mode 2")
+        res = {}
+        for fused in (True, False):
+            ctx.set_fused_pass(fused)
+            ctx.filter_set(sc["x_init"], P0)
+            p = ctx.correct()
+            assert ctx.last_update_fused() == fused
+            res[fused] = (ctx.filter_get(), p)
+        ctx.set_fused_pass(True)
+    (xf, Pf), pf = res[True]
+    (xt, Pt), pt = res[False]
+    assert pf == pt == a[2]
+    np.testing.assert_allclose(xf, xt, rtol=0, atol=TOL_X)
+    np.testing.assert_allclose(Pf, Pt, rtol=TOL_P_REL, atol=1e-13)   # (small entries are differences of larger ones)
+    np.testing.assert_allclose(xf, a[0], rtol=0, atol=TOL_X)   # lv_correct == lv_update from the same state
+
+
+def test_many_updates_are_bit_reproducible(capi, scene_small):
+    """No atomics on the data path (the queue's slot counter only decides which wavefront serves a point; the bookkeeping
+    workgroup is chosen by last launch's timings but computes what any other would): identical bits run to run."""
+    sc = scene_small
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x0, P0, p0, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+        for _ in range(200):
+            x, P, p, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+            assert p == p0 and np.array_equal(x, x0) and np.array_equal(P, P0)
