@@ -31,17 +31,17 @@ def _both(ctx, sc, x0, P0, scan=None):
     return (xf, Pf, pf, trf, sf, fused), (xt, Pt, pt, trt, st)
 
 
-def _agree(a, b):
+def _agree(a, b, tol_x=TOL_X, tol_p_rel=TOL_P_REL):
     xf, Pf, pf, trf, sf, _ = a
     xt, Pt, pt, trt, st = b
     assert pf == pt
-    np.testing.assert_allclose(xf, xt, rtol=0, atol=TOL_X)
-    np.testing.assert_allclose(Pf, Pt, rtol=TOL_P_REL, atol=1e-13)   # (small entries are differences of larger ones)
+    np.testing.assert_allclose(xf, xt, rtol=0, atol=tol_x)
+    np.testing.assert_allclose(Pf, Pt, rtol=tol_p_rel, atol=1e-13)   # (small entries are differences of larger ones)
     assert [s["n_valid"] for s in sf] == [s["n_valid"] for s in st]
     for u, v in zip(sf, st):
         scale = max(np.abs(v["HTH"]).max(), 1.0)
         assert np.abs(u["HTH"] - v["HTH"]).max() <= 1e-12 * scale
-    np.testing.assert_allclose(np.asarray(trf), np.asarray(trt), rtol=0, atol=1e-11)   # dx_ and the state after every pass
+    np.testing.assert_allclose(np.asarray(trf), np.asarray(trt), rtol=0, atol=10 * tol_x)   # dx_ and the state after every pass
 
 
 @pytest.mark.parametrize("n", [1, 31, 33, 1000, 4096, 8192, 32_640, 32_768, 32_769, 65_280, 65_281, 65_536])
@@ -152,3 +152,17 @@ def test_many_updates_are_bit_reproducible(capi, scene_small):
         for _ in range(200):
             x, P, p, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
             assert p == p0 and np.array_equal(x, x0) and np.array_equal(P, P0)
+
+
+def test_extrinsics_variant(capi, scene_small, monkeypatch):
+    """estimate_extrinsics = true (12-column rows, 92 live sums, 12 x 12 gain blocks): the one-launch form is admitted by
+    LV_FUSED_EXT=1 (off by default: no faster than the three-kernel pass there) and must agree with it."""
+    sc = scene_small
+    monkeypatch.setenv("LV_FUSED_EXT", "1")
+    with capi.Context(capi.default_params(estimate_extrinsics=1)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        a, b = _both(ctx, sc, sc["x_init"], sc["P0"], sc["scan_xyz"])
+        assert a[5]
+        # (the extrinsics are weakly observable from one scan: the 12 x 12 gain blocks amplify the 1e-16 difference of the
+        # summation orders more than the 6 x 6 ones do)
+        _agree(a, b, tol_x=1e-10, tol_p_rel=1e-6)
