@@ -1102,7 +1102,7 @@ __device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& 
         }
         ps_out->x[tid] = v;
         K.x[tid] = v;
-        Bk.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
+        K.xp[tid] = a.mode == 0 ? v : kf->x_prop[tid];
     }
     if (a.mode == 0 && tid >= 128 && tid < 128 + NW32)
         reinterpret_cast<uint32_t*>(&kf->pose)[tid - 128] = reinterpret_cast<const uint32_t*>(&begin.pose)[tid - 128];
@@ -1118,7 +1118,8 @@ __device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& 
         ps_out->iter = -1;
         ps_out->passes = 0;
     }
-    prepare_next<W, T>(Bk, ps_out, K.x, a.sp.R_inv, tid, bar, clk);   // (its first barrier publishes K.x / Bk.B / Bk.xp)
+    bar();   // K.x / K.xp are read by other wavefronts next
+    prepare_next<W, T>(Bk, ps_out, K.x, K.xp, a.sp.R_inv, tid, bar, clk);
 }
 
 // CLOSING: the closing launch of an update as its own (search-free) kernel: the solve of the last pass and the terminal

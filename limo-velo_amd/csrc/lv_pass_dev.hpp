@@ -132,19 +132,12 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     if (tid >= 128 && tid < 128 + NW * NW) L.G[(tid - 128) / NW][(tid - 128) % NW] = in->prep_A1[tid - 128];
     if (tid < SUMS_LEN) L.rec[tid] = 0.0;
     if (tid == 448) { L.kf_t = in->t; L.kf_iter = in->iter; L.pass = in->passes; L.done = kf->done; L.conv = 1; L.last = 0; L.n_valid0 = 0; }
-    if (tid >= 960) {   // the last wavefront: argmin of the previous launch's workgroup times (key = time << 10 | 1023 - index)
-        const int ln = tid - 960;
-        unsigned long long best = ~0ull;
-        for (int w = ln; w < ncost; w += 64) {
-            const unsigned long long key = ((unsigned long long)cost_in[w] << 16) | (unsigned long long)(65535 - w);
-            best = key < best ? key : best;
-        }
+    // the previous launch's workgroup times: loaded with everything else (one round trip for up to 512 workgroups; more are
+    // simply never chosen), reduced by the last wavefront AFTER the fold's barrier, beside the solve chain
+    uint32_t cv[8];
+    if (tid >= 960) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const unsigned long long o = (unsigned long long)__shfl_xor((long long)best, m);
-            best = o < best ? o : best;
-        }
-        if (ln == 0) L.cheapest = (cost_in && ncost > 0) ? 65535 - (int)(best & 0xFFFFull) : -1;
+        for (int u = 0; u < 8; ++u) cv[u] = (tid - 960 + 64 * u < ncost) ? cost_in[tid - 960 + 64 * u] : 0xFFFFFFFFu;
     }
     // ---- fold, fixed order: thread (fo, fpart) sums records fpart, fpart + PARTS, ... (four interleaved running sums),
     // the PARTS part sums are then added left to right
@@ -160,6 +153,22 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     __syncthreads();
     if (L.done) return false;   // (the loads above were issued before this word was known: one round trip, not two)
     if (clk && tid == 0) { clk[1] = clock64(); clk[17] = wall_clock64(); }
+    if (tid >= 960) {   // argmin of the workgroup times (key = time << 16 | 65535 - index: ties go to the highest index)
+        const int ln = tid - 960;
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = ln + 64 * u;
+            const unsigned long long key = w < ncost ? (((unsigned long long)cv[u] << 16) | (unsigned long long)(65535 - w)) : ~0ull;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_xor((long long)best, m);
+            best = o < best ? o : best;
+        }
+        if (ln == 0) L.cheapest = (cost_in && ncost > 0) ? 65535 - (int)(best & 0xFFFFull) : -1;
+    }
     if (tid < NOUT) {
         double s = L.part[tid];
 #pragma unroll
@@ -298,17 +307,25 @@ __device__ inline void gj_spd_bar(double (*W)[12][13], int& cur, int tid, Bar& b
 // pass is evaluated at (LDS).  The caller's threads have stored the propagated covariance in Bk.B and the propagated
 // state in Bk.xp (no barrier needed in between).
 template <int NW, int T, class Bar>
-__device__ inline void prepare_next(BookLds& Bk, KfDev::PassState* __restrict__ out, const double* x, double R_inv, int tid, Bar& bar,
-                                    long long* clk) {
+__device__ inline void prepare_next(BookLds& Bk, KfDev::PassState* __restrict__ out, const double* x, const double* xprop, double R_inv,
+                                    int tid, Bar& bar, long long* clk) {
+    // x / xprop: LDS, published before the call (a barrier lies between their last write and this call); Bk.B = P_prop:
+    // written by the caller's threads right before the call (the first barrier below publishes it)
     const int wave = tid >> 6, lane = tid & 63;
-    set_identity<T>(Bk.J, tid);
-    bar();
+    // J = identity outside the three manifold blocks; those are written by manifold_block below: disjoint, no barrier needed
+    for (int e = tid; e < NS * NS; e += T) {
+        const int i = e / NS, j = e % NS;
+        int bi, ni, bj, nj;
+        blk_range(i, bi, ni);
+        blk_range(j, bj, nj);
+        if (!(ni > 1 && bi == bj)) Bk.J[i][j] = (i == j) ? 1.0 : 0.0;
+    }
     if (clk && tid == 0) { clk[11] = clock64(); clk[27] = wall_clock64(); }
-    if (wave < 3 && lane == 0) manifold_block(wave, 0, x, Bk.xp, nullptr, Bk.dx, Bk.J);
+    if (wave < 3 && lane == 0) manifold_block(wave, 0, x, xprop, nullptr, Bk.dx, Bk.J);
     if (wave == 3 && lane < 15) {
         const int dof = lane < 3 ? lane : lane + 6;  // 0..2, 9..20
         const int si = vect_state_index(dof);
-        Bk.dx[dof] = x[si] - Bk.xp[si];
+        Bk.dx[dof] = x[si] - xprop[si];
     }
     bar();
     if (clk && tid == 0) { clk[12] = clock64(); clk[28] = wall_clock64(); }
@@ -322,10 +339,18 @@ __device__ inline void prepare_next(BookLds& Bk, KfDev::PassState* __restrict__ 
     }
     congruence<T>(Bk.P, Bk.J, Bk.B, tid);  // P_ = J P_prop J^T
     bar();
+    if (clk && tid == 0) { clk[13] = clock64(); clk[29] = wall_clock64(); }
     for (int e = tid; e < NS * NS; e += T) out->prep_P[e] = Bk.P[e / NS][e % NS];
+    if (NW == 6) {   // A1 = (P_/R)_ww^-1 straight from P_ in the registers of one wavefront
+        if (tid < 64) {
+            const int l = tid < 36 ? tid : 35;
+            const double w = gj6_in_lanes(Bk.P[l / 6][l % 6] * R_inv, tid);
+            if (tid < 36) out->prep_A1[tid] = w;
+        }
+        return;
+    }
     if (tid < NW * NW) Bk.W[0][tid / NW][tid % NW] = Bk.P[tid / NW][tid % NW] * R_inv;
     bar();
-    if (clk && tid == 0) { clk[13] = clock64(); clk[29] = wall_clock64(); }
     int cur = 0;
     gj_spd_bar<NW>(Bk.W, cur, tid, bar);
     if (tid < NW * NW) out->prep_A1[tid] = Bk.W[cur][tid / NW][tid % NW];
@@ -373,8 +398,7 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
     }
     if (!last) {
         for (int e = tid; e < NS * NS; e += T) Bk.B[e / NS][e % NS] = Pprop[e];
-        if (tid < NX) Bk.xp[tid] = xprop[tid];
-        prepare_next<NW, T>(Bk, out, K.x, prm.R_inv, tid, bar, clk);
+        prepare_next<NW, T>(Bk, out, K.x, xprop, prm.R_inv, tid, bar, clk);
         return;
     }
     if (tid < NX) LV_IO_STORE(&io->x[tid], K.x[tid]);
