@@ -71,7 +71,7 @@ struct lv_ctx {
     long long* d_pclk = nullptr;   // LV_PASS_CLK=1: phase stamps of pass_kernel's workgroups (lv_get_pass_clocks)
     int pclk_wg = 0;
     bool keeper_by_cost = true;       // LV_KEEPER_BY_COST=0: the last searching workgroup always keeps the books (A/B knob)
-    bool fused_multi_round = false;   // LV_FUSED_MULTI=1: pass_kernel also for scans that need several rounds per workgroup
+    bool fused_multi_round = false;   // LV_FUSED_MULTI=1: pass_kernel also for scans that need more than two rounds per workgroup
     bool fused_ext = false;        // LV_FUSED_EXT=1: pass_kernel also with estimate_extrinsics (12-column rows: 3 waves per SIMD only)
 
     // capture (debug / API-parity) buffers, sized for the current scan
@@ -287,11 +287,12 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 // One launch per pass (pass_kernel) applies to the plain single-GPU update: no capture / phase clocks, no
 // communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
 bool pass_fused_applies(const lv_ctx* c) {
-    // (scans of more than one round per workgroup — beyond 64 points per wavefront slot of the chip — stay with the
-    // three-kernel pass: pass_kernel would idle twelve of sixteen wavefronts during every round's plane fits)
+    // (scans of more than two rounds per workgroup — beyond 131 072 points on a 256-CU part — stay with the three-kernel
+    // pass: pass_kernel idles twelve of sixteen wavefronts during every round's plane fits; measured: 131 072 points 223 vs
+    // 233 us per update, 262 144 points 371 vs 354)
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
-    if (rounds > 1 && !c->fused_multi_round) return false;
+    if (rounds > 2 && !c->fused_multi_round) return false;
     return c->fused_pass && !c->capture && !c->phase_clocks && c->comm == nullptr && c->prm.degeneracy_mode == 0 &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->scan.n > 0 && c->map.view.m > 0;
 }

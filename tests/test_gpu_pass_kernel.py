@@ -44,14 +44,15 @@ def _agree(a, b, tol_x=TOL_X, tol_p_rel=TOL_P_REL):
     np.testing.assert_allclose(np.asarray(trf), np.asarray(trt), rtol=0, atol=10 * tol_x)   # dx_ and the state after every pass
 
 
-@pytest.mark.parametrize("n", [1, 31, 33, 1000, 4096, 8192, 32_640, 32_768, 32_769, 65_280, 65_281, 65_536])
+@pytest.mark.parametrize("n", [1, 31, 33, 1000, 4096, 8192, 32_640, 32_768, 32_769, 65_280, 65_281, 65_536, 65_537, 100_000, 131_072])
 def test_geometries_match_the_three_kernel_pass(capi, lv, n):
     """n crosses pass_grid_size's cases on a 256-CU part: <= 1024 tiles of 32 points: one search step (32 768 points fill
     every CU: the bookkeeper searches too; below that a dedicated one); up to 2040 tiles: two steps + dedicated bookkeeper;
-    2041..2048 tiles: every CU searches, the books follow the bookkeeper's fits."""
+    2041..2048 tiles: every CU searches, the books follow the bookkeeper's fits; up to 4096 tiles: two rounds per workgroup
+    (the records and the candidate stage are reused, the fit wavefronts accumulate across the rounds)."""
     from limo_velo_amd import synth
 
-    sc = synth.make_scene(300_000, 65_536)
+    sc = synth.make_scene(300_000, 131_072)
     with capi.Context() as ctx:
         ctx.map_build(sc["map_xyz"])
         a, b = _both(ctx, sc, sc["x_init"], sc["P0"], sc["scan_xyz"][:n])
@@ -62,12 +63,12 @@ def test_geometries_match_the_three_kernel_pass(capi, lv, n):
 def test_larger_scans_take_the_three_kernel_pass(capi, lv):
     from limo_velo_amd import synth
 
-    sc = synth.make_scene(300_000, 70_000)
+    sc = synth.make_scene(300_000, 140_000)
     with capi.Context() as ctx:
         ctx.map_build(sc["map_xyz"])
         ctx.scan_set(sc["scan_xyz"])
         ctx.update(sc["x_init"], sc["P0"])
-        assert not ctx.last_update_fused()   # several rounds per workgroup: pass_kernel would idle during every round's fits
+        assert not ctx.last_update_fused()   # three rounds per workgroup: pass_kernel would idle during every round's fits
 
 
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
