@@ -127,6 +127,7 @@ def main() -> None:
     ap.add_argument("--extrinsics", action="store_true", help="estimate_extrinsics = true (12 live Jacobian columns; not the headline config)")
     ap.add_argument("--rotate", type=int, default=16, help="cold-cache leg (N=1): cycle this many distinct scans / poses of the same map (their "
                     "neighbourhood buckets together exceed the 256 MB Infinity Cache); 0 = skip")
+    ap.add_argument("--no-phases", action="store_true", help="skip the in-kernel phase stamps leg (N=1, one launch per pass)")
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     args = ap.parse_args()
 
@@ -253,6 +254,31 @@ def main() -> None:
                 "achieved": b_alg(M_POINTS) * N_POINTS / cold_s / 1e9 if cold_s > 0 else 0.0,
                 "first_pass_us": c_first / max(c_upd, 1) * 1e3, "later_pass_us": c_rest / max(c_cnt - c_upd, 1) * 1e3}
         cold["frac"] = cold["achieved"] / HBM_PEAK_GBS
+    # ---- inside the dominant kernel (one launch per pass only): wall-clock stamps of pass_kernel's phases, taken by a
+    # SECOND context created with LV_PASS_CLK=1 (the timed context above carries no instrumentation): how long the search
+    # phase of a launch lasts (prologue end -> the workgroup's search barrier, median over the workgroups), per launch
+    phases = None
+    if world == 1 and ctx.last_update_fused() and not args.no_phases:
+        os.environ["LV_PASS_CLK"] = "1"
+        try:
+            with capi.Context(prm, device=local_rank) as c2:
+                c2.map_build(sc["map_xyz"])
+                c2.scan_set(sc["scan_xyz"])
+                acc = []
+                for i in range(25):
+                    c2.update(sc["x_init"], sc["P0"], want_trace=False)
+                    if i >= 5:
+                        clk, nwg_c = c2.pass_clocks()
+                        w = clk[:, :nwg_c, 16:].astype(np.float64) / 100.0          # wall clock, us (100 MHz)
+                        acc.append([[np.median(w[li, :, 3] - w[li, :, 0]), np.median(w[li, :, 6] - w[li, :, 3]),
+                                     np.median(w[li, :, 9] - w[li, :, 6]), w[li, :, 9].max() - w[li, :, 0].min()]
+                                    for li in range(clk.shape[0] - 1)])
+                m = np.median(np.array(acc), axis=0)
+                phases = {"per_launch_us": {"prologue": [round(v, 2) for v in m[:, 0]], "search": [round(v, 2) for v in m[:, 1]],
+                                            "fit_and_partial": [round(v, 2) for v in m[:, 2]], "span": [round(v, 2) for v in m[:, 3]]},
+                          "note": "medians over the workgroups (span: first start -> last search/fit end) and over 20 updates; wall clock inside the kernel"}
+        finally:
+            del os.environ["LV_PASS_CLK"]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,6 +338,15 @@ def main() -> None:
                 # the same kernel priced with the PMC-measured bytes instead of the algorithmic ones
                 "measured_traffic_gbs": (pmc_traffic_bytes(kname)[0] / avg_kernel_s / 1e9) if (world == 1 and pmc_traffic_bytes(kname)[0] and avg_kernel_s > 0) else None,
                 "cold": cold,
+                # inside pass_kernel (in-kernel wall-clock stamps, separate instrumented context): the search phase alone —
+                # what round 1's search_kernel figure measured, minus launch ramp and the record stores that no longer exist
+                "pass_kernel_phases": phases,
+                "search_phase": None if not phases else {
+                    "us_converged": phases["per_launch_us"]["search"][-1],
+                    "alg_gbs": alg_bytes / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9,
+                    "alg_frac": alg_bytes / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "traffic_gbs": (pmc_traffic_bytes(kname)[0] / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9) if pmc_traffic_bytes(kname)[0] else None,
+                },
             },
             "fallback": ctx.timing()["fallback_queries"],
             "state_check": {"pos_err_m": float(np.linalg.norm(x[:3] - sc["x_true"][:3]))},
