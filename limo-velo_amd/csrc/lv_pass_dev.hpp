@@ -7,10 +7,11 @@
 // solve -> search) and the single-workgroup solve kernel's launch ramp; it costs every workgroup the
 // solve's ~5 us latency chain once, at a time when the GPU would otherwise idle behind that chain anyway.
 // All workgroups execute the same instructions on the same inputs, so they derive bit-identical states and
-// pass constants (no broadcast, no inter-workgroup wait).  One workgroup (the one with the lightest search
-// share) also keeps the books AFTER its own search and fits: state / trace / sums log in KfDev, the
-// record-independent half of the NEXT solve (prepare), and on the pass that ends the update the posterior
-// covariance and the host mailbox.  What a launch hands to the next one lives in KfDev::ps[launch parity].
+// pass constants (no broadcast, no inter-workgroup wait).  One workgroup also keeps the books — a dedicated
+// one when the scan leaves a CU free, otherwise the searching workgroup that was quickest in the previous
+// launch, AFTER its own search and fits: state / trace / sums log in KfDev, the record-independent half of
+// the NEXT solve (prepare_next), and on the pass that ends the update the posterior covariance and the host
+// mailbox.  What a launch hands to the next one lives in KfDev::ps[launch parity].
 //
 // Same algebra as solve_kernel / solve_prep (lv_solve.hip, lv_solve_dev.hpp):
 // esekf::update_iterated_dyn_share_modified [IKFoM absent from the reference mount; UPSTREAM-RECALL of
