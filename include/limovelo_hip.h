@@ -311,6 +311,11 @@ int lv_fetch_neighbors(lv_ctx* ctx, float* nbr_xyz, float* d2, float* p_world, i
  * lv_update / lv_correct took the one-launch-per-pass route, 0 if the three-kernel pass (search / fit / solve). */
 int lv_set_record_dump(lv_ctx* ctx, int enabled);
 int lv_last_update_fused(lv_ctx* ctx);
+/* Geometry of the one-launch-per-pass kernel for an n_scan-point scan on a part with n_cus compute units (pure host
+ * logic, no GPU needed): out = {searching workgroups, search steps per round (1 or 2), rounds per workgroup,
+ * 1 if one more workgroup only keeps the books (a CU is left over) else 0}.  A workgroup searches 4 tiles of 32 points
+ * per step; lv_update takes this route up to 2 rounds. */
+int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]);
 /* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);
 /* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): for every launch of the last update

@@ -879,6 +879,12 @@ int lv_set_record_dump(lv_ctx* c, int enabled) {
 
 int lv_last_update_fused(lv_ctx* c) { return (c && c->last_update_fused) ? 1 : 0; }
 
+int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]) {
+    if (!out || n_cus < 1 || n_scan > 0xFFFFFFF0ull) { set_error("lv_pass_geometry: bad arguments"); return LV_EINVAL; }
+    pass_grid_size((uint32_t)n_scan, n_cus, &out[0], &out[1], &out[2], &out[3]);
+    return LV_OK;
+}
+
 int lv_set_fused_pass(lv_ctx* c, int enabled) {
     LV_CHECK_CTX(c);
     c->fused_pass = enabled != 0;

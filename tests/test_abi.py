@@ -105,3 +105,27 @@ def test_cpp_shim_builds_with_reference_method_names(capi):
                  "Localizator::correct(", "Localizator::calculate_H(", "Localizator::latest_state()",
                  "Localizator::propagate_to(", "Localizator::propagate(", "Compensator::compensate(", "State::operator+=("):
         assert name in syms, name
+
+
+def test_pass_kernel_geometry_policy(capi):
+    """pass_grid_size (host logic of the one-launch-per-pass kernel): every 32-point tile of the scan has exactly one owner
+    slot, never more searching workgroups than CUs, one search step while a step per workgroup covers the scan, a dedicated
+    bookkeeping workgroup exactly when a CU is left over, and the sizes at which lv_update switches routes."""
+    for cus in (8, 64, 256, 304):
+        for n in list(range(1, 300, 7)) + [1000, 4096, 32 * 4 * cus - 1, 32 * 4 * cus, 32 * 4 * cus + 1, 32 * 8 * (cus - 1), 32 * 8 * (cus - 1) + 1,
+                                            32 * 8 * cus, 32 * 8 * cus + 1, 32 * 16 * cus, 32 * 16 * cus + 1, 1_000_000]:
+            g, steps, rounds, ded = capi.pass_geometry(n, cus)
+            tiles = (n + 31) // 32
+            assert 1 <= g <= cus and steps in (1, 2) and rounds >= 1 and ded in (0, 1)
+            assert g * 4 * steps * rounds >= tiles                       # every tile has a slot ...
+            assert g * 4 * steps * (rounds - 1) < tiles                   # ... and no round is empty
+            if rounds == 1:
+                assert (g - 1) * 4 * steps < tiles                        # no workgroup without a tile
+            assert (steps == 1) == (tiles <= 4 * cus)
+            assert ded == (1 if g < cus else 0)
+            assert g + ded <= cus                                        # everything resident at once: one workgroup per CU
+    assert capi.pass_geometry(65_536, 256) == (256, 2, 1, 0)             # the headline: every CU searches, the books follow the fits
+    assert capi.pass_geometry(65_280, 256) == (255, 2, 1, 1)
+    assert capi.pass_geometry(32_768, 256) == (256, 1, 1, 0)
+    assert capi.pass_geometry(8_192, 256) == (64, 1, 1, 1)
+    assert capi.pass_geometry(131_072, 256)[2] == 2 and capi.pass_geometry(131_073, 256)[2] == 3
