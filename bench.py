@@ -11,8 +11,10 @@ A "step" = one full iterated update (lv_update: up to 4 passes of world transfor
 plane fit -> Jacobian row -> H^T H / H^T h reduction -> 23-dof solve), with map and scan already
 resident in HBM.  value = measurement passes per second over the whole job.
 
-N > 1: the scan's points are sharded contiguously across ranks (map replicated); every pass
-all-reduces the 96-double sums record over RCCL/xGMI; total work is fixed => "scaling": "strong".
+N > 1: the scan's points are sharded contiguously across ranks (map replicated); every pass ends in ONE
+collective over RCCL/xGMI issued by the library on its stream — the all-gather of every rank's workgroup
+partials (one launch per pass; every rank folds them itself), or, if that form fails its start-up self-check,
+the all-reduce of the 96-double sums record (three-kernel pass); total work is fixed => "scaling": "strong".
 """
 from __future__ import annotations
 
@@ -194,6 +196,35 @@ def main() -> None:
     upd = ShardedUpdater(engine, rank, world, dist, torch)
     upd.scan_set(sc["scan_xyz"])
     n_local = upd.n_local
+    if collective.startswith("rccl (library"):
+        # With the library's communicator a pass is ONE launch + ONE collective: every rank's workgroup partials are
+        # all-gathered (in place, on the context stream) and every rank's next launch folds them itself.  Checked here, on
+        # the ranks this run really has, against the three-kernel form (search / fit / reduce -> all-reduce -> solve): any
+        # rank that fails, or disagrees, sends every rank back to the three-kernel form.
+        from limo_velo_amd.distributed import shard_bounds
+
+        lo0, hi0 = shard_bounds(N_POINTS, 0, world)
+        ok = 1
+        try:
+            ctx.comm_set_shard_max(hi0 - lo0)
+            xa, Pa, pa = upd.update(sc["x_init"], sc["P0"])
+            took = ctx.last_update_fused()
+            ctx.set_comm_fused(False)
+            xb, Pb, pb = upd.update(sc["x_init"], sc["P0"])
+            ctx.set_comm_fused(True)
+            ok = int(bool(took) and pa == pb and np.abs(xa - xb).max() < 1e-9 and np.abs(Pa - Pb).max() < 1e-9)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] all-gather form failed on rank {rank}: {e}", file=sys.stderr)
+            ok = 0
+        if dist is not None:
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            collective += ": one launch per pass, ncclAllGather of the workgroup partials"
+        else:
+            ctx.set_comm_fused(False)
+            collective += ": three-kernel pass, ncclAllReduce of the 96-double record (the all-gather form failed its self-check)"
 
     def barrier_sync():
         ctx.synchronize()
@@ -310,7 +341,7 @@ def main() -> None:
                 "workload": "iterated KF update: 65536-pt scan vs 1048576-pt map, k=5, MAX_NUM_ITERS=3 (4 passes/update)",
                 "passes_per_update": total_passes / args.steps,
                 "points_per_gpu": n_local,
-                "parallelism": f"scan points sharded x{world}, map replicated, 768 B all-reduce per pass" if world > 1 else "1 GPU",
+                "parallelism": f"scan points sharded x{world}, map replicated, one collective per pass (see collective)" if world > 1 else "1 GPU",
                 "collective": collective,
                 "estimate_extrinsics": bool(prm.estimate_extrinsics),
                 "lanes_per_query": prm.lanes_per_query,

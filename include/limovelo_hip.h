@@ -289,6 +289,15 @@ int lv_comm_unique_id(const char* rccl_library, void* id128);
 int lv_comm_init(lv_ctx* ctx, const char* rccl_library, const void* id128, int rank, int world);
 int lv_comm_destroy(lv_ctx* ctx);
 int lv_comm_world(lv_ctx* ctx);
+/* With a communicator lv_update / lv_correct run a pass as search / fit / reduce -> ncclAllReduce -> solve (three kernels
+ * and a collective).  If the caller tells the LARGEST shard of the current scan over the ranks — n_max, the same value on
+ * every rank, after every lv_scan_set* (which forgets it) — they take the one-launch-per-pass form instead: every rank
+ * launches the same grid (sized for n_max), leaves its workgroup partials in its slot of a gather buffer, ncclAllGather
+ * (in place, on the context stream) hands every rank all partials, and the next launch's prologue folds them in the same
+ * fixed order on every rank: identical states without a broadcast, one launch + one collective per pass.
+ * lv_set_comm_fused(ctx, 0) (or LV_COMM_FUSED=0) keeps the three-kernel form. */
+int lv_comm_set_shard_max(lv_ctx* ctx, size_t n_max);
+int lv_set_comm_fused(lv_ctx* ctx, int enabled);
 
 /* ---- API-parity / debug fetches (results of the most recent CAPTURED pass; original scan order) --
  * lv_iterate always captures; lv_update captures only after lv_set_capture(ctx, 1) (the last pass

@@ -63,6 +63,11 @@ struct lv_ctx {
     uint32_t qstride = 0;
     // one launch per pass (pass_kernel, lv_pass_dev.hpp): compact workgroup partials, ping-pong by pass parity
     double* d_cpart[2] = {nullptr, nullptr};
+    // multi-GPU form of the one-launch-per-pass update: every rank's partials gathered on every rank (ncclAllGather, in place)
+    double* d_gather[2] = {nullptr, nullptr};
+    size_t gather_cap = 0;            // doubles per buffer
+    size_t comm_shard_max = 0;        // largest shard of the CURRENT scan over the ranks (lv_comm_set_shard_max); 0: unknown
+    bool comm_fused = true;           // lv_set_comm_fused / LV_COMM_FUSED=0: always the three-kernel pass + all-reduce with a communicator
     uint32_t* d_wgcost[2] = {nullptr, nullptr};   // per searching workgroup: how long its search + fits took (picks the next bookkeeper)
     int pass_max_wg = 256;         // search workgroups of pass_kernel: all resident at once (one 1024-thread workgroup per CU)
     bool fused_pass = true;        // LV_FUSED_PASS=0: the three-kernel pass (search / fit / solve) also where pass_kernel applies
@@ -286,15 +291,29 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 
 // One launch per pass (pass_kernel) applies to the plain single-GPU update: no capture / phase clocks, no
 // communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
+// the scan size that fixes pass_kernel's geometry: the local scan, or with a communicator the largest shard over the ranks
+// (every rank launches the same grid; workgroups without a tile contribute zero partials)
+uint32_t pass_geometry_points(const lv_ctx* c) { return c->comm ? (uint32_t)c->comm_shard_max : c->scan.n; }
+
 bool pass_fused_applies(const lv_ctx* c) {
     // (scans of more than two rounds per workgroup — beyond 131 072 points on a 256-CU part — stay with the three-kernel
     // pass: pass_kernel idles twelve of sixteen wavefronts during every round's plane fits; measured: 131 072 points 223 vs
     // 233 us per update, 262 144 points 371 vs 354)
+    if (c->comm) {
+        // with a communicator: the caller has told the largest shard of this scan (lv_comm_set_shard_max), librccl has
+        // ncclAllGather, the gather buffers are in place; a rank without points still runs every launch
+        if (!c->comm_fused || c->comm_shard_max == 0 || c->scan.n > c->comm_shard_max || !comm_has_allgather() || !c->d_gather[0] ||
+            c->prm.estimate_extrinsics)
+            return false;
+    } else if (c->scan.n == 0) {
+        return false;
+    }
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
-    pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
+    pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     if (rounds > 2 && !c->fused_multi_round) return false;
-    return c->fused_pass && !c->capture && !c->phase_clocks && c->comm == nullptr && c->prm.degeneracy_mode == 0 &&
-           c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->scan.n > 0 && c->map.view.m > 0;
+    if (c->comm && (size_t)nwg * (size_t)c->comm_world * 32u > c->gather_cap) return false;
+    return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 &&
+           c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;
 }
 
 // The whole iterated update as npass + 1 launches: launch i = [solve of pass i-1 in every workgroup] + pass i, the
@@ -323,7 +342,9 @@ int update_fused(lv_ctx* c) {
     pl.sp.degeneracy_mode = 0;
     pl.sp.degeneracy_threshold = c->prm.degeneracy_threshold;
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
-    pass_grid_size(c->scan.n, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
+    pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
+    const bool gathered = c->comm != nullptr;                 // multi-GPU: the partials of all ranks, gathered after every launch
+    const size_t slot = (size_t)nwg * 32u;                    // doubles per rank in the gather buffers (compact records, 6-column case)
     pl.qrec = c->record_dump ? c->d_qrec : nullptr;
     c->pclk_wg = nwg + dedicated;   // (the last slot is the bookkeeping workgroup either way)
     pl.qstride = c->qstride;
@@ -332,9 +353,9 @@ int update_fused(lv_ctx* c) {
     for (int i = 0; i <= npass; ++i) {
         const bool closing = i == npass;
         pl.mode = i == 0 ? (c->begin_pending ? 0 : 2) : 1;
-        pl.recs_in = c->d_cpart[(i + 1) & 1];
-        pl.part_out = c->d_cpart[i & 1];
-        pl.nrec = nwg;
+        pl.recs_in = gathered ? c->d_gather[(i + 1) & 1] : c->d_cpart[(i + 1) & 1];
+        pl.part_out = gathered ? c->d_gather[i & 1] + (size_t)c->comm_rank * slot : c->d_cpart[i & 1];
+        pl.nrec = gathered ? nwg * c->comm_world : nwg;
         pl.cost_in = (i > 0 && c->keeper_by_cost) ? c->d_wgcost[(i + 1) & 1] : nullptr;
         pl.cost_out = c->d_wgcost[i & 1];
         pl.nwg = nwg;
@@ -347,6 +368,10 @@ int update_fused(lv_ctx* c) {
         int rc = launch_pass(c->stream, pl, (i == 0 && c->begin_pending) ? &c->h_begin : nullptr);
         c->begin_pending = false;
         if (rc) return rc;
+        if (gathered && !closing) {
+            rc = comm_allgather_inplace(c->comm, c->d_gather[i & 1], slot, c->comm_rank, c->stream);
+            if (rc) return rc;
+        }
         if (c->profiling && !closing) {
             LV_HIP(hipEventRecord(c->ev_pass[3 * i + 1], c->stream));
             LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
@@ -419,6 +444,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0;
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
+    if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
     if (const char* e = getenv("LV_PASS_CLK")) {
         if (atoi(e) != 0) {
             const size_t words = (size_t)(MAX_PASSES + 1) * (c->pass_max_wg + 1) * pass_clock_words();   // per launch of an update
@@ -478,6 +504,7 @@ void lv_destroy(lv_ctx* c) {
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
     hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk); hipFree(c->d_wgcost[0]); hipFree(c->d_wgcost[1]);
+    hipFree(c->d_gather[0]); hipFree(c->d_gather[1]);
     hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
@@ -661,6 +688,7 @@ int lv_scan_set(lv_ctx* c, const void* points, size_t stride, size_t n) {
         if (z < bmin[2]) bmin[2] = z;
     }
     c->scan.n = (uint32_t)n;
+    c->comm_shard_max = 0;   // (a new scan: the caller tells its largest shard again)
     c->dbg_valid = false;
     c->qrec_valid = false;
     if (n == 0) return LV_OK;
@@ -678,6 +706,7 @@ int lv_scan_deskew(lv_ctx* c, const void* points, size_t stride, size_t time_off
     c->dbg_valid = false;
     c->qrec_valid = false;
     c->scan.n = 0;
+    c->comm_shard_max = 0;
     if (n == 0) return LV_OK;
     int rc = ensure_stage(c, n + (n + 1) / 2);  // float4 xyz + packed doubles behind them
     if (rc) return rc;
@@ -708,6 +737,7 @@ int lv_scan_downsample(lv_ctx* c, const void* points, size_t stride, size_t n, f
     c->dbg_valid = false;
     c->qrec_valid = false;
     c->scan.n = 0;
+    c->comm_shard_max = 0;
     if (n == 0) return LV_OK;
     int rc = ensure_stage(c, n);
     if (rc) return rc;
@@ -835,6 +865,7 @@ int lv_scan_deskew_window(lv_ctx* c, double t1, double t2, const lv_motion_state
     c->dbg_valid = false;
     c->qrec_valid = false;
     c->scan.n = 0;
+    c->comm_shard_max = 0;
     uint32_t lo = 0, hi = 0;
     int rc = c->cloud.window(c->stream, t1, t2, &lo, &hi);
     if (rc) return rc;
@@ -970,6 +1001,37 @@ int lv_comm_destroy(lv_ctx* c) {
 }
 
 int lv_comm_world(lv_ctx* c) { return c ? c->comm_world : 0; }
+
+int lv_comm_set_shard_max(lv_ctx* c, size_t n_max) {
+    LV_CHECK_CTX(c);
+    if (c->in_update) { set_error("lv_comm_set_shard_max inside an update"); return LV_ESTATE; }
+    if (n_max > 0xFFFFFFF0ull) { set_error("shard too large"); return LV_EINVAL; }
+    c->comm_shard_max = n_max;
+    if (!c->comm || n_max == 0) return LV_OK;
+    int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
+    pass_grid_size((uint32_t)n_max, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
+    const size_t need = (size_t)nwg * 32u * (size_t)c->comm_world;
+    if (need > c->gather_cap) {
+        LV_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 2; ++i) {
+            hipFree(c->d_gather[i]);
+            c->d_gather[i] = nullptr;
+        }
+        c->gather_cap = 0;
+        for (int i = 0; i < 2; ++i) {
+            LV_HIP(hipMalloc(&c->d_gather[i], need * sizeof(double)));
+            LV_HIP(hipMemset(c->d_gather[i], 0, need * sizeof(double)));
+        }
+        c->gather_cap = need;
+    }
+    return LV_OK;
+}
+
+int lv_set_comm_fused(lv_ctx* c, int enabled) {
+    LV_CHECK_CTX(c);
+    c->comm_fused = enabled != 0;
+    return LV_OK;
+}
 
 void* lv_sums_device_ptr(lv_ctx* c) { return c ? (void*)c->d_sums : nullptr; }
 

@@ -21,6 +21,7 @@ struct RcclApi {
     int (*GetUniqueId)(void* id) = nullptr;
     int (*CommInitRank)(void** comm, int nranks, UniqueId128 id, int rank) = nullptr;  // id by value (128-byte struct)
     int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t sendcount, int dtype, void* comm, hipStream_t stream) = nullptr;   // optional
     int (*CommDestroy)(void* comm) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     char path[1024] = {0};
@@ -46,6 +47,7 @@ int bind_rccl(const char* library) {
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) {
@@ -91,6 +93,18 @@ int comm_destroy(void* comm) {
 int comm_allreduce_record(void* comm, double* record, hipStream_t stream) {
     const int e = g_rccl.AllReduce(record, record, (size_t)SUMS_LEN, kNcclFloat64, kNcclSum, comm, stream);
     if (e) { set_error("ncclAllReduce: %s", rccl_error(e)); return LV_EHIP; }
+    return LV_OK;
+}
+
+// The one-launch-per-pass form of the multi-GPU update: every rank's pass_kernel leaves its workgroup partials in ITS slot
+// of `buf` (world slots of count_per_rank doubles); this gathers all slots on every rank, in place, ordered on `stream`.
+// Every rank's next launch then folds all ranks' partials itself, in the same fixed order: identical states without a
+// broadcast, and no reduce / solve kernels between the passes.
+bool comm_has_allgather() { return g_rccl.AllGather != nullptr; }
+int comm_allgather_inplace(void* comm, double* buf, size_t count_per_rank, int rank, hipStream_t stream) {
+    if (!g_rccl.AllGather) { set_error("librccl does not export ncclAllGather"); return LV_ENODEV; }
+    const int e = g_rccl.AllGather(buf + (size_t)rank * count_per_rank, buf, count_per_rank, kNcclFloat64, comm, stream);
+    if (e) { set_error("ncclAllGather: %s", rccl_error(e)); return LV_EHIP; }
     return LV_OK;
 }
 

@@ -152,6 +152,8 @@ int comm_unique_id(const char* library, void* id128);
 int comm_init(const char* library, const void* id128, int rank, int world, void** comm_out);
 int comm_destroy(void* comm);
 int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
+bool comm_has_allgather();
+int comm_allgather_inplace(void* comm, double* buf, size_t count_per_rank, int rank, hipStream_t stream);
 
 // lv_match.hip
 // search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries);

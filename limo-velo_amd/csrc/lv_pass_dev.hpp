@@ -116,7 +116,8 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     constexpr int T = PK_THREADS;
     constexpr int OW = PassDims<NW>::OW, NOUT = PassDims<NW>::NOUT;
     constexpr int PARTS = T / OW;                 // 32 / 10
-    constexpr int DEPTH = NW == 6 ? 8 : 28;       // records per thread issued in one memory round trip (x PARTS >= 256 workgroups)
+    constexpr int DEPTH = NW == 6 ? 16 : 28;      // records per thread issued in one memory round trip: x PARTS = 512 records (one
+                                                  // per CU on one GPU; all ranks' workgroups in the multi-GPU form), more in further trips
     const int wave = tid >> 6, lane = tid & 63;
     const int fo = tid % OW, fpart = tid / OW;
     // ---- every global read up front (one memory round trip)

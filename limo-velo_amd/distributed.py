@@ -123,6 +123,11 @@ class ShardedUpdater:
         lo, hi = shard_bounds(len(scan_xyz), self.rank, self.world)
         self.n_local = hi - lo
         self.engine.scan_set(scan_xyz[lo:hi])
+        if getattr(self.engine, "library_comm", False):
+            # the library's own communicator: tell it the largest shard (rank 0's), so that every rank sizes the
+            # one-launch-per-pass grid alike (lv_comm_set_shard_max)
+            lo0, hi0 = shard_bounds(len(scan_xyz), 0, self.world)
+            self.engine.ctx.comm_set_shard_max(hi0 - lo0)
 
     def update(self, x, P):
         """Returns (x_post, P_post, passes).  Every rank computes the identical posterior: the solve

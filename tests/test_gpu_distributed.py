@@ -89,6 +89,24 @@ def test_library_communicator_world1(lv, scene_small):
         ctx.filter_set(sc["x_init"], sc["P0"])
         p3 = ctx.correct()
         x3, P3 = ctx.filter_get()
+        # the one-launch-per-pass form with a communicator: told the largest shard, the update all-gathers the workgroup
+        # partials instead (one rank: in place, a copy) — the very kernel, buffers and fold of the multi-GPU route
+        ctx.scan_set(sc["scan_xyz"])
+        ctx.comm_set_shard_max(len(sc["scan_xyz"]))
+        for _ in range(2):
+            x5, P5, p5, _, s5 = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+        ctx.filter_set(sc["x_init"], sc["P0"])
+        p6 = ctx.correct()
+        assert ctx.last_update_fused()
+        x6, P6 = ctx.filter_get()
+        ctx.set_comm_fused(False)
+        ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+        assert not ctx.last_update_fused()
+        ctx.set_comm_fused(True)
+        ctx.scan_set(sc["scan_xyz"])                      # a new scan forgets the shard size: three-kernel form until told again
+        ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+        assert not ctx.last_update_fused()
         ctx.comm_destroy()
         x4, P4, p4, _, _ = ctx.update(sc["x_init"], sc["P0"], want_trace=False)
     assert p0 == p1 == p2 == p3 == p4
@@ -97,6 +115,9 @@ def test_library_communicator_world1(lv, scene_small):
     # without a communicator the update is one launch per pass again: same arithmetic, the workgroup partials are summed
     # in a different (fixed) order -> ~1e-16 relative on H^T H
     assert np.array_equal(x0, x4) and np.array_equal(P0, P4)
+    # gathered partials of one rank = its own partials in the same order: bit for bit the single-GPU one-launch update
+    assert p5 == p6 == p0 and np.array_equal(x0, x5) and np.array_equal(P0, P5)
+    assert np.array_equal(x0, x6) and np.array_equal(P0, P6)
     np.testing.assert_allclose(x0, x1, rtol=0, atol=1e-12)
     np.testing.assert_allclose(P0, P1, rtol=1e-9, atol=1e-15)
 
