@@ -100,6 +100,19 @@ def test_library_communicator_world1(lv, scene_small):
         p6 = ctx.correct()
         assert ctx.last_update_fused()
         x6, P6 = ctx.filter_get()
+        # a rank whose shard is smaller than the largest one launches the same grid: workgroups without a tile contribute
+        # zero partials (same sums, folded in a different grouping) ...
+        ctx.scan_set(sc["scan_xyz"])
+        ctx.comm_set_shard_max(3 * len(sc["scan_xyz"]) + 17)
+        x7, P7, p7, _, s7 = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+        # ... and a rank without any point still runs every launch and every collective
+        ctx.scan_set(sc["scan_xyz"][:0])
+        ctx.comm_set_shard_max(len(sc["scan_xyz"]))
+        x8, P8, p8, _, s8 = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused() and p8 == 4 and [s["n_valid"] for s in s8] == [0] * 4 and np.array_equal(x8, sc["x_init"])
+        ctx.scan_set(sc["scan_xyz"])
+        ctx.comm_set_shard_max(len(sc["scan_xyz"]))
         ctx.set_comm_fused(False)
         ctx.update(sc["x_init"], sc["P0"], want_trace=False)
         assert not ctx.last_update_fused()
@@ -118,6 +131,9 @@ def test_library_communicator_world1(lv, scene_small):
     # gathered partials of one rank = its own partials in the same order: bit for bit the single-GPU one-launch update
     assert p5 == p6 == p0 and np.array_equal(x0, x5) and np.array_equal(P0, P5)
     assert np.array_equal(x0, x6) and np.array_equal(P0, P6)
+    assert p7 == p0 and [s["n_valid"] for s in s7] == [s["n_valid"] for s in s5]
+    np.testing.assert_allclose(x7, x0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(P7, P0, rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(x0, x1, rtol=0, atol=1e-12)
     np.testing.assert_allclose(P0, P1, rtol=1e-9, atol=1e-15)
 
