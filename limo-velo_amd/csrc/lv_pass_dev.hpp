@@ -440,6 +440,7 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
         Bk.XA[i][c] = s;
     }
     bar();
+    uint32_t mine = 0u;   // this thread's share of the mailbox checksum (xor: order-free), reduced per wavefront before LDS
     for (int e = tid; e < NS * NS; e += T) {
         const int i = e / NS, j = e % NS;
         double s = 0;
@@ -447,10 +448,13 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
         const double pv = Bk.B[i][j] - s;
         kf->P_post[e] = pv;
         LV_IO_STORE(&io->P_post[e], pv);
-        atomicXor(&Bk.chk, mailbox_mix(pv, (uint32_t)e));
+        mine ^= mailbox_mix(pv, (uint32_t)e);
     }
-    if (tid < NX) atomicXor(&Bk.chk, mailbox_mix(K.x[tid], 1000u + (uint32_t)tid));
-    if (tid == 0) atomicXor(&Bk.chk, mailbox_mix((double)(pass + 1), 2000u));
+    if (tid < NX) mine ^= mailbox_mix(K.x[tid], 1000u + (uint32_t)tid);
+    if (tid == 0) mine ^= mailbox_mix((double)(pass + 1), 2000u);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mine ^= (uint32_t)__shfl_xor((int)mine, m);
+    if (lane == 0 && mine) atomicXor(&Bk.chk, mine);
     // every mailbox store is a system-scope write-through store: once a lane's stores have retired they are visible to
     // the host; the host verifies the checksum (lv_update_end)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

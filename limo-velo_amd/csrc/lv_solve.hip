@@ -361,6 +361,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         sX[i][c] = s;
     }
     __syncthreads();
+    uint32_t mine = 0u;   // this thread's share of the mailbox checksum (xor: order-free), reduced per wavefront before LDS:
+                          // 556 atomics on one LDS word were 2.7 us of the terminal pass
     if (tid < NS * NS) {
         const int i = tid / NS, j = tid % NS;
         double s = 0;
@@ -368,10 +370,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
         const double pv = sB[i][j] - s;
         kf->P_post[tid] = pv;
         IO_STORE(&io->P_post[tid], pv);
-        atomicXor(&s_chk, mailbox_mix(pv, (uint32_t)tid));
+        mine ^= mailbox_mix(pv, (uint32_t)tid);
     }
-    if (tid < NX) atomicXor(&s_chk, mailbox_mix(sx[tid], 1000u + (uint32_t)tid));
-    if (tid == 0) atomicXor(&s_chk, mailbox_mix((double)(pass + 1), 2000u));
+    if (tid < NX) mine ^= mailbox_mix(sx[tid], 1000u + (uint32_t)tid);
+    if (tid == 0) mine ^= mailbox_mix((double)(pass + 1), 2000u);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mine ^= (uint32_t)__shfl_xor((int)mine, m);
+    if (lane == 0 && mine) atomicXor(&s_chk, mine);
     SV_STAMP(9);
     // the update is final (kf->done was set above): every result store is ordered before the sequence number
     // the host waits on
