@@ -425,7 +425,14 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
     if (wave < 3 && lane == 0) manifold_block(wave, 1, K.x, Bk.xp, K.dxo, nullptr, Bk.J);
     bar();
     congruence<T>(Bk.B, Bk.J, Bk.P, tid);  // B = L_ = J2 P_ J2^T
-    mm<T>(Bk.A, Bk.P, Bk.J, true, tid);    // A = P_ J2^T
+    for (int e = tid; e < NS * NS; e += T) {   // A = P_ J2^T (J2 = identity outside its three blocks: at most 3 terms each)
+        const int i = e / NS, j = e % NS;
+        int jb, nb;
+        blk_range(j, jb, nb);
+        double t = 0.0;
+        for (int b = 0; b < nb; ++b) t += Bk.P[i][jb + b] * Bk.J[j][jb + b];
+        Bk.A[i][j] = t;
+    }
     if (tid < NS * NW) {                    // K_x[:, :NW] = X HTH (columns >= NW are zero)
         const int i = tid / NW, c = tid % NW;
         double t = 0.0;
@@ -433,10 +440,12 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
         Bk.Kx[i][c] = t;
     }
     bar();
-    if (tid < NS * NW) {                    // K_x <- J2 K_x (rows)
+    if (tid < NS * NW) {                    // K_x <- J2 K_x (rows; block structure again)
         const int i = tid / NW, c = tid % NW;
+        int ib, nb;
+        blk_range(i, ib, nb);
         double s = 0;
-        for (int r = 0; r < NS; ++r) s += Bk.J[i][r] * Bk.Kx[r][c];
+        for (int r = 0; r < nb; ++r) s += Bk.J[i][ib + r] * Bk.Kx[ib + r][c];
         Bk.XA[i][c] = s;
     }
     bar();
