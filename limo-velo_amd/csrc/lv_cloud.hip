@@ -86,27 +86,40 @@ __global__ void cloud_gather_kernel(const CloudPoint* __restrict__ in, const uin
 
 // Accumulator::get_points(t1, t2): the buffered points with t1 <= time <= t2, oldest first.  The buffer is time
 // ordered (messages arrive in order and each is sorted), so the window is one contiguous range [lo, hi).
-__global__ void cloud_window_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t1, double t2, uint32_t* __restrict__ out) {
-    if (threadIdx.x >= 2) return;
-    const bool upper = threadIdx.x == 1;
-    uint32_t lo = head, hi = n;
-    while (lo < hi) {   // first index with time >= t1 (lower) / time > t2 (upper)
-        const uint32_t mid = lo + (hi - lo) / 2;
-        const double t = pts[mid].time;
-        const bool go_right = upper ? (t <= t2) : (t < t1);
-        if (go_right) lo = mid + 1; else hi = mid;
+// first index in [lo, hi) whose time does NOT satisfy `t < bound` (strict) / `t <= bound`: the buffer is time ordered, so
+// a wavefront narrows the range 64-fold per round trip (a scalar bisection was 17 dependent loads, 7 us)
+__device__ __forceinline__ uint32_t wave_time_bound(const CloudPoint* __restrict__ pts, uint32_t lo, uint32_t hi, double bound, bool inclusive) {
+    const uint32_t lane = threadIdx.x & 63u;
+    while (lo < hi) {
+        const uint32_t span = hi - lo;
+        const uint32_t step = (span + 63u) / 64u;
+        const uint32_t idx = lo + lane * step;
+        bool right = false;
+        if (idx < hi) {
+            const double t = pts[idx].time;
+            right = inclusive ? (t <= bound) : (t < bound);
+        }
+        const uint32_t c = (uint32_t)__popcll(__ballot(right));   // the predicate is monotone: the first c samples go right
+        if (step == 1u) return lo + c;
+        if (c == 0u) return lo;
+        const uint32_t nlo = lo + (c - 1u) * step + 1u;
+        const uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
+        lo = nlo;
+        hi = nhi;
     }
-    out[threadIdx.x] = lo;
+    return lo;
+}
+__global__ void cloud_window_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t1, double t2, uint32_t* __restrict__ out) {
+    const uint32_t wave = threadIdx.x >> 6;   // wavefront 0: first index with time >= t1; wavefront 1: first with time > t2
+    if (wave >= 2) return;
+    const uint32_t r = wave_time_bound(pts, head, n, wave ? t2 : t1, wave != 0);
+    if ((threadIdx.x & 63u) == 0) out[wave] = r;
 }
 // Buffer::clear(t) (Buffer.cpp:57-62): drop from the old end while t >= time
 __global__ void cloud_clear_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t, uint32_t* __restrict__ out) {
-    if (threadIdx.x != 0) return;
-    uint32_t lo = head, hi = n;
-    while (lo < hi) {   // first index with time > t
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (pts[mid].time <= t) lo = mid + 1; else hi = mid;
-    }
-    out[0] = lo;
+    if (threadIdx.x >= 64) return;
+    const uint32_t r = wave_time_bound(pts, head, n, t, true);   // first index with time > t
+    if (threadIdx.x == 0) out[0] = r;
 }
 __global__ void cloud_unpack_kernel(const CloudPoint* __restrict__ pts, uint32_t n, float4* __restrict__ xyz, double* __restrict__ times) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,7 +227,7 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
 int CloudStore::window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi) {
     *lo = *hi = head;
     if (size <= head) return LV_OK;
-    hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(64), 0, stream, d_buf, head, size, t1, t2, d_count);
+    hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(128), 0, stream, d_buf, head, size, t1, t2, d_count);
     LV_HIP(hipMemcpyAsync(h_count, d_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
     *lo = h_count[0];

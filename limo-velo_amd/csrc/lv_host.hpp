@@ -255,6 +255,7 @@ struct ScanStore {
     int voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell);
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
     int order_tiles(hipStream_t stream, uint32_t tile_points);
+    int reserve_tiles(uint32_t nt);
     void release();
 };
 

@@ -985,9 +985,13 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     hipLaunchKernelGGL(inc_box_keys_kernel, dim3(gk), dim3(B), 0, stream, M, d_new, k, box_length, d_nkeys, d_nidx, d_nalive, downsample, 1);
     uint32_t n_dead = 0;
     if (downsample) {
-        size_t tmp = ntmp_bytes;
-        LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_ntmp, tmp, d_nkeys, d_nkeys_sorted, d_nidx, d_nidx_sorted, (int)k, 0, 63,
-                                                               stream));
+        if (k <= (uint32_t)SMALL_BATCH) {
+            hipLaunchKernelGGL(inc_sort_small_kernel, dim3(1), dim3(1024), 0, stream, d_nkeys, d_nidx, k, d_nkeys_sorted, d_nidx_sorted);
+        } else {
+            size_t tmp = ntmp_bytes;
+            LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_ntmp, tmp, d_nkeys, d_nkeys_sorted, d_nidx, d_nidx_sorted, (int)k, 0,
+                                                                   63, stream));
+        }
         hipLaunchKernelGGL(inc_box_rule_kernel, dim3(gk), dim3(B), 0, stream, Bx, d_orig, d_new, d_nkeys_sorted, d_nidx_sorted, k,
                            d_nalive, d_dead, (uint32_t)dead_cap, d_cnt);
     }
@@ -1000,7 +1004,6 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     // voxel groups of the survivors on every level
     GroupRW G{};
     for (int l = 0; l < REPL_LEVELS; ++l) {
-        LV_HIP(hipMemsetAsync(d_gtab[l], 0xFF, (size_t)gtab_size * sizeof(uint4), stream));
         G.table[l] = d_gtab[l];
         G.gbase[l] = d_gbase[l];
         G.gslot[l] = d_gslot[l];
@@ -1010,10 +1013,14 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     G.size = gtab_size;
     G.prank = d_prank;
     G.pslot = d_pslot;
-    LV_HIP(hipMemsetAsync(d_gcnt, 0, 4 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(inc_clear_groups_kernel, dim3((uint32_t)(((uint64_t)gtab_size * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, G,
+                       d_gcnt);
     hipLaunchKernelGGL(inc_group_kernel, dim3((uint32_t)(((uint64_t)k * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, M, G, d_new,
                        d_nalive, k);
-    if (downsample) {   // the occupants that lost: how many is only known on the device
+    const bool counted_kill = downsample && k <= (uint32_t)SMALL_BATCH;
+    if (counted_kill) {   // the occupants that lost: how many is only known on the device — a small batch leaves it there
+        hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(256), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
+    } else if (downsample) {
         LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipStreamSynchronize(stream));
         n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
@@ -1026,8 +1033,12 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     const uint64_t t_rel = (uint64_t)(reloc_cap < (1u << 18) ? reloc_cap : (1u << 18)) * RELOC_LANES;   // runs moved per batch (more: re-linearise)
     hipLaunchKernelGGL(inc_register_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
-    hipLaunchKernelGGL(inc_relocate_kernel, dim3((uint32_t)((t_rel + B - 1) / B)), dim3(B), 0, stream, M, d_reloc,
-                       (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+    {   // at most one run per (group, target) of this batch can be listed; 2048 workgroups walk longer lists in strides
+        const uint64_t t_need = t_grp * RELOC_LANES < t_rel ? t_grp * RELOC_LANES : t_rel;
+        const uint64_t g_need = (t_need + B - 1) / B;
+        hipLaunchKernelGGL(inc_relocate_kernel, dim3((uint32_t)(g_need < 2048 ? g_need : 2048)), dim3(B), 0, stream, M, d_reloc,
+                           (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+    }
     hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
     hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank);
@@ -1035,6 +1046,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     LV_HIP(hipGetLastError());
     LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
+    if (counted_kill) n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
     n_ids += h_cnt->n_new;
     m += h_cnt->n_new;
     m -= n_dead;

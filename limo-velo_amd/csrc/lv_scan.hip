@@ -88,13 +88,39 @@ __device__ __forceinline__ unsigned flip_f32(float f) {  // order-preserving flo
 __device__ __forceinline__ float unflip_f32(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
-__global__ void vg_bounds_kernel(const float4* __restrict__ pts, uint32_t n, unsigned* __restrict__ bounds /*min xyz, max xyz*/) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
-    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return;
-    atomicMin(&bounds[0], flip_f32(p.x)); atomicMin(&bounds[1], flip_f32(p.y)); atomicMin(&bounds[2], flip_f32(p.z));
-    atomicMax(&bounds[3], flip_f32(p.x)); atomicMax(&bounds[4], flip_f32(p.y)); atomicMax(&bounds[5], flip_f32(p.z));
+__global__ __launch_bounds__(256) void vg_bounds_kernel(const float4* __restrict__ pts, uint32_t n, unsigned* __restrict__ bounds /*min xyz, max xyz*/) {
+    // bounds per workgroup in LDS first (six same-address device atomics per POINT were 14 us for an 11k-point window)
+    __shared__ unsigned s_b[6];
+    if (threadIdx.x < 3) s_b[threadIdx.x] = 0xFFFFFFFFu;
+    else if (threadIdx.x < 6) s_b[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 p = pts[i];
+        if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
+        const unsigned f[3] = {flip_f32(p.x), flip_f32(p.y), flip_f32(p.z)};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = f[a] < lo[a] ? f[a] : lo[a]; hi[a] = f[a] > hi[a] ? f[a] : hi[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        unsigned l = lo[a], h = hi[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned l2 = __shfl_xor(l, o), h2 = __shfl_xor(h, o);
+            l = l2 < l ? l2 : l;
+            h = h2 > h ? h2 : h;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_b[a], l); atomicMax(&s_b[3 + a], h); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s_b[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s_b[threadIdx.x]);
+}
+// bounds scratch back to "nothing seen" (its last two words: the result record of voxel_and_sort)
+__global__ void vg_bounds_init_kernel(unsigned* __restrict__ bounds) {
+    if (threadIdx.x < 8) bounds[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
 }
 __global__ void vg_keys_kernel(const float4* __restrict__ pts, uint32_t n, const unsigned* __restrict__ bounds, float inv_leaf,
                                uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
@@ -122,15 +148,37 @@ __global__ void vg_heads_kernel(const uint64_t* __restrict__ keys_sorted, uint32
 }
 __global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint64_t* __restrict__ keys_sorted,
                                    const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ heads,
-                                   const uint32_t* __restrict__ hpos, uint32_t n, float4* __restrict__ out) {
+                                   const uint32_t* __restrict__ hpos, uint32_t n, float4* __restrict__ out,
+                                   unsigned* __restrict__ n_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !heads[i]) return;
+    if (i >= n) return;
+    if (i == n - 1) *n_out = hpos[i] + heads[i];   // leaves in all (read back with the bounds)
+    if (!heads[i]) return;
     const uint64_t k = keys_sorted[i];
     float sx = 0.f, sy = 0.f, sz = 0.f;
+    // the leaf's points in input order, eight loads in flight at a time (one dependent key -> index -> point chain per
+    // member made this kernel 26 us for an 11k-point window); the SUM stays sequential: it is the oracle's order
+    constexpr int C = 8;
     uint32_t j = i;
-    for (; j < n && keys_sorted[j] == k; ++j) {
-        const float4 p = pts[idx_sorted[j]];
-        sx += p.x; sy += p.y; sz += p.z;
+    bool more = true;
+    while (more) {
+        uint64_t kk[C];
+        uint32_t id[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uint32_t jj = j + c < n ? j + c : n - 1;
+            kk[c] = keys_sorted[jj];
+            id[c] = idx_sorted[jj];
+        }
+        float4 pp[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) pp[c] = pts[id[c]];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (more && j + c < n && kk[c] == k) { sx += pp[c].x; sy += pp[c].y; sz += pp[c].z; }
+            else if (more) { more = false; j += c; }
+        }
+        if (more) j += C;
     }
     const float cnt = (float)(j - i);
     const uint32_t o = hpos[i];
@@ -192,11 +240,10 @@ int ScanStore::voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, flo
     const int B = 256;
     const uint32_t grid = (n_in + B - 1) / B;
     float4* desk = leaf > 0.f ? d_desk : d_raw;
-    const unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-    LV_HIP(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(vg_bounds_kernel, dim3(grid), dim3(B), 0, stream, desk, n_in, d_bounds);
+    hipLaunchKernelGGL(vg_bounds_init_kernel, dim3(1), dim3(64), 0, stream, d_bounds);
+    const uint32_t bgrid = grid < 64u ? grid : 64u;   // (grid-stride: at most 64 workgroups touch the six device words)
+    hipLaunchKernelGGL(vg_bounds_kernel, dim3(bgrid), dim3(B), 0, stream, desk, n_in, d_bounds);
     uint32_t n_out = n_in;
-    uint32_t last_pos = 0, last_head = 0;
     if (leaf > 0.f) {
         hipLaunchKernelGGL(vg_keys_kernel, dim3(grid), dim3(B), 0, stream, d_desk, n_in, d_bounds, 1.0f / leaf, d_vkeys, d_vidx);
         size_t tmp = vsort_tmp_bytes;
@@ -206,14 +253,12 @@ int ScanStore::voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, flo
         size_t stmp = vscan_tmp_bytes;
         LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_vscan_tmp, stmp, d_heads, d_hpos, (int)n_in, stream));
         hipLaunchKernelGGL(vg_centroid_kernel, dim3(grid), dim3(B), 0, stream, d_desk, d_vkeys_sorted, d_vidx_sorted, d_heads, d_hpos,
-                           n_in, d_raw);
-        LV_HIP(hipMemcpyAsync(&last_pos, d_hpos + (n_in - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LV_HIP(hipMemcpyAsync(&last_head, d_heads + (n_in - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                           n_in, d_raw, d_bounds + 6);
     }
-    unsigned hb[8];
+    unsigned hb[8];   // bounds (6 words) + the number of leaves: one copy back
     LV_HIP(hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
-    if (leaf > 0.f) n_out = last_pos + last_head;
+    if (leaf > 0.f) n_out = hb[6];
     n = n_out;
     if (hb[0] == 0xFFFFFFFFu) n = 0;  // no finite point survived
     if (n == 0) return LV_OK;
@@ -252,8 +297,87 @@ void ScanStore::release() {
     *this = ScanStore();
 }
 
+// Small scans (the 0.01 s windows of a stream: a few hundred points after the voxel grid): keys, sort, gather, tile ranges
+// and tile order by ONE workgroup — the five-launch chain below it costs ~35 us whatever the size.  Same keys, same
+// (key, index) order as the stable radix sort, same tile keys: the result is the one the general path produces.
+constexpr int SMALL_SCAN = 2048;
+__global__ __launch_bounds__(1024) void scan_sort_small_kernel(const float4* __restrict__ pts, uint32_t n, float ox, float oy, float oz,
+                                                               float inv_cell, uint32_t tile_points, float4* __restrict__ sorted,
+                                                               uint32_t* __restrict__ tile_order) {
+    __shared__ uint64_t s_key[SMALL_SCAN];
+    __shared__ float s_r2[SMALL_SCAN];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < SMALL_SCAN / 1024; ++h) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)h * 1024u;
+        uint64_t k = ~0ull;
+        if (i < n) {
+            const float4 p = pts[i];
+            const float fx = fminf(fmaxf((p.x - ox) * inv_cell, 0.f), 1023.f);
+            const float fy = fminf(fmaxf((p.y - oy) * inv_cell, 0.f), 1023.f);
+            const float fz = fminf(fmaxf((p.z - oz) * inv_cell, 0.f), 1023.f);
+            const uint32_t key = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+            k = ((uint64_t)key << 32) | i;
+        }
+        s_key[i] = k;
+    }
+    __syncthreads();
+    // bitonic network over the smallest power of two that holds n (padding sorts last)
+    uint32_t len = 64;
+    while (len < n) len <<= 1;
+    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < len / 2; t += 1024) {
+                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool up = (lo & k2) == 0;
+                const uint64_t a = s_key[lo], b = s_key[hi];
+                if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < SMALL_SCAN / 1024; ++h) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)h * 1024u;
+        if (i < n) {
+            const float4 p = pts[(uint32_t)s_key[i]];
+            sorted[i] = p;
+            s_r2[i] = p.x * p.x + p.y * p.y + p.z * p.z;
+        }
+    }
+    __syncthreads();
+    if (tile_points == 0) return;
+    const uint32_t nt = (n + tile_points - 1) / tile_points;   // <= SMALL_SCAN / tile_points
+    uint64_t mine = ~0ull;
+    if ((uint32_t)tid < nt) {
+        float r2 = 0.f;
+        const uint32_t b = (uint32_t)tid * tile_points;
+        for (uint32_t i = 0; i < tile_points && b + i < n; ++i) r2 = fmaxf(r2, s_r2[b + i]);
+        mine = ((uint64_t)(~__float_as_uint(r2)) << 32) | (uint32_t)tid;   // complement ascending = range descending; ties by tile
+    }
+    __syncthreads();
+    if ((uint32_t)tid < nt) s_key[tid] = mine;   // (nt <= 1024 whenever tile_points >= 2)
+    __syncthreads();
+    if ((uint32_t)tid < nt) {
+        uint32_t rank = 0;
+        for (uint32_t u = 0; u < nt; ++u) rank += s_key[u] < mine ? 1u : 0u;
+        tile_order[rank] = (uint32_t)tid;
+    }
+}
+
 int ScanStore::sort(hipStream_t stream, const float bbox_min[3], float cell) {
     if (n == 0) return LV_OK;
+    if (n <= (uint32_t)SMALL_SCAN && tile_points != 1) {
+        n_tiles = 0;
+        const uint32_t nt = tile_points ? (n + tile_points - 1) / tile_points : 0;
+        int rc = reserve_tiles(nt);
+        if (rc) return rc;
+        hipLaunchKernelGGL(scan_sort_small_kernel, dim3(1), dim3(1024), 0, stream, d_raw, n, bbox_min[0], bbox_min[1], bbox_min[2],
+                           1.0f / cell, tile_points, d_sorted, d_tile_order);
+        LV_HIP(hipGetLastError());
+        n_tiles = nt;
+        return LV_OK;
+    }
     const int B = 256;
     const uint32_t grid = (n + B - 1) / B;
     hipLaunchKernelGGL(scan_keys_kernel, dim3(grid), dim3(B), 0, stream, d_raw, n, bbox_min[0], bbox_min[1], bbox_min[2],
@@ -264,6 +388,18 @@ int ScanStore::sort(hipStream_t stream, const float bbox_min[3], float cell) {
     hipLaunchKernelGGL(scan_gather_kernel, dim3(grid), dim3(B), 0, stream, d_raw, d_idx_sorted, n, d_sorted);
     LV_HIP(hipGetLastError());
     return order_tiles(stream, tile_points);
+}
+
+int ScanStore::reserve_tiles(uint32_t nt) {
+    if (nt <= tile_cap) return LV_OK;
+    hipFree(d_tile_order);
+    d_tile_order = nullptr;
+    tile_cap = 0;
+    uint32_t cap = 1024;
+    while (cap < nt) cap *= 2;
+    LV_HIP(hipMalloc(&d_tile_order, cap * sizeof(uint32_t)));
+    tile_cap = cap;
+    return LV_OK;
 }
 
 // Dispatch order of the search kernel's point tiles: tiles whose points lie farthest from the sensor first.
@@ -289,15 +425,8 @@ int ScanStore::order_tiles(hipStream_t stream, uint32_t tile_points) {
     n_tiles = 0;
     if (n == 0 || tile_points == 0) return LV_OK;
     const uint32_t nt = (n + tile_points - 1) / tile_points;
-    if (nt > tile_cap) {
-        hipFree(d_tile_order);
-        d_tile_order = nullptr;
-        tile_cap = 0;
-        uint32_t cap = 1024;
-        while (cap < nt) cap *= 2;
-        LV_HIP(hipMalloc(&d_tile_order, cap * sizeof(uint32_t)));
-        tile_cap = cap;
-    }
+    int rc = reserve_tiles(nt);
+    if (rc) return rc;
     // d_keys / d_idx / d_keys_sorted are free again once the points are gathered (nt <= n <= capacity)
     hipLaunchKernelGGL(tile_range_keys_kernel, dim3((nt + 255) / 256), dim3(256), 0, stream, d_sorted, n, tile_points, nt, d_keys, d_idx);
     size_t tmp = sort_tmp_bytes;
