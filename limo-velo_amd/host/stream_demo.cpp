@@ -7,6 +7,7 @@
 // IMU samples and LiDAR messages are fed in time order; after every IMU sample the loop body runs as often as it can.
 // Output: u32 n_updates, { f64 t2, f64 x[26], u32 n_points } * n_updates.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -67,6 +68,7 @@ int main(int argc, char** argv) {
         std::vector<uint32_t> out_n;
         size_t mi = 0;
         bool positioned = false;
+        const auto wall0 = std::chrono::steady_clock::now();   // the whole replay: message ingest, IMU handling, every cycle
         for (const ImuRec& r : imus) {
             while (mi < msgs.size() && msgs[mi].arrival <= r.t) {
                 accum.receive_lidar(msgs[mi].data.data(), msgs[mi].n, fmt, msgs[mi].stamp);
@@ -106,6 +108,7 @@ int main(int argc, char** argv) {
                 out_n.push_back((uint32_t)np);
             }
         }
+        const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
         std::ofstream o(argv[2], std::ios::binary);
         const uint32_t n = (uint32_t)out_t.size();
         o.write(reinterpret_cast<const char*>(&n), 4);
@@ -115,6 +118,12 @@ int main(int argc, char** argv) {
             o.write(reinterpret_cast<const char*>(&out_n[i]), 4);
         }
         std::cout << "stream_demo: " << n << " updates, map " << map.size() << " points\n";
+        // one JSON line for scripts/stream_bench_cpp.py: the reference's loop as a C++ host program runs it (no per-stage
+        // synchronisation beyond what the calls themselves need)
+        double mean_pts = 0;
+        for (uint32_t v : out_n) mean_pts += v;
+        printf("{\"updates\": %u, \"wall_s\": %.6f, \"updates_per_s\": %.1f, \"on_device\": %d, \"scan_points_mean\": %.1f, \"map_points\": %zu}\n", n,
+               wall_s, n / wall_s, (int)on_device, n ? mean_pts / n : 0.0, (size_t)map.size());
         HipRuntime::shutdown();
         return 0;
     } catch (const std::exception& e) {

@@ -1,0 +1,54 @@
+"""BASELINE configs[4] through the C++ host program: limo-velo_amd/host/stream_demo (main_loop.hpp = the reference's
+src/main.cpp:52-128 over the shim's Accumulator / Compensator / Localizator / Mapper).  Same synthetic stream as
+scripts/stream_bench.py (64 rings x n_az azimuth steps per 0.1 s sweep, delta = 0.01 s, prior map of LV_STREAM_MAP points,
+mapping online), but the host side is compiled code with no per-stage synchronisation: what a ROS-free node would see.
+Prints one JSON line: updates/s for the reference's by-value hand-overs and for the device-resident ones, RMSE vs truth."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import lvamd  # noqa: E402
+
+lvamd.load()
+import test_gpu_shim as S  # noqa: E402
+from limo_velo_amd import synth  # noqa: E402
+
+M = int(os.environ.get("LV_STREAM_MAP", 10_000_000))
+N_AZ = int(os.environ.get("LV_STREAM_AZ", 2048))
+N_REVS = int(os.environ.get("LV_STREAM_REVS", 30))
+
+host = os.path.join(ROOT, "limo-velo_amd", "host")
+exe = os.path.join(host, "stream_demo")
+if not os.path.exists(exe):
+    subprocess.check_call(["make", "-s", "-C", host])
+t0 = time.time()
+stream = synth.make_stream(M, N_REVS, n_az=N_AZ)
+gen_s = time.time() - t0
+t_init = 0.30 - 0.1
+pos0, _, vel0, _, q0 = synth.stream_truth(t_init)
+x0 = synth.make_state(pos0 + [0.02, -0.015, 0.01], synth.quat_mul(q0, synth.quat_from_rotvec([0.002, -0.001, 0.003])), vel=vel0,
+                      grav=(0, 0, synth.STREAM_G))
+out = {"workload": f"{M}-pt prior map, 64 rings x {N_AZ} azimuth steps per 0.1 s sweep, delta = 0.01 s, {N_REVS} sweeps, mapping online, "
+                   "1 GPU, C++ host (stream_demo over the shim)", "stream_generation_s": gen_s}
+with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+    for on_device in (1, 0):
+        inp, res = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        S._write_stream_input(inp, on_device, 0.01, stream, N_REVS, x0)
+        r = subprocess.run([exe, inp, res], capture_output=True, text=True, timeout=1500)
+        if r.returncode != 0:
+            raise SystemExit(r.stdout + r.stderr)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        rec = json.loads(line)
+        t, x, npts = S._read_stream_output(res)
+        truth = np.array([synth.stream_truth(tt)[0] for tt in t])
+        rec["rmse_vs_truth_m"] = float(np.sqrt(np.mean(np.sum((x[:, :3] - truth) ** 2, axis=1))))
+        out["device_resident" if on_device else "by_value"] = rec
+print(json.dumps(out))
