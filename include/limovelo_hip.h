@@ -298,6 +298,17 @@ int lv_comm_world(lv_ctx* ctx);
  * lv_set_comm_fused(ctx, 0) (or LV_COMM_FUSED=0) keeps the three-kernel form. */
 int lv_comm_set_shard_max(lv_ctx* ctx, size_t n_max);
 int lv_set_comm_fused(lv_ctx* ctx, int enabled);
+/* The same one-launch-per-pass multi-rank form with the CALLER's transport instead of librccl (bring-up on fabrics RCCL
+ * does not serve, and the two-ranks-on-one-GPU test of exactly the kernels, buffers and fold the RCCL route uses): after
+ * every searching launch the library copies this rank's slot of the gather buffer to host memory and calls
+ *   fn(user, slots, bytes_per_rank, rank, world)
+ * with `slots` = world x bytes_per_rank bytes of host memory holding this rank's partials at slots + rank * bytes_per_rank;
+ * fn fills in every other rank's slot (an all-gather by whatever means; it returns 0 when they are all there) and the
+ * library copies the whole buffer back.  Tell the largest shard with lv_comm_set_shard_max as above; without it, or for
+ * scans the one-launch form does not take, lv_update / lv_correct fail with LV_ESTATE (there is no all-reduce transport
+ * here).  fn = NULL removes it.  Not combinable with lv_comm_init. */
+typedef int (*lv_gather_fn)(void* user, void* slots, size_t bytes_per_rank, int rank, int world);
+int lv_comm_set_host_gather(lv_ctx* ctx, int rank, int world, lv_gather_fn fn, void* user);
 
 /* ---- API-parity / debug fetches (results of the most recent CAPTURED pass; original scan order) --
  * lv_iterate always captures; lv_update captures only after lv_set_capture(ctx, 1) (the last pass

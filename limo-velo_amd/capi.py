@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_downsample", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_set_fused_pass", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
-    "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused",
+    "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
 ]
 
@@ -454,6 +454,32 @@ class Context:
 
     def set_comm_fused(self, on=True):
         self._check(self.lib.lv_set_comm_fused(self.h, int(on)))
+
+    GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+
+    def comm_set_host_gather(self, rank: int, world: int, fn):
+        """The one-launch-per-pass multi-rank form with the caller's transport (lv_comm_set_host_gather).
+        fn(slots: float64 array of world * n, n, rank, world) fills every other rank's slots[r * n:(r + 1) * n] in place
+        (this rank's partials are already at [rank * n:(rank + 1) * n]); None removes the transport."""
+        self.lib.lv_comm_set_host_gather.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        if fn is None:
+            self._check(self.lib.lv_comm_set_host_gather(self.h, 0, 1, None, None))
+            self._gather_cb = None
+            return
+
+        def tramp(_user, slots, bytes_per_rank, r, w):
+            try:
+                n = bytes_per_rank // 8
+                arr = np.ctypeslib.as_array((C.c_double * (n * w)).from_address(slots))
+                fn(arr, n, r, w)
+                return 0
+            except Exception as e:  # noqa: BLE001 — an exception must not unwind through the C frames
+                print(f"[limo_velo_amd] host gather callback failed: {e!r}", flush=True)
+                return 1
+
+        cb = self.GATHER_FN(tramp)
+        self._check(self.lib.lv_comm_set_host_gather(self.h, int(rank), int(world), C.cast(cb, C.c_void_p), None))
+        self._gather_cb = cb   # (keeps the trampoline alive as long as the library may call it)
 
     def set_fused_pass(self, on=True):
         self._check(self.lib.lv_set_fused_pass(self.h, int(on)))

@@ -68,6 +68,10 @@ struct lv_ctx {
     size_t gather_cap = 0;            // doubles per buffer
     size_t comm_shard_max = 0;        // largest shard of the CURRENT scan over the ranks (lv_comm_set_shard_max); 0: unknown
     bool comm_fused = true;           // lv_set_comm_fused / LV_COMM_FUSED=0: always the three-kernel pass + all-reduce with a communicator
+    lv_gather_fn gather_cb = nullptr;  // lv_comm_set_host_gather: the partials of the ranks exchanged by the caller through host memory
+    void* gather_user = nullptr;       //   (test / bring-up transport of the one-launch-per-pass multi-rank form; no librccl involved)
+    double* h_gather = nullptr;        //   pinned staging, world x slot doubles
+    size_t h_gather_cap = 0;
     uint32_t* d_wgcost[2] = {nullptr, nullptr};   // per searching workgroup: how long its search + fits took (picks the next bookkeeper)
     int pass_max_wg = 256;         // search workgroups of pass_kernel: all resident at once (one 1024-thread workgroup per CU)
     bool fused_pass = true;        // LV_FUSED_PASS=0: the three-kernel pass (search / fit / solve) also where pass_kernel applies
@@ -293,17 +297,19 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 // communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
 // the scan size that fixes pass_kernel's geometry: the local scan, or with a communicator the largest shard over the ranks
 // (every rank launches the same grid; workgroups without a tile contribute zero partials)
-uint32_t pass_geometry_points(const lv_ctx* c) { return c->comm ? (uint32_t)c->comm_shard_max : c->scan.n; }
+static inline bool multi_rank(const lv_ctx* c) { return c->comm != nullptr || c->gather_cb != nullptr; }
+uint32_t pass_geometry_points(const lv_ctx* c) { return multi_rank(c) ? (uint32_t)c->comm_shard_max : c->scan.n; }
 
 bool pass_fused_applies(const lv_ctx* c) {
     // (scans of more than two rounds per workgroup — beyond 131 072 points on a 256-CU part — stay with the three-kernel
     // pass: pass_kernel idles twelve of sixteen wavefronts during every round's plane fits; measured: 131 072 points 223 vs
     // 233 us per update, 262 144 points 371 vs 354)
-    if (c->comm) {
+    if (multi_rank(c)) {
         // with a communicator: the caller has told the largest shard of this scan (lv_comm_set_shard_max), librccl has
-        // ncclAllGather, the gather buffers are in place; a rank without points still runs every launch
-        if (!c->comm_fused || c->comm_shard_max == 0 || c->scan.n > c->comm_shard_max || !comm_has_allgather() || !c->d_gather[0] ||
-            c->prm.estimate_extrinsics)
+        // ncclAllGather (or the caller exchanges the partials itself: lv_comm_set_host_gather), the gather buffers are in
+        // place; a rank without points still runs every launch
+        if (!c->comm_fused || c->comm_shard_max == 0 || c->scan.n > c->comm_shard_max || (c->comm && !comm_has_allgather()) ||
+            !c->d_gather[0] || c->prm.estimate_extrinsics)
             return false;
     } else if (c->scan.n == 0) {
         return false;
@@ -311,7 +317,7 @@ bool pass_fused_applies(const lv_ctx* c) {
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     if (rounds > 2 && !c->fused_multi_round) return false;
-    if (c->comm && (size_t)nwg * (size_t)c->comm_world * 32u > c->gather_cap) return false;
+    if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * 32u > c->gather_cap) return false;
     return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;
 }
@@ -343,7 +349,7 @@ int update_fused(lv_ctx* c) {
     pl.sp.degeneracy_threshold = c->prm.degeneracy_threshold;
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
-    const bool gathered = c->comm != nullptr;                 // multi-GPU: the partials of all ranks, gathered after every launch
+    const bool gathered = multi_rank(c);                      // multi-GPU: the partials of all ranks, gathered after every launch
     const size_t slot = (size_t)nwg * 32u;                    // doubles per rank in the gather buffers (compact records, 6-column case)
     pl.qrec = c->record_dump ? c->d_qrec : nullptr;
     c->pclk_wg = nwg + dedicated;   // (the last slot is the bookkeeping workgroup either way)
@@ -369,7 +375,21 @@ int update_fused(lv_ctx* c) {
         c->begin_pending = false;
         if (rc) return rc;
         if (gathered && !closing) {
-            rc = comm_allgather_inplace(c->comm, c->d_gather[i & 1], slot, c->comm_rank, c->stream);
+            if (c->gather_cb) {
+                // the caller's transport: this rank's slot to pinned host memory, the callback fills in the other ranks' slots
+                // (it blocks until they are there), everything back — the launches of an update are no longer back to back
+                double* own = c->h_gather + (size_t)c->comm_rank * slot;
+                LV_HIP(hipMemcpyAsync(own, c->d_gather[i & 1] + (size_t)c->comm_rank * slot, slot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                LV_HIP(hipStreamSynchronize(c->stream));
+                if (c->gather_cb(c->gather_user, c->h_gather, slot * sizeof(double), c->comm_rank, c->comm_world) != 0) {
+                    set_error("host gather callback failed (launch %d)", i);
+                    return LV_ESTATE;
+                }
+                LV_HIP(hipMemcpyAsync(c->d_gather[i & 1], c->h_gather, slot * sizeof(double) * (size_t)c->comm_world, hipMemcpyHostToDevice, c->stream));
+                rc = LV_OK;
+            } else {
+                rc = comm_allgather_inplace(c->comm, c->d_gather[i & 1], slot, c->comm_rank, c->stream);
+            }
             if (rc) return rc;
         }
         if (c->profiling && !closing) {
@@ -504,6 +524,7 @@ void lv_destroy(lv_ctx* c) {
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
     hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk); hipFree(c->d_wgcost[0]); hipFree(c->d_wgcost[1]);
+    if (c->h_gather) hipHostFree(c->h_gather);
     hipFree(c->d_gather[0]); hipFree(c->d_gather[1]);
     hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
@@ -1000,6 +1021,20 @@ int lv_comm_destroy(lv_ctx* c) {
     return rc;
 }
 
+int lv_comm_set_host_gather(lv_ctx* c, int rank, int world, lv_gather_fn fn, void* user) {
+    LV_CHECK_CTX(c);
+    if (c->in_update) { set_error("lv_comm_set_host_gather inside an update"); return LV_ESTATE; }
+    if (c->comm) { set_error("a library communicator is in place"); return LV_ESTATE; }
+    if (fn && (world < 1 || rank < 0 || rank >= world)) { set_error("lv_comm_set_host_gather: bad arguments (rank %d, world %d)", rank, world); return LV_EINVAL; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    c->gather_cb = fn;
+    c->gather_user = fn ? user : nullptr;
+    c->comm_rank = fn ? rank : 0;
+    c->comm_world = fn ? world : 1;
+    c->comm_shard_max = 0;
+    return LV_OK;
+}
+
 int lv_comm_world(lv_ctx* c) { return c ? c->comm_world : 0; }
 
 int lv_comm_set_shard_max(lv_ctx* c, size_t n_max) {
@@ -1007,10 +1042,19 @@ int lv_comm_set_shard_max(lv_ctx* c, size_t n_max) {
     if (c->in_update) { set_error("lv_comm_set_shard_max inside an update"); return LV_ESTATE; }
     if (n_max > 0xFFFFFFF0ull) { set_error("shard too large"); return LV_EINVAL; }
     c->comm_shard_max = n_max;
-    if (!c->comm || n_max == 0) return LV_OK;
+    if (!multi_rank(c) || n_max == 0) return LV_OK;
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size((uint32_t)n_max, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     const size_t need = (size_t)nwg * 32u * (size_t)c->comm_world;
+    if (c->gather_cb && need > c->h_gather_cap) {
+        LV_HIP(hipStreamSynchronize(c->stream));
+        if (c->h_gather) hipHostFree(c->h_gather);
+        c->h_gather = nullptr;
+        c->h_gather_cap = 0;
+        LV_HIP(hipHostMalloc((void**)&c->h_gather, need * sizeof(double), hipHostMallocDefault));
+        std::memset(c->h_gather, 0, need * sizeof(double));
+        c->h_gather_cap = need;
+    }
     if (need > c->gather_cap) {
         LV_HIP(hipStreamSynchronize(c->stream));
         for (int i = 0; i < 2; ++i) {
@@ -1117,6 +1161,11 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     if (rc) return rc;
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_begin, c->stream));
     c->last_update_fused = false;
+    if (c->gather_cb && !pass_fused_applies(c)) {
+        c->in_update = false;
+        set_error("host-staged gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
+        return LV_ESTATE;
+    }
     if (pass_fused_applies(c)) {
         rc = update_fused(c);
         if (rc) { c->in_update = false; return rc; }
@@ -1200,6 +1249,11 @@ int lv_correct(lv_ctx* c, int* passes) {
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     c->last_update_fused = false;
+    if (c->gather_cb && !pass_fused_applies(c)) {
+        c->in_update = false;
+        set_error("host-staged gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
+        return LV_ESTATE;
+    }
     if (pass_fused_applies(c)) {
         rc = update_fused(c);
         if (rc) { c->in_update = false; return rc; }

@@ -48,6 +48,22 @@ def init_library_comm(ctx, dist, torch, rank: int, world: int):
     ctx.comm_init(box[0], rank, world, path)
 
 
+def init_host_gather(ctx, dist, torch, rank: int, world: int):
+    """The one-launch-per-pass multi-rank form without librccl: the workgroup partials of the ranks are all-gathered
+    through `dist` on CPU tensors (lv_comm_set_host_gather).  For process groups RCCL cannot serve — two ranks on one
+    GPU in the tests, a `gloo` group — with exactly the kernels, buffers and fold of the RCCL route."""
+
+    def gather(slots, n, r, w):
+        mine = torch.from_numpy(slots[r * n:(r + 1) * n].copy())
+        outs = [torch.empty(n, dtype=torch.float64) for _ in range(w)]
+        dist.all_gather(outs, mine)
+        for q in range(w):
+            if q != r:
+                slots[q * n:(q + 1) * n] = outs[q].numpy()
+
+    ctx.comm_set_host_gather(rank, world, gather)
+
+
 class HipEngine:
     """Per-rank engine over the C-ABI split form (lv_update_begin / lv_pass_reduce / lv_pass_solve /
     lv_update_end).  The sums record lives in a torch tensor so RCCL can reduce it in place."""

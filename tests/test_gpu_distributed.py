@@ -205,3 +205,85 @@ def test_world2_hip_engine_on_one_gpu(lv, n_scan):
         assert passes == p1
         assert np.abs(x - x1).max() < 1e-10
         assert np.abs(P - P1).max() < 1e-10 * max(1.0, np.abs(P1).max())
+
+
+def _world2_gather_worker(rank, world, port, n_scan, out_q):
+    """One rank of a world-size-2 run with BOTH ranks on GPU 0, one launch per pass: the workgroup partials of the two
+    ranks are all-gathered through a gloo group (lv_comm_set_host_gather) — the kernels, gather buffers, geometry and fold
+    are the ones the RCCL route (lv_comm_init + lv_comm_set_shard_max) runs on N GPUs."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    import lvamd
+
+    lvamd.load()
+    from limo_velo_amd import capi, synth
+    from limo_velo_amd.distributed import HipEngine, ShardedUpdater, init_host_gather
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = synth.make_scene(50_000, max(n_scan, 8))
+        scan = sc["scan_xyz"][:n_scan]
+        with capi.Context() as ctx:
+            ctx.map_build(sc["map_xyz"])
+            init_host_gather(ctx, dist, torch, rank, world)
+            upd = ShardedUpdater(HipEngine(ctx, torch, multi=False, library_comm=True), rank, world, dist, torch)
+            upd.scan_set(scan)
+            for _ in range(2):
+                x, P, passes = upd.update(sc["x_init"], sc["P0"])
+            fused = ctx.last_update_fused()
+            # resident-filter route through the same launches
+            ctx.filter_set(sc["x_init"], sc["P0"])
+            p2 = ctx.correct()
+            x2, P2 = ctx.filter_get()
+            # without the largest shard there is no transport for the three-kernel form: a clean error, no hang
+            ctx.scan_set(scan[:0] if upd.n_local == 0 else scan[:upd.n_local])
+            try:
+                ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+                refused = False
+            except Exception:  # noqa: BLE001
+                refused = True
+        out_q.put((rank, upd.n_local, x, P, passes, fused, np.array_equal(x, x2) and np.array_equal(P, P2) and p2 == passes, refused))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scan", [2001, 1, 20_000])
+def test_world2_one_launch_form_on_one_gpu(lv, n_scan):
+    """The one-launch-per-pass multi-rank form with world = 2 (uneven shards 1001 + 1000; one EMPTY shard 1 + 0; 10 000 +
+    10 000: several workgroups per rank): both ranks end bitwise equal and within 1e-10 of the single-process update of
+    the whole scan (the partials of the two shards are folded in a different grouping)."""
+    import torch.multiprocessing as mp
+
+    from limo_velo_amd import capi, synth
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_world2_gather_worker, args=(r, 2, port, n_scan, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    with capi.Context() as ref:
+        ref.map_build(sc["map_xyz"])
+        ref.scan_set(sc["scan_xyz"][:n_scan])
+        x1, P1, p1, _, _ = ref.update(sc["x_init"], sc["P0"])
+    assert res[0][1] + res[1][1] == n_scan and abs(res[0][1] - res[1][1]) <= 1
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3]) and res[0][4] == res[1][4]
+    for _, _, x, P, passes, fused, same_filter, refused in res:
+        assert fused and same_filter and refused
+        assert passes == p1
+        assert np.abs(x - x1).max() < 1e-10
+        assert np.abs(P - P1).max() < 1e-10 * max(1.0, np.abs(P1).max())
