@@ -886,6 +886,47 @@ int MapStore::kill_dead_list(hipStream_t stream, uint32_t n_dead) {
     return LV_OK;
 }
 
+// (the kernels of the incremental insert that are not one-thread-per-item live here, not in lv_mapinc.hpp: that header is
+// also compiled for the host by tests/emu)
+// Stable sort of a small batch's (box key, input index) pairs by ONE workgroup (bitonic network in LDS over the composite
+// (key, index): the order a stable radix sort of the keys gives) — the library sort costs ~20 us in two launches at any size.
+constexpr int SMALL_BATCH = 2048;
+__global__ __launch_bounds__(1024) void inc_sort_small_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t k,
+                                                              uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted) {
+    __shared__ uint64_t s_key[SMALL_BATCH];
+    __shared__ uint32_t s_idx[SMALL_BATCH];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)SMALL_BATCH; i += 1024) {
+        s_key[i] = i < k ? keys[i] : ~0ull;
+        s_idx[i] = i < k ? idx[i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    uint32_t len = 64;
+    while (len < k) len <<= 1;
+    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < len / 2; t += 1024) {
+                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool up = (lo & k2) == 0;
+                const uint64_t a = s_key[lo], b = s_key[hi];
+                const uint32_t ia = s_idx[lo], ib = s_idx[hi];
+                const bool gt = a > b || (a == b && ia > ib);
+                if (gt == up) { s_key[lo] = b; s_key[hi] = a; s_idx[lo] = ib; s_idx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
+}
+
+// the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
+__global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 4u) gcnt[t] = 0u;
+    const uint32_t l = t / G.size, e = t % G.size;
+    if (l < (uint32_t)REPL_LEVELS) G.table[l][e] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+
 static int reset_batch_counters(MapStore& S, hipStream_t stream) {
     // n_new .. dropped are contiguous (MapCounters)
     LV_HIP(hipMemsetAsync(&S.d_cnt->n_new, 0, offsetof(MapCounters, box_slots_used) - offsetof(MapCounters, n_new), stream));

@@ -208,37 +208,6 @@ __global__ void inc_box_keys_kernel(MapRW M, const float4* __restrict__ newp, ui
     alive[j] = downsample ? 0u : 1u;   // without down-sampling every insertable point lives
 }
 
-// Stable sort of a small batch's (box key, input index) pairs by ONE workgroup (bitonic network in LDS over the composite
-// (key, index): the order a stable radix sort of the keys gives) — the library sort costs ~20 us in two launches at any size.
-constexpr int SMALL_BATCH = 2048;
-__global__ __launch_bounds__(1024) void inc_sort_small_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t k,
-                                                              uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted) {
-    __shared__ uint64_t s_key[SMALL_BATCH];
-    __shared__ uint32_t s_idx[SMALL_BATCH];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < (uint32_t)SMALL_BATCH; i += 1024) {
-        s_key[i] = i < k ? keys[i] : ~0ull;
-        s_idx[i] = i < k ? idx[i] : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    uint32_t len = 64;
-    while (len < k) len <<= 1;
-    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < len / 2; t += 1024) {
-                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
-                const bool up = (lo & k2) == 0;
-                const uint64_t a = s_key[lo], b = s_key[hi];
-                const uint32_t ia = s_idx[lo], ib = s_idx[hi];
-                const bool gt = a > b || (a == b && ia > ib);
-                if (gt == up) { s_key[lo] = b; s_key[hi] = a; s_idx[lo] = ib; s_idx[hi] = ia; }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
-}
-
 // One thread per box touched by the batch replays upstream's sequential rule: for every new point p of the box, in
 // input order, the point nearest to the box centre among {p} U (points currently in the box) survives if the box
 // held more than one point or p itself is that nearest point (occupants must be STRICTLY closer to beat p; among
@@ -408,14 +377,6 @@ constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + (level 2 only) the
 // (No global work lists or group counters: an atomic whose result is needed costs ~10 ns when every thread of a
 // launch hits the same address — 400 000 list appends were 4 ms of a 6 ms insert.  The group that reserves the
 // FIRST share of a target's tail (offset 0) owns that target for the rest of the batch: it makes room and commits.)
-
-// the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
-__global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 4u) gcnt[t] = 0u;
-    const uint32_t l = t / G.size, e = t % G.size;
-    if (l < (uint32_t)REPL_LEVELS) G.table[l][e] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-}
 
 // pass 1: every surviving new point joins its voxel group on each level
 __global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
