@@ -1307,8 +1307,9 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
                 rec[slot * PK_GROUPS + gqv] = v;
                 if (a.qrec && live) a.qrec[(size_t)slot * a.qstride + q] = v;
             }
-            if (round == 0) PK_STAMP(4 + step, tid == 0);
+            if (round == 0 && step == 0) PK_STAMP(4, tid == 0);   // (wavefront 0: the end of its last task of the first 16)
         }
+        if (round == 0) PK_STAMP(5, tid == 0);                    // (wavefront 0 has no task left)
         __syncthreads();   // the records of both steps are complete; nobody reads the candidate stage any more
         if (tid == 0) s_qn[1] = 0;   // (next round's tasks; the barrier after the fits publishes it)
         if (round == 0) PK_STAMP(6, tid == 0);

@@ -12,7 +12,7 @@ from limo_velo_amd import capi, synth
 
 NU = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 sc = synth.make_scene(1_048_576, 65_536)
-names = ["fold", "W + gauss-jordan", "gain, [+], consts", "search step 0", "search step 1", "barrier", "fit rows", "contraction", "tail"]
+names = ["fold", "W + gauss-jordan", "gain, [+], consts", "search: wavefront 0, first task(s)", "search: wavefront 0, later tasks", "barrier", "fit rows", "contraction", "tail"]
 W = 16
 runs = []
 with capi.Context() as ctx:
