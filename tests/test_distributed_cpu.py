@@ -156,3 +156,117 @@ def test_two_rank_gloo_update_equals_single_process(oracle, lv):
         assert passes == po
         assert np.abs(x - xo).max() < 1e-10 and np.abs(P - Po).max() < 1e-12
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])  # ranks agree bitwise
+
+
+class _GatherEngine(OracleEngine):
+    """CPU stand-in for the one-launch-per-pass multi-rank form (lv_comm_set_host_gather / lv_comm_set_shard_max): every rank
+    cuts its shard into the SAME number of workgroup slices (pass_kernel's geometry for the largest shard, the C-ABI's own
+    lv_pass_geometry), leaves one compact 32-double partial per slice in its slot of a gather buffer, the ranks' slots are
+    exchanged by the gather function limo_velo_amd.distributed.init_host_gather installs, and every rank folds world x slices
+    partials in the same fixed order before its solve."""
+
+    def comm_set_host_gather(self, rank, world, fn):   # what init_host_gather calls on a capi.Context
+        self.rank, self.world, self.gather_fn = rank, world, fn
+
+    def set_shard_max(self, n_max, capi):
+        self.nwg = capi.pass_geometry(max(int(n_max), 1), 256)[0]
+
+    @staticmethod
+    def compact(s):   # the 29 live sums of the 6-column case in a 32-double record
+        rec = np.zeros(32)
+        k = 0
+        for i in range(6):
+            for j in range(i, 6):
+                rec[k] = s["HTH"][i, j]
+                k += 1
+        rec[21:27] = s["HTh"][:6]
+        rec[27] = s["n_valid"]
+        rec[28] = s["sum_h2"]
+        return rec
+
+    def reduce(self):
+        n = 32 * self.nwg
+        slots = np.zeros(n * self.world)
+        if not self.done and len(self.scan):
+            cuts = np.linspace(0, len(self.scan), self.nwg + 1).astype(int)
+            for g in range(self.nwg):
+                if cuts[g + 1] > cuts[g]:
+                    s = self.lo.iterate(self.x, self.map_xyz, self.scan[cuts[g]:cuts[g + 1]], tree=self.tree, details=False)
+                    slots[self.rank * n + 32 * g:self.rank * n + 32 * (g + 1)] = self.compact(s)
+        self.gather_fn(slots, n, self.rank, self.world)
+        tot = np.zeros(32)
+        for r in range(self.world * self.nwg):   # the fold: every record, rank-major, in order
+            tot += slots[32 * r:32 * (r + 1)]
+        HTH = np.zeros((12, 12))
+        k = 0
+        for i in range(6):
+            for j in range(i, 6):
+                HTH[i, j] = HTH[j, i] = tot[k]
+                k += 1
+        HTh = np.zeros(12)
+        HTh[:6] = tot[21:27]
+        self.rec = self.torch.from_numpy(pack_record(dict(HTH=HTH, HTh=HTh, n_valid=int(round(tot[27])), sum_h2=float(tot[28]))))
+        return self.rec
+
+
+def _gather_worker(rank, world, port, n_scan, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import lvamd
+
+    lvamd.load()
+    from limo_velo_amd import capi, synth
+    from limo_velo_amd.distributed import init_host_gather, shard_bounds
+
+    import lvoracle as lo
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    scan = sc["scan_xyz"][:n_scan]
+    eng = _GatherEngine(lo, torch, sc["map_xyz"])
+    init_host_gather(eng, dist, torch, rank, world)           # the product's gather function, on a stand-in context
+    lo_, hi_ = shard_bounds(n_scan, rank, world)
+    eng.scan_set(scan[lo_:hi_])
+    l0, h0 = shard_bounds(n_scan, 0, world)
+    eng.set_shard_max(h0 - l0, capi)                          # every rank: the largest shard (rank 0's)
+    eng.begin(sc["x_init"], sc["P0"])
+    for _ in range(eng.max_passes):
+        eng.reduce()
+        eng.solve()
+    x, P, passes = eng.end()
+    out_q.put((rank, hi_ - lo_, eng.nwg, x, P, passes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scan", [2001, 1])
+def test_two_rank_gloo_one_launch_form(oracle, lv, n_scan):
+    """The protocol of the one-launch-per-pass multi-rank form on CPU (world size 2, gloo): same slice count on both ranks
+    from the largest shard, partial slots exchanged by the gather function the product installs (init_host_gather), fixed-order
+    fold — ranks bitwise equal, the single-process update within 1e-10; uneven shards and an empty one."""
+    import torch.multiprocessing as mp
+
+    from limo_velo_amd import synth
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n_scan, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    tree = oracle.KdTree(sc["map_xyz"])
+    xo, Po, po, _, _ = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"][:n_scan], tree=tree)
+    assert res[0][1] + res[1][1] == n_scan and res[0][2] == res[1][2] >= 1
+    for rank, n_local, nwg, x, P, passes in res:
+        assert passes == po
+        assert np.abs(x - xo).max() < 1e-10 and np.abs(P - Po).max() < 1e-12
+    assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])  # ranks agree bitwise
