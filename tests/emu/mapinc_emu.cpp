@@ -327,7 +327,10 @@ struct Emu {
         launch(inc_commit_points_kernel, k, M, B, have_boxes ? 1 : 0, (const float4*)newp.data(), (const uint32_t*)alive.data(),
                (const uint32_t*)apos.data(), k, n_ids);
         const uint32_t n_dead = cnt.n_dead;
-        if (n_dead) launch(inc_kill_kernel, (uint64_t)n_dead * INC_SLOTS_PER_POINT, M, (const float4*)dead.data(), n_dead);
+        // small batches leave the list's length on the device (inc_kill_counted_kernel, a fixed grid walking it in strides);
+        // alternate between the two forms so that both run under every thread order
+        if (n_dead && (k & 1u)) launch(inc_kill_kernel, (uint64_t)n_dead * INC_SLOTS_PER_POINT, M, (const float4*)dead.data(), n_dead);
+        else if (n_dead) launch(inc_kill_counted_kernel, 512, M, (const float4*)dead.data(), (uint32_t)dead.size());
         // voxel groups (twin of the GroupRW set-up in MapStore::add_staged)
         const uint32_t gsize = next_pow2((uint64_t)k * 4);
         std::vector<uint4> gtab[REPL_LEVELS];
@@ -352,7 +355,9 @@ struct Emu {
         const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
         launch(inc_register_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
         launch(inc_reserve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k, reloc.data(), (uint32_t)reloc.size(), gcnt.data());
-        launch(inc_relocate_kernel, (uint64_t)reloc.size() * RELOC_LANES, M, (const uint4*)reloc.data(), (uint32_t)reloc.size(), (const uint32_t*)gcnt.data());
+        // (the product launches a grid for the runs a batch can list, at most 2048 workgroups, and walks longer lists in strides:
+        // 16 runs per sweep here, so that the stride loop is exercised)
+        launch(inc_relocate_kernel, (uint64_t)16 * RELOC_LANES, M, (const uint4*)reloc.data(), (uint32_t)reloc.size(), (const uint32_t*)gcnt.data());
         launch(inc_fill_kernel, t_all, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids);
         launch(inc_rank_kernel, t_rep, M, G, (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids, rank.data());
         launch(inc_place_kernel, t_rep, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
