@@ -1001,6 +1001,7 @@ int lv_comm_init(lv_ctx* c, const char* rccl_library, const void* id128, int ran
     if (!id128 || world < 1 || rank < 0 || rank >= world) { set_error("lv_comm_init: bad arguments (rank %d, world %d)", rank, world); return LV_EINVAL; }
     if (c->in_update) { set_error("lv_comm_init inside an update"); return LV_ESTATE; }
     if (c->comm) { set_error("communicator already initialised"); return LV_ESTATE; }
+    if (c->gather_cb) { set_error("a host gather transport is in place (lv_comm_set_host_gather)"); return LV_ESTATE; }
     void* comm = nullptr;
     int rc = comm_init(rccl_library, id128, rank, world, &comm);   // collective: every rank calls it
     if (rc) return rc;
