@@ -64,6 +64,117 @@ def pmc_traffic_bytes(kernel="search"):
     return fetch + write, os.path.basename(files[-1])
 
 
+def upd_scan_local(sc, rank: int, world: int):
+    from limo_velo_amd.distributed import shard_bounds
+
+    lo, hi = shard_bounds(len(sc["scan_xyz"]), rank, world)
+    return sc["scan_xyz"][lo:hi]
+
+
+def parity_check(g: dict, sc, scan_local, nthreads: int = 16) -> dict:
+    """SURVEY 8(d) "parity gates reported with every perf number": the GPU results of THIS run (collected by main(): one
+    capturing pass over this rank's points at the initial state, and the timed build's update with its per-pass log) against
+    the CPU oracle on the identical inputs — the oracle is the checker here, never the thing measured.  Exact kNN (index
+    mismatches, distance bits), valid-mask flips, plane / residual bits, H^T H / H^T h of that pass; then the iterated update:
+    pass count, per-pass n_valid, state after every pass, final state and covariance.  The oracle is a restatement of the
+    reference (no reference binary or golden vectors exist: parity unpinned), so "ok" means "equal to the oracle within the
+    stated tolerances"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lvoracle as lo
+
+    tol = {"sums_rel": 1e-10, "state_abs": 1e-9, "P_rel": 1e-9}
+    tree = lo.KdTree(sc["map_xyz"])
+    o = lo.iterate(sc["x_init"], sc["map_xyz"], scan_local, tree=tree, nthreads=nthreads)
+    xo, Po, po, tro, so = lo.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree, nthreads=nthreads)
+    scale = float(np.abs(o["HTH"]).max())
+    g0 = g["g0"]
+    out = {
+        "against": "oracle/ (CPU restatement of the reference; parity unpinned: the reference ships no vectors and cannot be built here)",
+        "points_checked_per_point": int(len(scan_local)),
+        "knn_index_mismatches": int((g["idx"] != o["knn_idx"]).any(axis=1).sum()),
+        "knn_distance_bit_mismatches": int((g["d2"].view(np.uint32) != o["knn_d2"].view(np.uint32)).any(axis=1).sum()),
+        "valid_mask_flips": int((g["valid"] != o["valid"]).sum()),
+        "plane_abcd_bit_mismatches": int((g["abcd"].view(np.uint32) != o["abcd"].view(np.uint32)).any(axis=1).sum()),
+        "residual_bit_mismatches": int((g["dist"].view(np.uint32) != o["dist"].view(np.uint32)).sum()),
+        "max_rel_dHTH": float(np.abs(g0["HTH"] - o["HTH"]).max() / scale),
+        "max_abs_dHTh": float(np.abs(g0["HTh"] - o["HTh"]).max()),
+        "passes": [int(g["passes"]), int(po)],
+        "max_abs_dx": float(np.abs(g["x"] - xo).max()),
+        "max_rel_dP": float(np.abs(g["P"] - Po).max() / max(1.0, float(np.abs(Po).max()))),
+        "tolerances": tol,
+    }
+    ok = (out["knn_index_mismatches"] == 0 and out["knn_distance_bit_mismatches"] == 0 and out["valid_mask_flips"] == 0
+          and out["plane_abcd_bit_mismatches"] == 0 and out["residual_bit_mismatches"] == 0
+          and out["max_rel_dHTH"] <= tol["sums_rel"] and out["max_abs_dHTh"] <= tol["sums_rel"] * max(1.0, float(np.abs(o["HTh"]).max()))
+          and out["passes"][0] == out["passes"][1] and out["max_abs_dx"] < tol["state_abs"] and out["max_rel_dP"] < tol["P_rel"])
+    if g.get("sums") is not None:
+        np_ = min(int(g["passes"]), int(po))
+        out["n_valid_per_pass"] = [[int(v["n_valid"]) for v in g["sums"]], [int(v["n_valid"]) for v in so]]
+        out["max_abs_dstate_per_pass"] = [float(np.abs(g["tr"][i] - tro[i]).max()) for i in range(np_)]
+        ok = ok and out["n_valid_per_pass"][0] == out["n_valid_per_pass"][1] and all(v < tol["state_abs"] for v in out["max_abs_dstate_per_pass"])
+    out["ok"] = bool(ok)
+    return out
+
+
+def cycle_64k(ctx, sc, capi, reps: int = 10) -> dict:
+    """One whole cycle of the reference's loop (src/main.cpp:75-103) at the headline size, device-resident stages timed with
+    the PCIe legs beside them: a 65 536-point hesai PointCloud2 message in (lv_cloud_ingest: H2D + decode + time sort) ->
+    de-skew of the buffered window + Morton order (lv_scan_deskew_window, no voxel grid so the scan keeps its 64k points) ->
+    the iterated update on the resident filter (lv_correct) -> map insert with ikd-Tree down-sampling (lv_map_add_scan) ->
+    lv_cloud_clear.  The sensor is at rest (identity de-skew), so every cycle sees the benchmark's scan."""
+    import struct  # noqa: F401
+
+    n = len(sc["scan_xyz"])
+    rec = np.zeros(n, np.dtype({"names": ["x", "y", "z", "intensity", "timestamp", "ring"], "formats": ["<f4", "<f4", "<f4", "u1", "<f8", "<u2"],
+                                "offsets": [0, 4, 8, 16, 24, 32], "itemsize": 48}))
+    rec["x"], rec["y"], rec["z"] = sc["scan_xyz"].T
+    t0 = 100.0
+    rec["timestamp"] = t0 + np.arange(n) * (0.1 / n)
+    raw = rec.tobytes()
+    fmt = ctx.cloud_format_preset(capi.LIDAR_HESAI)
+    prm = capi.IngestParams(int(t0 * 1e6), 0, 0, 0.1, 1, 0.0)   # stamp, not real time, stamp at the end, rotation time, every point, min_dist 0
+    states = np.concatenate([capi.motion_state(time=t0 - 0.01), capi.motion_state(time=t0 + 0.11)])
+    xt2 = capi.motion_state(time=t0 + 0.1)
+    m0 = ctx.map_size()
+
+    def one(timed):
+        ts = []
+        ctx.synchronize(); a = time.perf_counter()
+        ctx.cloud_ingest(raw, n, fmt, prm); ctx.synchronize(); b = time.perf_counter()
+        nw = ctx.scan_deskew_window(t0 - 1.0, t0 + 1.0, states, xt2, 0.0); ctx.synchronize(); c = time.perf_counter()
+        ctx.filter_set(sc["x_init"], sc["P0"])
+        ctx.correct(want_passes=False); ctx.synchronize(); d = time.perf_counter()
+        ctx.map_add_scan(True); ctx.synchronize(); e = time.perf_counter()
+        ctx.cloud_clear(1e300); ctx.synchronize(); f = time.perf_counter()
+        return nw, [b - a, c - b, d - c, e - d, f - e]
+
+    for _ in range(3):
+        nw, _ = one(False)
+    acc = np.zeros(5)
+    for _ in range(reps):
+        nw, t = one(True)
+        acc += t
+    acc = acc / reps * 1e3
+    # without a synchronisation between the stages (what a host program does): the device-resident part back to back
+    ctx.synchronize(); a = time.perf_counter()
+    for _ in range(reps):
+        ctx.cloud_ingest(raw, n, fmt, prm)
+        ctx.scan_deskew_window(t0 - 1.0, t0 + 1.0, states, xt2, 0.0)
+        ctx.filter_set(sc["x_init"], sc["P0"])
+        ctx.correct(want_passes=False)
+        ctx.map_add_scan(True)
+        ctx.cloud_clear(1e300)
+    ctx.synchronize()
+    chained = (time.perf_counter() - a) / reps * 1e3
+    out = {"points_in_window": int(nw), "ingest_pcie_ms": round(float(acc[0]), 4), "deskew_sort_ms": round(float(acc[1]), 4),
+           "correct_ms": round(float(acc[2]), 4), "map_insert_ms": round(float(acc[3]), 4), "clear_ms": round(float(acc[4]), 4),
+           "device_resident_ms": round(float(acc[1] + acc[2] + acc[3]), 4), "pcie_inclusive_ms": round(float(acc.sum()), 4),
+           "pcie_inclusive_chained_ms": round(float(chained), 4),
+           "map_points_before_after": [int(m0), int(ctx.map_size())],
+           "note": "stage times with a synchronisation after every stage; chained = the same calls back to back"}
+    return out
+
+
 def cpu_baseline(sc, passes_expected: int, budget_s: float = 20.0) -> dict:
     """Times the CPU oracle (a port/restatement — the reference binary cannot be built here) on this
     host's cores, same scene, same update, bounded to ~budget_s seconds."""
@@ -131,6 +242,8 @@ def main() -> None:
                     "neighbourhood buckets together exceed the 256 MB Infinity Cache); 0 = skip")
     ap.add_argument("--no-phases", action="store_true", help="skip the in-kernel phase stamps leg (N=1, one launch per pass)")
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (GPU results of this run vs the CPU oracle)")
+    ap.add_argument("--no-cycle", action="store_true", help="skip the whole-cycle leg (message in -> de-skew -> correct -> map insert)")
     args = ap.parse_args()
 
     import torch
@@ -248,16 +361,60 @@ def main() -> None:
     # ---- the same K steps again with HIP events around the dominant kernel (ctx stream) --------------
     # (event records between kernels add ~5 us gaps each, so they are kept out of the timed region; kernel
     # durations themselves are unaffected and must agree with the rocprofv3 summary under profiles/)
-    ctx.set_profiling(True)
-    kern_ms, kern_cnt, solve_ms = 0.0, 0, 0.0
-    if world == 1 or collective.startswith("rccl (library"):   # lv_update itself runs the passes: per-kernel events exist
-        for _ in range(args.steps):
+    lib_comm = collective.startswith("rccl (library")
+
+    def events_leg(steps):
+        """steps profiled updates: average device time of the dominant kernel, of the rest of a pass, and — with a library
+        communicator — of the pass' collective (HIP events on the context stream around each)."""
+        ctx.set_profiling(True)
+        k_ms, s_ms, cnt, c_us = 0.0, 0.0, 0, np.zeros(8)
+        for _ in range(steps):
             _, _, p = upd.update(sc["x_init"], sc["P0"])
             tm = ctx.timing()
-            kern_ms += tm["last_reduce_ms"] * p
-            solve_ms += tm["last_solve_ms"] * p
-            kern_cnt += p
-    ctx.set_profiling(False)
+            k_ms += tm["last_reduce_ms"] * p
+            s_ms += tm["last_solve_ms"] * p
+            c_us[:p] += np.array(tm["pass_collective_ms"][:p]) * 1e3
+            cnt += p
+        ctx.set_profiling(False)
+        return k_ms, s_ms, cnt, (c_us / max(steps, 1))
+
+    kern_ms, kern_cnt, solve_ms, coll_us = 0.0, 0, 0.0, np.zeros(8)
+    if world == 1 or lib_comm:   # lv_update itself runs the passes: per-kernel events exist
+        kern_ms, solve_ms, kern_cnt, coll_us = events_leg(args.steps)
+    fused_main = bool(ctx.last_update_fused())
+    # ---- N > 1: the OTHER form of the multi-GPU pass, the same K steps (timed like the headline region, then with events), so
+    # that the first run on a node yields the breakdown of both: "allgather_one_launch" = one launch per pass + ncclAllGather
+    # of the workgroup partials, "allreduce_three_kernel" = search / fit / reduce -> ncclAllReduce of 768 bytes -> solve
+    forms = None
+    if world > 1 and lib_comm:
+        def timed_form():
+            barrier_sync()
+            a, tp = time.perf_counter(), 0
+            for _ in range(args.steps):
+                tp += upd.update(sc["x_init"], sc["P0"])[2]
+            barrier_sync()
+            d = time.perf_counter() - a
+            if dist is not None:
+                t = torch.tensor([d], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            return tp / d, d / args.steps * 1e3
+
+        def describe(rate_ms, ev):
+            k_ms, s_ms, cnt, c_us = ev
+            return {"iters_per_s": rate_ms[0], "ms_per_step": rate_ms[1], "avg_kernel_us": k_ms / max(cnt, 1) * 1e3,
+                    "avg_rest_of_pass_us": s_ms / max(cnt, 1) * 1e3, "collective_us_per_pass": [round(float(v), 2) for v in c_us[:4]]}
+
+        main_name = "allgather_one_launch" if fused_main else "allreduce_three_kernel"
+        forms = {main_name: describe((None, None), (kern_ms, solve_ms, kern_cnt, coll_us))}   # (its rate = the headline value, filled in below)
+        if fused_main:   # the headline ran the all-gather form: also time the all-reduce form
+            ctx.set_comm_fused(False)
+            for _ in range(max(args.warmup // 2, 2)):
+                upd.update(sc["x_init"], sc["P0"])
+            r = timed_form()
+            forms["allreduce_three_kernel"] = describe(r, events_leg(args.steps))
+            ctx.set_comm_fused(True)
+            upd.update(sc["x_init"], sc["P0"])
     # ---- cold-cache leg: the headline loop replays ONE scan, whose ~45 MB of buckets stay in the 256 MB Infinity
     # Cache from step to step; here K scans from K poses of the same map are cycled (lv_scan_set + lv_update each),
     # so the buckets a scan touches have been evicted since its previous turn.  Only the search kernel's HIP-event
@@ -314,16 +471,42 @@ def main() -> None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- parity gate, GPU side (every rank: with a communicator the update is a collective): one capturing pass over this
+    # rank's shard at the initial state + the timed build once more with its per-pass log; rank 0 then checks against the oracle
+    gate = None
+    if not args.no_parity:
+        try:
+            g0 = ctx.iterate(sc["x_init"])
+            g_idx, g_d2 = ctx.fetch_knn()
+            g_valid, _, g_abcd, g_dist = ctx.fetch_matches()
+            if world == 1 or lib_comm:
+                xg, Pg, pg, trg, sumsg = ctx.update(sc["x_init"], sc["P0"])
+            else:
+                xg, Pg, pg = upd.update(sc["x_init"], sc["P0"])
+                trg, sumsg = None, None
+            gate = dict(g0=g0, idx=g_idx, d2=g_d2, valid=g_valid, abcd=g_abcd, dist=g_dist, x=xg, P=Pg, passes=pg, tr=trg, sums=sumsg)
+        except Exception as e:  # noqa: BLE001
+            gate = {"error": str(e)}
+    cycle = None
+    if world == 1 and not args.no_cycle:
+        try:
+            cycle = cycle_64k(ctx, sc, capi)     # (last: it inserts into the map)
+        except Exception as e:  # noqa: BLE001
+            cycle = {"error": str(e)}
 
+    rc = 0
     if rank == 0:
         value = total_passes / dt
         # which kernel ran the passes: one launch per pass (pass_kernel: the solve of the previous pass in every workgroup +
-        # search + plane fits; the single-GPU default) or the three-kernel pass (search / fit / solve; with a communicator)
-        fused = bool(ctx.last_update_fused())
+        # search + plane fits) or the three-kernel pass (search / fit / solve)
+        fused = fused_main
         kname = "pass" if fused else "search"
         avg_kernel_s = (kern_ms / max(kern_cnt, 1)) * 1e-3
         alg_bytes = b_alg(M_POINTS) * n_local
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        traffic, traffic_file = pmc_traffic_bytes(kname) if world == 1 else (None, None)
+        if forms:
+            forms["allgather_one_launch" if fused else "allreduce_three_kernel"].update(iters_per_s=value, ms_per_step=dt / args.steps * 1e3)
         out = {
             "metric": "KF-update iters/sec, 64k-pt scan vs 1M-pt map",
             "value": value,
@@ -356,8 +539,13 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(kname)[0] if world == 1 else None,
-                "traffic_source": pmc_traffic_bytes(kname)[1],
+                # HBM bytes per launch from the PMC counters: NOT measured in this run (rocprofv3 wraps a process; it cannot be
+                # started from inside one) but read from the committed summary of the same command (scripts/gpu_profile.sh)
+                "traffic": traffic,
+                "traffic_source": None if traffic is None else f"from_committed_profile: profiles/{traffic_file} (PMC pass of this command, not this run)",
+                # the same kernel priced with the bytes it really moves instead of the algorithmic ones
+                "frac_measured_bytes": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
+                "measured_traffic_gbs": (traffic / avg_kernel_s / 1e9) if (traffic and avg_kernel_s > 0) else None,
                 "alg_bytes_per_launch": alg_bytes,
                 "alg_bytes_per_point_pass": b_alg(M_POINTS),
                 "avg_kernel_us": avg_kernel_s * 1e6,
@@ -366,8 +554,6 @@ def main() -> None:
                 "last_update_match_us_per_pass": [round(v * 1e3, 1) for v in ctx.timing()["pass_match_ms"][:4]],
                 # SURVEY 8(d) metric 3: algorithmic bytes of ALL passes of a step over the step's wall time
                 "whole_update_frac": alg_bytes * (total_passes / args.steps) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                # the same kernel priced with the PMC-measured bytes instead of the algorithmic ones
-                "measured_traffic_gbs": (pmc_traffic_bytes(kname)[0] / avg_kernel_s / 1e9) if (world == 1 and pmc_traffic_bytes(kname)[0] and avg_kernel_s > 0) else None,
                 "cold": cold,
                 # inside pass_kernel (in-kernel wall-clock stamps, separate instrumented context): the search phase alone —
                 # what round 1's search_kernel figure measured, minus launch ramp and the record stores that no longer exist
@@ -376,19 +562,35 @@ def main() -> None:
                     "us_converged": phases["per_launch_us"]["search"][-1],
                     "alg_gbs": alg_bytes / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9,
                     "alg_frac": alg_bytes / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "traffic_gbs": (pmc_traffic_bytes(kname)[0] / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9) if pmc_traffic_bytes(kname)[0] else None,
+                    "traffic_gbs": (traffic / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e9) if traffic else None,
                 },
             },
             "fallback": ctx.timing()["fallback_queries"],
-            "state_check": {"pos_err_m": float(np.linalg.norm(x[:3] - sc["x_true"][:3]))},
+            "state_check": {"pos_err_m_from_ground_truth": float(np.linalg.norm(x[:3] - sc["x_true"][:3]))},
         }
+        if world > 1:
+            out["multi_gpu"] = {"measured_on": f"{world} ranks", "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]],
+                                "forms": forms}
+        if cycle is not None:
+            out["cycle_ms_64k"] = cycle
+        if gate is not None:
+            if "error" in gate:
+                out["parity"] = {"ok": False, "error": gate["error"]}
+            else:
+                out["parity"] = parity_check(gate, sc, upd_scan_local(sc, rank, world))
+            if not out["parity"]["ok"]:
+                rc = 3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, int(total_passes / args.steps))
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+        sys.stdout.flush()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        print("bench.py: PARITY GATE FAILED (see \"parity\" in the JSON line)", file=sys.stderr)
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

@@ -338,11 +338,16 @@ int lv_last_update_fused(lv_ctx* ctx);
 int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]);
 /* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);
+/* Tuning / test knobs by name (the environment variables LV_<NAME> set the defaults at lv_create): "fused_pass",
+ * "fused_ext" (one launch per pass also with estimate_extrinsics), "fused_multi_round" (... also for scans of more than two
+ * rounds per workgroup), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused".  None of them changes a result beyond
+ * the summation order of the workgroup partials.  LV_EINVAL for an unknown name. */
+int lv_set_option(lv_ctx* ctx, const char* name, int value);
 /* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): for every launch of the last update
  * (MAX_NUM_ITERS + 2 of them) and every workgroup slot (capacity_wg >= CUs + 1 of them per launch; slot *n_wg is the
  * launch's designated workgroup), 16 shader-clock stamps followed by 16 wall-clock stamps (100 MHz) at its phase
  * boundaries: out holds (MAX_NUM_ITERS + 2) x capacity_wg... see scripts/pass_clocks.py for the layout. */
-int lv_get_pass_clocks(lv_ctx* ctx, long long* out, int capacity_wg, int* n_wg);
+int lv_get_pass_clocks(lv_ctx* ctx, long long* out, int capacity_wg, int* n_wg);   /* out = NULL: *n_wg = slots per launch */
 /* Mapper::match outputs: valid N (Match::is_chosen), p_world N x 3, abcd N x 4 (Normal A,B,C,D),
  * dist N (Match::distance).  Any pointer may be NULL. */
 int lv_fetch_matches(lv_ctx* ctx, uint8_t* valid, float* p_world, float* abcd, float* dist);
@@ -367,7 +372,10 @@ typedef struct lv_timing {
     float pass_match_ms[8];    /* device time of search_kernel per pass of the last profiled lv_update */
     float pass_solve_ms[8];    /* device time of fit_reduce_kernel + solve_kernel per pass */
     int   mailbox_resyncs;     /* updates (since lv_create) whose result mailbox failed its checksum at first sight: the host
-                                  then waited with hipStreamSynchronize instead (expected: 0) */
+                                  then waited with hipStreamSynchronize instead (expected: 0; an update that ends on a pass
+                                  without matches carries no checksum and is not counted) */
+    float pass_collective_ms[8]; /* multi-GPU forms, profiled updates: device time of the pass' collective (ncclAllGather of the
+                                  workgroup partials / ncclAllReduce of the record), HIP events around it on the ctx stream */
 } lv_timing;
 int lv_get_timing(lv_ctx* ctx, lv_timing* out);
 /* 0 = off; 1 = per-kernel HIP-event timing inside lv_update (adds event records to the stream);

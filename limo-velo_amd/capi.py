@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_add_scan", "lv_map_evict_box", "lv_map_evict_oldest", "lv_map_relinearise", "lv_map_get_stats",
     "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_downsample", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
-    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_set_fused_pass", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
+    "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_set_fused_pass", "lv_set_option", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
 ]
@@ -83,7 +83,25 @@ class Sums(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("last_update_ms", C.c_float), ("last_reduce_ms", C.c_float), ("last_solve_ms", C.c_float),
                 ("last_passes", C.c_int), ("fallback_queries", C.c_int), ("pass_match_ms", C.c_float * 8),
-                ("pass_solve_ms", C.c_float * 8), ("mailbox_resyncs", C.c_int)]
+                ("pass_solve_ms", C.c_float * 8), ("mailbox_resyncs", C.c_int), ("pass_collective_ms", C.c_float * 8)]
+
+
+# lv_motion_state (include/limovelo_hip.h): the f32 State members State::propagate_f reads, 184 bytes
+MOTION_DTYPE = np.dtype([("R", "f4", 9), ("pos", "f4", 3), ("vel", "f4", 3), ("bw", "f4", 3), ("ba", "f4", 3), ("g", "f4", 3),
+                         ("RLI", "f4", 9), ("tLI", "f4", 3), ("a", "f4", 3), ("w", "f4", 3), ("pad_", "f4", 2), ("time", "f8")])
+assert MOTION_DTYPE.itemsize == 184
+
+
+def motion_state(time=0.0, R=None, pos=(0, 0, 0), vel=(0, 0, 0), a=(0, 0, 9.807), w=(0, 0, 0), RLI=None, tLI=(0, 0, 0),
+                 g=(0, 0, -9.807), bw=(0, 0, 0), ba=(0, 0, 0)) -> np.ndarray:
+    """One lv_motion_state record (a numpy array of length 1)."""
+    s = np.zeros(1, MOTION_DTYPE)
+    s["R"] = np.eye(3, dtype=np.float32).ravel() if R is None else np.asarray(R, np.float32).ravel()
+    s["RLI"] = np.eye(3, dtype=np.float32).ravel() if RLI is None else np.asarray(RLI, np.float32).ravel()
+    for k, v in (("pos", pos), ("vel", vel), ("a", a), ("w", w), ("tLI", tLI), ("g", g), ("bw", bw), ("ba", ba)):
+        s[k] = np.asarray(v, np.float32)
+    s["time"] = time
+    return s
 
 
 class MapStats(C.Structure):  # lv_map_stats
@@ -433,6 +451,7 @@ class Context:
         out = {k: getattr(t, k) for k, _ in Timing._fields_}
         out["pass_match_ms"] = list(t.pass_match_ms)
         out["pass_solve_ms"] = list(t.pass_solve_ms)
+        out["pass_collective_ms"] = list(t.pass_collective_ms)
         return out
 
     # --- fetches
@@ -484,9 +503,17 @@ class Context:
     def set_fused_pass(self, on=True):
         self._check(self.lib.lv_set_fused_pass(self.h, int(on)))
 
-    def pass_clocks(self, slots=257):
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.lv_set_option(self.h, name.encode(), int(value)))
+
+    def pass_clocks(self, slots=None):
         """[launch][workgroup slot][32] stamps of the last update's pass_kernel launches, and the number of search
-        workgroups n (slot n - 1 of a launch = its bookkeeping workgroup, stamp 10 = books done).  slots = CUs + 1."""
+        workgroups n (slot n - 1 of a launch = its bookkeeping workgroup, stamp 10 = books done).  The slot count
+        (the library's stride: its workgroup limit + 1) is asked from the library."""
+        if slots is None:
+            q = C.c_int(0)
+            self._check(self.lib.lv_get_pass_clocks(self.h, None, 0, C.byref(q)))
+            slots = q.value
         nl = self.params.MAX_NUM_ITERS + 2
         buf = np.zeros((nl, slots, 32), np.int64)
         n = C.c_int(0)

@@ -42,6 +42,8 @@ struct lv_ctx {
     FilterDev* d_filter = nullptr;  // x, P resident between lv_predict / lv_correct (row f-3)
     FilterDev* h_filter = nullptr;  // pinned staging
     bool filter_set = false;
+    int state_src = 0;          // who produced the latest state: 0 nobody yet, 1 the resident filter (lv_filter_set / lv_predict /
+                                // lv_correct), 2 lv_update (d_kf->x) — lv_map_add_scan transforms the scan with that state
     KfDev* h_kf = nullptr;  // pinned mirror (logs / trace downloads)
     KfHostIO* h_io = nullptr;  // pinned, host-mapped mailbox: update inputs and results (no copy kernels)
     KfHostIO* d_io = nullptr;  // its device address
@@ -95,6 +97,8 @@ struct lv_ctx {
     int fallback_base = 0;         // device counter value before the update in flight (the device never resets it)
     long mailbox_resyncs = 0;      // updates whose mailbox checksum did not match at first sight (stream synchronised instead)
 
+    int pass_index = -1;           // index of the pass being enqueued by lv_update's three-kernel loop (events of its collective)
+    bool coll_timed = false;       // the last profiled update recorded events around its collectives
     bool in_update = false;
     bool want_log = false;         // download trace / per-pass sums at lv_update_end
     int passes_issued = 0;
@@ -105,6 +109,7 @@ struct lv_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pass;  // 3 per pass: before match kernel, after it, after reduce_partials + solve
     hipEvent_t ev_mid = nullptr;      // set while a profiled pass is in flight: recorded right after the match kernel
+    std::vector<hipEvent_t> ev_coll;  // 2 per pass: around the pass' collective (multi-GPU forms, profiled updates)
     lv_timing timing{};
 };
 
@@ -272,8 +277,12 @@ int pass_full(lv_ctx* c) {
     int rc = pass_reduce(c, c->comm != nullptr);
     if (rc) return rc;
     if (c->comm) {
+        const int i = c->pass_index;
+        const bool timed = c->profiling && i >= 0 && (size_t)(2 * i + 1) < c->ev_coll.size();
+        if (timed) LV_HIP(hipEventRecord(c->ev_coll[2 * i], c->stream));
         rc = comm_allreduce_record(c->comm, c->d_sums, c->stream);
         if (rc) return rc;
+        if (timed) { LV_HIP(hipEventRecord(c->ev_coll[2 * i + 1], c->stream)); c->coll_timed = true; }
     }
     return pass_solve(c, c->comm == nullptr);
 }
@@ -298,6 +307,8 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 // the scan size that fixes pass_kernel's geometry: the local scan, or with a communicator the largest shard over the ranks
 // (every rank launches the same grid; workgroups without a tile contribute zero partials)
 static inline bool multi_rank(const lv_ctx* c) { return c->comm != nullptr || c->gather_cb != nullptr; }
+// doubles per compact workgroup partial (PassDims<W>::OW, lv_pass_dev.hpp): 32 for the 6-column rows, 96 with extrinsics
+static inline size_t partial_width(const lv_ctx* c) { return c->prm.estimate_extrinsics ? 96u : 32u; }
 uint32_t pass_geometry_points(const lv_ctx* c) { return multi_rank(c) ? (uint32_t)c->comm_shard_max : c->scan.n; }
 
 bool pass_fused_applies(const lv_ctx* c) {
@@ -309,7 +320,7 @@ bool pass_fused_applies(const lv_ctx* c) {
         // ncclAllGather (or the caller exchanges the partials itself: lv_comm_set_host_gather), the gather buffers are in
         // place; a rank without points still runs every launch
         if (!c->comm_fused || c->comm_shard_max == 0 || c->scan.n > c->comm_shard_max || (c->comm && !comm_has_allgather()) ||
-            !c->d_gather[0] || c->prm.estimate_extrinsics)
+            !c->d_gather[0])
             return false;
     } else if (c->scan.n == 0) {
         return false;
@@ -317,7 +328,7 @@ bool pass_fused_applies(const lv_ctx* c) {
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     if (rounds > 2 && !c->fused_multi_round) return false;
-    if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * 32u > c->gather_cap) return false;
+    if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * partial_width(c) > c->gather_cap) return false;
     return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;
 }
@@ -350,7 +361,7 @@ int update_fused(lv_ctx* c) {
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     const bool gathered = multi_rank(c);                      // multi-GPU: the partials of all ranks, gathered after every launch
-    const size_t slot = (size_t)nwg * 32u;                    // doubles per rank in the gather buffers (compact records, 6-column case)
+    const size_t slot = (size_t)nwg * partial_width(c);       // doubles per rank in the gather buffers (compact records)
     pl.qrec = c->record_dump ? c->d_qrec : nullptr;
     c->pclk_wg = nwg + dedicated;   // (the last slot is the bookkeeping workgroup either way)
     pl.qstride = c->qstride;
@@ -374,7 +385,9 @@ int update_fused(lv_ctx* c) {
         int rc = launch_pass(c->stream, pl, (i == 0 && c->begin_pending) ? &c->h_begin : nullptr);
         c->begin_pending = false;
         if (rc) return rc;
+        if (c->profiling && !closing) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 1], c->stream));   // (the pass kernel alone)
         if (gathered && !closing) {
+            if (c->profiling) LV_HIP(hipEventRecord(c->ev_coll[2 * i], c->stream));
             if (c->gather_cb) {
                 // the caller's transport: this rank's slot to pinned host memory, the callback fills in the other ranks' slots
                 // (it blocks until they are there), everything back — the launches of an update are no longer back to back
@@ -391,12 +404,11 @@ int update_fused(lv_ctx* c) {
                 rc = comm_allgather_inplace(c->comm, c->d_gather[i & 1], slot, c->comm_rank, c->stream);
             }
             if (rc) return rc;
+            if (c->profiling) LV_HIP(hipEventRecord(c->ev_coll[2 * i + 1], c->stream));
         }
-        if (c->profiling && !closing) {
-            LV_HIP(hipEventRecord(c->ev_pass[3 * i + 1], c->stream));
-            LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
-        }
+        if (c->profiling && !closing) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
     }
+    c->coll_timed = gathered && c->profiling;
     return LV_OK;
 }
 
@@ -465,6 +477,9 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0;
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
+    // (the stamp buffer below is strided by pass_max_wg + 1 workgroup slots: fix the grid limit first)
+    c->pass_max_wg = prop.multiProcessorCount;
+    if (const char* e = getenv("LV_PASS_WG")) c->pass_max_wg = atoi(e) > 0 ? atoi(e) : c->pass_max_wg;
     if (const char* e = getenv("LV_PASS_CLK")) {
         if (atoi(e) != 0) {
             const size_t words = (size_t)(MAX_PASSES + 1) * (c->pass_max_wg + 1) * pass_clock_words();   // per launch of an update
@@ -472,8 +487,6 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
             LV_HIP(hipMemset(c->d_pclk, 0, words * sizeof(long long)));
         }
     }
-    c->pass_max_wg = prop.multiProcessorCount;
-    if (const char* e = getenv("LV_PASS_WG")) c->pass_max_wg = atoi(e) > 0 ? atoi(e) : c->pass_max_wg;
     c->max_blocks = prop.multiProcessorCount * per_cu;
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -504,6 +517,8 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipEventCreate(&c->ev_end));
     c->ev_pass.resize((size_t)(params->MAX_NUM_ITERS + 1) * 3);
     for (auto& ev : c->ev_pass) LV_HIP(hipEventCreate(&ev));
+    c->ev_coll.resize((size_t)(params->MAX_NUM_ITERS + 1) * 2);
+    for (auto& ev : c->ev_coll) LV_HIP(hipEventCreate(&ev));
     *out = c;
     return LV_OK;
 }
@@ -530,6 +545,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (auto ev : c->ev_pass) hipEventDestroy(ev);
+    for (auto ev : c->ev_coll) hipEventDestroy(ev);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -627,7 +643,9 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     if (n == 0) return LV_OK;   // Mapper::add returns on an empty cloud (Mapper.cpp:20)
     int rc = c->map.reserve_batch(n);
     if (rc) return rc;
-    const double* x = c->filter_set ? c->d_filter->x : c->d_kf->x;
+    // the state of whichever path ran last (main.cpp:92,102: Xt2 = the state the update just produced — or, before the first
+    // map exists, the propagated state the caller handed to lv_update)
+    const double* x = (c->state_src == 2 || !c->filter_set) ? c->d_kf->x : c->d_filter->x;
     hipLaunchKernelGGL(scan_to_world_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, c->scan.d_raw, n, c->map.d_new);
     LV_HIP(hipGetLastError());
     return c->map.add_staged(c->stream, n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
@@ -943,12 +961,32 @@ int lv_set_fused_pass(lv_ctx* c, int enabled) {
     return LV_OK;
 }
 
+int lv_set_option(lv_ctx* c, const char* name, int value) {
+    LV_CHECK_CTX(c);
+    if (!name) { set_error("null argument"); return LV_EINVAL; }
+    if (c->in_update) { set_error("lv_set_option inside an update"); return LV_ESTATE; }
+    const bool on = value != 0;
+    if (!std::strcmp(name, "fused_pass")) c->fused_pass = on;
+    else if (!std::strcmp(name, "fused_ext")) c->fused_ext = on;
+    else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on;
+    else if (!std::strcmp(name, "keeper_by_cost")) c->keeper_by_cost = on;
+    else if (!std::strcmp(name, "tile_lpt")) c->tile_lpt = on;
+    else if (!std::strcmp(name, "spin_wait")) c->spin_wait = on;
+    else if (!std::strcmp(name, "comm_fused")) c->comm_fused = on;
+    else { set_error("lv_set_option: unknown option '%s'", name); return LV_EINVAL; }
+    return LV_OK;
+}
+
 int lv_get_pass_clocks(lv_ctx* c, long long* out, int capacity_wg, int* n_wg) {
     LV_CHECK_CTX(c);
     if (!c->d_pclk) { set_error("no pass clocks: create the context with LV_PASS_CLK=1 in the environment"); return LV_ESTATE; }
     // layout: [launch 0 .. MAX_NUM_ITERS + 1][pass_max_wg + 1 workgroup slots][pass_clock_words()]; slot n_wg - 1 of a launch is
     // its bookkeeping workgroup (stamp 10 = books done); the closing launch has one workgroup (slot 0)
     const int slots = c->pass_max_wg + 1;
+    if (!out) {   // size query: *n_wg = workgroup slots per launch (the stride of the layout)
+        if (n_wg) *n_wg = slots;
+        return LV_OK;
+    }
     if (capacity_wg < slots) { set_error("lv_get_pass_clocks: capacity %d < %d workgroup slots per launch", capacity_wg, slots); return LV_EINVAL; }
     LV_HIP(hipStreamSynchronize(c->stream));
     LV_HIP(hipMemcpy(out, c->d_pclk, (size_t)(c->prm.MAX_NUM_ITERS + 2) * slots * pass_clock_words() * sizeof(long long), hipMemcpyDeviceToHost));
@@ -1046,7 +1084,7 @@ int lv_comm_set_shard_max(lv_ctx* c, size_t n_max) {
     if (!multi_rank(c) || n_max == 0) return LV_OK;
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size((uint32_t)n_max, c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
-    const size_t need = (size_t)nwg * 32u * (size_t)c->comm_world;
+    const size_t need = (size_t)nwg * partial_width(c) * (size_t)c->comm_world;
     if (c->gather_cb && need > c->h_gather_cap) {
         LV_HIP(hipStreamSynchronize(c->stream));
         if (c->h_gather) hipHostFree(c->h_gather);
@@ -1128,7 +1166,10 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
                 for (int i = 0; i < NX; ++i) chk ^= mailbox_mix(io->x[i], 1000u + (uint32_t)i);
                 chk ^= mailbox_mix((double)io->passes, 2000u);
                 if (chk == MAILBOX_UNCHECKED) chk = 0u;
-                if (want == MAILBOX_UNCHECKED || chk != want) { seen = false; ++c->mailbox_resyncs; }
+                // (MAILBOX_UNCHECKED: the update ended on a pass without matches — a legitimate path that carries no
+                // checksum: synchronise the stream without counting it)
+                if (want == MAILBOX_UNCHECKED) seen = false;
+                else if (chk != want) { seen = false; ++c->mailbox_resyncs; }
             }
         }
         if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
@@ -1156,12 +1197,20 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     LV_CHECK_CTX(c);
     if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
     if (passes) *passes = 0;
-    if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
+    c->state_src = 2;
+    if (c->map.view.m == 0) {  // Localizator::correct returns without a map (Localizator.cpp:24)
+        // ... but the state the caller propagated is the one the first map is built with (main.cpp:92,102 -> lv_map_add_scan)
+        LV_HIP(hipStreamSynchronize(c->stream));   // (x_in of an earlier update may still be in flight)
+        std::memcpy(c->h_io->x_in, x, sizeof(double) * NX);
+        LV_HIP(hipMemcpyAsync(c->d_kf->x, c->h_io->x_in, sizeof(double) * NX, hipMemcpyHostToDevice, c->stream));
+        return LV_OK;
+    }
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     int rc = lv_update_begin(c, x, P);
     if (rc) return rc;
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_begin, c->stream));
     c->last_update_fused = false;
+    c->coll_timed = false;
     if (c->gather_cb && !pass_fused_applies(c)) {
         c->in_update = false;
         set_error("host-staged gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
@@ -1174,7 +1223,9 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
         for (int i = 0; i < npass; ++i) {
             if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 0], c->stream));
             c->ev_mid = c->profiling ? c->ev_pass[3 * i + 1] : nullptr;
+            c->pass_index = i;
             rc = pass_full(c);
+            c->pass_index = -1;
             c->ev_mid = nullptr;
             if (rc) { c->in_update = false; return rc; }
             if (c->profiling) LV_HIP(hipEventRecord(c->ev_pass[3 * i + 2], c->stream));
@@ -1201,7 +1252,13 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
             hipEventElapsedTime(&b, c->ev_pass[3 * i + 1], c->ev_pass[3 * i + 2]);
             r += a;
             s += b;
-            if (i < 8) { c->timing.pass_match_ms[i] = a; c->timing.pass_solve_ms[i] = b; }
+            if (i < 8) {
+                c->timing.pass_match_ms[i] = a;
+                c->timing.pass_solve_ms[i] = b;
+                float cm = 0.f;
+                if (c->coll_timed) hipEventElapsedTime(&cm, c->ev_coll[2 * i], c->ev_coll[2 * i + 1]);
+                c->timing.pass_collective_ms[i] = cm;
+            }
         }
         c->timing.last_reduce_ms = r / cnt;
         c->timing.last_solve_ms = s / cnt;
@@ -1218,6 +1275,7 @@ int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
     std::memcpy(c->h_filter->P, P, sizeof(double) * NS * NS);
     LV_HIP(hipMemcpyAsync(c->d_filter, c->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, c->stream));
     c->filter_set = true;
+    c->state_src = 1;
     return LV_OK;
 }
 
@@ -1235,12 +1293,14 @@ int lv_predict(lv_ctx* c, double dt, const double* Q, const double acc[3], const
     LV_CHECK_CTX(c);
     if (!Q || !acc || !gyro) { set_error("null argument"); return LV_EINVAL; }
     if (!c->filter_set) { set_error("lv_predict before lv_filter_set"); return LV_ESTATE; }
+    c->state_src = 1;
     return launch_predict(c->stream, c->d_filter, dt, Q, acc, gyro);
 }
 
 int lv_correct(lv_ctx* c, int* passes) {
     LV_CHECK_CTX(c);
     if (!c->filter_set) { set_error("lv_correct before lv_filter_set"); return LV_ESTATE; }
+    c->state_src = 1;
     if (passes) *passes = 0;
     if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);

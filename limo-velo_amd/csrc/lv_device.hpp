@@ -6,6 +6,7 @@
 // in the evaluation order of the reference expression it mirrors (cited per function).
 #pragma once
 
+#include "lv_sincos.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -265,36 +266,7 @@ struct MotionState {  // == lv_motion_state (include/limovelo_hip.h): f32 member
     double time;
 };
 
-// sin / cos of an f32 argument through a fixed f64 polynomial (Cody-Waite + Taylor), rounded to f32: the
-// same operation sequence as the oracle's, so both produce the same bits (std::sin(float) of
-// SO3Math::Exp, include/Headers/Utils.hpp:45, is libm- and platform-dependent in the last ulp).
-__device__ inline void sincos_f32(float xf, float& sn, float& cs) {
-    const double x = (double)xf;
-    const double k = rint(x * 0.63661977236758134308);
-    double r = x - k * 1.57079632673412561417e+00;
-    r = r - k * 6.07710050650619224932e-11;
-    r = r - k * 2.02226624879595063154e-21;
-    const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = ps * z - 2.50507602534068634195e-08;
-    ps = ps * z + 2.75573137070700676789e-06;
-    ps = ps * z - 1.98412698298579493134e-04;
-    ps = ps * z + 8.33333333332248946124e-03;
-    ps = ps * z - 1.66666666666666324348e-01;
-    const double s0 = r + r * z * ps;
-    double pc = -1.13596475577881948265e-11;
-    pc = pc * z + 2.08757232129817482790e-09;
-    pc = pc * z - 2.75573143513906633035e-07;
-    pc = pc * z + 2.48015872894767294178e-05;
-    pc = pc * z - 1.38888888888741095749e-03;
-    pc = pc * z + 4.16666666666666019037e-02;
-    const double c0 = 1.0 - 0.5 * z + z * z * pc;
-    const int q = (int)k & 3;
-    const double sd = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
-    const double cd = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
-    sn = (float)sd;
-    cs = (float)cd;
-}
+// sin / cos of an f32 argument: lv_sincos.hpp (the single definition shared with the host shim)
 
 // SO3Math::Exp<float,float>(ang_vel, dt) — reference include/Headers/Utils.hpp:30-53
 __device__ inline void so3_exp_f32(const float w[3], float dt, float E[9]) {

@@ -707,7 +707,10 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         LV_HIP(hipStreamSynchronize(stream));
         const uint64_t total = (uint64_t)last_off + last_cap;   // entries laid out, slack included
         // the pool keeps room for runs that move and for the buckets of newly mapped space
-        const uint64_t want = total + total / 4 + (8ull << 20);
+        // (the floor follows the map: 1 Mi entries for the small maps of tests and multi-context processes, up to the 8 Mi a
+        // streaming map wants for a few scans' worth of newly mapped space between two re-linearisations)
+        const uint64_t floor_entries = total < (1ull << 20) ? (1ull << 20) : (total > (8ull << 20) ? (8ull << 20) : total);
+        const uint64_t want = total + total / 4 + floor_entries;
         if (want > 0xFFFFFFF0ull) { set_error("bucket pool exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
         if (level < SORTED_LEVELS) {   // ascending id, then packed to 12-byte points + id array
             if (total > bucket_tmp_cap) {

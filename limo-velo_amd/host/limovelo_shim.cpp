@@ -1,5 +1,6 @@
 // limovelo_shim.cpp — see limovelo_shim.hpp.  Bulk computation is in liblimovelo_hip.so; the host keeps the
 // reference's bookkeeping (buffers, single-state motion model, single transforms).
+#include "../csrc/lv_sincos.hpp"
 #include "limovelo_shim.hpp"
 
 struct Params Config;
@@ -88,26 +89,7 @@ State::State(const state_ikfom& s, double t) : State() {
 
 namespace {
 inline float dot3(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
-// sin / cos of an f32 argument through the same fixed f64 polynomial the device uses (lv_device.hpp sincos_f32)
-void sincos_f32(float xf, float& sn, float& cs) {
-    const double x = (double)xf;
-    const double k = std::rint(x * 0.63661977236758134308);
-    double r = x - k * 1.57079632673412561417e+00;
-    r = r - k * 6.07710050650619224932e-11;
-    r = r - k * 2.02226624879595063154e-21;
-    const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = ps * z - 2.50507602534068634195e-08; ps = ps * z + 2.75573137070700676789e-06; ps = ps * z - 1.98412698298579493134e-04;
-    ps = ps * z + 8.33333333332248946124e-03; ps = ps * z - 1.66666666666666324348e-01;
-    const double s0 = r + r * z * ps;
-    double pc = -1.13596475577881948265e-11;
-    pc = pc * z + 2.08757232129817482790e-09; pc = pc * z - 2.75573143513906633035e-07; pc = pc * z + 2.48015872894767294178e-05;
-    pc = pc * z - 1.38888888888741095749e-03; pc = pc * z + 4.16666666666666019037e-02;
-    const double c0 = 1.0 - 0.5 * z + z * z * pc;
-    const int q = (int)k & 3;
-    sn = (float)((q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0);
-    cs = (float)((q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0);
-}
+using lv::sincos_f32;   // ../csrc/lv_sincos.hpp: the one definition the device kernels use too
 }  // namespace
 
 // State::update / propagate_f — reference src/Objects/State.cpp:94-121 (SO3Math::Exp: Utils.hpp:30-53)
@@ -196,6 +178,16 @@ int before_t(const std::deque<T>& c, double t) {
     }
     return lo;   // == size() when every content is newer than t
 }
+// number of contents with time >= t at the front of a new -> old deque (= index of the first one strictly older than t)
+template <typename T>
+int before_t_inclusive(const std::deque<T>& c, double t) {
+    int lo = 0, hi = (int)c.size();
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (c[(size_t)mid].time >= t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 template <typename T>
 std::deque<T> get_between(Buffer<T>& src, double t1, double t2) {   // Accumulator.hpp:62-74: t1 <= time <= t2, old -> new
     std::deque<T> result;
@@ -235,8 +227,18 @@ State Accumulator::get_prev_state(double t) {                           // Accum
         X.time = t;
         return X;
     }
-    for (const State& X : BUFFER_X.content)     // new -> old: the newest state strictly before t
-        if (t > X.time) return X;
+    // The reference's index arithmetic, quirks included (Accumulator.hpp:94-107 over Algorithms::binary_search, Utils.hpp:9-23):
+    // with F = number of buffered states at or after t (new -> old deque), binary_search returns max(0, F - 2), get_prev starts at
+    // that index + 1 (clamped to the oldest) and walks towards NEWER states until one lies strictly before t.  Hence: one state
+    // at or after t -> the newest state before t; NO state at or after t (every state is older: a cycle skipped for too few
+    // points, or real time ahead of the last update) -> the SECOND newest; two or more at or after t -> a default State().
+    // Compensator::path starts from this state, so the de-skewed points follow the reference bit for bit only with the same choice.
+    const std::deque<State>& c = BUFFER_X.content;
+    const int F = before_t_inclusive(c, t);
+    int k_t = (F - 2 > 0 ? F - 2 : 0) + 1;
+    if (k_t >= (int)c.size()) k_t = (int)c.size() - 1;
+    for (int k = k_t; k >= 0; --k)
+        if (t > c[(size_t)k].time) return c[(size_t)k];
     return State();
 }
 bool Accumulator::enough_imus() { return BUFFER_I.size() > 2 * Config.real_time_delay * Config.imu_rate + 10; }   // :156-158

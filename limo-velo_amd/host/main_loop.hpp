@@ -3,7 +3,8 @@
 //   ref:  while (accum.ready()) { ... loc.propagate_to(t2); comp.compensate(t1, t2); comp.downsample(...);
 //          loc.correct(ds_compensated, t2); State Xt2 = loc.latest_state(); accum.add(Xt2, t2);
 //          Points global_ds_compensated = Xt2 * Xt2.I_Rt_L() * ds_compensated; map.add(global_ds_compensated, t2, true);
-//          accum.clear_lidar(t2 - Config.empty_lidar_time); break; }
+//          (or, mapping offline, :105-116: if (map.hasToMap(t2)) { comp.compensate(t2 - full_rotation_time, t2) -> world ->
+//          comp.downsample -> map.add })   accum.clear_lidar(t2 - Config.empty_lidar_time); break; }
 // run_cycle() is one turn of that inner loop; `on_device` selects the three calls that keep the scan on the GPU
 // between the stages (same results, no host round trips) instead of the reference's by-value hand-overs.
 #pragma once
@@ -46,6 +47,16 @@ inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, M
         accum.add(Xt2, clk.t2);
         if (Config.mapping_online) map.add_current_scan(clk.t2, true);
         if (n_points) *n_points = n_ds;
+    }
+    // Step 2, mapping offline (:105-116): once per full rotation the whole sweep [t2 - FULL_ROTATION_TIME, t2] is de-skewed
+    // to t2, taken to the world frame, down-sampled THERE (the voxel grid of the reference acts on the global points) and
+    // added; the reference's own by-value hand-overs in both modes (it runs every tenth cycle at delta = 0.01)
+    if (!Config.mapping_online && map.hasToMap(clk.t2)) {
+        State X = loc.latest_state();
+        Points full_compensated = comp.compensate(clk.t2 - Config.full_rotation_time, clk.t2);
+        Points global_full_compensated = X * X.I_Rt_L() * full_compensated;
+        Points global_full_ds_compensated = comp.downsample(global_full_compensated);
+        map.add(global_full_ds_compensated, clk.t2, true);
     }
     // Step 3. ERASE OLD DATA (:116-118)
     accum.clear_lidar(clk.t2 - Config.empty_lidar_time);

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
         Config.real_time_delay = 0.1;
         Config.imu_rate = 100;
         Config.empty_lidar_time = 1.0;
-        Config.mapping_online = true;
+        Config.mapping_online = getenv("LV_DEMO_MAPPING_OFFLINE") == nullptr;   // (offline: main.cpp:105-116, once per full rotation)
         Config.initial_gravity = {0.f, 0.f, -9.809f};
 
         Accumulator& accum = Accumulator::getInstance();

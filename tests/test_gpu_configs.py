@@ -1,0 +1,204 @@
+"""The reference's OTHER shipped configurations on the GPU, against the oracle (round-2 verdict: only params.yaml's hot keys
+had been run):
+
+* `estimate_extrinsics: true` (config/xaloc.yaml:13, src/Modules/Localizator.cpp:52): the iterated update with 12 live
+  Jacobian columns — 12 x 12 gain blocks, 92 live sums — on BOTH routes (one launch per pass, three kernels), per pass
+  against `oracle.update`, at configs[0] size and at the headline size, plus the record pin of the timed build;
+* kitti.yaml:44-45 (`MAX_DIST_PLANE 2.23`, `PLANES_THRESHOLD 0.1`) and ouster.yaml:51-52 (`2.0`, `0.1`): the keys steer the
+  plane gates AND the bounded stop of the timed search (lv_match.hip knn_coarse);
+* `voxel_size` 0.35 / 1.0 (a build knob of this implementation: the results must not depend on it);
+* configs[3] size (260k-point scan vs 5M-point map) as a FULL 4-pass non-capturing update (the three-kernel pass, and the
+  one-launch form admitted beyond two rounds per workgroup), not only a single captured pass.
+Tolerances as in test_gpu_parity.py: kNN / f32 quantities / rows bit-exact, sums 1e-10 relative, state 1e-9 per pass."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_SUMS_REL = 1e-10
+TOL_STATE = 1e-9
+
+# (name, MAX_DIST_PLANE, PLANES_THRESHOLD) — config/{params,kitti,ouster}.yaml
+YAML_KEYS = [("params", 2.0, 0.05), ("kitti", 2.23, 0.1), ("ouster", 2.0, 0.1)]
+
+
+@pytest.fixture(scope="module")
+def capi(lv):
+    from limo_velo_amd import capi as c
+
+    return c
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _check_update(res, ref, tol_state=TOL_STATE, tol_P=1e-9):
+    x, P, passes, tr, sums = res
+    xo, Po, po, tro, so = ref
+    assert passes == po, (passes, po)
+    assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+    for i in range(passes):
+        scale = max(np.abs(so[i]["HTH"]).max(), 1e-300)
+        assert np.abs(sums[i]["HTH"] - so[i]["HTH"]).max() <= 1e-7 * scale, f"pass {i}"   # (states differ by <= tol_state: not the 1e-10 of equal states)
+        assert np.abs(tr[i] - tro[i]).max() < tol_state, f"pass {i}: {np.abs(tr[i] - tro[i]).max()}"
+    assert np.abs(x - xo).max() < tol_state, np.abs(x - xo).max()
+    assert np.abs(P - Po).max() < tol_P * max(1.0, np.abs(Po).max()), np.abs(P - Po).max()
+
+
+def _pin_records(capi, oracle, sc, tree, prm_kw, prm_o, states, orc, fused_ext=False):
+    """The hand-over records of the NON-capturing launch that runs pass k (the last pass of an update limited to k passes)
+    against the oracle's neighbours at the state the device held before it — test_gpu_parity.py's pin, with the gate at
+    MAX_DIST_PLANE^2 of the configuration under test."""
+    mdp2 = float(prm_o.max_dist_plane) ** 2
+    for k in range(len(states)):
+        with capi.Context(capi.default_params(MAX_NUM_ITERS=k, **prm_kw)) as ctx:
+            if fused_ext:
+                ctx.set_option("fused_ext", 1)
+            ctx.map_build(sc["map_xyz"])
+            ctx.scan_set(sc["scan_xyz"])
+            ctx.set_record_dump(True)
+            xk, _, pk, trk, _ = ctx.update(sc["x_init"], sc["P0"])
+            assert pk == k + 1
+            if k:
+                assert np.array_equal(trk[k - 1][23:49], states[k])   # deterministic: same state before pass k
+            nbr, d2, pw, found = ctx.fetch_neighbors()
+        o = orc[k]
+        have = o["knn_idx"] != 0xFFFFFFFF
+        near = have.all(axis=1) & (o["knn_d2"][:, 4].astype(np.float64) < mdp2)
+        assert near.mean() > 0.9
+        rejected = (found < 5) | ~(d2[:, 4].astype(np.float64) < mdp2)
+        assert rejected[~near].all(), f"pass {k}"
+        assert np.array_equal(found[near], have.sum(axis=1)[near]), f"pass {k}"
+        exp = np.where(have[..., None], sc["map_xyz"][np.where(have, o["knn_idx"], 0)], np.float32(0))
+        assert np.array_equal(_bits(nbr[near]), _bits(exp[near])), f"pass {k}"
+        assert np.array_equal(_bits(d2[near]), _bits(o["knn_d2"][near])), f"pass {k}"
+        assert np.array_equal(_bits(pw), _bits(oracle.transform_scan(states[k], sc["scan_xyz"]))), f"pass {k}"
+
+
+# ---- estimate_extrinsics = true --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(50_000, 2_000), (1_048_576, 65_536)])
+@pytest.mark.parametrize("route", ["one-launch", "three-kernel"])
+def test_extrinsics_update_against_the_oracle(capi, oracle, lv, m, n, route):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(m, n, extrinsics="xaloc")
+    tree = oracle.KdTree(sc["map_xyz"])
+    prm_o = oracle.default_params(estimate_extrinsics=1)
+    ref = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=prm_o, tree=tree)
+    with capi.Context(capi.default_params(estimate_extrinsics=1)) as ctx:
+        ctx.set_option("fused_ext", int(route == "one-launch"))
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        res = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused() == (route == "one-launch")
+    assert ref[2] == 4 and np.abs(ref[4][0]["HTH"][6:, 6:]).max() > 0   # the extrinsic columns are live
+    _check_update(res, ref)
+    # per pass: sums at the state the DEVICE held, 1e-10 (equal inputs)
+    x, P, passes, tr, sums = res
+    states = [sc["x_init"]] + [tr[i][23:49].copy() for i in range(passes - 1)]
+    orc = [oracle.iterate(st, sc["map_xyz"], sc["scan_xyz"], params=prm_o, tree=tree) for st in states]
+    for i, (g, o) in enumerate(zip(sums, orc)):
+        assert g["n_valid"] == o["n_valid"], f"pass {i}"
+        assert np.abs(g["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * np.abs(o["HTH"]).max(), f"pass {i}"
+        assert np.abs(g["HTh"] - o["HTh"]).max() <= TOL_SUMS_REL * max(np.abs(o["HTh"]).max(), 1.0), f"pass {i}"
+    if route == "one-launch":
+        _pin_records(capi, oracle, sc, tree, dict(estimate_extrinsics=1), prm_o, states, orc, fused_ext=True)
+
+
+def test_extrinsics_single_pass_per_point(capi, oracle, lv):
+    """Per-point parity (kNN, plane, 12-column rows) of a captured pass at the headline size with xaloc's extrinsics."""
+    from limo_velo_amd import synth
+    from test_gpu_parity import _compare_pass
+
+    sc = synth.make_scene(1_048_576, 65_536, extrinsics="xaloc")
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context(capi.default_params(estimate_extrinsics=1)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        g, o = _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], sc["scan_xyz"], tree, oracle.default_params(estimate_extrinsics=1))
+        assert np.abs(o["Hrows"][:, 6:]).max() > 0
+
+
+# ---- the YAML hot keys and the voxel size ------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,mdp,pth", YAML_KEYS)
+@pytest.mark.parametrize("voxel", [0.35, 0.5, 1.0])
+def test_yaml_hot_keys_single_pass_and_update(capi, oracle, scene_small, name, mdp, pth, voxel):
+    from test_gpu_parity import _compare_pass
+
+    if name == "params" and voxel == 0.5:
+        pytest.skip("the default combination is test_gpu_parity.py")
+    sc = scene_small
+    tree = oracle.KdTree(sc["map_xyz"])
+    prm_o = oracle.default_params(max_dist_plane=mdp, planes_threshold=pth)
+    kw = dict(MAX_DIST_PLANE=mdp, PLANES_THRESHOLD=pth, voxel_size=voxel)
+    # a scan with points far from every surface too (the MAX_DIST_PLANE gate and the bounded stop must see both sides)
+    rng = np.random.default_rng(11)
+    stray = sc["scan_xyz"][:200] + rng.uniform(-3.0, 3.0, (200, 3)).astype(np.float32)
+    scan = np.concatenate([sc["scan_xyz"], stray])
+    ref = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], scan, params=prm_o, tree=tree)
+    with capi.Context(capi.default_params(**kw)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(scan)
+        g, o = _compare_pass(ctx, oracle, sc["x_init"], sc["map_xyz"], scan, tree, prm_o)
+        res = {}
+        for fused in (True, False):
+            ctx.set_fused_pass(fused)
+            res[fused] = ctx.update(sc["x_init"], sc["P0"])
+            assert ctx.last_update_fused() == fused
+    far = o["knn_d2"][:, 4].astype(np.float64)
+    assert ((far >= mdp * mdp) & (far < 1e30)).sum() > 10 and (far < mdp * mdp).sum() > 1500   # both sides of the gate
+    for fused in (True, False):
+        _check_update(res[fused], ref)
+
+
+@pytest.mark.parametrize("name,mdp,pth", YAML_KEYS[1:])
+@pytest.mark.parametrize("m,n", [(50_000, 2_000), (1_048_576, 65_536)])
+def test_timed_build_is_pinned_with_the_yaml_keys(capi, oracle, lv, name, mdp, pth, m, n):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(m, n)
+    tree = oracle.KdTree(sc["map_xyz"])
+    prm_o = oracle.default_params(max_dist_plane=mdp, planes_threshold=pth)
+    kw = dict(MAX_DIST_PLANE=mdp, PLANES_THRESHOLD=pth)
+    with capi.Context(capi.default_params(**kw)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+    ref = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=prm_o, tree=tree)
+    _check_update((x, P, passes, tr, sums), ref)
+    states = [sc["x_init"]] + [tr[i][23:49].copy() for i in range(passes - 1)]
+    orc = [oracle.iterate(st, sc["map_xyz"], sc["scan_xyz"], params=prm_o, tree=tree) for st in states]
+    for i, (g, o) in enumerate(zip(sums, orc)):
+        assert g["n_valid"] == o["n_valid"], f"pass {i}"
+        assert np.abs(g["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * np.abs(o["HTH"]).max(), f"pass {i}"
+    _pin_records(capi, oracle, sc, tree, kw, prm_o, states, orc)
+
+
+# ---- configs[3] size: the full iterated update ------------------------------------------------------------------------
+@pytest.mark.parametrize("route", ["three-kernel", "one-launch-multi-round"])
+def test_cfg3_size_full_update(capi, oracle, lv, route):
+    """260k-point scan vs 5M-point map (BASELINE configs[3], one GPU's worth): all four passes of the NON-capturing
+    update against the oracle — the default route at this size (three kernels: more than two rounds per workgroup) and the
+    one-launch form admitted for it (its hand-over records and the fit accumulators are reused across five rounds)."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(5_000_000, 260_000)
+    tree = oracle.KdTree(sc["map_xyz"])
+    ref = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    with capi.Context() as ctx:
+        ctx.set_option("fused_multi_round", int(route != "three-kernel"))
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        res = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused() == (route != "three-kernel")
+    assert ref[2] == 4
+    _check_update(res, ref)
+    x, P, passes, tr, sums = res
+    states = [sc["x_init"]] + [tr[i][23:49].copy() for i in range(passes - 1)]
+    for i, st in enumerate(states):
+        o = oracle.iterate(st, sc["map_xyz"], sc["scan_xyz"], tree=tree, details=False)
+        assert sums[i]["n_valid"] == o["n_valid"], f"pass {i}"
+        assert np.abs(sums[i]["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * np.abs(o["HTH"]).max(), f"pass {i}"
+        assert np.abs(sums[i]["HTh"] - o["HTh"]).max() <= TOL_SUMS_REL * max(np.abs(o["HTh"]).max(), 1.0), f"pass {i}"

@@ -124,3 +124,44 @@ def test_reference_main_loop_through_the_shim(lv, tmp_path):
     # the device-resident hand-overs change nothing beyond rounding: the two free-running runs see world points that differ
     # in the last f32 bit now and then (one ulp = 4e-6 m at 60 m), which 70 mapping updates amplify to the 1e-5 m level
     assert np.abs(xa - xb).max() < 3e-5
+
+
+def test_reference_main_loop_mapping_offline(lv, tmp_path):
+    """The other mapping branch of the reference's loop (src/main.cpp:105-116, `mapping_online: false`): no insert per
+    localisation; once per FULL_ROTATION_TIME the whole sweep [t2 - full_rotation_time, t2] is de-skewed to t2, taken to the
+    world frame, down-sampled there and added (Mapper::hasToMap).  Both hand-over modes of the localisation step track the
+    truth, agree with each other, and the map grows by whole sweeps."""
+    import re
+
+    from limo_velo_amd import synth
+
+    host = os.path.join(ROOT, "limo-velo_amd", "host")
+    exe = os.path.join(host, "stream_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", host])
+    n_revs, delta = 9, 0.01
+    stream = synth.make_stream(1_048_576, n_revs, n_az=512, map_radius=62.0)
+    t_init = 0.30 - 0.1
+    pos0, _, vel0, _, q0 = synth.stream_truth(t_init)
+    x0 = synth.make_state(pos0 + [0.02, -0.015, 0.01], synth.quat_mul(q0, synth.quat_from_rotvec([0.002, -0.001, 0.003])), vel=vel0,
+                          grav=(0, 0, synth.STREAM_G))
+    res, sizes = {}, {}
+    env = dict(os.environ, LV_DEMO_MAPPING_OFFLINE="1")
+    for on_device in (0, 1):
+        inp, out = tmp_path / f"in{on_device}.bin", tmp_path / f"out{on_device}.bin"
+        _write_stream_input(inp, on_device, delta, stream, n_revs, x0)
+        r = subprocess.run([exe, str(inp), str(out)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[on_device] = _read_stream_output(out)
+        sizes[on_device] = int(re.search(r"map (\d+) points", r.stdout).group(1))
+    t0, xa, na = res[0]
+    t1, xb, nb = res[1]
+    assert len(t0) >= 50 and np.array_equal(t0, t1) and np.array_equal(na, nb)
+    truth = np.array([synth.stream_truth(t)[0] for t in t0])
+    for x in (xa, xb):
+        err = np.linalg.norm(x[:, :3] - truth, axis=1)
+        assert np.sqrt(np.mean(err ** 2)) < 0.03, err
+    assert np.abs(xa - xb).max() < 3e-5
+    n_prior = len(stream["map_xyz"])
+    assert sizes[0] > n_prior and sizes[1] > n_prior       # whole sweeps were added ...
+    assert abs(sizes[0] - sizes[1]) <= 0.001 * n_prior     # ... the same ones (up to a last-bit voxel flip) in both modes
