@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblimovelo_hip.so")
+# (LV_LIB_PATH: another build of the same library, for A/B measurements of two builds in one box — scripts/gpu_ab_multi.sh)
+LIB_PATH = os.environ.get("LV_LIB_PATH") or os.path.join(_HERE, "liblimovelo_hip.so")
 
 LV_OK = 0
 SUMS_LEN = 96
