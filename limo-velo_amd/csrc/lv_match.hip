@@ -1074,7 +1074,7 @@ __device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& 
                                              const KfDev::PassState* __restrict__ ps_in, KfDev::PassState* __restrict__ ps_out,
                                              const PoseConsts* pose, int tid, Bar& bar, long long* clk) {
     if (a.mode == 1) {
-        bookkeeping<W, T>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp, pose, K.Pprop, K.xp, false, tid, bar, clk);
+        bookkeeping<W, T>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, pose, K.Pprop, K.xp, false, tid, bar, clk);
         return;
     }
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
@@ -1122,6 +1122,8 @@ __device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& 
     prepare_next<W, T>(Bk, ps_out, K.x, K.xp, a.sp.R_inv, tid, bar, clk);
 }
 
+constexpr int PK_BOOKW = PK_THREADS / 64 - PK_FITW;   // wavefronts of a workgroup that do not fit planes (12)
+
 // CLOSING: the closing launch of an update as its own (search-free) kernel: the solve of the last pass and the terminal
 // books by one workgroup.
 template <bool EXT, bool CLOSING>
@@ -1159,7 +1161,8 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     int* s_qn = reinterpret_cast<int*>(smem + PK_OFF_QN);   // entries in the queue of points left to the coarse levels
     float4* s_queue = reinterpret_cast<float4*>(smem + PK_OFF_QUEUE);
     uint32_t* s_queueq = reinterpret_cast<uint32_t*>(smem + PK_OFF_QUEUEQ);
-    if (threadIdx.x < 2) s_qn[threadIdx.x] = 0;   // [0] queue entries, [1] search-task counter (the prologue's barriers publish them)
+    if (threadIdx.x < 3) s_qn[threadIdx.x] = 0;   // [0] queue entries, [1] search-task counter, [2] the books' sub-barrier (the prologue's barriers publish them)
+    bool books_done = false;
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
     long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
 #define PK_STAMP(i, cond) do { if (clk && (cond)) { clk[i] = clock64(); clk[16 + (i)] = wall_clock64(); } } while (0)
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             // the books by the whole workgroup
             WgBar bar;
             const bool closing = a.rounds == 0;
-            bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp, &s_pose, closing ? kf->P_prop : K.Pprop,
+            bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, closing ? kf->P_prop : K.Pprop,
                                        closing ? kf->x_prop : K.xp, closing, tid, bar, clk);
             PK_STAMP(10, tid == 0);
             return;
@@ -1227,6 +1230,33 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     }
     for (int t = tid; t < PK_FITW * 2 * SUMS_LEN; t += PK_THREADS) (&s_out[0][0][0])[t] = 0.0;
     const DebugOut nodbg{};
+    auto do_fits = [&](bool stamp) __attribute__((always_inline)) {
+        const float4* rec = s_rec + (size_t)fstep * QREC_SLOTS * PK_GROUPS + fbase;
+        float4 r[QREC_SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = rec[sl * PK_GROUPS + lane];
+        float P[KNN][3];
+        uint32_t nidx[KNN], dbits[KNN];
+#pragma unroll
+        for (int j = 0; j < KNN; ++j) { P[j][0] = r[j].x; P[j][1] = r[j].y; P[j][2] = r[j].z; nidx[j] = __float_as_uint(r[j].w); }
+        dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
+        dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
+        const int found = __float_as_int(r[7].y);
+        double* srow = &s_rows[wave][lane][0];
+        fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
+        wave_lds_fence();   // this wavefront's 64 rows are staged
+        if (stamp) PK_STAMP(7, tid == 0);
+        const double (*rows)[ROW_W] = s_rows[wave];
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) {
+            if (olane + c * 64 < NOUT) {
+                double sacc = acc[c];
+#pragma unroll 8
+                for (int p = 0; p < (HALVES ? 32 : 64); ++p) sacc += rows[prow0 + p][oa[c]] * rows[prow0 + p][ob[c]];
+                acc[c] = sacc;
+            }
+        }
+    };
     for (int round = 0; round < a.rounds; ++round) {
         // The round's wave-level tasks — one per (step, wavefront slot): 8 points, 8 lanes each — are handed out through an
         // LDS counter instead of two fixed tasks per wavefront: a wavefront that drew short buckets takes a third task instead
@@ -1350,35 +1380,28 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             __syncthreads();
             if (tid == 0) *s_qn = 0;   // (next round; the barrier after the fits publishes it)
         }
-        if (fitter) {
-            const float4* rec = s_rec + (size_t)fstep * QREC_SLOTS * PK_GROUPS + fbase;
-            float4 r[QREC_SLOTS];
-#pragma unroll
-            for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = rec[sl * PK_GROUPS + lane];
-            float P[KNN][3];
-            uint32_t nidx[KNN], dbits[KNN];
-#pragma unroll
-            for (int j = 0; j < KNN; ++j) { P[j][0] = r[j].x; P[j][1] = r[j].y; P[j][2] = r[j].z; nidx[j] = __float_as_uint(r[j].w); }
-            dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
-            dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
-            const int found = __float_as_int(r[7].y);
-            double* srow = &s_rows[wave][lane][0];
-            fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
-            wave_lds_fence();   // this wavefront's 64 rows are staged
-            if (round == 0) PK_STAMP(7, tid == 0);
-            const double (*rows)[ROW_W] = s_rows[wave];
-#pragma unroll
-            for (int c = 0; c < NACC; ++c) {
-                if (olane + c * 64 < NOUT) {
-                    double sacc = acc[c];
-#pragma unroll 8
-                    for (int p = 0; p < (HALVES ? 32 : 64); ++p) sacc += rows[prow0 + p][oa[c]] * rows[prow0 + p][ob[c]];
-                    acc[c] = sacc;
-                }
-            }
+        if (round + 1 < a.rounds) {   // (not the last round: its fits are part of the loop; the last round's follow the loop)
+            if (fitter) do_fits(false);
+            __syncthreads();   // the next round reuses the stage (under the rows) and the records
         }
-        if (round == 0) PK_STAMP(8, tid == 0);
-        __syncthreads();   // the next round reuses the stage (under the rows) and the records
+    }
+    // ---- 3b. the fits of the last round — and, in the bookkeeping workgroup of a launch whose prologue solved a pass that does
+    // not end the update (mode 1), BESIDE them the books, by the twelve wavefronts that do not fit planes: scratch above the
+    // staged rows, nothing in the books depends on this launch's search.  Out here, after the round loop, the books' register
+    // appetite competes with nothing that is live (inlined INTO the loop it spilled the search: round 2, 60 % slower).
+    {
+        const bool beside = !EXT && a.mode == 1 && keeper;
+        if (fitter) {
+            do_fits(true);
+        } else if (beside && wave >= PK_FITW) {
+            SubBar bar(s_qn + 2, PK_BOOKW);
+            bookkeeping<W, 64 * PK_BOOKW>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, K.Pprop, K.xp, false,
+                                          tid - 64 * PK_FITW, bar, clk);
+            PK_STAMP(10, tid == 64 * PK_FITW);
+        }
+        books_done = beside;
+        PK_STAMP(8, tid == 0);
+        __syncthreads();
     }
     // ---- 4. the workgroup partial, compact layout, fixed order
     if (fitter) {
@@ -1400,7 +1423,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     if (a.cost_out && tid == 0 && bid < nwg) a.cost_out[bid] = (uint32_t)(wall_clock64() - t_begin);
     }   // !CLOSING
     PK_STAMP(9, tid == 0);
-    if (!keeper) return;
+    if (!keeper || books_done) return;
     // ---- 5. the books (one workgroup, after its own search and fits; its scratch lies above the staged rows) ---------
     // (Running them on the twelve wavefronts that do not fit planes, beside the fits, over an LDS-counter barrier was tried:
     // inlined into the round loop the books' register appetite spilled the search, the whole kernel ran 60 % longer.)

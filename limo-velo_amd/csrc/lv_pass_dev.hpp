@@ -274,6 +274,21 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
 struct WgBar {
     __device__ __forceinline__ void operator()() { __syncthreads(); }
 };
+// Barrier among a SUBSET of a workgroup's wavefronts (nw of them, all must call) over an LDS counter: the bookkeeping
+// workgroup's twelve idle wavefronts keep the books beside the four that fit planes.  The counter only grows (the k-th
+// barrier waits for k * nw arrivals), starts at zero at kernel start and is private to one use per launch.
+struct SubBar {
+    int* ctr;
+    int nw, target;
+    __device__ __forceinline__ SubBar(int* c, int n) : ctr(c), nw(n), target(0) {}
+    __device__ __forceinline__ void operator()() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wavefront's LDS / memory writes are out
+        target += nw;
+        if ((threadIdx.x & 63u) == 0) atomicAdd(ctr, 1);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
 // in-place (ping-pong) Gauss-Jordan inverse of an SPD NW x NW matrix as gj_spd (lv_solve_dev.hpp), synchronising through bar
 template <int NW, class Bar>
 __device__ inline void gj_spd_bar(double (*W)[12][13], int& cur, int tid, Bar& bar) {
@@ -365,9 +380,9 @@ __device__ inline void prepare_next(BookLds& Bk, KfDev::PassState* __restrict__ 
 // part), otherwise prepare_next.  Pprop / xprop: the propagated covariance / state (K's early-fetched copies, or kf's);
 // prep_preloaded: Bk.P already holds in->prep_P and Bk.xp the propagated state (closing launch).
 template <int NW, int T, class Bar>
-__device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
+__device__ __forceinline__ void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
                                    KfDev::PassState* __restrict__ out, KfHostIO* io, double* __restrict__ sums_out,
-                                   const SolveParams& prm, const PoseConsts* pose, const double* Pprop, const double* xprop,
+                                   double prm_R_inv, int prm_seq, const PoseConsts* pose, const double* Pprop, const double* xprop,
                                    bool prep_preloaded, int tid, Bar& bar, long long* clk) {
     const int wave = tid >> 6, lane = tid & 63;
     const int pass = K.pass, last = K.last, kf_iter = K.kf_iter;
@@ -400,7 +415,7 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
     }
     if (!last) {
         for (int e = tid; e < NS * NS; e += T) Bk.B[e / NS][e % NS] = Pprop[e];
-        prepare_next<NW, T>(Bk, out, K.x, xprop, prm.R_inv, tid, bar, clk);
+        prepare_next<NW, T>(Bk, out, K.x, xprop, prm_R_inv, tid, bar, clk);
         return;
     }
     if (tid < NX) LV_IO_STORE(&io->x[tid], K.x[tid]);
@@ -410,7 +425,7 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar();
         if (tid == 0)
-            __hip_atomic_store(&io->seqcheck, ((unsigned long long)MAILBOX_UNCHECKED << 32) | (unsigned long long)(uint32_t)prm.seq,
+            __hip_atomic_store(&io->seqcheck, ((unsigned long long)MAILBOX_UNCHECKED << 32) | (unsigned long long)(uint32_t)prm_seq,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
@@ -471,7 +486,7 @@ __device__ inline void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restr
     if (tid == 0) {
         uint32_t chk = Bk.chk;
         if (chk == MAILBOX_UNCHECKED) chk = 0u;
-        __hip_atomic_store(&io->seqcheck, ((unsigned long long)chk << 32) | (unsigned long long)(uint32_t)prm.seq, __ATOMIC_RELAXED,
+        __hip_atomic_store(&io->seqcheck, ((unsigned long long)chk << 32) | (unsigned long long)(uint32_t)prm_seq, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -2,13 +2,13 @@
 # Round artefacts: bench line + rocprofv3 kernel stats + PMC traffic for the same command.
 set -u
 export TMPDIR=/tmp
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py 2>$OUT/bench.stderr | tail -1 > $OUT/bench_$R.json
 cat $OUT/bench_$R.json | python scripts/summ.py
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity --no-cycle"
 cd /tmp
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $R -- $CMD > $OUT/stats.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $R -- $CMD > $OUT/pmc_fetch.log 2>&1
