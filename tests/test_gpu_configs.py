@@ -19,10 +19,15 @@ TOL_SUMS_REL = 1e-10
 TOL_STATE = 1e-9
 # 12-column solve at the headline size: the information matrix (P/R)_ww^-1 + H^T H has condition number 3e6 there (163 /
 # 1.2e4 for the 6-column solve at configs[0] / headline size, 3.5e3 for 12 columns at configs[0]): the oracle's OWN dx moves by
-# 4e-10 when its sums are perturbed by 1e-15 relative (measured with oracle.kf_step), i.e. by as much as two correct f64
-# implementations with different summation orders differ — the device's fixed-order partial sums and unpivoted 12 x 12
-# Gauss-Jordan against the oracle's sequential sums and pivoted 23 x 23 LU.  Per pass the difference compounds.
-TOL_STATE_EXT = 2e-8
+# 4e-10 when its sums are perturbed by 1e-15 relative (measured with oracle.kf_step).  So the comparison is decomposed:
+#  (a) every pass on its own, from the state the DEVICE held: sums vs oracle.iterate at 1e-10 relative, and the device's dx /
+#      new state vs oracle.kf_step fed with the device's sums at 1e-9 (measured <= 2.6e-10 on both routes: the solve is exact
+#      to the conditioning floor);
+#  (b) the free-running four-pass traces against the oracle's own run: a 1e-9 m state difference after one pass moves a few
+#      f32 world points across a rounding boundary (one ulp = 4e-6 m at 60 m), the ill-conditioned extrinsic columns amplify
+#      that in the next pass — 3.6e-7 measured on the three-kernel route, 7e-9 on the one-launch route (which branch of the
+#      f32 rounding a route lands on is chance) — the f32-map noise floor already documented for the stream tests.
+TOL_STATE_EXT = 2e-6
 
 # (name, MAX_DIST_PLANE, PLANES_THRESHOLD) — config/{params,kitti,ouster}.yaml
 YAML_KEYS = [("params", 2.0, 0.05), ("kitti", 2.23, 0.1), ("ouster", 2.0, 0.1)]
@@ -110,6 +115,10 @@ def test_extrinsics_update_against_the_oracle(capi, oracle, lv, m, n, route):
         assert g["n_valid"] == o["n_valid"], f"pass {i}"
         assert np.abs(g["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * np.abs(o["HTH"]).max(), f"pass {i}"
         assert np.abs(g["HTh"] - o["HTh"]).max() <= TOL_SUMS_REL * max(np.abs(o["HTh"]).max(), 1.0), f"pass {i}"
+        # the solve of this pass on its own: the oracle's step from the device's sums at the device's state
+        xs, dxs, _, _ = oracle.kf_step(states[i], sc["x_init"], sc["P0"], g, params=prm_o, finalize=False)
+        assert np.abs(np.asarray(dxs) - tr[i][:23]).max() < TOL_STATE, f"pass {i}: {np.abs(np.asarray(dxs) - tr[i][:23]).max():.3e}"
+        assert np.abs(np.asarray(xs) - tr[i][23:49]).max() < TOL_STATE, f"pass {i}"
     if route == "one-launch":
         _pin_records(capi, oracle, sc, tree, dict(estimate_extrinsics=1), prm_o, states, orc, fused_ext=True)
 
