@@ -331,6 +331,10 @@ int lv_fetch_neighbors(lv_ctx* ctx, float* nbr_xyz, float* d2, float* p_world, i
  * lv_update / lv_correct took the one-launch-per-pass route, 0 if the three-kernel pass (search / fit / solve). */
 int lv_set_record_dump(lv_ctx* ctx, int enabled);
 int lv_last_update_fused(lv_ctx* ctx);
+/* Measurement passes of the most recent lv_update / lv_correct.  lv_correct(ctx, NULL) does not wait for the device: the figure
+ * is then valid after the next call that does (lv_filter_get, lv_synchronize) — one host/device round trip per cycle instead
+ * of two when the caller fetches the state anyway (Localizator::latest_state after ::correct, src/main.cpp:88-89). */
+int lv_last_passes(lv_ctx* ctx);
 /* Geometry of the one-launch-per-pass kernel for an n_scan-point scan on a part with n_cus compute units (pure host
  * logic, no GPU needed): out = {searching workgroups, search steps per round (1 or 2), rounds per workgroup,
  * 1 if one more workgroup only keeps the books (a CU is left over) else 0}.  A workgroup searches 4 tiles of 32 points

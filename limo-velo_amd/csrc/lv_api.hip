@@ -37,6 +37,9 @@ struct lv_ctx {
     CloudStore cloud;   // row f-4: device-resident LiDAR buffer
     float4* h_stage = nullptr;  // pinned upload staging
     size_t h_stage_cap = 0;
+    MotionState* h_states_ring = nullptr;   // pinned: the motion states of lv_scan_deskew_window, 8 slots of 64 (a copy out of the
+    int states_slot = 0;                    // caller's pageable memory blocks the host; every cycle synchronises at least once, so
+                                            // a slot is free again long before its turn comes round)
 
     KfDev* d_kf = nullptr;
     FilterDev* d_filter = nullptr;  // x, P resident between lv_predict / lv_correct (row f-3)
@@ -126,6 +129,13 @@ namespace {
             set_error("hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(_e)); \
             return LV_EHIP;                      \
         }                                        \
+    } while (0)
+
+// an incremental insert leaves its outcome in flight (MapStore::settle): pick it up before the map's bookkeeping is used
+#define LV_SETTLE_MAP(c)                               \
+    do {                                               \
+        int _rs = (c)->map.settle((c)->stream);        \
+        if (_rs) return _rs;                           \
     } while (0)
 
 int ensure_stage(lv_ctx* c, size_t n) {
@@ -536,6 +546,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_kf) hipHostFree(c->h_kf);
     if (c->h_io) hipHostFree(c->h_io);
     if (c->h_filter) hipHostFree(c->h_filter);
+    if (c->h_states_ring) hipHostFree(c->h_states_ring);
     hipFree(c->d_filter);
     if (c->h_sums) hipHostFree(c->h_sums);
     hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk); hipFree(c->d_wgcost[0]); hipFree(c->d_wgcost[1]);
@@ -590,6 +601,7 @@ static int check_map_points(const void* points, size_t stride, size_t n) {
 
 int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     int rc = check_map_points(points, stride, n);   // bad input leaves the previous map untouched
     if (rc) return rc;
     LV_HIP(hipStreamSynchronize(c->stream));
@@ -609,6 +621,7 @@ int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
 
 int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downsample) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (n == 0) return LV_OK;
     int rc = check_map_points(points, stride, n);
     if (rc) return rc;
@@ -639,6 +652,7 @@ __global__ void scan_to_world_kernel(const double* __restrict__ x, const float4*
 
 int lv_map_add_scan(lv_ctx* c, int downsample) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     const uint32_t n = c->scan.n;
     if (n == 0) return LV_OK;   // Mapper::add returns on an empty cloud (Mapper.cpp:20)
     int rc = c->map.reserve_batch(n);
@@ -670,12 +684,14 @@ int lv_map_evict_oldest(lv_ctx* c, size_t n_oldest, size_t* n_evicted) {
 
 int lv_map_relinearise(lv_ctx* c) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (!c->map.built) return LV_OK;
     return c->map.relinearise(c->stream);
 }
 
 int lv_map_get_stats(lv_ctx* c, lv_map_stats* out) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (!out) { set_error("null argument"); return LV_EINVAL; }
     static_assert(sizeof(lv_map_stats) == sizeof(MapStats), "lv_map_stats layout");
     MapStats st;
@@ -684,11 +700,16 @@ int lv_map_get_stats(lv_ctx* c, lv_map_stats* out) {
     return LV_OK;
 }
 
-size_t lv_map_size(lv_ctx* c) { return c ? c->map.m : 0; }
+size_t lv_map_size(lv_ctx* c) {
+    if (!c) return 0;
+    c->map.settle(c->stream);
+    return c->map.m;
+}
 
 // the living points in map order (ids ascending): the index space of lv_fetch_knn
 int lv_map_fetch(lv_ctx* c, float* xyz_out, size_t capacity) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     const size_t m = c->map.m, ids = c->map.n_ids;
     if (capacity < m || (!xyz_out && capacity)) { set_error("capacity too small"); return LV_EINVAL; }
     if (m == 0) return LV_OK;
@@ -795,7 +816,7 @@ int lv_scan_downsample(lv_ctx* c, const void* points, size_t stride, size_t n, f
     }
     float4* dst = downsample_prec > 0.f ? c->scan.d_desk : c->scan.d_raw;
     LV_HIP(hipMemcpyAsync(dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    return c->scan.voxel_and_sort(c->stream, (uint32_t)n, downsample_prec, c->prm.voxel_size);
+    return c->scan.voxel_and_sort(c->stream, (uint32_t)n, downsample_prec, c->prm.voxel_size, true);
 }
 
 // ---- row f-4: LiDAR wire formats ----------------------------------------------------------------------------
@@ -875,7 +896,11 @@ int lv_cloud_ingest(lv_ctx* c, const void* data, size_t n, const lv_cloud_format
     return c->cloud.ingest(c->stream, data, n, cf, ip, begin, n_kept);
 }
 
-size_t lv_cloud_size(lv_ctx* c) { return c ? (size_t)(c->cloud.size - c->cloud.head) : 0; }
+size_t lv_cloud_size(lv_ctx* c) {
+    if (!c) return 0;
+    c->cloud.settle();
+    return (size_t)(c->cloud.size - c->cloud.head);
+}
 
 int lv_cloud_fetch(lv_ctx* c, double t1, double t2, void* out, size_t capacity, size_t* n) {
     LV_CHECK_CTX(c);
@@ -915,7 +940,15 @@ int lv_scan_deskew_window(lv_ctx* c, double t1, double t2, const lv_motion_state
     if (rc) return rc;
     rc = c->cloud.unpack(c->stream, lo, n, c->scan.d_in, c->scan.d_times);
     if (rc) return rc;
-    LV_HIP(hipMemcpyAsync(c->scan.d_states, states, n_states * sizeof(MotionState), hipMemcpyHostToDevice, c->stream));
+    if (n_states <= 64) {
+        if (!c->h_states_ring) LV_HIP(hipHostMalloc((void**)&c->h_states_ring, 8 * 64 * sizeof(MotionState), hipHostMallocDefault));
+        MotionState* slot = c->h_states_ring + (size_t)c->states_slot * 64;
+        c->states_slot = (c->states_slot + 1) & 7;
+        std::memcpy(slot, states, n_states * sizeof(MotionState));
+        LV_HIP(hipMemcpyAsync(c->scan.d_states, slot, n_states * sizeof(MotionState), hipMemcpyHostToDevice, c->stream));
+    } else {
+        LV_HIP(hipMemcpyAsync(c->scan.d_states, states, n_states * sizeof(MotionState), hipMemcpyHostToDevice, c->stream));
+    }
     MotionState xt2;
     std::memcpy(&xt2, Xt2, sizeof(xt2));
     return c->scan.deskew_downsample(c->stream, n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size);
@@ -948,6 +981,7 @@ int lv_set_record_dump(lv_ctx* c, int enabled) {
 }
 
 int lv_last_update_fused(lv_ctx* c) { return (c && c->last_update_fused) ? 1 : 0; }
+int lv_last_passes(lv_ctx* c) { return c ? c->h_io->passes : 0; }
 
 int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]) {
     if (!out || n_cus < 1 || n_scan > 0xFFFFFFF0ull) { set_error("lv_pass_geometry: bad arguments"); return LV_EINVAL; }
@@ -996,6 +1030,7 @@ int lv_get_pass_clocks(lv_ctx* c, long long* out, int capacity_wg, int* n_wg) {
 
 int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (!x || !out) { set_error("null argument"); return LV_EINVAL; }
     std::memset(out, 0, sizeof(*out));
     if (c->map.view.m == 0 || c->scan.n == 0) { c->dbg_valid = false; return LV_OK; }  // Mapper.cpp:42 — empty Matches
@@ -1016,6 +1051,7 @@ int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
 
 int lv_update_begin(lv_ctx* c, const lv_state* x, const double* P) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
     c->in_update = true;
     c->passes_issued = 0;
@@ -1195,6 +1231,7 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
 
 int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass, double* trace) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
     if (passes) *passes = 0;
     c->state_src = 2;
@@ -1299,6 +1336,7 @@ int lv_predict(lv_ctx* c, double dt, const double* Q, const double acc[3], const
 
 int lv_correct(lv_ctx* c, int* passes) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     if (!c->filter_set) { set_error("lv_correct before lv_filter_set"); return LV_ESTATE; }
     c->state_src = 1;
     if (passes) *passes = 0;
@@ -1342,6 +1380,7 @@ static int fetch_check(lv_ctx* c) {
 
 int lv_fetch_knn(lv_ctx* c, uint32_t* idx, float* d2) {
     LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
     int rc = fetch_check(c);
     if (rc) return rc;
     const size_t n = c->scan.n;

@@ -196,6 +196,8 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
     if (n == 0) return LV_OK;
     int rc = init();
     if (rc) return rc;
+    rc = settle();
+    if (rc) return rc;
     const size_t bytes = n * (size_t)fmt.point_step;
     rc = reserve_msg(n, bytes);
     if (rc) return rc;
@@ -224,7 +226,18 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
     return LV_OK;
 }
 
+int CloudStore::settle() {
+    if (!clear_pending) return LV_OK;
+    clear_pending = false;
+    LV_HIP(hipEventSynchronize(ev_clear));
+    head = h_count[3];
+    if (head >= size) head = size = 0;
+    return LV_OK;
+}
+
 int CloudStore::window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi) {
+    int rcs = settle();
+    if (rcs) return rcs;
     *lo = *hi = head;
     if (size <= head) return LV_OK;
     hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(128), 0, stream, d_buf, head, size, t1, t2, d_count);
@@ -236,12 +249,14 @@ int CloudStore::window(hipStream_t stream, double t1, double t2, uint32_t* lo, u
 }
 
 int CloudStore::clear_before(hipStream_t stream, double t) {
+    int rcs = settle();
+    if (rcs) return rcs;
     if (size <= head) return LV_OK;
-    hipLaunchKernelGGL(cloud_clear_kernel, dim3(1), dim3(64), 0, stream, d_buf, head, size, t, d_count);
-    LV_HIP(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    head = h_count[0];
-    if (head >= size) head = size = 0;
+    if (!ev_clear) LV_HIP(hipEventCreateWithFlags(&ev_clear, hipEventDisableTiming));
+    hipLaunchKernelGGL(cloud_clear_kernel, dim3(1), dim3(64), 0, stream, d_buf, head, size, t, d_count + 3);
+    LV_HIP(hipMemcpyAsync(h_count + 3, d_count + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipEventRecord(ev_clear, stream));
+    clear_pending = true;   // (head is settled by the next window / ingest / clear / size query)
     return LV_OK;
 }
 
@@ -257,6 +272,7 @@ void CloudStore::release() {
     hipFree(d_ids); hipFree(d_ids_sorted); hipFree(d_tmp); hipFree(d_buf); hipFree(d_count);
     if (h_rawmsg) hipHostFree(h_rawmsg);
     if (h_count) hipHostFree(h_count);
+    if (ev_clear) hipEventDestroy(ev_clear);
     *this = CloudStore();
 }
 

@@ -113,6 +113,13 @@ struct MapStore {
     size_t box_next_cap = 0;
     bool have_boxes = false;
 
+    // the tail of an incremental insert (new ids / living points / overflow, read from the device counters) is settled by the
+    // next call that needs the map's bookkeeping, not by a wait at the end of the insert
+    hipEvent_t ev_counters = nullptr;
+    bool counters_pending = false;
+    bool pending_counted_kill = false;
+    uint32_t pending_n_dead = 0;
+    int settle(hipStream_t stream);
     bool origin_set = false;
     float origin[3] = {0, 0, 0};
     float cell = 0.5f;
@@ -252,7 +259,10 @@ struct ScanStore {
     int reserve(size_t cap);
     int reserve_raw(size_t cap, size_t n_states);
     int deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf, float sort_cell);
-    int voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell);
+    int voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell, bool try_small = false);
+    bool small_window_applies(uint32_t n_in) const;
+    int window_small(hipStream_t stream, const float4* src, uint32_t n_in, uint32_t n_states, const MotionState* xt2, float leaf,
+                     float sort_cell, bool* fell_back);
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
     int order_tiles(hipStream_t stream, uint32_t tile_points);
     int reserve_tiles(uint32_t nt);
@@ -301,6 +311,12 @@ struct CloudStore {
     size_t tmp_bytes = 0, msg_cap = 0;
     uint32_t* d_count = nullptr;
     uint32_t* h_count = nullptr;   // pinned
+    // clear_before does not wait for its result (the new head): the kernel's answer is copied to h_count[3] and picked up by
+    // whoever touches the buffer next (settle), by which time it has long arrived — the wait was one of six host/device round
+    // trips of a 100 Hz cycle
+    hipEvent_t ev_clear = nullptr;
+    bool clear_pending = false;
+    int settle();
     int init();
     int reserve_msg(size_t n, size_t bytes);
     int reserve_buffer(hipStream_t stream, size_t total);

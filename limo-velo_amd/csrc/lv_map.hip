@@ -471,6 +471,7 @@ void MapStore::release() {
     hipFree(d_napos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_box); hipFree(d_box_next);
     for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_gtab[l]); hipFree(d_gbase[l]); hipFree(d_gslot[l]); }
+    if (ev_counters) hipEventDestroy(ev_counters);
     hipFree(d_prank); hipFree(d_pslot); hipFree(d_gcnt); hipFree(d_reloc);
     *this = MapStore();
 }
@@ -922,6 +923,73 @@ __global__ __launch_bounds__(1024) void inc_sort_small_kernel(const uint64_t* __
     for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
 }
 
+// The front half of a small batch's insert by ONE workgroup: box keys -> stable sort -> the sequential box rule -> exclusive
+// scan of the survivors -> ids / orig / box chains -> voxel groups.  Seven launches (two of them library calls) of a few
+// microseconds of work each otherwise; the stages are the *_item functions of lv_mapinc.hpp, separated by workgroup barriers
+// (one workgroup: a barrier also orders its global-memory traffic).
+__global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx, int have_boxes, GroupRW G, const float4* __restrict__ newp,
+                                                               uint32_t k, float len, int downsample, uint64_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ idx, uint64_t* __restrict__ keys_sorted,
+                                                               uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ alive,
+                                                               uint32_t* __restrict__ apos, float4* __restrict__ dead, uint32_t dead_cap,
+                                                               uint32_t id_base) {
+    __shared__ uint64_t s_key[SMALL_BATCH];
+    __shared__ uint32_t s_idx[SMALL_BATCH];
+    __shared__ uint32_t s_wsum[1024 / 64 + 1];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t j = tid; j < k; j += 1024) inc_box_keys_item(M, newp, k, len, keys, idx, alive, downsample, 1, j);
+    __syncthreads();
+    if (downsample) {
+        for (uint32_t i = tid; i < (uint32_t)SMALL_BATCH; i += 1024) {
+            s_key[i] = i < k ? keys[i] : ~0ull;
+            s_idx[i] = i < k ? idx[i] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        uint32_t len2 = 64;
+        while (len2 < k) len2 <<= 1;
+        for (uint32_t k2 = 2; k2 <= len2; k2 <<= 1) {
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < len2 / 2; t += 1024) {
+                    const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                    const bool up = (lo & k2) == 0;
+                    const uint64_t a = s_key[lo], b = s_key[hi];
+                    const uint32_t ia = s_idx[lo], ib = s_idx[hi];
+                    const bool gt = a > b || (a == b && ia > ib);
+                    if (gt == up) { s_key[lo] = b; s_key[hi] = a; s_idx[lo] = ib; s_idx[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
+        __syncthreads();
+        for (uint32_t i = tid; i < k; i += 1024) inc_box_rule_item(Bx, M.orig, newp, keys_sorted, idx_sorted, k, alive, dead, dead_cap, M.cnt, i);
+        __syncthreads();
+    }
+    {   // exclusive scan of alive[0 .. k) (k <= 2048: two elements per thread)
+        const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
+        const uint32_t a0 = i0 < k ? alive[i0] : 0u, a1 = i1 < k ? alive[i1] : 0u;
+        uint32_t incl = a0 + a1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if ((tid & 63u) >= (uint32_t)o) incl += v;
+        }
+        if ((tid & 63u) == 63u) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int w = 0; w < 1024 / 64; ++w) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; }
+        }
+        __syncthreads();
+        const uint32_t excl = s_wsum[tid >> 6] + incl - (a0 + a1);
+        if (i0 < k) apos[i0] = excl;
+        if (i1 < k) apos[i1] = excl + a0;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < k; j += 1024) inc_commit_points_item(M, Bx, have_boxes, newp, alive, apos, k, id_base, j);
+    for (uint32_t t = tid; t < k * (uint32_t)REPL_LEVELS; t += 1024) inc_group_item(M, G, newp, alive, k, t);
+}
+
 // the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
 __global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -947,7 +1015,8 @@ int MapStore::ensure_counters() {
 
 int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float box_length, bool build_if_empty) {
     if (k == 0) return LV_OK;
-    int rc;
+    int rc = settle(stream);
+    if (rc) return rc;
     if ((!built || m == 0) && downsample && !build_if_empty) {
         // KD_TREE::Add_Points(points, true) into an EMPTY map: the box rule among the new points themselves (every box
         // keeps, of its points in input order, the one the sequential rule leaves), then a build from the survivors
@@ -1026,8 +1095,28 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         Bx = BoxRW{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
     const int B = 256;
     const uint32_t gk = (k + B - 1) / B;
-    hipLaunchKernelGGL(inc_box_keys_kernel, dim3(gk), dim3(B), 0, stream, M, d_new, k, box_length, d_nkeys, d_nidx, d_nalive, downsample, 1);
+    // voxel-group tables of the batch (cleared first: the small batch's front kernel fills them)
+    GroupRW G{};
+    for (int l = 0; l < REPL_LEVELS; ++l) {
+        G.table[l] = d_gtab[l];
+        G.gbase[l] = d_gbase[l];
+        G.gslot[l] = d_gslot[l];
+    }
+    G.mask = gtab_size - 1;
+    G.shift = (uint32_t)(64 - log2u(gtab_size));
+    G.size = gtab_size;
+    G.prank = d_prank;
+    G.pslot = d_pslot;
+    hipLaunchKernelGGL(inc_clear_groups_kernel, dim3((uint32_t)(((uint64_t)gtab_size * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, G,
+                       d_gcnt);
+    static const bool small_front = [] { const char* e = getenv("LV_SMALL_INSERT"); return !e || atoi(e) != 0; }();   // (A/B knob)
+    const bool fused_front = small_front && k <= (uint32_t)SMALL_BATCH;
     uint32_t n_dead = 0;
+    if (fused_front) {
+        hipLaunchKernelGGL(inc_small_front_kernel, dim3(1), dim3(1024), 0, stream, M, Bx, have_boxes ? 1 : 0, G, d_new, k, box_length,
+                           downsample, d_nkeys, d_nidx, d_nkeys_sorted, d_nidx_sorted, d_nalive, d_napos, d_dead, (uint32_t)dead_cap, n_ids);
+    } else {
+    hipLaunchKernelGGL(inc_box_keys_kernel, dim3(gk), dim3(B), 0, stream, M, d_new, k, box_length, d_nkeys, d_nidx, d_nalive, downsample, 1);
     if (downsample) {
         if (k <= (uint32_t)SMALL_BATCH) {
             hipLaunchKernelGGL(inc_sort_small_kernel, dim3(1), dim3(1024), 0, stream, d_nkeys, d_nidx, k, d_nkeys_sorted, d_nidx_sorted);
@@ -1046,21 +1135,9 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     hipLaunchKernelGGL(inc_commit_points_kernel, dim3(gk), dim3(B), 0, stream, M, Bx, have_boxes ? 1 : 0, d_new, d_nalive, d_napos, k,
                        n_ids);
     // voxel groups of the survivors on every level
-    GroupRW G{};
-    for (int l = 0; l < REPL_LEVELS; ++l) {
-        G.table[l] = d_gtab[l];
-        G.gbase[l] = d_gbase[l];
-        G.gslot[l] = d_gslot[l];
-    }
-    G.mask = gtab_size - 1;
-    G.shift = (uint32_t)(64 - log2u(gtab_size));
-    G.size = gtab_size;
-    G.prank = d_prank;
-    G.pslot = d_pslot;
-    hipLaunchKernelGGL(inc_clear_groups_kernel, dim3((uint32_t)(((uint64_t)gtab_size * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, G,
-                       d_gcnt);
     hipLaunchKernelGGL(inc_group_kernel, dim3((uint32_t)(((uint64_t)k * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, M, G, d_new,
                        d_nalive, k);
+    }   // !fused_front
     const bool counted_kill = downsample && k <= (uint32_t)SMALL_BATCH;
     if (counted_kill) {   // the occupants that lost: how many is only known on the device — a small batch leaves it there
         hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(256), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
@@ -1088,9 +1165,23 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_commit_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     LV_HIP(hipGetLastError());
+    // the insert's outcome (ids handed out, occupants that lost, overflow) is read back WITHOUT waiting for it: settle() picks
+    // it up when the map's bookkeeping is needed next (the following search or insert), by which time it has long arrived
+    if (!ev_counters) LV_HIP(hipEventCreateWithFlags(&ev_counters, hipEventDisableTiming));
     LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    if (counted_kill) n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
+    LV_HIP(hipEventRecord(ev_counters, stream));
+    counters_pending = true;
+    pending_counted_kill = counted_kill;
+    pending_n_dead = n_dead;
+    return LV_OK;
+}
+
+int MapStore::settle(hipStream_t stream) {
+    if (!counters_pending) return LV_OK;
+    counters_pending = false;
+    LV_HIP(hipEventSynchronize(ev_counters));
+    uint32_t n_dead = pending_n_dead;
+    if (pending_counted_kill) n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
     n_ids += h_cnt->n_new;
     m += h_cnt->n_new;
     m -= n_dead;
@@ -1104,6 +1195,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
 
 int MapStore::evict_box(hipStream_t stream, const float lo[3], const float hi[3], int keep_inside, uint32_t* n_evicted) {
     if (n_evicted) *n_evicted = 0;
+    { int rcs = settle(stream); if (rcs) return rcs; }
     if (!built || m == 0) return LV_OK;
     int rc = reset_batch_counters(*this, stream);
     if (rc) return rc;
@@ -1126,6 +1218,7 @@ int MapStore::evict_box(hipStream_t stream, const float lo[3], const float hi[3]
 
 int MapStore::evict_oldest(hipStream_t stream, uint32_t n_oldest, uint32_t* n_evicted) {
     if (n_evicted) *n_evicted = 0;
+    { int rcs = settle(stream); if (rcs) return rcs; }
     if (!built || m == 0 || n_oldest == 0) return LV_OK;
     if (n_oldest > m) n_oldest = m;
     int rc = ensure_alive_scratch();

@@ -191,9 +191,11 @@ __global__ void box_build_kernel(BoxRW B, const float4* __restrict__ orig, uint3
 // keys of the new points for the stable sort by box; points that cannot be inserted sort last
 // (check_range == 0: the map is empty and has no origin yet — only finiteness is checked, the build that follows
 // validates the extent)
-__global__ void inc_box_keys_kernel(MapRW M, const float4* __restrict__ newp, uint32_t k, float len, uint64_t* __restrict__ keys,
-                                    uint32_t* __restrict__ idx, uint32_t* __restrict__ alive, int downsample, int check_range) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// (every one-thread-per-item kernel below is a thin wrapper around its *_item function: small batches run several of them
+// back to back inside ONE workgroup — inc_small_front_kernel, lv_map.hip — instead of one launch each)
+__device__ __forceinline__ void inc_box_keys_item(const MapRW& M, const float4* __restrict__ newp, uint32_t k, float len,
+                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ alive,
+                                                  int downsample, int check_range, uint32_t j) {
     if (j >= k) return;
     const float4 p = newp[j];
     idx[j] = j;
@@ -207,16 +209,20 @@ __global__ void inc_box_keys_kernel(MapRW M, const float4* __restrict__ newp, ui
     keys[j] = inc_box_key(p, len);
     alive[j] = downsample ? 0u : 1u;   // without down-sampling every insertable point lives
 }
+__global__ void inc_box_keys_kernel(MapRW M, const float4* __restrict__ newp, uint32_t k, float len, uint64_t* __restrict__ keys,
+                                    uint32_t* __restrict__ idx, uint32_t* __restrict__ alive, int downsample, int check_range) {
+    inc_box_keys_item(M, newp, k, len, keys, idx, alive, downsample, check_range, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // One thread per box touched by the batch replays upstream's sequential rule: for every new point p of the box, in
 // input order, the point nearest to the box centre among {p} U (points currently in the box) survives if the box
 // held more than one point or p itself is that nearest point (occupants must be STRICTLY closer to beat p; among
 // equally near occupants the oldest wins); otherwise the box is left alone.  Old occupants that lose are put on
 // the dead list (coordinates + id) and their slot in `orig` is marked; `alive` flags the new points that live.
-__global__ void inc_box_rule_kernel(BoxRW B, float4* __restrict__ orig, const float4* __restrict__ newp,
-                                    const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ idx_sorted, uint32_t k,
-                                    uint32_t* __restrict__ alive, float4* __restrict__ dead, uint32_t dead_cap, MapCounters* cnt) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void inc_box_rule_item(const BoxRW& B, float4* __restrict__ orig, const float4* __restrict__ newp,
+                                                  const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ idx_sorted,
+                                                  uint32_t k, uint32_t* __restrict__ alive, float4* __restrict__ dead, uint32_t dead_cap,
+                                                  MapCounters* cnt, uint32_t i) {
     if (i >= k) return;
     const uint64_t key = keys_sorted[i];
     if (key == (~0ull >> 1)) return;                       // dropped points
@@ -291,13 +297,17 @@ __global__ void inc_box_rule_kernel(BoxRW B, float4* __restrict__ orig, const fl
         }
     }
 }
+__global__ void inc_box_rule_kernel(BoxRW B, float4* __restrict__ orig, const float4* __restrict__ newp,
+                                    const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ idx_sorted, uint32_t k,
+                                    uint32_t* __restrict__ alive, float4* __restrict__ dead, uint32_t dead_cap, MapCounters* cnt) {
+    inc_box_rule_item(B, orig, newp, keys_sorted, idx_sorted, k, alive, dead, dead_cap, cnt, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // surviving new points get their ids (id_base + rank among the survivors, input order), their slot in `orig` and,
 // if the box table exists, their place at the head of their box chain
-__global__ void inc_commit_points_kernel(MapRW M, BoxRW B, int have_boxes, const float4* __restrict__ newp,
-                                         const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
-                                         uint32_t id_base) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void inc_commit_points_item(const MapRW& M, const BoxRW& B, int have_boxes, const float4* __restrict__ newp,
+                                                       const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                                       uint32_t id_base, uint32_t j) {
     if (j >= k) return;
     if (j == k - 1) M.cnt->n_new = apos[j] + alive[j];
     if (!alive[j]) return;
@@ -309,6 +319,11 @@ __global__ void inc_commit_points_kernel(MapRW M, BoxRW B, int have_boxes, const
         if (slot == ID_NONE) return;
         B.next[id] = atomicExch(&B.table[slot].z, id);
     }
+}
+__global__ void inc_commit_points_kernel(MapRW M, BoxRW B, int have_boxes, const float4* __restrict__ newp,
+                                         const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                         uint32_t id_base) {
+    inc_commit_points_item(M, B, have_boxes, newp, alive, apos, k, id_base, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- tombstones ------------------------------------------------------------------------------------------------
@@ -379,8 +394,8 @@ constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + (level 2 only) the
 // FIRST share of a target's tail (offset 0) owns that target for the rest of the batch: it makes room and commits.)
 
 // pass 1: every surviving new point joins its voxel group on each level
-__global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void inc_group_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp,
+                                               const uint32_t* __restrict__ alive, uint32_t k, uint32_t t) {
     const uint32_t j = t / (uint32_t)REPL_LEVELS;
     const int l = (int)(t % (uint32_t)REPL_LEVELS);
     if (j >= k || !alive[j]) return;
@@ -405,6 +420,9 @@ __global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ 
         slot = (slot + 1) & G.mask;
     }
     atomicExch(&M.cnt->overflow, 1u);
+}
+__global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
+    inc_group_item(M, G, newp, alive, k, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // slot of `key` in a bucket / list table, inserting it if absent (plain probe first: most slots exist)

@@ -41,13 +41,8 @@ __global__ void scan_gather_kernel(const float4* __restrict__ pts, const uint32_
 
 // ---- row f-2: Compensator::compensate + voxelgrid_downsample on the device ------------------------------
 // de-skew: one lane per raw point (reference src/Modules/Compensator.cpp:123-146)
-__global__ void deskew_kernel(const float4* __restrict__ raw, const double* __restrict__ times, uint32_t n,
-                              const MotionState* __restrict__ states, uint32_t n_states, MotionState xt2,
-                              float4* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = raw[i];
-    const double t = times[i];
+__device__ __forceinline__ float4 deskew_point(const float4 p, const double t, uint32_t i, const MotionState* __restrict__ states,
+                                               uint32_t n_states, const MotionState& xt2) {
     const float qnan = __uint_as_float(0x7fc00000u);
     float4 o = make_float4(qnan, qnan, qnan, __uint_as_float(i));
     // the reference's two-pointer walk puts a point into the FIRST interval [states[s].time, states[s+1].time]
@@ -77,7 +72,14 @@ __global__ void deskew_kernel(const float4* __restrict__ raw, const double* __re
         const RT32 back = rt_compose(rt_inv(LI2), rt_inv(X2));            // Xt2.I_Rt_L().inv() * Xt2.inv()      :138
         rt_apply(back, gx, gy, gz, o.x, o.y, o.z);
     }
-    out[i] = o;
+    return o;
+}
+__global__ void deskew_kernel(const float4* __restrict__ raw, const double* __restrict__ times, uint32_t n,
+                              const MotionState* __restrict__ states, uint32_t n_states, MotionState xt2,
+                              float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = deskew_point(raw[i], times[i], i, states, n_states, xt2);
 }
 
 // pcl::VoxelGrid [UPSTREAM-RECALL PCL 1.8 applyFilter]: bounds -> leaf index -> sort -> centroid per leaf
@@ -185,6 +187,203 @@ __global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint64_
     out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
 }
 
+// ---- small windows: the whole chain in ONE launch --------------------------------------------------------------------
+// A 0.01 s window of a stream holds 1-2 thousand raw points.  De-skew, bounds, leaf keys, stable sort, leaf heads, scan,
+// centroids, Morton keys, sort, gather, tile order were twelve launches (+ two library sorts) of a few microseconds of work
+// each; here ONE workgroup runs the same stages over LDS, separated by workgroup barriers.  Every stage computes what its
+// stand-alone kernel computes (same expressions, same order of every sum: the leaf centroid stays the sequential f32 sum
+// in input order), so the result is bit-identical to the general path (tests/test_gpu_deskew.py runs both).
+// bounds[0..5]: min / max of the de-skewed points (flipped floats), [6]: points out, [7]: 1 = the leaf grid does not fit the
+// packed sort key (the caller then takes the general path).
+constexpr int SMALL_WINDOW = 2048;
+constexpr int SW_THREADS = 1024;
+__device__ __forceinline__ void lds_bitonic_u64(uint64_t* s_key, uint32_t n, int tid) {
+    uint32_t len = 64;
+    while (len < n) len <<= 1;
+    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < len / 2; t += SW_THREADS) {
+                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool up = (lo & k2) == 0;
+                const uint64_t a = s_key[lo], b = s_key[hi];
+                if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* __restrict__ raw, const double* __restrict__ times,
+                                                                  uint32_t n_in, const MotionState* __restrict__ states,
+                                                                  uint32_t n_states, MotionState xt2, int do_deskew, float leaf,
+                                                                  float inv_sort_cell, uint32_t tile_points,
+                                                                  float4* __restrict__ out_raw, float4* __restrict__ out_sorted,
+                                                                  uint32_t* __restrict__ tile_order, unsigned* __restrict__ bounds) {
+    __shared__ float4 s_pt[SMALL_WINDOW];       // de-skewed input
+    __shared__ float4 s_out[SMALL_WINDOW];      // output points (voxel-grid order)
+    __shared__ uint64_t s_key[SMALL_WINDOW];
+    __shared__ float s_r2[SMALL_WINDOW];
+    __shared__ unsigned s_b[8];
+    __shared__ uint32_t s_wsum[SW_THREADS / 64 + 1];
+    const int tid = threadIdx.x;
+    if (tid < 3) s_b[tid] = 0xFFFFFFFFu;
+    else if (tid < 8) s_b[tid] = 0u;
+    // ---- de-skew (or take the points as they are: Compensator::downsample on its own)
+    for (uint32_t i = tid; i < (uint32_t)SMALL_WINDOW; i += SW_THREADS) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_in) {
+            const float4 p = raw[i];
+            o = do_deskew ? deskew_point(p, times[i], i, states, n_states, xt2) : p;
+        }
+        s_pt[i] = o;
+    }
+    __syncthreads();
+    // ---- bounds of the finite points (vg_bounds_kernel)
+    {
+        unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+        for (uint32_t i = tid; i < n_in; i += SW_THREADS) {
+            const float4 p = s_pt[i];
+            if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
+            const unsigned f[3] = {flip_f32(p.x), flip_f32(p.y), flip_f32(p.z)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = f[a] < lo[a] ? f[a] : lo[a]; hi[a] = f[a] > hi[a] ? f[a] : hi[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            unsigned l = lo[a], h = hi[a];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned l2 = __shfl_xor(l, o), h2 = __shfl_xor(h, o);
+                l = l2 < l ? l2 : l;
+                h = h2 > h ? h2 : h;
+            }
+            if ((tid & 63) == 0) { atomicMin(&s_b[a], l); atomicMax(&s_b[3 + a], h); }
+        }
+    }
+    __syncthreads();
+    uint32_t n_out = n_in;
+    if (s_b[0] == 0xFFFFFFFFu) {   // no finite point: nothing to match
+        if (tid < 8) bounds[tid] = tid < 6 ? s_b[tid] : 0u;
+        return;
+    }
+    if (leaf > 0.f) {
+        // ---- leaf keys (vg_keys_kernel), packed with the input index so that one u64 order == the stable sort by key
+        const float inv_leaf = 1.0f / leaf;
+        long long minb[3], divb[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            minb[a] = (long long)floorf(unflip_f32(s_b[a]) * inv_leaf);
+            divb[a] = (long long)floorf(unflip_f32(s_b[3 + a]) * inv_leaf) - minb[a] + 1;
+        }
+        // (the packed key needs leaf index < 2^52: the extent of a window in leaves; otherwise the general path)
+        const double cells = (double)divb[0] * (double)divb[1] * (double)divb[2];
+        if (!(cells < 4.0e15)) {
+            if (tid < 8) bounds[tid] = tid < 6 ? s_b[tid] : (tid == 7 ? 1u : 0u);
+            return;
+        }
+        for (uint32_t i = tid; i < (uint32_t)SMALL_WINDOW; i += SW_THREADS) {
+            uint64_t k = ~0ull;                                    // padding and dropped points sort last
+            if (i < n_in) {
+                const float4 p = s_pt[i];
+                if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+                    const long long i0 = (long long)floorf(p.x * inv_leaf) - minb[0], i1 = (long long)floorf(p.y * inv_leaf) - minb[1],
+                                    i2 = (long long)floorf(p.z * inv_leaf) - minb[2];
+                    k = ((uint64_t)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]) << 11) | (uint64_t)i;
+                }
+            }
+            s_key[i] = k;
+        }
+        __syncthreads();
+        lds_bitonic_u64(s_key, n_in, tid);
+        // ---- leaf heads + exclusive scan (vg_heads_kernel, DeviceScan) — two elements per thread
+        uint32_t h0 = 0, h1 = 0;
+        {
+            const uint32_t i = 2u * (uint32_t)tid;
+            if (i < n_in) { const uint64_t k = s_key[i]; h0 = (k != ~0ull && (i == 0 || (s_key[i - 1] >> 11) != (k >> 11))) ? 1u : 0u; }
+            if (i + 1 < n_in) { const uint64_t k = s_key[i + 1]; h1 = (k != ~0ull && ((s_key[i] >> 11) != (k >> 11))) ? 1u : 0u; }
+        }
+        uint32_t incl = h0 + h1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += v;
+        }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int w = 0; w < SW_THREADS / 64; ++w) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; }
+            s_wsum[SW_THREADS / 64] = run;
+        }
+        __syncthreads();
+        const uint32_t excl = s_wsum[tid >> 6] + incl - (h0 + h1);
+        n_out = s_wsum[SW_THREADS / 64];
+        // ---- centroid per leaf: the sequential f32 sum of its points in input order (vg_centroid_kernel)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t i = 2u * (uint32_t)tid + (uint32_t)e;
+            const bool head = e == 0 ? h0 != 0u : h1 != 0u;
+            if (!head) continue;
+            const uint64_t leafk = s_key[i] >> 11;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            uint32_t j = i;
+            while (j < n_in && (s_key[j] >> 11) == leafk && s_key[j] != ~0ull) {
+                const float4 p = s_pt[(uint32_t)(s_key[j] & 2047u)];
+                sx += p.x; sy += p.y; sz += p.z;
+                ++j;
+            }
+            const float cnt = (float)(j - i);
+            const uint32_t o = excl + (e == 1 ? h0 : 0u);
+            s_out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
+        }
+        __syncthreads();
+    } else {
+        for (uint32_t i = tid; i < n_in; i += SW_THREADS) s_out[i] = s_pt[i];
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n_out; i += SW_THREADS) out_raw[i] = s_out[i];
+    if (tid < 8) bounds[tid] = tid < 6 ? s_b[tid] : (tid == 6 ? n_out : 0u);
+    if (n_out == 0) return;
+    // ---- Morton order of the output, tile ranges, tile order (scan_sort_small_kernel)
+    const float ox = unflip_f32(s_b[0]), oy = unflip_f32(s_b[1]), oz = unflip_f32(s_b[2]);
+    for (uint32_t i = tid; i < (uint32_t)SMALL_WINDOW; i += SW_THREADS) {
+        uint64_t k = ~0ull;
+        if (i < n_out) {
+            const float4 p = s_out[i];
+            const float fx = fminf(fmaxf((p.x - ox) * inv_sort_cell, 0.f), 1023.f);
+            const float fy = fminf(fmaxf((p.y - oy) * inv_sort_cell, 0.f), 1023.f);
+            const float fz = fminf(fmaxf((p.z - oz) * inv_sort_cell, 0.f), 1023.f);
+            const uint32_t key = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+            k = ((uint64_t)key << 32) | i;
+        }
+        s_key[i] = k;
+    }
+    __syncthreads();
+    lds_bitonic_u64(s_key, n_out, tid);
+    for (uint32_t i = tid; i < n_out; i += SW_THREADS) {
+        const float4 p = s_out[(uint32_t)s_key[i]];
+        out_sorted[i] = p;
+        s_r2[i] = p.x * p.x + p.y * p.y + p.z * p.z;
+    }
+    __syncthreads();
+    if (tile_points == 0) return;
+    const uint32_t nt = (n_out + tile_points - 1) / tile_points;
+    uint64_t mine = ~0ull;
+    if ((uint32_t)tid < nt) {
+        float r2 = 0.f;
+        const uint32_t b = (uint32_t)tid * tile_points;
+        for (uint32_t i = 0; i < tile_points && b + i < n_out; ++i) r2 = fmaxf(r2, s_r2[b + i]);
+        mine = ((uint64_t)(~__float_as_uint(r2)) << 32) | (uint32_t)tid;   // complement ascending = range descending; ties by tile
+    }
+    __syncthreads();
+    if ((uint32_t)tid < nt) s_key[tid] = mine;   // (nt <= 1024 whenever tile_points >= 2)
+    __syncthreads();
+    if ((uint32_t)tid < nt) {
+        uint32_t rank = 0;
+        for (uint32_t u = 0; u < nt; ++u) rank += s_key[u] < mine ? 1u : 0u;
+        tile_order[rank] = (uint32_t)tid;
+    }
+}
+
 int ScanStore::reserve_raw(size_t cap, size_t n_states) {
     if (cap > raw_cap) {
         size_t ncap = raw_cap ? raw_cap : 4096;
@@ -229,14 +428,52 @@ int ScanStore::deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_s
     const uint32_t grid = (n_in + B - 1) / B;
     int rc = reserve(n_in);
     if (rc) return rc;
+    if (small_window_applies(n_in)) {
+        bool fell_back = false;
+        rc = window_small(stream, d_in, n_in, n_states, &xt2, leaf, sort_cell, &fell_back);
+        if (rc || !fell_back) return rc;
+    }
     float4* desk = leaf > 0.f ? d_desk : d_raw;
     hipLaunchKernelGGL(deskew_kernel, dim3(grid), dim3(B), 0, stream, d_in, d_times, n_in, d_states, n_states, xt2, desk);
     return voxel_and_sort(stream, n_in, leaf, sort_cell);
 }
 
+bool ScanStore::small_window_applies(uint32_t n_in) const {
+    static const bool enabled = [] { const char* e = getenv("LV_SMALL_WINDOW"); return !e || atoi(e) != 0; }();   // (A/B knob)
+    return enabled && n_in > 0 && n_in <= (uint32_t)SMALL_WINDOW && tile_points >= 2;
+}
+
+// the one-launch chain for windows of up to SMALL_WINDOW points; src = d_in with time stamps (xt2 != nullptr: de-skew) or
+// the points as they are.  *fell_back: the kernel declined (leaf grid too large for the packed key): nothing was produced.
+int ScanStore::window_small(hipStream_t stream, const float4* src, uint32_t n_in, uint32_t n_states, const MotionState* xt2, float leaf,
+                            float sort_cell, bool* fell_back) {
+    *fell_back = false;
+    int rc = reserve(n_in);
+    if (rc) return rc;
+    rc = reserve_tiles((n_in + tile_points - 1) / tile_points);
+    if (rc) return rc;
+    n_tiles = 0;
+    static const MotionState none{};
+    hipLaunchKernelGGL(window_small_kernel, dim3(1), dim3(SW_THREADS), 0, stream, src, d_times, n_in, d_states, n_states,
+                       xt2 ? *xt2 : none, xt2 ? 1 : 0, leaf, 1.0f / sort_cell, tile_points, d_raw, d_sorted, d_tile_order, d_bounds);
+    LV_HIP(hipGetLastError());
+    unsigned hb[8];
+    LV_HIP(hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
+    LV_HIP(hipStreamSynchronize(stream));
+    if (hb[7]) { *fell_back = true; return LV_OK; }
+    n = hb[0] == 0xFFFFFFFFu ? 0u : hb[6];
+    n_tiles = n ? (n + tile_points - 1) / tile_points : 0;
+    return LV_OK;
+}
+
 // the points (de-skewed, or uploaded as they are: Compensator::downsample on its own) wait in d_desk (leaf > 0) or
 // d_raw (leaf <= 0): voxel grid, then the Morton order the search kernel wants
-int ScanStore::voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell) {
+int ScanStore::voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell, bool try_small) {
+    if (try_small && small_window_applies(n_in)) {   // (Compensator::downsample on its own: the points wait in d_desk / d_raw)
+        bool fell_back = false;
+        int rc = window_small(stream, leaf > 0.f ? d_desk : d_raw, n_in, 0, nullptr, leaf, sort_cell, &fell_back);
+        if (rc || !fell_back) return rc;
+    }
     const int B = 256;
     const uint32_t grid = (n_in + B - 1) / B;
     float4* desk = leaf > 0.f ? d_desk : d_raw;

@@ -475,6 +475,7 @@ Localizator::Localizator() {
 void Localizator::pull() {
     if (!host_stale_) return;
     check(lv_filter_get(HipRuntime::ctx(), &x_, P_), "lv_filter_get");
+    if (passes_stale_) { last_passes = lv_last_passes(HipRuntime::ctx()); passes_stale_ = false; }
     host_stale_ = false;
 }
 void Localizator::push() { check(lv_filter_set(HipRuntime::ctx(), &x_, P_), "lv_filter_set"); host_stale_ = false; }
@@ -538,7 +539,8 @@ void Localizator::initialize(double t) {                                 // :119
 void Localizator::correct_current_scan(double time) {                    // :23-27 on the device-resident scan
     if (!Mapper::getInstance().exists()) return;
     if (!initialized) { push(); initialized = true; }
-    check(lv_correct(HipRuntime::ctx(), &last_passes), "lv_correct");
+    check(lv_correct(HipRuntime::ctx(), nullptr), "lv_correct");   // (no wait here: pull() fetches the state AND the pass count)
+    passes_stale_ = true;
     host_stale_ = true;
     last_time_updated = time;
 }

@@ -320,4 +320,5 @@ class Localizator {
     state_ikfom x_;
     double P_[23 * 23];
     bool host_stale_ = false;
+    bool passes_stale_ = false;   // last_passes is refreshed by the next pull() (correct_current_scan does not wait for the device)
 };

@@ -38,17 +38,25 @@ x0 = synth.make_state(pos0 + [0.02, -0.015, 0.01], synth.quat_mul(q0, synth.quat
                       grav=(0, 0, synth.STREAM_G))
 out = {"workload": f"{M}-pt prior map, 64 rings x {N_AZ} azimuth steps per 0.1 s sweep, delta = 0.01 s, {N_REVS} sweeps, mapping online, "
                    "1 GPU, C++ host (stream_demo over the shim)", "stream_generation_s": gen_s}
+# LV_STREAM_AB="NAME=ENV1=v,ENV2=v;NAME2=..." : extra device-resident runs of the SAME stream with those environment
+# settings (A/B of library knobs in one box), e.g. LV_STREAM_AB="separate_launches=LV_SMALL_WINDOW=0,LV_SMALL_INSERT=0"
+variants = [("device_resident", 1, {}), ("by_value", 0, {})]
+for item in filter(None, os.environ.get("LV_STREAM_AB", "").split(";")):
+    name, _, envs = item.partition("=")
+    variants.append((name, 1, dict(e.split("=", 1) for e in envs.split(",") if e)))
 with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
-    for on_device in (1, 0):
-        inp, res = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
-        S._write_stream_input(inp, on_device, 0.01, stream, N_REVS, x0)
-        r = subprocess.run([exe, inp, res], capture_output=True, text=True, timeout=1500)
-        if r.returncode != 0:
-            raise SystemExit(r.stdout + r.stderr)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-        rec = json.loads(line)
-        t, x, npts = S._read_stream_output(res)
-        truth = np.array([synth.stream_truth(tt)[0] for tt in t])
-        rec["rmse_vs_truth_m"] = float(np.sqrt(np.mean(np.sum((x[:, :3] - truth) ** 2, axis=1))))
-        out["device_resident" if on_device else "by_value"] = rec
+    for rep in range(int(os.environ.get("LV_STREAM_REPS", 1))):
+        for name, on_device, env in variants:
+            inp, res = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+            S._write_stream_input(inp, on_device, 0.01, stream, N_REVS, x0)
+            r = subprocess.run([exe, inp, res], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
+            if r.returncode != 0:
+                raise SystemExit(r.stdout + r.stderr)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            rec = json.loads(line)
+            t, x, npts = S._read_stream_output(res)
+            truth = np.array([synth.stream_truth(tt)[0] for tt in t])
+            rec["rmse_vs_truth_m"] = float(np.sqrt(np.mean(np.sum((x[:, :3] - truth) ** 2, axis=1))))
+            rec["final_state_hash"] = float(np.abs(x[-1]).sum())
+            out[name if rep == 0 else f"{name}#{rep + 1}"] = rec
 print(json.dumps(out))
