@@ -344,7 +344,8 @@ int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]);
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);
 /* Tuning / test knobs by name (the environment variables LV_<NAME> set the defaults at lv_create): "fused_pass",
  * "fused_ext" (one launch per pass also with estimate_extrinsics), "fused_multi_round" (... also for scans of more than two
- * rounds per workgroup), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused".  None of them changes a result beyond
+ * rounds per workgroup), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused", "small_window" / "small_insert" (windows /
+ * insert batches of up to 2048 points take their one-launch forms).  None of them changes a result beyond
  * the summation order of the workgroup partials.  LV_EINVAL for an unknown name. */
 int lv_set_option(lv_ctx* ctx, const char* name, int value);
 /* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): for every launch of the last update

@@ -487,6 +487,8 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0;
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
+    if (const char* e = getenv("LV_SMALL_WINDOW")) c->scan.small_enabled = atoi(e) != 0;
+    if (const char* e = getenv("LV_SMALL_INSERT")) c->map.small_front = atoi(e) != 0;
     // (the stamp buffer below is strided by pass_max_wg + 1 workgroup slots: fix the grid limit first)
     c->pass_max_wg = prop.multiProcessorCount;
     if (const char* e = getenv("LV_PASS_WG")) c->pass_max_wg = atoi(e) > 0 ? atoi(e) : c->pass_max_wg;
@@ -1007,6 +1009,8 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "tile_lpt")) c->tile_lpt = on;
     else if (!std::strcmp(name, "spin_wait")) c->spin_wait = on;
     else if (!std::strcmp(name, "comm_fused")) c->comm_fused = on;
+    else if (!std::strcmp(name, "small_window")) c->scan.small_enabled = on;
+    else if (!std::strcmp(name, "small_insert")) c->map.small_front = on;
     else { set_error("lv_set_option: unknown option '%s'", name); return LV_EINVAL; }
     return LV_OK;
 }

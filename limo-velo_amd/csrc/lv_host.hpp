@@ -115,6 +115,7 @@ struct MapStore {
 
     // the tail of an incremental insert (new ids / living points / overflow, read from the device counters) is settled by the
     // next call that needs the map's bookkeeping, not by a wait at the end of the insert
+    bool small_front = true;     // batches of up to 2048 points: the insert's front half in one workgroup launch (LV_SMALL_INSERT=0: off)
     hipEvent_t ev_counters = nullptr;
     bool counters_pending = false;
     bool pending_counted_kill = false;
@@ -259,6 +260,7 @@ struct ScanStore {
     int reserve(size_t cap);
     int reserve_raw(size_t cap, size_t n_states);
     int deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf, float sort_cell);
+    bool small_enabled = true;   // windows of up to 2048 points take the one-launch chain (LV_SMALL_WINDOW=0 / lv_set_option: off)
     int voxel_and_sort(hipStream_t stream, uint32_t n_in, float leaf, float sort_cell, bool try_small = false);
     bool small_window_applies(uint32_t n_in) const;
     int window_small(hipStream_t stream, const float4* src, uint32_t n_in, uint32_t n_states, const MotionState* xt2, float leaf,

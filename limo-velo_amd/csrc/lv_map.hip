@@ -1109,7 +1109,6 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     G.pslot = d_pslot;
     hipLaunchKernelGGL(inc_clear_groups_kernel, dim3((uint32_t)(((uint64_t)gtab_size * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, G,
                        d_gcnt);
-    static const bool small_front = [] { const char* e = getenv("LV_SMALL_INSERT"); return !e || atoi(e) != 0; }();   // (A/B knob)
     const bool fused_front = small_front && k <= (uint32_t)SMALL_BATCH;
     uint32_t n_dead = 0;
     if (fused_front) {

@@ -439,8 +439,7 @@ int ScanStore::deskew_downsample(hipStream_t stream, uint32_t n_in, uint32_t n_s
 }
 
 bool ScanStore::small_window_applies(uint32_t n_in) const {
-    static const bool enabled = [] { const char* e = getenv("LV_SMALL_WINDOW"); return !e || atoi(e) != 0; }();   // (A/B knob)
-    return enabled && n_in > 0 && n_in <= (uint32_t)SMALL_WINDOW && tile_points >= 2;
+    return small_enabled && n_in > 0 && n_in <= (uint32_t)SMALL_WINDOW && tile_points >= 2;
 }
 
 // the one-launch chain for windows of up to SMALL_WINDOW points; src = d_in with time stamps (xt2 != nullptr: de-skew) or

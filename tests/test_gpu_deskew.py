@@ -90,3 +90,33 @@ def test_downsample_alone_is_the_voxel_grid(lv, oracle, scene_small):
             assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), leaf
         ctx.scan_downsample(pts, 0.0)      # no voxel grid: the points become the scan as they are
         assert np.array_equal(ctx.scan_fetch().view(np.uint32), pts.view(np.uint32))
+
+
+@pytest.mark.parametrize("n_pts,leaf", [(3, 0.5), (63, 0.5), (700, 0.5), (2048, 0.5), (2048, 0.2), (1500, 0.0), (2049, 0.5)])
+def test_small_window_chain_equals_the_general_path(lv, oracle, scene_small, n_pts, leaf):
+    """Windows of up to 2048 points run de-skew -> bounds -> leaf keys -> stable sort -> heads -> scan -> centroids -> Morton
+    sort -> tile order in ONE launch (window_small_kernel); larger ones (and the knob off) the twelve-launch chain.  Same
+    points in the same order, the same Morton order and tile order behind them: the iterated update that consumes the scan is
+    bit-identical."""
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    xyz, times, states = _motion(oracle, n_pts)
+    xyz = (xyz * np.float32([0.3, 0.3, 0.5])).astype(np.float32)     # inside the test map
+    xt2 = states[-1:]
+    res = {}
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        for on in (1, 0):
+            ctx.set_option("small_window", on)
+            ctx.scan_deskew(xyz, times, states, xt2, downsample_prec=leaf)
+            pts = ctx.scan_fetch()
+            x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+            res[on] = (pts, x, P, passes, [s["n_valid"] for s in sums])
+    ref = oracle.deskew(xyz, times, states, xt2)
+    if leaf > 0:
+        ref = oracle.voxelgrid(ref, leaf)
+    assert np.array_equal(_bits(res[1][0]), _bits(ref))
+    assert np.array_equal(_bits(res[1][0]), _bits(res[0][0]))
+    assert res[1][3] == res[0][3] and res[1][4] == res[0][4]
+    assert np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2])

@@ -228,3 +228,32 @@ def test_map_add_scan_builds_an_empty_map(capi, oracle, scene_small):
         ctx.map_add_scan(downsample=True)
         want = oracle.map_add(want, oracle.transform_scan(sc["x_true"], sc["scan_xyz"][1500:]), downsample=True)
         assert np.array_equal(_bits(ctx.map_fetch()), _bits(want))
+
+
+def test_small_batch_front_kernel_equals_the_separate_launches(lv, scene_small):
+    """Insert batches of up to 2048 points run box keys -> sort -> box rule -> scan -> ids -> voxel groups in ONE workgroup
+    launch; the knob off (and larger batches) the seven separate launches: identical map contents, order and search results
+    after every one of 12 consecutive small inserts."""
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    rng = np.random.default_rng(7)
+    batches = [(sc["map_xyz"][rng.integers(0, len(sc["map_xyz"]), n)] + rng.normal(0, 0.05, (n, 3))).astype(np.float32)
+               for n in (1, 17, 640, 2048, 800, 1200, 33, 2047, 5, 900, 1999, 64)]
+    maps = {}
+    for on in (1, 0):
+        with capi.Context() as ctx:
+            ctx.set_option("small_insert", on)
+            ctx.map_build(sc["map_xyz"][:20000])
+            sizes = []
+            for b in batches:
+                ctx.map_add(b, downsample=True)
+                sizes.append(ctx.map_size())
+            ctx.scan_set(sc["scan_xyz"])
+            g = ctx.iterate(sc["x_init"])
+            idx, d2 = ctx.fetch_knn()
+            maps[on] = (ctx.map_fetch(), sizes, idx, d2, g["n_valid"], g["HTH"])
+    assert maps[1][1] == maps[0][1]
+    assert np.array_equal(maps[1][0].view(np.uint32), maps[0][0].view(np.uint32))
+    assert np.array_equal(maps[1][2], maps[0][2]) and np.array_equal(maps[1][3].view(np.uint32), maps[0][3].view(np.uint32))
+    assert maps[1][4] == maps[0][4] and np.array_equal(maps[1][5], maps[0][5])
