@@ -338,7 +338,7 @@ int lv_last_passes(lv_ctx* ctx);
 /* Geometry of the one-launch-per-pass kernel for an n_scan-point scan on a part with n_cus compute units (pure host
  * logic, no GPU needed): out = {searching workgroups, search steps per round (1 or 2), rounds per workgroup,
  * 1 if one more workgroup only keeps the books (a CU is left over) else 0}.  A workgroup searches 4 tiles of 32 points
- * per step; lv_update takes this route up to 2 rounds. */
+ * per step; lv_update takes this route up to 3 rounds (196 608 points on a 256-CU part). */
 int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]);
 /* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);

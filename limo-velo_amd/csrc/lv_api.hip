@@ -322,9 +322,9 @@ static inline size_t partial_width(const lv_ctx* c) { return c->prm.estimate_ext
 uint32_t pass_geometry_points(const lv_ctx* c) { return multi_rank(c) ? (uint32_t)c->comm_shard_max : c->scan.n; }
 
 bool pass_fused_applies(const lv_ctx* c) {
-    // (scans of more than two rounds per workgroup — beyond 131 072 points on a 256-CU part — stay with the three-kernel
-    // pass: pass_kernel idles twelve of sixteen wavefronts during every round's plane fits; measured: 131 072 points 223 vs
-    // 233 us per update, 262 144 points 371 vs 354)
+    // (scans of more than three rounds per workgroup — beyond 196 608 points on a 256-CU part — stay with the three-kernel
+    // pass: pass_kernel idles twelve of sixteen wavefronts during the plane fits of every round but the last; measured r03:
+    // 131 072 points 217 vs 230 us per update, 196 608 points 286 vs 294, 262 144 points 356 vs 352)
     if (multi_rank(c)) {
         // with a communicator: the caller has told the largest shard of this scan (lv_comm_set_shard_max), librccl has
         // ncclAllGather (or the caller exchanges the partials itself: lv_comm_set_host_gather), the gather buffers are in
@@ -337,7 +337,7 @@ bool pass_fused_applies(const lv_ctx* c) {
     }
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
-    if (rounds > 2 && !c->fused_multi_round) return false;
+    if (rounds > 3 && !c->fused_multi_round) return false;   // (measured r03: 196 608 points 286 vs 294 us, 262 144 points 356 vs 352)
     if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * partial_width(c) > c->gather_cap) return false;
     return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;

@@ -9,8 +9,10 @@ from limo_velo_amd import capi, synth
 sc = synth.make_scene(1_048_576, 262_144)
 ctx = capi.Context(); ctx.map_build(sc["map_xyz"])
 if len(sys.argv) > 1:
-    ctx.set_fused_pass(int(sys.argv[1]) != 0)   # 0: the three-kernel pass, 1: one launch per pass (the default)
-for n in (512, 2048, 8192, 16384, 32768, 65536, 131072, 262144):
+    ctx.set_fused_pass(int(sys.argv[1]) != 0)   # 0: the three-kernel pass, 1: one launch per pass (the default), 2: ... also beyond two rounds
+    if int(sys.argv[1]) == 2:
+        ctx.set_option("fused_multi_round", 1)
+for n in (512, 2048, 8192, 16384, 32768, 65536, 131072, 196608, 262144):
     ctx.scan_set(sc["scan_xyz"][:n])
     for _ in range(10):
         ctx.update(sc["x_init"], sc["P0"], want_trace=False)
@@ -19,4 +21,4 @@ for n in (512, 2048, 8192, 16384, 32768, 65536, 131072, 262144):
     for _ in range(reps):
         p += ctx.update(sc["x_init"], sc["P0"], want_trace=False)[2]
     dt = time.perf_counter() - t0
-    print("scan %7d points: %.1f us per update, %.0f iterations/s, %.2f Gpoint-passes/s" % (n, dt / reps * 1e6, p / dt, p * n / reps / (dt / reps) / 1e9 / (p / reps) * (p / reps)))
+    print("fused" if ctx.last_update_fused() else "3-kernel", "scan %7d points: %.1f us per update, %.0f iterations/s, %.2f Gpoint-passes/s" % (n, dt / reps * 1e6, p / dt, p * n / reps / (dt / reps) / 1e9 / (p / reps) * (p / reps)))

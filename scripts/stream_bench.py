@@ -22,6 +22,12 @@ from limo_velo_amd import capi, synth  # noqa: E402
 M = int(os.environ.get("LV_STREAM_MAP", 10_000_000))
 N_AZ = int(os.environ.get("LV_STREAM_AZ", 2048))
 N_UPD = int(os.environ.get("LV_STREAM_UPDATES", 300))
+# LV_STREAM_LOCKSTEP = k: every k-th update is ALSO computed by the oracle from exactly what the device holds at that moment
+# (propagated state and covariance, de-skewed scan, the incrementally maintained 10 M-point map) — "pose vs CPU reference" of
+# BASELINE configs[4] at full scale.  The oracle searches the map points within 95 m of the sensor (its kd-tree over them; the scan
+# reaches 80 m: every neighbour that can pass the MAX_DIST_PLANE gate lies inside; a full-map kd-tree per check would cost
+# minutes of CPU); the checked updates are excluded from the timing.
+LOCKSTEP = int(os.environ.get("LV_STREAM_LOCKSTEP", 0))
 
 t0 = time.time()
 stream = synth.make_stream(M, N_UPD // 10, n_az=N_AZ)
@@ -39,6 +45,8 @@ with capi.Context() as ctx:
                          grav=(0, 0, synth.STREAM_G))
     ctx.filter_set(x, synth.default_P0())
     traj, n_scan, n_upd = [], [], 0
+    lock = {"checked": 0, "passes_equal": 0, "worst_dx": 0.0, "worst_dP_rel": 0.0, "map_points_near": 0}
+    lock_s = 0.0
     msgs = [T.hesai_message(r) for r in stream["revs"]]
     wall0 = time.perf_counter()
 
@@ -64,7 +72,25 @@ with capi.Context() as ctx:
         n_ds = timed("deskew_window", pipe.window, t1, t2, states, states[-1:])
         if n_ds < T.MAX_POINTS2MATCH:
             continue
-        timed("correct", pipe.correct)
+        if LOCKSTEP and k % LOCKSTEP == LOCKSTEP // 2:
+            t_ls = time.perf_counter()
+            x_b, P_b = ctx.filter_get()
+            scan_b, map_b = ctx.scan_fetch(), ctx.map_fetch()
+            passes_g = ctx.correct()
+            x_g, P_g = ctx.filter_get()
+            sensor = x_b[:3].astype(np.float32)
+            near = map_b[np.sum((map_b - sensor) ** 2, axis=1) < np.float32(95.0 * 95.0)]
+            tree = oracle.KdTree(near)
+            x_o, P_o, passes_o, _, _ = oracle.update(x_b, P_b, near, scan_b, tree=tree, nthreads=int(os.environ.get("LV_ORACLE_THREADS", 16)))
+            tree.close()
+            lock["checked"] += 1
+            lock["passes_equal"] += int(passes_g == passes_o)
+            lock["worst_dx"] = max(lock["worst_dx"], float(np.abs(x_g - x_o).max()))
+            lock["worst_dP_rel"] = max(lock["worst_dP_rel"], float(np.abs(P_g - P_o).max() / max(1.0, np.abs(P_o).max())))
+            lock["map_points_near"] = int(len(near))
+            lock_s += time.perf_counter() - t_ls
+        else:
+            timed("correct", pipe.correct)
         timed("map_add_scan", pipe.map_add)
         if k % 20 == 0:
             c = synth.stream_truth(t2)[0].astype(np.float32)
@@ -73,7 +99,7 @@ with capi.Context() as ctx:
         traj.append(ctx.filter_get()[0])
         n_scan.append(n_ds)
         n_upd += 1
-    wall = time.perf_counter() - wall0
+    wall = time.perf_counter() - wall0 - lock_s
     st = ctx.map_stats()
 traj = np.array(traj)
 truth = np.array([synth.stream_truth((i + 1) * T.DELTA)[0] for i in range(len(traj))])
@@ -89,5 +115,6 @@ out = {
     "map_stats": st,
     "rmse_vs_truth_m": float(np.sqrt(np.mean(np.sum((traj[:, :3] - truth) ** 2, axis=1)))),
     "stream_generation_s": gen_s,
+    "lockstep_vs_oracle": lock if LOCKSTEP else None,
 }
 print(json.dumps(out))

@@ -63,12 +63,16 @@ def test_geometries_match_the_three_kernel_pass(capi, lv, n):
 def test_larger_scans_take_the_three_kernel_pass(capi, lv):
     from limo_velo_amd import synth
 
-    sc = synth.make_scene(300_000, 140_000)
+    sc = synth.make_scene(300_000, 200_000)
     with capi.Context() as ctx:
         ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"][:190_000])
+        a, b = _both(ctx, sc, sc["x_init"], sc["P0"])
+        assert a[5]                          # three rounds per workgroup: still one launch per pass ...
+        _agree(a, b)
         ctx.scan_set(sc["scan_xyz"])
         ctx.update(sc["x_init"], sc["P0"])
-        assert not ctx.last_update_fused()   # three rounds per workgroup: pass_kernel would idle during every round's fits
+        assert not ctx.last_update_fused()   # ... four: pass_kernel would idle twelve wavefronts during three rounds' fits
 
 
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
