@@ -248,6 +248,12 @@ def main() -> None:
 
     import torch
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # a multi-rank run that stops making progress (a rank lost inside a collective) must end with a traceback, not hang
+        # until somebody else's limit kills it
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ.get("LV_BENCH_WATCHDOG_S", "900")), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -407,6 +413,31 @@ def main() -> None:
 
         main_name = "allgather_one_launch" if fused_main else "allreduce_three_kernel"
         forms = {main_name: describe((None, None), (kern_ms, solve_ms, kern_cnt, coll_us))}   # (its rate = the headline value, filled in below)
+        if os.environ.get("LV_BENCH_PEER") == "1":
+            # opt-in (not yet run across GPUs): the same one-launch form with the partials pulled out of peer-mapped buffers
+            # (lv_comm_peer_export / _init) by a second context per rank
+            try:
+                from limo_velo_amd.distributed import init_peer_gather
+
+                with capi.Context(prm, device=local_rank) as c2:
+                    c2.map_build(sc["map_xyz"])
+                    init_peer_gather(c2, dist, rank, world)
+                    u2 = ShardedUpdater(HipEngine(c2, torch, multi=False, library_comm=True), rank, world, dist, torch)
+                    u2.scan_set(sc["scan_xyz"])
+                    for _ in range(max(args.warmup // 2, 2)):
+                        x2, P2, p2 = u2.update(sc["x_init"], sc["P0"])
+                    barrier_sync(); c2.synchronize()
+                    a2, tp2 = time.perf_counter(), 0
+                    for _ in range(args.steps):
+                        tp2 += u2.update(sc["x_init"], sc["P0"])[2]
+                    c2.synchronize(); barrier_sync()
+                    d2 = time.perf_counter() - a2
+                    t = torch.tensor([d2], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    forms["peer_mapped_one_launch"] = {"iters_per_s": tp2 / float(t.item()), "ms_per_step": float(t.item()) / args.steps * 1e3,
+                                                       "agrees_with_headline_form": bool(np.abs(x2 - x).max() < 1e-9)}
+            except Exception as e:  # noqa: BLE001
+                forms["peer_mapped_one_launch"] = {"error": str(e)}
         if fused_main:   # the headline ran the all-gather form: also time the all-reduce form
             ctx.set_comm_fused(False)
             for _ in range(max(args.warmup // 2, 2)):

@@ -310,6 +310,19 @@ int lv_set_comm_fused(lv_ctx* ctx, int enabled);
 typedef int (*lv_gather_fn)(void* user, void* slots, size_t bytes_per_rank, int rank, int world);
 int lv_comm_set_host_gather(lv_ctx* ctx, int rank, int world, lv_gather_fn fn, void* user);
 
+/* The same one-launch-per-pass multi-rank form over PEER-MAPPED memory (HIP IPC over xGMI), no collective library: every
+ * rank exports the handle of its gather buffers (lv_comm_peer_export: 64 bytes, LV_PEER_HANDLE_BYTES), the caller carries
+ * the handles of all ranks to every rank by whatever means it has (they are plain bytes), and lv_comm_peer_init maps them.
+ * After each pass one small kernel publishes "my partials of this launch are in memory" and pulls the other ranks' slots
+ * straight out of their buffers — a one-shot peer read instead of a ring collective.  Tell the largest shard
+ * with lv_comm_set_shard_max as above; ranks end bitwise equal.  A rank that never publishes ends the others' wait after
+ * 50 ms: lv_update then returns LV_ESTATE.  At most 8 ranks (one node); HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in the
+ * environment of every rank.  Opt-in: verified with two processes on one GPU, not yet across GPUs.  Not combinable with
+ * lv_comm_init / lv_comm_set_host_gather. */
+#define LV_PEER_HANDLE_BYTES 64
+int lv_comm_peer_export(lv_ctx* ctx, void* handle64);
+int lv_comm_peer_init(lv_ctx* ctx, int rank, int world, const void* handles /* world x LV_PEER_HANDLE_BYTES, in rank order */);
+
 /* ---- API-parity / debug fetches (results of the most recent CAPTURED pass; original scan order) --
  * lv_iterate always captures; lv_update captures only after lv_set_capture(ctx, 1) (the last pass
  * executed wins).  Capturing writes ~200 B per scan point and is off on the fast path. */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_downsample", "lv_scan_size", "lv_scan_fetch", "lv_iterate",
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_last_passes", "lv_set_fused_pass", "lv_set_option", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
-    "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather",
+    "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather", "lv_comm_peer_export", "lv_comm_peer_init",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
 ]
 
@@ -500,6 +500,16 @@ class Context:
         cb = self.GATHER_FN(tramp)
         self._check(self.lib.lv_comm_set_host_gather(self.h, int(rank), int(world), C.cast(cb, C.c_void_p), None))
         self._gather_cb = cb   # (keeps the trampoline alive as long as the library may call it)
+
+    def comm_peer_export(self) -> bytes:
+        buf = (C.c_ubyte * 64)()
+        self._check(self.lib.lv_comm_peer_export(self.h, buf))
+        return bytes(buf)
+
+    def comm_peer_init(self, rank: int, world: int, handles):
+        blob = b"".join(handles)
+        assert len(blob) == 64 * world
+        self._check(self.lib.lv_comm_peer_init(self.h, int(rank), int(world), blob))
 
     def set_fused_pass(self, on=True):
         self._check(self.lib.lv_set_fused_pass(self.h, int(on)))

@@ -73,6 +73,7 @@ struct lv_ctx {
     size_t gather_cap = 0;            // doubles per buffer
     size_t comm_shard_max = 0;        // largest shard of the CURRENT scan over the ranks (lv_comm_set_shard_max); 0: unknown
     bool comm_fused = true;           // lv_set_comm_fused / LV_COMM_FUSED=0: always the three-kernel pass + all-reduce with a communicator
+    PeerSet peer;                      // lv_comm_peer_export / _init: the partials pulled out of the other ranks' peer-mapped buffers (lv_peer.hip)
     lv_gather_fn gather_cb = nullptr;  // lv_comm_set_host_gather: the partials of the ranks exchanged by the caller through host memory
     void* gather_user = nullptr;       //   (test / bring-up transport of the one-launch-per-pass multi-rank form; no librccl involved)
     double* h_gather = nullptr;        //   pinned staging, world x slot doubles
@@ -316,7 +317,9 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 // communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
 // the scan size that fixes pass_kernel's geometry: the local scan, or with a communicator the largest shard over the ranks
 // (every rank launches the same grid; workgroups without a tile contribute zero partials)
-static inline bool multi_rank(const lv_ctx* c) { return c->comm != nullptr || c->gather_cb != nullptr; }
+static inline bool multi_rank(const lv_ctx* c) { return c->comm != nullptr || c->gather_cb != nullptr || c->peer.active; }
+// transports that only carry the one-launch form's partials (no 96-double all-reduce behind them)
+static inline bool gather_only(const lv_ctx* c) { return c->gather_cb != nullptr || c->peer.active; }
 // doubles per compact workgroup partial (PassDims<W>::OW, lv_pass_dev.hpp): 32 for the 6-column rows, 96 with extrinsics
 static inline size_t partial_width(const lv_ctx* c) { return c->prm.estimate_extrinsics ? 96u : 32u; }
 uint32_t pass_geometry_points(const lv_ctx* c) { return multi_rank(c) ? (uint32_t)c->comm_shard_max : c->scan.n; }
@@ -410,6 +413,8 @@ int update_fused(lv_ctx* c) {
                 }
                 LV_HIP(hipMemcpyAsync(c->d_gather[i & 1], c->h_gather, slot * sizeof(double) * (size_t)c->comm_world, hipMemcpyHostToDevice, c->stream));
                 rc = LV_OK;
+            } else if (c->peer.active) {
+                rc = peer_gather(c->peer, i & 1, slot, c->stream);   // publish this rank's slot, pull the others' (one small kernel)
             } else {
                 rc = comm_allgather_inplace(c->comm, c->d_gather[i & 1], slot, c->comm_rank, c->stream);
             }
@@ -553,6 +558,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_sums) hipHostFree(c->h_sums);
     hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk); hipFree(c->d_wgcost[0]); hipFree(c->d_wgcost[1]);
     if (c->h_gather) hipHostFree(c->h_gather);
+    if (c->peer.local_alloc) { c->d_gather[0] = c->d_gather[1] = nullptr; peer_close(c->peer); }   // (the gather buffers were the peer allocation)
     hipFree(c->d_gather[0]); hipFree(c->d_gather[1]);
     hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
@@ -1080,6 +1086,7 @@ int lv_comm_init(lv_ctx* c, const char* rccl_library, const void* id128, int ran
     if (c->in_update) { set_error("lv_comm_init inside an update"); return LV_ESTATE; }
     if (c->comm) { set_error("communicator already initialised"); return LV_ESTATE; }
     if (c->gather_cb) { set_error("a host gather transport is in place (lv_comm_set_host_gather)"); return LV_ESTATE; }
+    if (c->peer.local_alloc) { set_error("a peer-mapped gather is in place (lv_comm_peer_export)"); return LV_ESTATE; }
     void* comm = nullptr;
     int rc = comm_init(rccl_library, id128, rank, world, &comm);   // collective: every rank calls it
     if (rc) return rc;
@@ -1104,12 +1111,42 @@ int lv_comm_set_host_gather(lv_ctx* c, int rank, int world, lv_gather_fn fn, voi
     LV_CHECK_CTX(c);
     if (c->in_update) { set_error("lv_comm_set_host_gather inside an update"); return LV_ESTATE; }
     if (c->comm) { set_error("a library communicator is in place"); return LV_ESTATE; }
+    if (c->peer.local_alloc) { set_error("a peer-mapped gather is in place (lv_comm_peer_export)"); return LV_ESTATE; }
     if (fn && (world < 1 || rank < 0 || rank >= world)) { set_error("lv_comm_set_host_gather: bad arguments (rank %d, world %d)", rank, world); return LV_EINVAL; }
     LV_HIP(hipStreamSynchronize(c->stream));
     c->gather_cb = fn;
     c->gather_user = fn ? user : nullptr;
     c->comm_rank = fn ? rank : 0;
     c->comm_world = fn ? world : 1;
+    c->comm_shard_max = 0;
+    return LV_OK;
+}
+
+int lv_comm_peer_export(lv_ctx* c, void* handle64) {
+    LV_CHECK_CTX(c);
+    if (!handle64) { set_error("null argument"); return LV_EINVAL; }
+    if (c->in_update) { set_error("lv_comm_peer_export inside an update"); return LV_ESTATE; }
+    if (c->comm || c->gather_cb) { set_error("another multi-rank transport is in place"); return LV_ESTATE; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    // sized once for the largest case (every CU a workgroup, 96-double partials, LV_PEER_MAX ranks): the other ranks map this
+    // allocation, so it never moves
+    const size_t cap = (size_t)(c->pass_max_wg + 8) * 96u * (size_t)LV_PEER_MAX;
+    return peer_export(c->peer, cap, handle64);
+}
+
+int lv_comm_peer_init(lv_ctx* c, int rank, int world, const void* handles) {
+    LV_CHECK_CTX(c);
+    if (!handles) { set_error("null argument"); return LV_EINVAL; }
+    if (c->in_update) { set_error("lv_comm_peer_init inside an update"); return LV_ESTATE; }
+    int rc = peer_init(c->peer, rank, world, handles);
+    if (rc) return rc;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    hipFree(c->d_gather[0]); hipFree(c->d_gather[1]);
+    c->d_gather[0] = c->peer.buf[0];
+    c->d_gather[1] = c->peer.buf[1];
+    c->gather_cap = c->peer.cap;
+    c->comm_rank = rank;
+    c->comm_world = world;
     c->comm_shard_max = 0;
     return LV_OK;
 }
@@ -1133,6 +1170,10 @@ int lv_comm_set_shard_max(lv_ctx* c, size_t n_max) {
         LV_HIP(hipHostMalloc((void**)&c->h_gather, need * sizeof(double), hipHostMallocDefault));
         std::memset(c->h_gather, 0, need * sizeof(double));
         c->h_gather_cap = need;
+    }
+    if (need > c->gather_cap && c->peer.active) {
+        set_error("peer-mapped gather: %zu doubles exceed the exported buffers (%zu)", need, c->gather_cap);
+        return LV_EINVAL;
     }
     if (need > c->gather_cap) {
         LV_HIP(hipStreamSynchronize(c->stream));
@@ -1252,9 +1293,9 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_begin, c->stream));
     c->last_update_fused = false;
     c->coll_timed = false;
-    if (c->gather_cb && !pass_fused_applies(c)) {
+    if (gather_only(c) && !pass_fused_applies(c)) {
         c->in_update = false;
-        set_error("host-staged gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
+        set_error("host-staged / peer-mapped gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
         return LV_ESTATE;
     }
     if (pass_fused_applies(c)) {
@@ -1278,6 +1319,12 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     rc = lv_update_end(c, x, P, &np);
     c->want_log = false;
     if (rc) return rc;
+    if (c->peer.active) {   // a rank of the node that never published its partials ends the wait (50 ms) instead of hanging the GPU
+        int timed_out = 0;
+        rc = peer_status(c->peer, c->stream, &timed_out);
+        if (rc) return rc;
+        if (timed_out) { set_error("peer-mapped gather: a rank of the node did not publish its partials within 50 ms"); return LV_ESTATE; }
+    }
     if (passes) *passes = np;
     if (per_pass)
         for (int i = 0; i < np && i < MAX_PASSES; ++i) unpack_sums(c->h_kf->sums_log + (size_t)i * SUMS_LEN, &per_pass[i]);
@@ -1352,9 +1399,9 @@ int lv_correct(lv_ctx* c, int* passes) {
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     c->last_update_fused = false;
-    if (c->gather_cb && !pass_fused_applies(c)) {
+    if (gather_only(c) && !pass_fused_applies(c)) {
         c->in_update = false;
-        set_error("host-staged gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
+        set_error("host-staged / peer-mapped gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
         return LV_ESTATE;
     }
     if (pass_fused_applies(c)) {

@@ -162,6 +162,26 @@ int comm_destroy(void* comm);
 int comm_allreduce_record(void* comm, double* record, hipStream_t stream);
 bool comm_has_allgather();
 int comm_allgather_inplace(void* comm, double* buf, size_t count_per_rank, int rank, hipStream_t stream);
+// lv_peer.hip — the same exchange by peer-mapped memory (HIP IPC), no collective library
+constexpr int LV_PEER_MAX = 8;
+struct PeerSet {
+    void* local_alloc = nullptr;                 // [gather buffer 0 | gather buffer 1 | flag word | status word]
+    double* buf[2] = {nullptr, nullptr};
+    unsigned long long* flag = nullptr;
+    uint32_t* status = nullptr;
+    void* mapped[LV_PEER_MAX] = {};              // the other ranks' allocations as mapped here
+    double* peer_buf[2][LV_PEER_MAX] = {};
+    unsigned long long* peer_flag[LV_PEER_MAX] = {};
+    size_t cap = 0;                              // doubles per gather buffer
+    int rank = 0, world = 1;
+    unsigned long long seq = 0;                  // launches published so far (every rank counts alike)
+    bool active = false;
+};
+int peer_export(PeerSet& P, size_t cap_doubles, void* handle64);
+int peer_init(PeerSet& P, int rank, int world, const void* handles);
+int peer_gather(PeerSet& P, int parity, size_t slot_doubles, hipStream_t stream);
+int peer_status(PeerSet& P, hipStream_t stream, int* timed_out);
+void peer_close(PeerSet& P);
 
 // lv_match.hip
 // search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries);

@@ -64,6 +64,17 @@ def init_host_gather(ctx, dist, torch, rank: int, world: int):
     ctx.comm_set_host_gather(rank, world, gather)
 
 
+def init_peer_gather(ctx, dist, rank: int, world: int):
+    """The one-launch-per-pass multi-rank form over peer-mapped memory (lv_comm_peer_export / lv_comm_peer_init): every rank
+    exports the HIP IPC handle of its gather buffers, `dist` (any backend: the handles are 64 plain bytes) carries them to
+    all ranks, every rank maps the others'.  After this, plain ctx.update() on every rank is the multi-GPU update with a
+    one-shot peer read per pass instead of a collective."""
+    mine = ctx.comm_peer_export()
+    handles = [None] * world
+    dist.all_gather_object(handles, mine)
+    ctx.comm_peer_init(rank, world, handles)
+
+
 class HipEngine:
     """Per-rank engine over the C-ABI split form (lv_update_begin / lv_pass_reduce / lv_pass_solve /
     lv_update_end).  The sums record lives in a torch tensor so RCCL can reduce it in place."""

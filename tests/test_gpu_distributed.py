@@ -294,3 +294,110 @@ def test_world2_one_launch_form_on_one_gpu(lv, n_scan, ext):
         assert passes == p1
         assert np.abs(x - x1).max() < tol_x
         assert np.abs(P - P1).max() < tol_P * max(1.0, np.abs(P1).max())
+
+
+def _world2_peer_worker(rank, world, port, n_scan, out_q, ext=0, absent_peer=False):
+    """One rank of a world-size-2 run with BOTH ranks on GPU 0 over PEER-MAPPED memory (lv_comm_peer_export / _init: HIP IPC):
+    after every pass one small kernel publishes this rank's partials and pulls the other rank's slot straight out of its
+    buffers.  absent_peer: rank 1 maps the buffers but never runs an update — rank 0's wait must end with an error, not hang."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    import lvamd
+
+    lvamd.load()
+    from limo_velo_amd import capi, synth
+    from limo_velo_amd.distributed import HipEngine, ShardedUpdater, init_peer_gather
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = synth.make_scene(50_000, max(n_scan, 8), extrinsics="xaloc" if ext else "identity")
+        scan = sc["scan_xyz"][:n_scan]
+        with capi.Context(capi.default_params(estimate_extrinsics=ext)) as ctx:
+            if ext:
+                ctx.set_option("fused_ext", 1)
+            ctx.map_build(sc["map_xyz"])
+            init_peer_gather(ctx, dist, rank, world)
+            upd = ShardedUpdater(HipEngine(ctx, torch, multi=False, library_comm=True), rank, world, dist, torch)
+            upd.scan_set(scan)
+            if absent_peer:
+                err = None
+                if rank == 0:
+                    try:
+                        upd.update(sc["x_init"], sc["P0"])
+                    except Exception as e:  # noqa: BLE001
+                        err = str(e)
+                dist.barrier()
+                out_q.put((rank, err))
+                return
+            for _ in range(3):     # (several updates: the flag words only grow, the buffers are reused)
+                x, P, passes = upd.update(sc["x_init"], sc["P0"])
+            fused = ctx.last_update_fused()
+            ctx.filter_set(sc["x_init"], sc["P0"])
+            p2 = ctx.correct()
+            x2, P2 = ctx.filter_get()
+        out_q.put((rank, upd.n_local, x, P, passes, fused, np.array_equal(x, x2) and np.array_equal(P, P2) and p2 == passes))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scan,ext", [(2001, 0), (1, 0), (20_000, 0), (2001, 1)])
+def test_world2_peer_mapped_gather_on_one_gpu(lv, n_scan, ext):
+    """The one-launch-per-pass multi-rank form with the partials exchanged through peer-mapped memory (HIP IPC; across GPUs the
+    same mapping goes over xGMI): both ranks end bitwise equal and within 1e-10 of the single-process update of the whole
+    scan; lv_correct takes the same launches."""
+    import torch.multiprocessing as mp
+
+    from limo_velo_amd import capi, synth
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_world2_peer_worker, args=(r, 2, port, n_scan, q, ext)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = synth.make_scene(50_000, max(n_scan, 8), extrinsics="xaloc" if ext else "identity")
+    with capi.Context(capi.default_params(estimate_extrinsics=ext)) as ref:
+        if ext:
+            ref.set_option("fused_ext", 1)
+        ref.map_build(sc["map_xyz"])
+        ref.scan_set(sc["scan_xyz"][:n_scan])
+        x1, P1, p1, _, _ = ref.update(sc["x_init"], sc["P0"])
+    assert res[0][1] + res[1][1] == n_scan and abs(res[0][1] - res[1][1]) <= 1
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3]) and res[0][4] == res[1][4]
+    tol_x, tol_P = (1e-10, 1e-10) if not ext else (1e-9, 1e-6)
+    for _, _, x, P, passes, fused, same_filter in res:
+        assert fused and same_filter
+        assert passes == p1
+        assert np.abs(x - x1).max() < tol_x
+        assert np.abs(P - P1).max() < tol_P * max(1.0, np.abs(P1).max())
+
+
+def test_peer_mapped_gather_times_out_instead_of_hanging(lv):
+    """A rank that never publishes its partials (here: it simply does not run the update) must not hang the others: the pull
+    kernel gives up after 50 ms per launch and lv_update reports LV_ESTATE."""
+    import torch.multiprocessing as mp
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_world2_peer_worker, args=(r, 2, port, 2001, q, 0, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] is not None and "did not publish" in res[0][1]
