@@ -71,7 +71,7 @@ def upd_scan_local(sc, rank: int, world: int):
     return sc["scan_xyz"][lo:hi]
 
 
-def parity_check(g: dict, sc, scan_local, nthreads: int = 16) -> dict:
+def parity_check(g: dict, sc, scan_local, prm, nthreads: int = 16) -> dict:
     """SURVEY 8(d) "parity gates reported with every perf number": the GPU results of THIS run (collected by main(): one
     capturing pass over this rank's points at the initial state, and the timed build's update with its per-pass log) against
     the CPU oracle on the identical inputs — the oracle is the checker here, never the thing measured.  Exact kNN (index
@@ -83,9 +83,14 @@ def parity_check(g: dict, sc, scan_local, nthreads: int = 16) -> dict:
     import lvoracle as lo
 
     tol = {"sums_rel": 1e-10, "state_abs": 1e-9, "P_rel": 1e-9}
+    if prm.estimate_extrinsics:   # 12-column solve at this size: condition number 3e6 (tests/test_gpu_configs.py)
+        tol = {"sums_rel": 1e-10, "state_abs": 2e-6, "P_rel": 1e-6}
+    # the oracle with the configuration the GPU context runs (the lv_params hot keys under the reference's names)
+    prm_o = lo.default_params(max_num_iters=prm.MAX_NUM_ITERS, max_dist_plane=prm.MAX_DIST_PLANE, planes_threshold=prm.PLANES_THRESHOLD,
+                              estimate_extrinsics=prm.estimate_extrinsics, lidar_noise=prm.LiDAR_noise)
     tree = lo.KdTree(sc["map_xyz"])
-    o = lo.iterate(sc["x_init"], sc["map_xyz"], scan_local, tree=tree, nthreads=nthreads)
-    xo, Po, po, tro, so = lo.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree, nthreads=nthreads)
+    o = lo.iterate(sc["x_init"], sc["map_xyz"], scan_local, params=prm_o, tree=tree, nthreads=nthreads)
+    xo, Po, po, tro, so = lo.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=prm_o, tree=tree, nthreads=nthreads)
     scale = float(np.abs(o["HTH"]).max())
     g0 = g["g0"]
     out = {
@@ -263,6 +268,11 @@ def main() -> None:
         raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # stdout carries exactly ONE line (the JSON record of rank 0): everything else that ends up on file descriptor 1 — RCCL's
+    # version banner at communicator teardown, library chatter — is sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -392,7 +402,7 @@ def main() -> None:
     # that the first run on a node yields the breakdown of both: "allgather_one_launch" = one launch per pass + ncclAllGather
     # of the workgroup partials, "allreduce_three_kernel" = search / fit / reduce -> ncclAllReduce of 768 bytes -> solve
     forms = None
-    if world > 1 and lib_comm:
+    if lib_comm and (world > 1 or args.force_comm):   # (--force-comm: the same legs with one rank, to exercise this code on one GPU)
         def timed_form():
             barrier_sync()
             a, tp = time.perf_counter(), 0
@@ -413,7 +423,7 @@ def main() -> None:
 
         main_name = "allgather_one_launch" if fused_main else "allreduce_three_kernel"
         forms = {main_name: describe((None, None), (kern_ms, solve_ms, kern_cnt, coll_us))}   # (its rate = the headline value, filled in below)
-        if os.environ.get("LV_BENCH_PEER") == "1":
+        if os.environ.get("LV_BENCH_PEER") == "1" and dist is not None:
             # opt-in (not yet run across GPUs): the same one-launch form with the partials pulled out of peer-mapped buffers
             # (lv_comm_peer_export / _init) by a second context per rank
             try:
@@ -599,7 +609,7 @@ def main() -> None:
             "fallback": ctx.timing()["fallback_queries"],
             "state_check": {"pos_err_m_from_ground_truth": float(np.linalg.norm(x[:3] - sc["x_true"][:3]))},
         }
-        if world > 1:
+        if world > 1 or forms:
             out["multi_gpu"] = {"measured_on": f"{world} ranks", "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]],
                                 "forms": forms}
         if cycle is not None:
@@ -608,14 +618,13 @@ def main() -> None:
             if "error" in gate:
                 out["parity"] = {"ok": False, "error": gate["error"]}
             else:
-                out["parity"] = parity_check(gate, sc, upd_scan_local(sc, rank, world))
+                out["parity"] = parity_check(gate, sc, upd_scan_local(sc, rank, world), prm)
             if not out["parity"]["ok"]:
                 rc = 3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, int(total_passes / args.steps))
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -338,8 +338,8 @@ int lv_fetch_knn(lv_ctx* ctx, uint32_t* idx, float* d2);
  * needs a capturing launch). */
 int lv_fetch_neighbors(lv_ctx* ctx, float* nbr_xyz, float* d2, float* p_world, int32_t* found);
 /* The single-GPU lv_update / lv_correct run ONE launch per pass (pass_kernel: the solve of the previous pass in every
- * workgroup, the search, the plane fits; no capture, no communicator, degeneracy_mode 0, lanes_per_query 8) and keep the
- * hand-over records in LDS.  lv_set_record_dump(ctx, 1) makes that same kernel also store them to memory so that
+ * workgroup, the search, the plane fits; no capture, degeneracy_mode 0, lanes_per_query 8, up to 196 608 scan points) and keep the
+ * hand-over records in LDS (also with estimate_extrinsics since round 3).  lv_set_record_dump(ctx, 1) makes that same kernel also store them to memory so that
  * lv_fetch_neighbors can pin it (one uniform branch; off by default).  lv_last_update_fused: 1 if the most recent
  * lv_update / lv_correct took the one-launch-per-pass route, 0 if the three-kernel pass (search / fit / solve). */
 int lv_set_record_dump(lv_ctx* ctx, int enabled);

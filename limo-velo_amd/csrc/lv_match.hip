@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     // staged rows, nothing in the books depends on this launch's search.  Out here, after the round loop, the books' register
     // appetite competes with nothing that is live (inlined INTO the loop it spilled the search: round 2, 60 % slower).
     {
-        const bool beside = !EXT && a.mode == 1 && keeper;
+        const bool beside = a.mode == 1 && keeper;
         if (fitter) {
             do_fits(true);
         } else if (beside && wave >= PK_FITW) {
