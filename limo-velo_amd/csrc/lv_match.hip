@@ -78,12 +78,19 @@ __device__ __forceinline__ void sort5(kkey (&c)[KNN]) {
     cswap(c[0], c[3]); cswap(c[0], c[2]); cswap(c[1], c[3]); cswap(c[1], c[2]);
 }
 // k, o sorted ascending (o: at least 5 entries) -> k = the 5 smallest of the union, sorted:
-// min(k[i], o[4-i]) selects exactly the 5 smallest (bitonic halving), sort5 orders them.
+// min(k[i], o[4-i]) selects exactly the 5 smallest (bitonic halving).  The selection is UNIMODAL — it follows the ascending k
+// while k[i] is the smaller one, then the descending o[4-i] — and a unimodal sequence of 5 needs 5 comparators, not the 9 of
+// a general sort5: (0,4) (1,3) (1,4) (2,4) (3,4), minimal by exhaustive search over all networks on the 0^p 1^m 0^q images
+// (0-1 principle restricted to unimodal inputs; scripts/merge5_network.py re-derives and checks it).  Round 3: the search
+// phase is 55 % VALU and the three DPP merge rounds were 99 of a task's ~450 instructions; they are 75 now.
+__device__ __forceinline__ void order_unimodal5(kkey (&c)[KNN]) {
+    cswap(c[0], c[4]); cswap(c[1], c[3]); cswap(c[1], c[4]); cswap(c[2], c[4]); cswap(c[3], c[4]);
+}
 template <typename T>
 __device__ __forceinline__ void merge5(kkey (&k)[KNN], const T& o) {
 #pragma unroll
     for (int i = 0; i < KNN; ++i) k[i] = kmin(o[KNN - 1 - i], k[i]);
-    sort5(k);
+    order_unimodal5(k);
 }
 // cross-lane exchange of a key through DPP (VALU data path, no LDS round trip):
 //   0xB1 quad_perm(1,0,3,2) = lane ^ 1, 0x4E quad_perm(2,3,0,1) = lane ^ 2,
