@@ -1280,7 +1280,10 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             const int step = task / (PK_THREADS / 64);
             const int gqv = (task % (PK_THREADS / 64)) * 8 + (lane >> 3);   // position among the step's 128 points
             // strided assignment: every workgroup gets far and near tiles
-            const uint32_t vbi = (uint32_t)((round * a.steps + step) * PK_UNITS + (gqv >> 5)) * nwg + bid;
+            // (snake: odd bands are dealt backwards, so that no workgroup gets the farther tile of every band — the first launch's
+            // span 39.9 -> 38.2 us, A/B in one box)
+            const uint32_t band = (uint32_t)((round * a.steps + step) * PK_UNITS + (gqv >> 5));
+            const uint32_t vbi = band * nwg + ((band & 1u) ? nwg - 1u - bid : bid);
             const bool tile_ok = vbi < a.n_tiles32;
             float4* rec = s_rec + (size_t)step * QREC_SLOTS * PK_GROUPS;
             if (!tile_ok) {   // (whole 256-thread unit: uniform per wavefront)
