@@ -534,6 +534,10 @@ class Context:
     def last_update_fused(self) -> bool:
         return bool(self.lib.lv_last_update_fused(self.h))
 
+    def last_passes(self) -> int:
+        """Passes of the last update whose results have been fetched (lv_update, or lv_correct + lv_filter_get)."""
+        return int(self.lib.lv_last_passes(self.h))
+
     def fetch_neighbors(self):
         """Neighbour coordinates / squared distances / world points / found counts out of the hand-over records of
         the most recent pass (works for the non-capturing, timed kernels)."""

@@ -29,6 +29,9 @@ struct lv_ctx {
     lv_params prm;
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;   // lv_map_add_scan's insert runs here, beside the next cycle's prediction / window (see there)
+    hipEvent_t ev_staged = nullptr;
+    bool overlap_insert = true;          // lv_set_option "overlap_insert" / LV_OVERLAP_INSERT=0: the insert stays on the context's stream
     hipStream_t stream = nullptr;
 
     MapStore map;
@@ -51,6 +54,8 @@ struct lv_ctx {
     KfHostIO* h_io = nullptr;  // pinned, host-mapped mailbox: update inputs and results (no copy kernels)
     KfHostIO* d_io = nullptr;  // its device address
     int update_seq = 0;        // number of the update in flight (the finishing pass echoes it into h_io->seq)
+    bool filter_in_mailbox = false;   // the resident filter == the results in the mailbox (set by lv_correct, cleared by whatever changes the filter)
+    bool mail_filter = true;          // lv_filter_get reads them from there (lv_set_option "mail_filter" 0: always copy)
     bool spin_wait = true;     // lv_update_end polls the mailbox before falling back to hipStreamSynchronize (LV_SPIN_WAIT=0: off)
     double* d_partials = nullptr;
     double* d_groups = nullptr;    // group records (reduce stage 1)
@@ -200,6 +205,7 @@ void unpack_sums(const double* rec, lv_sums* out) {
 // from the resident filter): take them over, derive the pass constants
 int begin_device(lv_ctx* c, const double* x_host, bool defer) {
     c->begin_pending = false;
+    c->filter_in_mailbox = false;   // (the mailbox is about to receive this update's results)
     if (c->capture) LV_HIP(hipMemsetAsync(c->d_kf->level_hist, 0, sizeof(int) * 8, c->stream));   // instrumentation of capturing passes
     if (defer && x_host && c->scan.n > 0 && c->map.view.m > 0) {
         // the first search launch installs everything (x_host: x followed by P_prop, KfHostIO layout)
@@ -493,6 +499,8 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
     if (const char* e = getenv("LV_SMALL_WINDOW")) c->scan.small_enabled = atoi(e) != 0;
+    if (const char* e = getenv("LV_LARGE_WINDOW")) c->scan.large_enabled = atoi(e) != 0;
+    if (const char* e = getenv("LV_MAIL_FILTER")) c->mail_filter = atoi(e) != 0;
     if (const char* e = getenv("LV_SMALL_INSERT")) c->map.small_front = atoi(e) != 0;
     // (the stamp buffer below is strided by pass_max_wg + 1 workgroup slots: fix the grid limit first)
     c->pass_max_wg = prop.multiProcessorCount;
@@ -508,6 +516,9 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (c->max_blocks < 64) c->max_blocks = 64;
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    LV_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    LV_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+    if (const char* e = getenv("LV_OVERLAP_INSERT")) c->overlap_insert = atoi(e) != 0;
     LV_HIP(hipMalloc(&c->d_kf, sizeof(KfDev)));
     LV_HIP(hipMemset(c->d_kf, 0, sizeof(KfDev)));
     LV_HIP(hipMalloc(&c->d_filter, sizeof(FilterDev)));
@@ -565,6 +576,8 @@ void lv_destroy(lv_ctx* c) {
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (auto ev : c->ev_pass) hipEventDestroy(ev);
     for (auto ev : c->ev_coll) hipEventDestroy(ev);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->ev_staged) hipEventDestroy(c->ev_staged);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -572,6 +585,7 @@ void lv_destroy(lv_ctx* c) {
 int lv_set_stream(lv_ctx* c, void* hip_stream) {
     LV_CHECK_CTX(c);
     LV_HIP(hipStreamSynchronize(c->stream));
+    if (c->side_stream) LV_HIP(hipStreamSynchronize(c->side_stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return LV_OK;
 }
@@ -579,6 +593,7 @@ void* lv_get_stream(lv_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int lv_synchronize(lv_ctx* c) {
     LV_CHECK_CTX(c);
     LV_HIP(hipStreamSynchronize(c->stream));
+    if (c->side_stream) LV_HIP(hipStreamSynchronize(c->side_stream));
     return LV_OK;
 }
 
@@ -670,7 +685,19 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     const double* x = (c->state_src == 2 || !c->filter_set) ? c->d_kf->x : c->d_filter->x;
     hipLaunchKernelGGL(scan_to_world_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, c->scan.d_raw, n, c->map.d_new);
     LV_HIP(hipGetLastError());
-    return c->map.add_staged(c->stream, n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
+    // The insert depends on nothing but the world points just staged, and nothing depends on it until the next search: it runs
+    // on the context's SIDE stream, beside whatever the caller enqueues next (in the reference's loop, src/main.cpp:52-128: the
+    // next cycle's IMU propagation, LiDAR window, de-skew and voxel grid — ~100 us of small launches while the insert's chain
+    // of ~150 us occupies a handful of CUs).  Everything that touches the map settles the insert first (LV_SETTLE_MAP: the
+    // host waits for the note the chain's last kernel posts), so no other ordering is needed.  Only with the context's own
+    // stream: a caller-provided stream keeps everything on that stream.
+    hipStream_t ms = c->stream;
+    if (c->overlap_insert && c->side_stream && c->stream == c->own_stream && c->map.built && c->map.m > 0) {
+        LV_HIP(hipEventRecord(c->ev_staged, c->stream));
+        LV_HIP(hipStreamWaitEvent(c->side_stream, c->ev_staged, 0));
+        ms = c->side_stream;
+    }
+    return c->map.add_staged(ms, n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
 }
 
 int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_inside, size_t* n_evicted) {
@@ -939,14 +966,14 @@ int lv_scan_deskew_window(lv_ctx* c, double t1, double t2, const lv_motion_state
     c->scan.n = 0;
     c->comm_shard_max = 0;
     uint32_t lo = 0, hi = 0;
-    int rc = c->cloud.window(c->stream, t1, t2, &lo, &hi);
+    int rc = c->scan.reserve_raw(1, n_states);   // (the bounds words exist: the window kernel resets them on the way)
+    if (rc) return rc;
+    rc = c->cloud.window(c->stream, t1, t2, &lo, &hi, c->scan.d_bounds);
     if (rc) return rc;
     const uint32_t n = hi - lo;
     if (n_window) *n_window = n;
     if (n == 0) return LV_OK;   // Compensator::compensate returns no points (Compensator.cpp:24)
     rc = c->scan.reserve_raw(n, n_states);
-    if (rc) return rc;
-    rc = c->cloud.unpack(c->stream, lo, n, c->scan.d_in, c->scan.d_times);
     if (rc) return rc;
     if (n_states <= 64) {
         if (!c->h_states_ring) LV_HIP(hipHostMalloc((void**)&c->h_states_ring, 8 * 64 * sizeof(MotionState), hipHostMallocDefault));
@@ -959,6 +986,13 @@ int lv_scan_deskew_window(lv_ctx* c, double t1, double t2, const lv_motion_state
     }
     MotionState xt2;
     std::memcpy(&xt2, Xt2, sizeof(xt2));
+    if (!c->scan.small_window_applies(n) && c->scan.large_window_applies(n, (uint32_t)n_states, downsample_prec)) {
+        bool fell_back = false;   // (more points out than the one-workgroup tail takes: the general chain, from the raw points)
+        rc = c->scan.window_large(c->stream, c->cloud.d_buf + lo, n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size, &fell_back);
+        if (rc || !fell_back) return rc;
+    }
+    rc = c->cloud.unpack(c->stream, lo, n, c->scan.d_in, c->scan.d_times);
+    if (rc) return rc;
     return c->scan.deskew_downsample(c->stream, n, (uint32_t)n_states, xt2, downsample_prec, c->prm.voxel_size);
 }
 
@@ -1015,7 +1049,10 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "tile_lpt")) c->tile_lpt = on;
     else if (!std::strcmp(name, "spin_wait")) c->spin_wait = on;
     else if (!std::strcmp(name, "comm_fused")) c->comm_fused = on;
+    else if (!std::strcmp(name, "mail_filter")) c->mail_filter = on;
+    else if (!std::strcmp(name, "overlap_insert")) c->overlap_insert = on;
     else if (!std::strcmp(name, "small_window")) c->scan.small_enabled = on;
+    else if (!std::strcmp(name, "large_window")) c->scan.large_enabled = on;
     else if (!std::strcmp(name, "small_insert")) c->map.small_front = on;
     else { set_error("lv_set_option: unknown option '%s'", name); return LV_EINVAL; }
     return LV_OK;
@@ -1214,6 +1251,39 @@ int lv_pass_solve(lv_ctx* c) {
     return pass_solve(c, false);
 }
 
+// The pass that finishes an update stores the sequence number after all results (system-scope stores): poll it for a bounded
+// time (an update takes ~0.2 ms) instead of paying the stream-synchronise wake-up; anything unusual (errors, very long updates)
+// still ends in hipStreamSynchronize (by the caller, when this returns false).
+static bool mailbox_wait(lv_ctx* c) {
+    bool seen = false;
+    if (c->spin_wait && !c->profiling && !c->phase_clocks && !c->capture) {
+        volatile const unsigned long long* sc = &c->h_io->seqcheck;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned long long word = 0;
+        for (int it = 0;; ++it) {
+            word = *sc;
+            if ((uint32_t)word == (uint32_t)c->update_seq) { seen = true; break; }
+            if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (seen) {
+            // the results were stored before the word, but only the checksum proves that they have all ARRIVED
+            const uint32_t want = (uint32_t)(word >> 32);
+            const KfHostIO* io = c->h_io;
+            uint32_t chk = 0;
+            for (int i = 0; i < NS * NS; ++i) chk ^= mailbox_mix(io->P_post[i], (uint32_t)i);
+            for (int i = 0; i < NX; ++i) chk ^= mailbox_mix(io->x[i], 1000u + (uint32_t)i);
+            chk ^= mailbox_mix((double)io->passes, 2000u);
+            if (chk == MAILBOX_UNCHECKED) chk = 0u;
+            // (MAILBOX_UNCHECKED: the update ended on a pass without matches — a legitimate path that carries no
+            // checksum: synchronise the stream without counting it)
+            if (want == MAILBOX_UNCHECKED) seen = false;
+            else if (chk != want) { seen = false; ++c->mailbox_resyncs; }
+        }
+    }
+    return seen;
+}
+
 int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
     LV_CHECK_CTX(c);
     if (!c->in_update) { set_error("lv_update_end without lv_update_begin"); return LV_ESTATE; }
@@ -1224,35 +1294,7 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
         LV_HIP(hipMemcpyAsync(c->h_kf, c->d_kf, offsetof(KfDev, pose), hipMemcpyDeviceToHost, c->stream));
         LV_HIP(hipStreamSynchronize(c->stream));
     } else {
-        // The pass that finishes the update stores the sequence number after all results (system-scope fence):
-        // poll it for a bounded time (an update takes ~0.2 ms) instead of paying the stream-synchronise wake-up;
-        // anything unusual (errors, very long updates) still ends in hipStreamSynchronize.
-        bool seen = false;
-        if (c->spin_wait && !c->profiling && !c->phase_clocks && !c->capture) {
-            volatile const unsigned long long* sc = &c->h_io->seqcheck;
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned long long word = 0;
-            for (int it = 0;; ++it) {
-                word = *sc;
-                if ((uint32_t)word == (uint32_t)c->update_seq) { seen = true; break; }
-                if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-            if (seen) {
-                // the results were stored before the word, but only the checksum proves that they have all ARRIVED
-                const uint32_t want = (uint32_t)(word >> 32);
-                const KfHostIO* io = c->h_io;
-                uint32_t chk = 0;
-                for (int i = 0; i < NS * NS; ++i) chk ^= mailbox_mix(io->P_post[i], (uint32_t)i);
-                for (int i = 0; i < NX; ++i) chk ^= mailbox_mix(io->x[i], 1000u + (uint32_t)i);
-                chk ^= mailbox_mix((double)io->passes, 2000u);
-                if (chk == MAILBOX_UNCHECKED) chk = 0u;
-                // (MAILBOX_UNCHECKED: the update ended on a pass without matches — a legitimate path that carries no
-                // checksum: synchronise the stream without counting it)
-                if (want == MAILBOX_UNCHECKED) seen = false;
-                else if (chk != want) { seen = false; ++c->mailbox_resyncs; }
-            }
-        }
+        const bool seen = mailbox_wait(c);
         if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
     }
     const KfHostIO* io = c->h_io;
@@ -1363,6 +1405,7 @@ int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
     std::memcpy(c->h_filter->P, P, sizeof(double) * NS * NS);
     LV_HIP(hipMemcpyAsync(c->d_filter, c->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, c->stream));
     c->filter_set = true;
+    c->filter_in_mailbox = false;
     c->state_src = 1;
     return LV_OK;
 }
@@ -1370,6 +1413,16 @@ int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
 int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
     LV_CHECK_CTX(c);
     if (!c->filter_set) { set_error("lv_filter_get before lv_filter_set"); return LV_ESTATE; }
+    if (c->filter_in_mailbox && c->mail_filter) {
+        // the resident filter is the posterior of the lv_correct just enqueued: its finishing pass stores x, P (and the pass count)
+        // into the host-mapped mailbox as well — wait for THAT (a poll) instead of a copy + stream synchronise (~30 us of wake-up,
+        // once per 100 Hz cycle: the reference's main loop reads the state after every correct, src/main.cpp:96-102)
+        if (!mailbox_wait(c)) LV_HIP(hipStreamSynchronize(c->stream));
+        const KfHostIO* io = c->h_io;
+        if (x) std::memcpy(x, io->x, sizeof(double) * NX);
+        if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
+        return LV_OK;
+    }
     LV_HIP(hipMemcpyAsync(c->h_filter, c->d_filter, sizeof(FilterDev), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
     if (x) std::memcpy(x, c->h_filter->x, sizeof(double) * NX);
@@ -1382,6 +1435,7 @@ int lv_predict(lv_ctx* c, double dt, const double* Q, const double acc[3], const
     if (!Q || !acc || !gyro) { set_error("null argument"); return LV_EINVAL; }
     if (!c->filter_set) { set_error("lv_predict before lv_filter_set"); return LV_ESTATE; }
     c->state_src = 1;
+    c->filter_in_mailbox = false;
     return launch_predict(c->stream, c->d_filter, dt, Q, acc, gyro);
 }
 
@@ -1394,6 +1448,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
     int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
     if (rc) return rc;
+    c->update_seq = (c->update_seq + 1) & 0x3fffffff;   // (the finishing pass echoes it into the mailbox: lv_filter_get polls for it)
     rc = begin_device(c, nullptr, false);
     if (rc) return rc;
     c->in_update = true;
@@ -1416,6 +1471,7 @@ int lv_correct(lv_ctx* c, int* passes) {
     c->in_update = false;
     rc = launch_kf_to_filter(c->stream, c->d_kf, c->d_filter);
     if (rc) return rc;
+    c->filter_in_mailbox = true;
     if (passes) {  // optional: the only synchronisation point
         LV_HIP(hipStreamSynchronize(c->stream));
         *passes = c->h_io->passes;   // stored by solve_kernel into the pinned mailbox

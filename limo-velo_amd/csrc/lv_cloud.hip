@@ -109,17 +109,21 @@ __device__ __forceinline__ uint32_t wave_time_bound(const CloudPoint* __restrict
     }
     return lo;
 }
-__global__ void cloud_window_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t1, double t2, uint32_t* __restrict__ out) {
+// (the answers go to the host as notes: lv_note.hpp)
+__global__ void cloud_window_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t1, double t2, uint32_t* __restrict__ out,
+                                    unsigned long long* __restrict__ note, uint32_t seq, unsigned* __restrict__ reset8) {
     const uint32_t wave = threadIdx.x >> 6;   // wavefront 0: first index with time >= t1; wavefront 1: first with time > t2
     if (wave >= 2) return;
+    if (reset8 && threadIdx.x < 8) reset8[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;   // (vg_bounds_init_kernel)
     const uint32_t r = wave_time_bound(pts, head, n, wave ? t2 : t1, wave != 0);
-    if ((threadIdx.x & 63u) == 0) out[wave] = r;
+    if ((threadIdx.x & 63u) == 0) { out[wave] = r; note_post(note + wave, seq, r); }
 }
 // Buffer::clear(t) (Buffer.cpp:57-62): drop from the old end while t >= time
-__global__ void cloud_clear_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t, uint32_t* __restrict__ out) {
+__global__ void cloud_clear_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t, uint32_t* __restrict__ out,
+                                   unsigned long long* __restrict__ note, uint32_t seq) {
     if (threadIdx.x >= 64) return;
     const uint32_t r = wave_time_bound(pts, head, n, t, true);   // first index with time > t
-    if (threadIdx.x == 0) out[0] = r;
+    if (threadIdx.x == 0) { out[0] = r; note_post(note, seq, r); }
 }
 __global__ void cloud_unpack_kernel(const CloudPoint* __restrict__ pts, uint32_t n, float4* __restrict__ xyz, double* __restrict__ times) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,6 +191,7 @@ int CloudStore::init() {
     if (d_count) return LV_OK;
     LV_HIP(hipMalloc(&d_count, 4 * sizeof(uint32_t)));
     LV_HIP(hipHostMalloc((void**)&h_count, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    LV_HIP(note_alloc(notes));
     return LV_OK;
 }
 
@@ -229,22 +234,25 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
 int CloudStore::settle() {
     if (!clear_pending) return LV_OK;
     clear_pending = false;
-    LV_HIP(hipEventSynchronize(ev_clear));
-    head = h_count[3];
+    uint32_t v = 0;
+    if (!note_wait(notes, 3, 1, clear_seq, &v, clear_stream)) { set_error("LiDAR buffer: the clear kernel did not report"); return LV_EHIP; }
+    head = v;
     if (head >= size) head = size = 0;
     return LV_OK;
 }
 
-int CloudStore::window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi) {
+int CloudStore::window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi, unsigned* reset8) {
     int rcs = settle();
     if (rcs) return rcs;
     *lo = *hi = head;
     if (size <= head) return LV_OK;
-    hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(128), 0, stream, d_buf, head, size, t1, t2, d_count);
-    LV_HIP(hipMemcpyAsync(h_count, d_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    *lo = h_count[0];
-    *hi = h_count[1] > h_count[0] ? h_count[1] : h_count[0];
+    const uint32_t seq = notes.next();
+    hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(128), 0, stream, d_buf, head, size, t1, t2, d_count, notes.d, seq, reset8);
+    LV_HIP(hipGetLastError());
+    uint32_t v[2] = {0, 0};
+    if (!note_wait(notes, 0, 2, seq, v, stream)) { set_error("LiDAR buffer: the window kernel did not report"); return LV_EHIP; }
+    *lo = v[0];
+    *hi = v[1] > v[0] ? v[1] : v[0];
     return LV_OK;
 }
 
@@ -252,10 +260,10 @@ int CloudStore::clear_before(hipStream_t stream, double t) {
     int rcs = settle();
     if (rcs) return rcs;
     if (size <= head) return LV_OK;
-    if (!ev_clear) LV_HIP(hipEventCreateWithFlags(&ev_clear, hipEventDisableTiming));
-    hipLaunchKernelGGL(cloud_clear_kernel, dim3(1), dim3(64), 0, stream, d_buf, head, size, t, d_count + 3);
-    LV_HIP(hipMemcpyAsync(h_count + 3, d_count + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipEventRecord(ev_clear, stream));
+    clear_seq = notes.next();
+    clear_stream = stream;
+    hipLaunchKernelGGL(cloud_clear_kernel, dim3(1), dim3(64), 0, stream, d_buf, head, size, t, d_count + 3, notes.d + 3, clear_seq);
+    LV_HIP(hipGetLastError());
     clear_pending = true;   // (head is settled by the next window / ingest / clear / size query)
     return LV_OK;
 }
@@ -272,7 +280,7 @@ void CloudStore::release() {
     hipFree(d_ids); hipFree(d_ids_sorted); hipFree(d_tmp); hipFree(d_buf); hipFree(d_count);
     if (h_rawmsg) hipHostFree(h_rawmsg);
     if (h_count) hipHostFree(h_count);
-    if (ev_clear) hipEventDestroy(ev_clear);
+    note_free(notes);
     *this = CloudStore();
 }
 

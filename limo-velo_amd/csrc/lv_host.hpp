@@ -1,5 +1,6 @@
 // lv_host.hpp — host-side state behind the C-ABI (include/limovelo_hip.h).
 #pragma once
+#include "lv_note.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -116,7 +117,9 @@ struct MapStore {
     // the tail of an incremental insert (new ids / living points / overflow, read from the device counters) is settled by the
     // next call that needs the map's bookkeeping, not by a wait at the end of the insert
     bool small_front = true;     // batches of up to 2048 points: the insert's front half in one workgroup launch (LV_SMALL_INSERT=0: off)
-    hipEvent_t ev_counters = nullptr;
+    NoteBoard notes;             // the insert's counters come back as a note (lv_note.hpp): n_new, n_dead, dropped, overflow
+    uint32_t counters_seq = 0;
+    hipStream_t counters_stream = nullptr;
     bool counters_pending = false;
     bool pending_counted_kill = false;
     uint32_t pending_n_dead = 0;
@@ -248,6 +251,7 @@ int launch_kf_to_filter(hipStream_t stream, const KfDev* kf, FilterDev* f);
 int launch_rows_from_matches(hipStream_t stream, const KfDev* kf, const float* p_world, const float* abcd, const float* dist,
                              uint32_t n, int estimate_extrinsics, double* H, double* h);
 // lv_scan.hip
+struct CloudPoint;
 struct ScanStore {
     float4* d_raw = nullptr;     // upload order; w = original index
     float4* d_sorted = nullptr;  // Morton order (LiDAR frame)
@@ -285,6 +289,11 @@ struct ScanStore {
     bool small_window_applies(uint32_t n_in) const;
     int window_small(hipStream_t stream, const float4* src, uint32_t n_in, uint32_t n_states, const MotionState* xt2, float leaf,
                      float sort_cell, bool* fell_back);
+    bool large_enabled = true;   // larger windows: de-skew + bounds, keys, sort, one tail workgroup (LV_LARGE_WINDOW=0 / lv_set_option: off)
+    bool large_window_applies(uint32_t n_in, uint32_t n_states, float leaf) const;
+    int window_large(hipStream_t stream, const struct CloudPoint* cloud, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf,
+                     float sort_cell, bool* fell_back);
+    NoteBoard notes;             // (points out, status) of the window kernels: lv_note.hpp
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
     int order_tiles(hipStream_t stream, uint32_t tile_points);
     int reserve_tiles(uint32_t nt);
@@ -333,10 +342,12 @@ struct CloudStore {
     size_t tmp_bytes = 0, msg_cap = 0;
     uint32_t* d_count = nullptr;
     uint32_t* h_count = nullptr;   // pinned
-    // clear_before does not wait for its result (the new head): the kernel's answer is copied to h_count[3] and picked up by
-    // whoever touches the buffer next (settle), by which time it has long arrived — the wait was one of six host/device round
-    // trips of a 100 Hz cycle
-    hipEvent_t ev_clear = nullptr;
+    // clear_before does not wait for its result (the new head): the kernel posts it as a note (lv_note.hpp) that is picked up
+    // by whoever touches the buffer next (settle), by which time it has long arrived — the wait was one of six host/device
+    // round trips of a 100 Hz cycle; the window's index range comes back as a note too (words 0, 1; the clear's: word 3)
+    NoteBoard notes;
+    uint32_t clear_seq = 0;
+    hipStream_t clear_stream = nullptr;
     bool clear_pending = false;
     int settle();
     int init();
@@ -344,7 +355,8 @@ struct CloudStore {
     int reserve_buffer(hipStream_t stream, size_t total);
     int ingest(hipStream_t stream, const void* data, size_t n, const CloudFormat& fmt, const IngestParams& prm, double begin_time,
                size_t* n_kept);
-    int window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi);
+    // reset8 != nullptr: the kernel also sets those eight words to the voxel grid's "no bounds seen" (ScanStore::d_bounds)
+    int window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi, unsigned* reset8 = nullptr);
     int clear_before(hipStream_t stream, double t);
     int unpack(hipStream_t stream, uint32_t lo, uint32_t n, float4* xyz, double* times);
     void release();

@@ -471,7 +471,7 @@ void MapStore::release() {
     hipFree(d_napos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_box); hipFree(d_box_next);
     for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_gtab[l]); hipFree(d_gbase[l]); hipFree(d_gslot[l]); }
-    if (ev_counters) hipEventDestroy(ev_counters);
+    note_free(notes);
     hipFree(d_prank); hipFree(d_pslot); hipFree(d_gcnt); hipFree(d_reloc);
     *this = MapStore();
 }
@@ -990,6 +990,15 @@ __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx
     for (uint32_t t = tid; t < k * (uint32_t)REPL_LEVELS; t += 1024) inc_group_item(M, G, newp, alive, k, t);
 }
 
+// the outcome of an insert for the host (MapStore::settle), as a note
+__global__ void inc_post_counters_kernel(const MapCounters* __restrict__ cnt, unsigned long long* __restrict__ note, uint32_t seq) {
+    if (threadIdx.x != 0) return;
+    note_post(note + 0, seq, cnt->n_new);
+    note_post(note + 1, seq, cnt->n_dead);
+    note_post(note + 2, seq, cnt->dropped);
+    note_post(note + 3, seq, cnt->overflow);
+}
+
 // the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
 __global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1166,9 +1175,11 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     LV_HIP(hipGetLastError());
     // the insert's outcome (ids handed out, occupants that lost, overflow) is read back WITHOUT waiting for it: settle() picks
     // it up when the map's bookkeeping is needed next (the following search or insert), by which time it has long arrived
-    if (!ev_counters) LV_HIP(hipEventCreateWithFlags(&ev_counters, hipEventDisableTiming));
-    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipEventRecord(ev_counters, stream));
+    LV_HIP(note_alloc(notes));
+    counters_seq = notes.next();
+    counters_stream = stream;
+    hipLaunchKernelGGL(inc_post_counters_kernel, dim3(1), dim3(64), 0, stream, d_cnt, notes.d, counters_seq);
+    LV_HIP(hipGetLastError());
     counters_pending = true;
     pending_counted_kill = counted_kill;
     pending_n_dead = n_dead;
@@ -1178,17 +1189,21 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
 int MapStore::settle(hipStream_t stream) {
     if (!counters_pending) return LV_OK;
     counters_pending = false;
-    LV_HIP(hipEventSynchronize(ev_counters));
+    // (the note is posted by the last kernel of the insert's chain, on the stream the chain ran on — the context's side stream
+    // when the insert overlaps the next cycle's prediction and window: once it has arrived the whole insert has completed, so
+    // whatever the caller enqueues next, on any stream, sees the finished map)
+    uint32_t v[4] = {0, 0, 0, 0};   // n_new, n_dead, dropped, overflow
+    if (!note_wait(notes, 0, 4, counters_seq, v, counters_stream)) { set_error("map insert: the counters never arrived"); return LV_EHIP; }
     uint32_t n_dead = pending_n_dead;
-    if (pending_counted_kill) n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
-    n_ids += h_cnt->n_new;
-    m += h_cnt->n_new;
+    if (pending_counted_kill) n_dead = v[1] < dead_cap ? v[1] : (uint32_t)dead_cap;
+    n_ids += v[0];
+    m += v[0];
     m -= n_dead;
     tombstones += (uint64_t)n_dead * INC_SLOTS_PER_POINT;
-    dropped_total += h_cnt->dropped;
+    dropped_total += v[2];
     ++incremental_adds;
     refresh_view();
-    if (h_cnt->overflow) return relinearise(stream);   // a pool / table ran full: the new points are in `orig`, rebuild around them
+    if (v[3]) return relinearise(stream);   // a pool / table ran full: the new points are in `orig`, rebuild around them
     return LV_OK;
 }
 

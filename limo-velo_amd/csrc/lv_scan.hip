@@ -217,7 +217,8 @@ __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* 
                                                                   uint32_t n_states, MotionState xt2, int do_deskew, float leaf,
                                                                   float inv_sort_cell, uint32_t tile_points,
                                                                   float4* __restrict__ out_raw, float4* __restrict__ out_sorted,
-                                                                  uint32_t* __restrict__ tile_order, unsigned* __restrict__ bounds) {
+                                                                  uint32_t* __restrict__ tile_order, unsigned* __restrict__ bounds,
+                                                                  unsigned long long* __restrict__ note, uint32_t seq) {
     __shared__ float4 s_pt[SMALL_WINDOW];       // de-skewed input
     __shared__ float4 s_out[SMALL_WINDOW];      // output points (voxel-grid order)
     __shared__ uint64_t s_key[SMALL_WINDOW];
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* 
     uint32_t n_out = n_in;
     if (s_b[0] == 0xFFFFFFFFu) {   // no finite point: nothing to match
         if (tid < 8) bounds[tid] = tid < 6 ? s_b[tid] : 0u;
+        if (tid == 0) { note_post(note, seq, 0u); note_post(note + 1, seq, 0u); }
         return;
     }
     if (leaf > 0.f) {
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* 
         const double cells = (double)divb[0] * (double)divb[1] * (double)divb[2];
         if (!(cells < 4.0e15)) {
             if (tid < 8) bounds[tid] = tid < 6 ? s_b[tid] : (tid == 7 ? 1u : 0u);
+            if (tid == 0) { note_post(note, seq, 0u); note_post(note + 1, seq, 1u); }
             return;
         }
         for (uint32_t i = tid; i < (uint32_t)SMALL_WINDOW; i += SW_THREADS) {
@@ -342,6 +345,9 @@ __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* 
     }
     for (uint32_t i = tid; i < n_out; i += SW_THREADS) out_raw[i] = s_out[i];
     if (tid < 8) bounds[tid] = tid < 6 ? s_b[tid] : (tid == 6 ? n_out : 0u);
+    // (the note goes out here: the host continues while the Morton order below is still being computed — everything that
+    // reads it is ordered behind this kernel on the stream)
+    if (tid == 0) { note_post(note, seq, n_out); note_post(note + 1, seq, 0u); }
     if (n_out == 0) return;
     // ---- Morton order of the output, tile ranges, tile order (scan_sort_small_kernel)
     const float ox = unflip_f32(s_b[0]), oy = unflip_f32(s_b[1]), oz = unflip_f32(s_b[2]);
@@ -382,6 +388,181 @@ __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* 
         for (uint32_t u = 0; u < nt; ++u) rank += s_key[u] < mine ? 1u : 0u;
         tile_order[rank] = (uint32_t)tid;
     }
+}
+
+// ---- larger windows (a 0.01 s window of a 64-ring sensor holds ~13 k raw points): four launches + the library sort ----------
+// The general chain below is thirteen launches and two host round trips for ~40 us of work.  Here: (1) de-skew straight from the
+// LiDAR buffer + bounds, (2) leaf keys, (3) the library's stable sort, (4) ONE workgroup for everything behind the sort — leaf
+// heads, their scan, the centroids (one leaf per thread: the sequential f32 sum in input order, eight loads in flight), the
+// Morton order of the few hundred output points, tile ranges and tile order — which posts (points out, status) as a note
+// (lv_note.hpp).  Every stage computes what its stand-alone kernel computes, in the same order: bit-identical results
+// (tests/test_gpu_deskew.py runs both).  Limit: WT_OUT output points; beyond it the tail declines (status 1) and the caller
+// continues with the general chain from the sorted keys.
+constexpr int WT_OUT = 4096;
+__global__ __launch_bounds__(256) void deskew_bounds_kernel(const CloudPoint* __restrict__ cloud, uint32_t n, const MotionState* __restrict__ states,
+                                                            uint32_t n_states, MotionState xt2, float4* __restrict__ out,
+                                                            unsigned* __restrict__ bounds) {
+    __shared__ unsigned s_b[6];
+    if (threadIdx.x < 3) s_b[threadIdx.x] = 0xFFFFFFFFu;
+    else if (threadIdx.x < 6) s_b[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    if (i < n) {
+        const CloudPoint c = cloud[i];
+        const float4 o = deskew_point(make_float4(c.x, c.y, c.z, 0.f), c.time, i, states, n_states, xt2);
+        out[i] = o;
+        if (isfinite(o.x) && isfinite(o.y) && isfinite(o.z)) {
+            lo[0] = hi[0] = flip_f32(o.x); lo[1] = hi[1] = flip_f32(o.y); lo[2] = hi[2] = flip_f32(o.z);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        unsigned l = lo[a], h = hi[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned l2 = __shfl_xor(l, o), h2 = __shfl_xor(h, o);
+            l = l2 < l ? l2 : l;
+            h = h2 > h ? h2 : h;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_b[a], l); atomicMax(&s_b[3 + a], h); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s_b[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s_b[threadIdx.x]);
+}
+__global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* __restrict__ desk, const uint64_t* __restrict__ keys_sorted,
+                                                                 const uint32_t* __restrict__ idx_sorted, uint32_t n_in, float inv_sort_cell,
+                                                                 uint32_t tile_points, float4* __restrict__ out_raw,
+                                                                 float4* __restrict__ out_sorted, uint32_t* __restrict__ tile_order,
+                                                                 unsigned* __restrict__ bounds, unsigned long long* __restrict__ note,
+                                                                 uint32_t seq) {
+    __shared__ float4 s_out[WT_OUT];
+    __shared__ uint64_t s_mkey[WT_OUT];
+    __shared__ float s_r2[WT_OUT];
+    __shared__ uint32_t s_headpos[WT_OUT];
+    __shared__ uint32_t s_wsum[SW_THREADS / 64 + 1];
+    const int tid = threadIdx.x;
+    auto report = [&](uint32_t n_out, uint32_t status) {
+        if (tid == 0) { bounds[6] = n_out; bounds[7] = status; note_post(note, seq, n_out); note_post(note + 1, seq, status); }
+    };
+    if (bounds[0] == 0xFFFFFFFFu) { report(0u, 0u); return; }   // no finite point: nothing to match
+    constexpr uint64_t DROPPED = ~0ull >> 1;                     // (vg_keys_kernel's key of a dropped point: sorted last)
+    // ---- leaf heads (vg_heads_kernel) of this thread's run of consecutive sorted elements, then their exclusive scan
+    const uint32_t per = (n_in + SW_THREADS - 1) / SW_THREADS;
+    const uint32_t b0 = per * (uint32_t)tid, b1 = b0 + per < n_in ? b0 + per : n_in;
+    uint32_t hcnt = 0;
+    {
+        uint64_t prev = b0 > 0 && b0 < n_in ? keys_sorted[b0 - 1] : 0ull;
+        for (uint32_t i = b0; i < b1; ++i) {
+            const uint64_t k = keys_sorted[i];
+            hcnt += (k != DROPPED && (i == 0 || k != prev)) ? 1u : 0u;
+            prev = k;
+        }
+    }
+    uint32_t incl = hcnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < SW_THREADS / 64; ++w) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; }
+        s_wsum[SW_THREADS / 64] = run;
+    }
+    __syncthreads();
+    const uint32_t n_out = s_wsum[SW_THREADS / 64];
+    if (n_out > (uint32_t)WT_OUT) { report(0u, 1u); return; }
+    {
+        uint32_t o = s_wsum[tid >> 6] + incl - hcnt;
+        uint64_t prev = b0 > 0 && b0 < n_in ? keys_sorted[b0 - 1] : 0ull;
+        for (uint32_t i = b0; i < b1; ++i) {
+            const uint64_t k = keys_sorted[i];
+            if (k != DROPPED && (i == 0 || k != prev)) s_headpos[o++] = i;
+            prev = k;
+        }
+    }
+    __syncthreads();
+    // ---- centroid per leaf (vg_centroid_kernel), one leaf per thread at a time
+    for (uint32_t o = tid; o < n_out; o += SW_THREADS) {
+        const uint32_t i = s_headpos[o];
+        const uint64_t k = keys_sorted[i];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        constexpr int C = 8;
+        uint32_t j = i;
+        bool more = true;
+        while (more) {
+            uint64_t kk[C];
+            uint32_t id[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const uint32_t jj = j + c < n_in ? j + c : n_in - 1;
+                kk[c] = keys_sorted[jj];
+                id[c] = idx_sorted[jj];
+            }
+            float4 pp[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) pp[c] = desk[id[c]];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (more && j + c < n_in && kk[c] == k) { sx += pp[c].x; sy += pp[c].y; sz += pp[c].z; }
+                else if (more) { more = false; j += c; }
+            }
+            if (more) j += C;
+        }
+        const float cnt = (float)(j - i);
+        const float4 cen = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
+        s_out[o] = cen;
+        out_raw[o] = cen;
+    }
+    __syncthreads();
+    if (n_out == 0) { report(0u, 0u); return; }
+    // ---- Morton order of the output, tile ranges, tile order (scan_sort_small_kernel)
+    const float ox = unflip_f32(bounds[0]), oy = unflip_f32(bounds[1]), oz = unflip_f32(bounds[2]);
+    uint32_t len2 = 64;
+    while (len2 < n_out) len2 <<= 1;
+    for (uint32_t i = tid; i < len2; i += SW_THREADS) {
+        uint64_t k = ~0ull;
+        if (i < n_out) {
+            const float4 p = s_out[i];
+            const float fx = fminf(fmaxf((p.x - ox) * inv_sort_cell, 0.f), 1023.f);
+            const float fy = fminf(fmaxf((p.y - oy) * inv_sort_cell, 0.f), 1023.f);
+            const float fz = fminf(fmaxf((p.z - oz) * inv_sort_cell, 0.f), 1023.f);
+            const uint32_t key = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+            k = ((uint64_t)key << 32) | i;
+        }
+        s_mkey[i] = k;
+    }
+    __syncthreads();
+    lds_bitonic_u64(s_mkey, n_out, tid);
+    for (uint32_t i = tid; i < n_out; i += SW_THREADS) {
+        const float4 p = s_out[(uint32_t)s_mkey[i]];
+        out_sorted[i] = p;
+        s_r2[i] = p.x * p.x + p.y * p.y + p.z * p.z;
+    }
+    __syncthreads();
+    if (tile_points != 0) {
+        const uint32_t nt = (n_out + tile_points - 1) / tile_points;   // <= 1024 (the caller checks tile_points >= 4)
+        uint64_t mine = ~0ull;
+        if ((uint32_t)tid < nt) {
+            float r2 = 0.f;
+            const uint32_t b = (uint32_t)tid * tile_points;
+            for (uint32_t i = 0; i < tile_points && b + i < n_out; ++i) r2 = fmaxf(r2, s_r2[b + i]);
+            mine = ((uint64_t)(~__float_as_uint(r2)) << 32) | (uint32_t)tid;   // complement ascending = range descending; ties by tile
+        }
+        __syncthreads();
+        if ((uint32_t)tid < nt) s_mkey[tid] = mine;
+        __syncthreads();
+        if ((uint32_t)tid < nt) {
+            uint32_t rank = 0;
+            for (uint32_t u = 0; u < nt; ++u) rank += s_mkey[u] < mine ? 1u : 0u;
+            tile_order[rank] = (uint32_t)tid;
+        }
+    }
+    report(n_out, 0u);
 }
 
 int ScanStore::reserve_raw(size_t cap, size_t n_states) {
@@ -453,14 +634,51 @@ int ScanStore::window_small(hipStream_t stream, const float4* src, uint32_t n_in
     if (rc) return rc;
     n_tiles = 0;
     static const MotionState none{};
+    LV_HIP(note_alloc(notes));
+    const uint32_t seq = notes.next();
     hipLaunchKernelGGL(window_small_kernel, dim3(1), dim3(SW_THREADS), 0, stream, src, d_times, n_in, d_states, n_states,
-                       xt2 ? *xt2 : none, xt2 ? 1 : 0, leaf, 1.0f / sort_cell, tile_points, d_raw, d_sorted, d_tile_order, d_bounds);
+                       xt2 ? *xt2 : none, xt2 ? 1 : 0, leaf, 1.0f / sort_cell, tile_points, d_raw, d_sorted, d_tile_order, d_bounds,
+                       notes.d, seq);
     LV_HIP(hipGetLastError());
-    unsigned hb[8];
-    LV_HIP(hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    if (hb[7]) { *fell_back = true; return LV_OK; }
-    n = hb[0] == 0xFFFFFFFFu ? 0u : hb[6];
+    uint32_t v[2] = {0, 0};   // points out (0: no finite point), status (1: declined)
+    if (!note_wait(notes, 0, 2, seq, v, stream)) { set_error("window kernel did not report"); return LV_EHIP; }
+    if (v[1]) { *fell_back = true; return LV_OK; }
+    n = v[0];
+    n_tiles = n ? (n + tile_points - 1) / tile_points : 0;
+    return LV_OK;
+}
+
+bool ScanStore::large_window_applies(uint32_t n_in, uint32_t n_states, float leaf) const {
+    return large_enabled && n_in > 0 && leaf > 0.f && tile_points >= 4 && n_states >= 2;
+}
+
+// windows beyond SMALL_WINDOW points, straight from the LiDAR buffer (cloud = its first point): deskew_bounds_kernel, leaf keys,
+// the library sort, window_tail_kernel.  d_bounds must hold "nothing seen" (CloudStore::window resets it when asked to).
+// *fell_back: the tail declined (more than WT_OUT points out): nothing was produced, d_desk holds the de-skewed points.
+int ScanStore::window_large(hipStream_t stream, const CloudPoint* cloud, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf,
+                            float sort_cell, bool* fell_back) {
+    *fell_back = false;
+    int rc = reserve(n_in);
+    if (rc) return rc;
+    rc = reserve_tiles(((uint32_t)WT_OUT + tile_points - 1) / tile_points);
+    if (rc) return rc;
+    n_tiles = 0;
+    LV_HIP(note_alloc(notes));
+    const uint32_t seq = notes.next();
+    const int B = 256;
+    const uint32_t grid = (n_in + B - 1) / B;
+    hipLaunchKernelGGL(deskew_bounds_kernel, dim3(grid), dim3(B), 0, stream, cloud, n_in, d_states, n_states, xt2, d_desk, d_bounds);
+    hipLaunchKernelGGL(vg_keys_kernel, dim3(grid), dim3(B), 0, stream, d_desk, n_in, d_bounds, 1.0f / leaf, d_vkeys, d_vidx);
+    size_t tmp = vsort_tmp_bytes;
+    LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_vsort_tmp, tmp, d_vkeys, d_vkeys_sorted, d_vidx, d_vidx_sorted, (int)n_in, 0, 63,
+                                                           stream));
+    hipLaunchKernelGGL(window_tail_kernel, dim3(1), dim3(SW_THREADS), 0, stream, d_desk, d_vkeys_sorted, d_vidx_sorted, n_in, 1.0f / sort_cell,
+                       tile_points, d_raw, d_sorted, d_tile_order, d_bounds, notes.d, seq);
+    LV_HIP(hipGetLastError());
+    uint32_t v[2] = {0, 0};
+    if (!note_wait(notes, 0, 2, seq, v, stream)) { set_error("window kernel did not report"); return LV_EHIP; }
+    if (v[1]) { *fell_back = true; return LV_OK; }
+    n = v[0];
     n_tiles = n ? (n + tile_points - 1) / tile_points : 0;
     return LV_OK;
 }
@@ -530,6 +748,7 @@ void ScanStore::release() {
     hipFree(d_in); hipFree(d_times); hipFree(d_desk); hipFree(d_vkeys); hipFree(d_vkeys_sorted); hipFree(d_vidx);
     hipFree(d_vidx_sorted); hipFree(d_heads); hipFree(d_hpos); hipFree(d_vsort_tmp); hipFree(d_vscan_tmp); hipFree(d_states);
     hipFree(d_bounds); hipFree(d_tile_order);
+    note_free(notes);
     *this = ScanStore();
 }
 

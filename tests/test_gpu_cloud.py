@@ -102,3 +102,46 @@ def test_deskew_window_equals_deskew_of_the_same_points(capi, oracle, lv):
     assert got.shape == want.shape and got.tobytes() == want.tobytes()
     ds = oracle.voxelgrid(oracle.deskew(xyz, sel["time"], states, xt2), 0.5)
     assert got.tobytes() == ds.tobytes()
+
+
+@pytest.mark.parametrize("n_msg,leaf,lo_frac,hi_frac", [(6000, 0.5, 0.05, 0.95), (20000, 1.0, 0.1, 0.9), (40000, 2.0, 0.2, 0.9),
+                                                        (40000, 0.5, 0.2, 0.9), (40000, 1.0, 0.45, 0.55), (3000, 0.5, 0.0, 1.0)])
+def test_large_window_chain_equals_the_general_chain(capi, oracle, lv, scene_small, n_msg, leaf, lo_frac, hi_frac):
+    """Windows beyond 2048 raw points take four launches + the library sort (deskew_bounds_kernel straight from the LiDAR
+    buffer, leaf keys, sort, window_tail_kernel: heads, scan, centroids, Morton order, tile order by one workgroup, the counts
+    back as a note) instead of the thirteen-launch chain; beyond 4096 points OUT the tail declines and the general chain runs.
+    Same points in the same order, the same Morton / tile order behind them: the update that consumes the scan is bit-identical."""
+    sc = scene_small
+    raw, f, stamp = cm.make_message("velodyne", n_msg, seed=11, wire=True, stamp_sec=50.2)
+    gf, of = _formats(capi, oracle, f)
+    prm = (stamp, 0, 0, 0.1, 2, 4.0)
+    pts = oracle.cloud_ingest(raw, n_msg, of, oracle.IngestParams(*prm))
+    t0, t3 = pts["time"][0], pts["time"][-1]
+    t1, t2 = t0 + lo_frac * (t3 - t0), t0 + hi_frac * (t3 - t0)
+    sel = pts[(pts["time"] >= t1) & (pts["time"] <= t2)]
+    s = oracle.motion_state(pos=(0.5, -0.3, 0.2), vel=(3.0, 0.4, 0.0), a=(0.2, -0.1, 9.8), w=(0.01, -0.02, 0.3), time=t1 - 0.003)
+    states = [s.copy()]
+    k = 0
+    while states[-1]["time"][0] < t2 + 0.002:
+        k += 1
+        s = oracle.state_integrate(s, (0.2, -0.1 + 0.01 * k, 9.8), (0.01, -0.02, 0.3 - 0.01 * k), t1 - 0.003 + 0.01 * k)
+        states.append(s.copy())
+    states = np.concatenate(states)
+    xt2 = states[-2:-1].copy()
+    res = {}
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.cloud_ingest(raw, n_msg, gf, capi.IngestParams(*prm))
+        for on in (1, 0):
+            ctx.set_option("large_window", on)
+            nw = ctx.scan_deskew_window(t1, t2, states, xt2, downsample_prec=leaf)
+            got = ctx.scan_fetch()
+            x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+            res[on] = (nw, got, x, P, passes, [s_["n_valid"] for s_ in sums])
+    assert res[1][0] == res[0][0] == len(sel)
+    assert res[1][1].shape == res[0][1].shape and res[1][1].tobytes() == res[0][1].tobytes()
+    assert res[1][4] == res[0][4] and res[1][5] == res[0][5]
+    assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][3], res[0][3])
+    xyz = np.stack([sel["x"], sel["y"], sel["z"]], axis=1)
+    ds = oracle.voxelgrid(oracle.deskew(xyz, sel["time"], states, xt2), leaf)
+    assert res[1][1].tobytes() == ds.tobytes()

@@ -170,3 +170,41 @@ def test_extrinsics_variant(capi, scene_small, monkeypatch):
         # (the extrinsics are weakly observable from one scan: the 12 x 12 gain blocks amplify the 1e-16 difference of the
         # summation orders more than the 6 x 6 ones do)
         _agree(a, b, tol_x=1e-10, tol_p_rel=1e-6)
+
+
+@pytest.mark.parametrize("case", ["all_passes", "early_convergence", "no_matches", "three_kernel"])
+def test_filter_get_from_the_mailbox_equals_the_copy(capi, scene_small, case):
+    """After lv_correct the posterior is read from the host-mapped mailbox its finishing pass writes (a poll) instead of a
+    device-to-host copy + stream synchronise: the same bits, however the update ended, and only while the mailbox still IS the
+    resident filter (a predict / filter_set / other update in between goes back to the copy)."""
+    sc = scene_small
+    scan = sc["scan_xyz"]
+    x0 = sc["x_init"]
+    if case == "early_convergence":
+        x0 = sc["x_true"]
+    if case == "no_matches":
+        scan = scan[:3000] + np.float32([500.0, 0.0, 0.0])
+    res = {}
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(scan)
+        ctx.set_fused_pass(case != "three_kernel")
+        for mail in (1, 0, 1):
+            ctx.set_option("mail_filter", mail)
+            ctx.filter_set(x0, sc["P0"])
+            ctx.correct(want_passes=False)   # (no synchronisation inside lv_correct)
+            x, P = ctx.filter_get()
+            res.setdefault(mail, []).append((x.copy(), P.copy(), ctx.last_passes()))
+        # a predict after the correct: the mailbox no longer is the filter
+        ctx.set_option("mail_filter", 1)
+        ctx.filter_set(x0, sc["P0"])
+        ctx.correct(want_passes=False)
+        Q = np.eye(12) * 1e-4
+        ctx.predict(0.01, Q, np.array([0.1, 0.0, 9.8]), np.array([0.0, 0.0, 0.1]))
+        xa, Pa = ctx.filter_get()
+        ctx.set_option("mail_filter", 0)
+        xb, Pb = ctx.filter_get()
+        assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+        assert not np.array_equal(xa, res[1][0][0])
+    for a in res[1]:
+        assert np.array_equal(a[0], res[0][0][0]) and np.array_equal(a[1], res[0][0][1]) and a[2] == res[0][0][2]
