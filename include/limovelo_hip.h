@@ -223,6 +223,10 @@ int    lv_cloud_ingest(lv_ctx* ctx, const void* data, size_t n_points, const lv_
 size_t lv_cloud_size(lv_ctx* ctx);
 int    lv_cloud_fetch(lv_ctx* ctx, double t1, double t2, void* points_out, size_t capacity, size_t* n);
 int    lv_cloud_clear(lv_ctx* ctx, double t);
+/* Optional: allocate the ingest staging (two pinned buffers + the device work arrays) for messages of up to
+ * max_points_per_message records of point_step bytes and a LiDAR buffer of buffer_points points now, instead of on the first
+ * message (pinned allocations take milliseconds: the first sweep of a stream otherwise pays them). */
+int    lv_cloud_reserve(lv_ctx* ctx, size_t max_points_per_message, size_t point_step, size_t buffer_points);
 int    lv_scan_deskew_window(lv_ctx* ctx, double t1, double t2, const lv_motion_state* states, size_t n_states,
                              const lv_motion_state* Xt2, float downsample_prec, size_t* n_window);
 

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_last_passes", "lv_set_fused_pass", "lv_set_option", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather", "lv_comm_peer_export", "lv_comm_peer_init",
-    "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_scan_deskew_window",
+    "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_cloud_reserve", "lv_scan_deskew_window",
 ]
 
 
@@ -292,6 +292,9 @@ class Context:
         n = C.c_size_t(0)
         self._check(self.lib.lv_cloud_fetch(self.h, C.c_double(t1), C.c_double(t2), out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(n)))
         return out[: n.value].copy()
+
+    def cloud_reserve(self, max_points_per_message: int, point_step: int, buffer_points: int):
+        self._check(self.lib.lv_cloud_reserve(self.h, C.c_size_t(max_points_per_message), C.c_size_t(point_step), C.c_size_t(buffer_points)))
 
     def cloud_clear(self, t: float):
         self._check(self.lib.lv_cloud_clear(self.h, C.c_double(t)))

@@ -54,6 +54,13 @@ struct lv_ctx {
     KfHostIO* h_io = nullptr;  // pinned, host-mapped mailbox: update inputs and results (no copy kernels)
     KfHostIO* d_io = nullptr;  // its device address
     int update_seq = 0;        // number of the update in flight (the finishing pass echoes it into h_io->seq)
+    // lv_predict calls are queued (same Q, up to PREDICT_BATCH steps) and launched together by whatever needs the filter next
+    double pred_Q[144] = {};
+    double pred_steps[PREDICT_BATCH][7] = {};
+    int pred_n = 0;
+    bool pred_src_kf = false;         // the first queued step reads the posterior from kf (filter_in_kf at the time it was queued)
+    bool batch_predict = true;        // lv_set_option "batch_predict" / LV_BATCH_PREDICT=0: one launch per lv_predict
+    bool filter_in_kf = false;        // the resident filter has not been copied out of kf->x / kf->P_post yet (see materialise_filter)
     bool filter_in_mailbox = false;   // the resident filter == the results in the mailbox (set by lv_correct, cleared by whatever changes the filter)
     bool mail_filter = true;          // lv_filter_get reads them from there (lv_set_option "mail_filter" 0: always copy)
     bool spin_wait = true;     // lv_update_end polls the mailbox before falling back to hipStreamSynchronize (LV_SPIN_WAIT=0: off)
@@ -203,7 +210,32 @@ void unpack_sums(const double* rec, lv_sums* out) {
 
 // from_host: x / P_prop wait in the pinned mailbox (lv_update_begin), otherwise they are in d_kf already (copied
 // from the resident filter): take them over, derive the pass constants
-int begin_device(lv_ctx* c, const double* x_host, bool defer) {
+// The resident filter after lv_correct IS kf->x / kf->P_post (filter_in_kf): the next lv_predict reads it from there and the
+// next lv_correct starts from there; only something that needs it in d_filter, or that is about to overwrite kf (an update
+// by value, lv_iterate), copies it out first — in the 100 Hz cycle that launch never happens.
+static int flush_predicts(lv_ctx* c) {
+    if (c->pred_n == 0) return LV_OK;
+    const int n = c->pred_n;
+    c->pred_n = 0;
+    const KfDev* src = c->pred_src_kf ? c->d_kf : nullptr;
+    c->pred_src_kf = false;
+    return launch_predict(c->stream, c->d_filter, src, c->pred_Q, n, c->pred_steps);
+}
+#define LV_FLUSH_PREDICTS(c)             \
+    do {                                 \
+        int _rp = flush_predicts(c);     \
+        if (_rp) return _rp;             \
+    } while (0)
+
+static int materialise_filter(lv_ctx* c) {
+    if (!c->filter_in_kf) return LV_OK;
+    c->filter_in_kf = false;
+    return launch_kf_to_filter(c->stream, c->d_kf, c->d_filter);
+}
+
+int begin_device(lv_ctx* c, const double* x_host, bool defer, bool from_filter) {
+    LV_FLUSH_PREDICTS(c);   // (a queued prediction may still have to read the posterior from kf, which this update is about to overwrite)
+    if (!from_filter) { int rm = materialise_filter(c); if (rm) return rm; }
     c->begin_pending = false;
     c->filter_in_mailbox = false;   // (the mailbox is about to receive this update's results)
     if (c->capture) LV_HIP(hipMemsetAsync(c->d_kf->level_hist, 0, sizeof(int) * 8, c->stream));   // instrumentation of capturing passes
@@ -214,8 +246,9 @@ int begin_device(lv_ctx* c, const double* x_host, bool defer) {
         compute_pose_consts(c->h_begin.x, &c->h_begin.pose);
         c->begin_pending = true;
     } else {
-        int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, x_host);
+        int rc = launch_kf_begin(c->stream, c->d_kf, c->d_io, x_host, from_filter ? c->d_filter : nullptr, (from_filter && c->filter_in_kf) ? 1 : 0);
         if (rc) return rc;
+        if (from_filter) c->filter_in_kf = false;   // (kf->P_post is about to become this update's working copy: the filter proper is d_filter again ... after kf_to_filter / the next predict)
     }
     c->grid = fit_grid_size(c->scan.n, c->max_blocks);
     if ((uint32_t)c->scan.n > c->qstride) {
@@ -240,7 +273,7 @@ int begin_common(lv_ctx* c, const lv_state* x, const double* P, bool defer = tru
         for (int i = 0; i < NS * NS; ++i) io->P_in[i] = (i / NS == i % NS) ? 1.0 : 0.0;
     }
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;
-    return begin_device(c, io->x_in, defer);   // x_in and P_in (contiguous) ride in the kernel arguments
+    return begin_device(c, io->x_in, defer, false);   // x_in and P_in (contiguous) ride in the kernel arguments
 }
 
 int pass_solve(lv_ctx* c, bool from_groups);
@@ -519,6 +552,8 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     LV_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     if (const char* e = getenv("LV_OVERLAP_INSERT")) c->overlap_insert = atoi(e) != 0;
+    if (const char* e = getenv("LV_BATCH_PREDICT")) c->batch_predict = atoi(e) != 0;
+    if (const char* e = getenv("LV_MERGED_INSERT")) c->map.merged_back = atoi(e) != 0;
     LV_HIP(hipMalloc(&c->d_kf, sizeof(KfDev)));
     LV_HIP(hipMemset(c->d_kf, 0, sizeof(KfDev)));
     LV_HIP(hipMalloc(&c->d_filter, sizeof(FilterDev)));
@@ -584,6 +619,7 @@ void lv_destroy(lv_ctx* c) {
 
 int lv_set_stream(lv_ctx* c, void* hip_stream) {
     LV_CHECK_CTX(c);
+    LV_FLUSH_PREDICTS(c);
     LV_HIP(hipStreamSynchronize(c->stream));
     if (c->side_stream) LV_HIP(hipStreamSynchronize(c->side_stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -592,6 +628,7 @@ int lv_set_stream(lv_ctx* c, void* hip_stream) {
 void* lv_get_stream(lv_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int lv_synchronize(lv_ctx* c) {
     LV_CHECK_CTX(c);
+    LV_FLUSH_PREDICTS(c);
     LV_HIP(hipStreamSynchronize(c->stream));
     if (c->side_stream) LV_HIP(hipStreamSynchronize(c->side_stream));
     return LV_OK;
@@ -678,11 +715,12 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     LV_SETTLE_MAP(c);
     const uint32_t n = c->scan.n;
     if (n == 0) return LV_OK;   // Mapper::add returns on an empty cloud (Mapper.cpp:20)
+    LV_FLUSH_PREDICTS(c);
     int rc = c->map.reserve_batch(n);
     if (rc) return rc;
     // the state of whichever path ran last (main.cpp:92,102: Xt2 = the state the update just produced — or, before the first
     // map exists, the propagated state the caller handed to lv_update)
-    const double* x = (c->state_src == 2 || !c->filter_set) ? c->d_kf->x : c->d_filter->x;
+    const double* x = (c->state_src == 2 || !c->filter_set || c->filter_in_kf) ? c->d_kf->x : c->d_filter->x;
     hipLaunchKernelGGL(scan_to_world_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, c->scan.d_raw, n, c->map.d_new);
     LV_HIP(hipGetLastError());
     // The insert depends on nothing but the world points just staged, and nothing depends on it until the next search: it runs
@@ -931,6 +969,18 @@ int lv_cloud_ingest(lv_ctx* c, const void* data, size_t n, const lv_cloud_format
     return c->cloud.ingest(c->stream, data, n, cf, ip, begin, n_kept);
 }
 
+int lv_cloud_reserve(lv_ctx* c, size_t max_points_per_message, size_t point_step, size_t buffer_points) {
+    LV_CHECK_CTX(c);
+    if (point_step < 12 || max_points_per_message > 0x7FFFFFF0ull || buffer_points > 0x7FFFFFF0ull) { set_error("bad sizes"); return LV_EINVAL; }
+    int rc = c->cloud.init();
+    if (rc) return rc;
+    if (max_points_per_message) rc = c->cloud.reserve_msg(max_points_per_message, max_points_per_message * point_step);
+    if (rc) return rc;
+    rc = c->cloud.settle();
+    if (rc) return rc;
+    return buffer_points ? c->cloud.reserve_buffer(c->stream, (size_t)c->cloud.size + buffer_points) : LV_OK;
+}
+
 size_t lv_cloud_size(lv_ctx* c) {
     if (!c) return 0;
     c->cloud.settle();
@@ -1051,6 +1101,8 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "comm_fused")) c->comm_fused = on;
     else if (!std::strcmp(name, "mail_filter")) c->mail_filter = on;
     else if (!std::strcmp(name, "overlap_insert")) c->overlap_insert = on;
+    else if (!std::strcmp(name, "batch_predict")) { int rp = flush_predicts(c); if (rp) return rp; c->batch_predict = on; }
+    else if (!std::strcmp(name, "merged_insert")) c->map.merged_back = on;
     else if (!std::strcmp(name, "small_window")) c->scan.small_enabled = on;
     else if (!std::strcmp(name, "large_window")) c->scan.large_enabled = on;
     else if (!std::strcmp(name, "small_insert")) c->map.small_front = on;
@@ -1400,12 +1452,15 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
 int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
     LV_CHECK_CTX(c);
     if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
+    c->pred_n = 0;   // (queued predictions of a filter that is being replaced)
+    c->pred_src_kf = false;
     LV_HIP(hipStreamSynchronize(c->stream));  // staging reuse
     std::memcpy(c->h_filter->x, x, sizeof(double) * NX);
     std::memcpy(c->h_filter->P, P, sizeof(double) * NS * NS);
     LV_HIP(hipMemcpyAsync(c->d_filter, c->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, c->stream));
     c->filter_set = true;
     c->filter_in_mailbox = false;
+    c->filter_in_kf = false;
     c->state_src = 1;
     return LV_OK;
 }
@@ -1413,6 +1468,7 @@ int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
 int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
     LV_CHECK_CTX(c);
     if (!c->filter_set) { set_error("lv_filter_get before lv_filter_set"); return LV_ESTATE; }
+    LV_FLUSH_PREDICTS(c);
     if (c->filter_in_mailbox && c->mail_filter) {
         // the resident filter is the posterior of the lv_correct just enqueued: its finishing pass stores x, P (and the pass count)
         // into the host-mapped mailbox as well — wait for THAT (a poll) instead of a copy + stream synchronise (~30 us of wake-up,
@@ -1423,6 +1479,7 @@ int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
         if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
         return LV_OK;
     }
+    { int rm = materialise_filter(c); if (rm) return rm; }
     LV_HIP(hipMemcpyAsync(c->h_filter, c->d_filter, sizeof(FilterDev), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
     if (x) std::memcpy(x, c->h_filter->x, sizeof(double) * NX);
@@ -1436,20 +1493,29 @@ int lv_predict(lv_ctx* c, double dt, const double* Q, const double acc[3], const
     if (!c->filter_set) { set_error("lv_predict before lv_filter_set"); return LV_ESTATE; }
     c->state_src = 1;
     c->filter_in_mailbox = false;
-    return launch_predict(c->stream, c->d_filter, dt, Q, acc, gyro);
+    if (c->pred_n > 0 && (c->pred_n >= PREDICT_BATCH || std::memcmp(c->pred_Q, Q, sizeof(c->pred_Q)) != 0)) LV_FLUSH_PREDICTS(c);
+    if (c->pred_n == 0) {
+        std::memcpy(c->pred_Q, Q, sizeof(c->pred_Q));
+        c->pred_src_kf = c->filter_in_kf;
+        c->filter_in_kf = false;
+    }
+    double* st = c->pred_steps[c->pred_n++];
+    st[0] = dt;
+    for (int i = 0; i < 3; ++i) { st[1 + i] = acc[i]; st[4 + i] = gyro[i]; }
+    if (!c->batch_predict) LV_FLUSH_PREDICTS(c);
+    return LV_OK;
 }
 
 int lv_correct(lv_ctx* c, int* passes) {
     LV_CHECK_CTX(c);
     LV_SETTLE_MAP(c);
     if (!c->filter_set) { set_error("lv_correct before lv_filter_set"); return LV_ESTATE; }
+    LV_FLUSH_PREDICTS(c);
     c->state_src = 1;
     if (passes) *passes = 0;
     if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
-    int rc = launch_filter_to_kf(c->stream, c->d_filter, c->d_kf);
-    if (rc) return rc;
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;   // (the finishing pass echoes it into the mailbox: lv_filter_get polls for it)
-    rc = begin_device(c, nullptr, false);
+    int rc = begin_device(c, nullptr, false, true);       // (kf_begin_kernel installs the filter in kf: no launch of its own)
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
@@ -1469,8 +1535,7 @@ int lv_correct(lv_ctx* c, int* passes) {
         }
     }
     c->in_update = false;
-    rc = launch_kf_to_filter(c->stream, c->d_kf, c->d_filter);
-    if (rc) return rc;
+    c->filter_in_kf = true;        // (the posterior stays where the update left it: materialise_filter)
     c->filter_in_mailbox = true;
     if (passes) {  // optional: the only synchronisation point
         LV_HIP(hipStreamSynchronize(c->stream));

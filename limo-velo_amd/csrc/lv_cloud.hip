@@ -17,6 +17,9 @@
 
 #include "lv_host.hpp"
 
+#include <chrono>
+#include <cstdlib>
+
 namespace lv {
 
 namespace {
@@ -110,13 +113,26 @@ __device__ __forceinline__ uint32_t wave_time_bound(const CloudPoint* __restrict
     return lo;
 }
 // (the answers go to the host as notes: lv_note.hpp)
+// do_clear: a Buffer::clear(t_clear) that has not been applied yet rides along — wavefront 2 finds the new head (first index
+// with time > t_clear), and the window is taken over what is left: lo = max(lo, head).
 __global__ void cloud_window_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t1, double t2, uint32_t* __restrict__ out,
-                                    unsigned long long* __restrict__ note, uint32_t seq, unsigned* __restrict__ reset8) {
+                                    unsigned long long* __restrict__ note, uint32_t seq, unsigned* __restrict__ reset8, int do_clear, double t_clear) {
+    __shared__ uint32_t s_r[3];
     const uint32_t wave = threadIdx.x >> 6;   // wavefront 0: first index with time >= t1; wavefront 1: first with time > t2
-    if (wave >= 2) return;
     if (reset8 && threadIdx.x < 8) reset8[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;   // (vg_bounds_init_kernel)
-    const uint32_t r = wave_time_bound(pts, head, n, wave ? t2 : t1, wave != 0);
-    if ((threadIdx.x & 63u) == 0) { out[wave] = r; note_post(note + wave, seq, r); }
+    uint32_t r = head;
+    if (wave < 2) r = wave_time_bound(pts, head, n, wave ? t2 : t1, wave != 0);
+    else if (wave == 2 && do_clear) r = wave_time_bound(pts, head, n, t_clear, true);
+    if ((threadIdx.x & 63u) == 0 && wave < 3) s_r[wave] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nh = s_r[2];
+        const uint32_t lo = s_r[0] > nh ? s_r[0] : nh, hi = s_r[1] > nh ? s_r[1] : nh;
+        out[0] = lo; out[1] = hi; out[3] = nh;
+        note_post(note, seq, lo);
+        note_post(note + 1, seq, hi);
+        note_post(note + 2, seq, nh);
+    }
 }
 // Buffer::clear(t) (Buffer.cpp:57-62): drop from the old end while t >= time
 __global__ void cloud_clear_kernel(const CloudPoint* __restrict__ pts, uint32_t head, uint32_t n, double t, uint32_t* __restrict__ out,
@@ -124,6 +140,9 @@ __global__ void cloud_clear_kernel(const CloudPoint* __restrict__ pts, uint32_t 
     if (threadIdx.x >= 64) return;
     const uint32_t r = wave_time_bound(pts, head, n, t, true);   // first index with time > t
     if (threadIdx.x == 0) { out[0] = r; note_post(note, seq, r); }
+}
+__global__ void cloud_post_count_kernel(const uint32_t* __restrict__ count, unsigned long long* __restrict__ note, uint32_t seq) {
+    if (threadIdx.x == 0) note_post(note, seq, count[0]);
 }
 __global__ void cloud_unpack_kernel(const CloudPoint* __restrict__ pts, uint32_t n, float4* __restrict__ xyz, double* __restrict__ times) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,11 +158,18 @@ int CloudStore::reserve_msg(size_t n, size_t bytes) {
     if (bytes > raw_cap) {
         size_t cap = raw_cap ? raw_cap : (1u << 20);
         while (cap < bytes) cap *= 2;
+        LV_HIP(hipDeviceSynchronize());   // (a staging buffer may still be in flight)
         hipFree(d_rawmsg);
         if (h_rawmsg) hipHostFree(h_rawmsg);
-        d_rawmsg = nullptr; h_rawmsg = nullptr; raw_cap = 0;
+        if (h_rawmsg2) hipHostFree(h_rawmsg2);
+        d_rawmsg = nullptr; h_rawmsg = h_rawmsg2 = nullptr; raw_cap = 0;
         LV_HIP(hipMalloc(&d_rawmsg, cap));
         LV_HIP(hipHostMalloc((void**)&h_rawmsg, cap, hipHostMallocDefault));
+        LV_HIP(hipHostMalloc((void**)&h_rawmsg2, cap, hipHostMallocDefault));
+        for (int b = 0; b < 2; ++b) {
+            if (!ev_stage[b]) LV_HIP(hipEventCreateWithFlags(&ev_stage[b], hipEventDisableTiming));
+            stage_busy[b] = false;
+        }
         raw_cap = cap;
     }
     if (n > msg_cap) {
@@ -173,6 +199,16 @@ int CloudStore::reserve_msg(size_t n, size_t bytes) {
 
 int CloudStore::reserve_buffer(hipStream_t stream, size_t total) {
     if (total <= buf_cap) return LV_OK;
+    // Buffer::clear only advances `head`: before the buffer grows, the living range [head, size) moves to the front when it
+    // fits there without overlapping itself (it does as soon as half of what was ever appended has been cleared) — the buffer of
+    // a stream then stays at a few sweeps instead of doubling for ever (and reallocating, 0.3 ms, every time)
+    const size_t live = size - head;
+    if (head >= live && total - head <= buf_cap) {
+        if (live) LV_HIP(hipMemcpyAsync(d_buf, d_buf + head, live * sizeof(CloudPoint), hipMemcpyDeviceToDevice, stream));
+        size = (uint32_t)live;
+        head = 0;
+        return LV_OK;
+    }
     size_t cap = buf_cap ? buf_cap : (1u << 18);
     while (cap < total) cap *= 2;
     CloudPoint* nb = nullptr;
@@ -199,6 +235,10 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
                        double begin_time, size_t* n_kept) {
     if (n_kept) *n_kept = 0;
     if (n == 0) return LV_OK;
+    static const bool timing = getenv("LV_INGEST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e6; };
+    const double tt0 = timing ? now() : 0.0;
+    double tt1 = 0, tt2 = 0, tt3 = 0, tt4 = 0;
     int rc = init();
     if (rc) return rc;
     rc = settle();
@@ -206,17 +246,36 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
     const size_t bytes = n * (size_t)fmt.point_step;
     rc = reserve_msg(n, bytes);
     if (rc) return rc;
-    LV_HIP(hipStreamSynchronize(stream));   // staging reuse
-    std::memcpy(h_rawmsg, data, bytes);
-    LV_HIP(hipMemcpyAsync(d_rawmsg, h_rawmsg, bytes, hipMemcpyHostToDevice, stream));
+    // The message goes through a pinned staging buffer in four pieces: the host copies piece i + 1 while piece i is on its way
+    // to the device (a 4 MB sweep: 0.3 ms of host memcpy + 0.1 ms of DMA back to back before), and the two staging buffers
+    // alternate between messages, so that this call does not wait for whatever the stream is still busy with (the previous
+    // cycle's map insert, typically) before it may touch the buffer.
+    if (timing) tt1 = now();
+    const int sb = stage_next;
+    stage_next ^= 1;
+    if (stage_busy[sb]) { LV_HIP(hipEventSynchronize(ev_stage[sb])); stage_busy[sb] = false; }   // (two messages ago: long done)
+    unsigned char* hs = sb ? h_rawmsg2 : h_rawmsg;
+    // (the device copy of the previous message is read by kernels of this stream that were enqueued before this copy: in order)
+    const size_t piece = ((bytes + 3) / 4 + 255) & ~(size_t)255;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t len = bytes - off < piece ? bytes - off : piece;
+        std::memcpy(hs + off, static_cast<const unsigned char*>(data) + off, len);
+        LV_HIP(hipMemcpyAsync(d_rawmsg + off, hs + off, len, hipMemcpyHostToDevice, stream));
+    }
+    LV_HIP(hipEventRecord(ev_stage[sb], stream));
+    stage_busy[sb] = true;
+    if (timing) tt2 = now();
     const int B = 256;
     const uint32_t grid = (uint32_t)((n + B - 1) / B);
     hipLaunchKernelGGL(cloud_decode_kernel, dim3(grid), dim3(B), 0, stream, d_rawmsg, (uint32_t)n, fmt, prm, begin_time, d_decoded, d_keep);
     size_t tmp = tmp_bytes;
     LV_HIP((hipError_t)hipcub::DeviceSelect::Flagged(d_tmp, tmp, d_decoded, d_keep, d_kept, d_count, (int)n, stream));
-    LV_HIP(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));   // the kept count sizes the sort and the append
-    const uint32_t m = h_count[0];
+    const uint32_t seq = notes.next();
+    hipLaunchKernelGGL(cloud_post_count_kernel, dim3(1), dim3(64), 0, stream, d_count, notes.d + 4, seq);
+    LV_HIP(hipGetLastError());
+    uint32_t m = 0;   // the kept count sizes the sort and the append
+    if (!note_wait(notes, 4, 1, seq, &m, stream)) { set_error("LiDAR buffer: the ingest did not report"); return LV_EHIP; }
+    if (timing) tt3 = now();
     if (n_kept) *n_kept = m;
     if (m == 0) return LV_OK;
     rc = reserve_buffer(stream, (size_t)size + m);
@@ -228,43 +287,50 @@ int CloudStore::ingest(hipStream_t stream, const void* data, size_t n, const Clo
     hipLaunchKernelGGL(cloud_gather_kernel, dim3(g2), dim3(B), 0, stream, d_kept, d_ids_sorted, m, d_buf + size);   // Accumulator::push
     LV_HIP(hipGetLastError());
     size += m;
+    if (timing) { tt4 = now(); fprintf(stderr, "ingest us: settle+reserve %.0f  staging+H2D %.0f  decode+select+note %.0f  append launches %.0f\n", tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3); }
     return LV_OK;
 }
 
+// A Buffer::clear(t) is only remembered (clears are monotone: the latest, largest t stands for all of them); it is applied by
+// the window kernel that follows it in the 100 Hz cycle, in the same launch, or — if something else needs the buffer's true
+// head first (an ingest, a size query) — by a launch of its own here.
 int CloudStore::settle() {
     if (!clear_pending) return LV_OK;
     clear_pending = false;
+    if (size <= head) { head = size = 0; return LV_OK; }
+    const uint32_t seq = notes.next();
+    hipLaunchKernelGGL(cloud_clear_kernel, dim3(1), dim3(64), 0, clear_stream, d_buf, head, size, clear_t, d_count + 3, notes.d + 3, seq);
+    LV_HIP(hipGetLastError());
     uint32_t v = 0;
-    if (!note_wait(notes, 3, 1, clear_seq, &v, clear_stream)) { set_error("LiDAR buffer: the clear kernel did not report"); return LV_EHIP; }
+    if (!note_wait(notes, 3, 1, seq, &v, clear_stream)) { set_error("LiDAR buffer: the clear kernel did not report"); return LV_EHIP; }
     head = v;
     if (head >= size) head = size = 0;
     return LV_OK;
 }
 
 int CloudStore::window(hipStream_t stream, double t1, double t2, uint32_t* lo, uint32_t* hi, unsigned* reset8) {
-    int rcs = settle();
-    if (rcs) return rcs;
     *lo = *hi = head;
-    if (size <= head) return LV_OK;
+    if (size <= head) { clear_pending = false; head = size = 0; *lo = *hi = 0; return LV_OK; }
     const uint32_t seq = notes.next();
-    hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(128), 0, stream, d_buf, head, size, t1, t2, d_count, notes.d, seq, reset8);
+    const int do_clear = clear_pending ? 1 : 0;
+    clear_pending = false;
+    hipLaunchKernelGGL(cloud_window_kernel, dim3(1), dim3(192), 0, stream, d_buf, head, size, t1, t2, d_count, notes.d, seq, reset8, do_clear,
+                       clear_t);
     LV_HIP(hipGetLastError());
-    uint32_t v[2] = {0, 0};
-    if (!note_wait(notes, 0, 2, seq, v, stream)) { set_error("LiDAR buffer: the window kernel did not report"); return LV_EHIP; }
+    uint32_t v[3] = {0, 0, 0};
+    if (!note_wait(notes, 0, 3, seq, v, stream)) { set_error("LiDAR buffer: the window kernel did not report"); return LV_EHIP; }
+    head = v[2];
+    if (head >= size) { head = size = 0; *lo = *hi = 0; return LV_OK; }
     *lo = v[0];
     *hi = v[1] > v[0] ? v[1] : v[0];
     return LV_OK;
 }
 
 int CloudStore::clear_before(hipStream_t stream, double t) {
-    int rcs = settle();
-    if (rcs) return rcs;
-    if (size <= head) return LV_OK;
-    clear_seq = notes.next();
+    if (size <= head && !clear_pending) return LV_OK;
+    clear_t = clear_pending ? (t > clear_t ? t : clear_t) : t;
     clear_stream = stream;
-    hipLaunchKernelGGL(cloud_clear_kernel, dim3(1), dim3(64), 0, stream, d_buf, head, size, t, d_count + 3, notes.d + 3, clear_seq);
-    LV_HIP(hipGetLastError());
-    clear_pending = true;   // (head is settled by the next window / ingest / clear / size query)
+    clear_pending = true;   // (applied by the next window, or by whatever needs the true head first: settle)
     return LV_OK;
 }
 
@@ -279,6 +345,8 @@ void CloudStore::release() {
     hipFree(d_rawmsg); hipFree(d_decoded); hipFree(d_kept); hipFree(d_keep); hipFree(d_keys); hipFree(d_keys_sorted);
     hipFree(d_ids); hipFree(d_ids_sorted); hipFree(d_tmp); hipFree(d_buf); hipFree(d_count);
     if (h_rawmsg) hipHostFree(h_rawmsg);
+    if (h_rawmsg2) hipHostFree(h_rawmsg2);
+    for (int b = 0; b < 2; ++b) if (ev_stage[b]) hipEventDestroy(ev_stage[b]);
     if (h_count) hipHostFree(h_count);
     note_free(notes);
     *this = CloudStore();

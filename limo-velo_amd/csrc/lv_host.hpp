@@ -116,6 +116,7 @@ struct MapStore {
 
     // the tail of an incremental insert (new ids / living points / overflow, read from the device counters) is settled by the
     // next call that needs the map's bookkeeping, not by a wait at the end of the insert
+    bool merged_back = true;     // independent stages of the insert's back half share launches (LV_MERGED_INSERT=0 / lv_set_option: off)
     bool small_front = true;     // batches of up to 2048 points: the insert's front half in one workgroup launch (LV_SMALL_INSERT=0: off)
     NoteBoard notes;             // the insert's counters come back as a note (lv_note.hpp): n_new, n_dead, dropped, overflow
     uint32_t counters_seq = 0;
@@ -198,7 +199,7 @@ int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, 
                       double* partials, int grid, const DebugOut& dbg);
 int fit_grid_size(uint32_t n, int max_blocks);
 // lv_solve.hip
-int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host);  // io: device pointer of the pinned mailbox;
+int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host, const FilterDev* filt = nullptr, int filt_in_kf = 0);  // io: device pointer of the pinned mailbox;
 // x_host != nullptr: x (NX doubles) followed by P_prop (NS*NS doubles) on the host, passed as kernel arguments
 int launch_reduce_groups(hipStream_t stream, const double* partials, int nblocks, double* groups, int* ngroups_out, KfDev* kf);
 int solve_direct_records();  // most records solve_kernel folds in one round trip
@@ -244,7 +245,10 @@ void pass_grid_size(uint32_t n, int max_wg, int* nsearch, int* steps, int* round
 int pass_clock_words();   // stamp words per workgroup (PassLaunch::clk)
 int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin);
 // lv_predict.hip
-int launch_predict(hipStream_t stream, FilterDev* f, double dt, const double* Q, const double* acc, const double* gyro);
+// src != nullptr: the state and covariance are read from kf->x / kf->P_post (the posterior of the update just run) instead of f
+constexpr int PREDICT_BATCH = 8;   // (== PREDICT_BATCH_MAX of lv_predict.hip)
+// n <= PREDICT_BATCH steps {dt, acc[3], gyro[3]} with one Q, in one launch
+int launch_predict(hipStream_t stream, FilterDev* f, const KfDev* src, const double* Q, int n, const double (*steps)[7]);
 int launch_filter_to_kf(hipStream_t stream, const FilterDev* f, KfDev* kf);
 int launch_kf_to_filter(hipStream_t stream, const KfDev* kf, FilterDev* f);
 // lv_rows.hip
@@ -329,7 +333,11 @@ struct CloudStore {
     uint32_t head = 0, size = 0;
     size_t buf_cap = 0;
     unsigned char* d_rawmsg = nullptr;
-    unsigned char* h_rawmsg = nullptr;   // pinned
+    unsigned char* h_rawmsg = nullptr;   // pinned staging, two buffers alternating between messages
+    unsigned char* h_rawmsg2 = nullptr;
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int stage_next = 0;
     size_t raw_cap = 0;
     CloudPoint* d_decoded = nullptr;
     CloudPoint* d_kept = nullptr;
@@ -346,7 +354,7 @@ struct CloudStore {
     // by whoever touches the buffer next (settle), by which time it has long arrived — the wait was one of six host/device
     // round trips of a 100 Hz cycle; the window's index range comes back as a note too (words 0, 1; the clear's: word 3)
     NoteBoard notes;
-    uint32_t clear_seq = 0;
+    double clear_t = 0.0;        // the pending Buffer::clear(t)
     hipStream_t clear_stream = nullptr;
     bool clear_pending = false;
     int settle();

@@ -13,6 +13,7 @@
 // Exactness of the search that uses these structures is argued in lv_match.hip.
 #define LV_MAPINC_KERNELS
 #include "lv_host.hpp"
+#include "lv_ldssort.hpp"
 
 #include <cstddef>
 #include <cstring>
@@ -905,21 +906,7 @@ __global__ __launch_bounds__(1024) void inc_sort_small_kernel(const uint64_t* __
         s_idx[i] = i < k ? idx[i] : 0xFFFFFFFFu;
     }
     __syncthreads();
-    uint32_t len = 64;
-    while (len < k) len <<= 1;
-    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < len / 2; t += 1024) {
-                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
-                const bool up = (lo & k2) == 0;
-                const uint64_t a = s_key[lo], b = s_key[hi];
-                const uint32_t ia = s_idx[lo], ib = s_idx[hi];
-                const bool gt = a > b || (a == b && ia > ib);
-                if (gt == up) { s_key[lo] = b; s_key[hi] = a; s_idx[lo] = ib; s_idx[hi] = ia; }
-            }
-            __syncthreads();
-        }
-    }
+    lds_bitonic_sort_u64_u32<1024>(s_key, s_idx, lds_sort_len(k), (int)tid);
     for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
 }
 
@@ -945,21 +932,7 @@ __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx
             s_idx[i] = i < k ? idx[i] : 0xFFFFFFFFu;
         }
         __syncthreads();
-        uint32_t len2 = 64;
-        while (len2 < k) len2 <<= 1;
-        for (uint32_t k2 = 2; k2 <= len2; k2 <<= 1) {
-            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = tid; t < len2 / 2; t += 1024) {
-                    const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
-                    const bool up = (lo & k2) == 0;
-                    const uint64_t a = s_key[lo], b = s_key[hi];
-                    const uint32_t ia = s_idx[lo], ib = s_idx[hi];
-                    const bool gt = a > b || (a == b && ia > ib);
-                    if (gt == up) { s_key[lo] = b; s_key[hi] = a; s_idx[lo] = ib; s_idx[hi] = ia; }
-                }
-                __syncthreads();
-            }
-        }
+        lds_bitonic_sort_u64_u32<1024>(s_key, s_idx, lds_sort_len(k), (int)tid);
         for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
         __syncthreads();
         for (uint32_t i = tid; i < k; i += 1024) inc_box_rule_item(Bx, M.orig, newp, keys_sorted, idx_sorted, k, alive, dead, dead_cap, M.cnt, i);
@@ -990,6 +963,32 @@ __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx
     for (uint32_t t = tid; t < k * (uint32_t)REPL_LEVELS; t += 1024) inc_group_item(M, G, newp, alive, k, t);
 }
 
+// ---- the back half of a small batch's insert in four launches instead of eight ---------------------------------------------------
+// Stages that do not depend on each other share a launch (the workgroup index picks the stage; the *_item functions are the
+// stand-alone kernels' bodies): the occupants that lost are tombstoned (kill) while the voxel groups find / create their
+// target slots (register: the probes of kill look for keys that exist, concurrent inserts of other keys do not disturb them);
+// the listed runs move (relocate: entries [0, count) of a run) while the new entries go to the tails behind them (fill); the
+// owners close their targets (commit: table counts, pending) while the new bucket entries go to their ranked places (place:
+// coordinates and ids inside the tail).  reserve and rank need everything before them: own launches.
+__global__ __launch_bounds__(256) void inc_kill_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k,
+                                                                const float4* __restrict__ dead, uint32_t dead_cap, uint32_t g_kill) {
+    if (blockIdx.x < g_kill) inc_kill_counted_item(M, dead, dead_cap, blockIdx.x * blockDim.x + threadIdx.x, g_kill * blockDim.x);
+    else inc_register_item(M, G, alive, k, (blockIdx.x - g_kill) * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void inc_relocate_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
+                                                                const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                                                uint32_t id_base, const uint4* __restrict__ reloc, uint32_t reloc_cap,
+                                                                const uint32_t* __restrict__ n_reloc, uint32_t g_rel) {
+    if (blockIdx.x < g_rel) inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, g_rel * blockDim.x);
+    else inc_fill_item(M, G, newp, alive, apos, k, id_base, (blockIdx.x - g_rel) * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void inc_place_commit_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
+                                                               const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                                               uint32_t id_base, const uint32_t* __restrict__ rank, uint32_t g_place) {
+    if (blockIdx.x < g_place) inc_place_item(M, G, newp, alive, apos, k, id_base, rank, blockIdx.x * blockDim.x + threadIdx.x);
+    else inc_commit_item(M, G, alive, k, (blockIdx.x - g_place) * blockDim.x + threadIdx.x);
+}
+
 // the outcome of an insert for the host (MapStore::settle), as a note
 __global__ void inc_post_counters_kernel(const MapCounters* __restrict__ cnt, unsigned long long* __restrict__ note, uint32_t seq) {
     if (threadIdx.x != 0) return;
@@ -1000,9 +999,10 @@ __global__ void inc_post_counters_kernel(const MapCounters* __restrict__ cnt, un
 }
 
 // the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
-__global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt) {
+__global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt, MapCounters* __restrict__ cnt) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4u) gcnt[t] = 0u;
+    if (t == 0u && cnt) { cnt->n_new = 0u; cnt->n_dead = 0u; cnt->overflow = 0u; cnt->dropped = 0u; }   // (reset_batch_counters)
     const uint32_t l = t / G.size, e = t % G.size;
     if (l < (uint32_t)REPL_LEVELS) G.table[l][e] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 }
@@ -1092,8 +1092,13 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     rc = reserve((size_t)n_ids + k);
     if (rc) return rc;
     if (have_boxes && box_next_cap < capacity) have_boxes = false;
-    rc = reset_batch_counters(*this, stream);
-    if (rc) return rc;
+    // the batch counters go back to zero in the launch that clears the group tables — unless the boxes are about to be built
+    // (the first down-sampling insert): their build may raise `overflow`, so the reset has to come before it
+    const bool reset_early = downsample && !have_boxes;
+    if (reset_early) {
+        rc = reset_batch_counters(*this, stream);
+        if (rc) return rc;
+    }
     const MapRW M = rw();
     BoxRW Bx{};
     if (downsample) {
@@ -1117,7 +1122,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     G.prank = d_prank;
     G.pslot = d_pslot;
     hipLaunchKernelGGL(inc_clear_groups_kernel, dim3((uint32_t)(((uint64_t)gtab_size * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, G,
-                       d_gcnt);
+                       d_gcnt, reset_early ? nullptr : d_cnt);
     const bool fused_front = small_front && k <= (uint32_t)SMALL_BATCH;
     uint32_t n_dead = 0;
     if (fused_front) {
@@ -1147,9 +1152,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
                        d_nalive, k);
     }   // !fused_front
     const bool counted_kill = downsample && k <= (uint32_t)SMALL_BATCH;
-    if (counted_kill) {   // the occupants that lost: how many is only known on the device — a small batch leaves it there
-        hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(256), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
-    } else if (downsample) {
+    if (!counted_kill && downsample) {
         LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipStreamSynchronize(stream));
         n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
@@ -1160,18 +1163,28 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
     const uint32_t g_grp = (uint32_t)((t_grp + B - 1) / B), g_all = (uint32_t)((t_all + B - 1) / B), g_rep = (uint32_t)((t_rep + B - 1) / B);
     const uint64_t t_rel = (uint64_t)(reloc_cap < (1u << 18) ? reloc_cap : (1u << 18)) * RELOC_LANES;   // runs moved per batch (more: re-linearise)
+    // at most one run per (group, target) of this batch can be listed; 2048 workgroups walk longer lists in strides
+    const uint64_t t_need = t_grp * RELOC_LANES < t_rel ? t_grp * RELOC_LANES : t_rel;
+    const uint64_t g_need = (t_need + B - 1) / B;
+    const uint32_t g_rel = (uint32_t)(g_need < 2048 ? g_need : 2048);
+    if (merged_back) {   // (see inc_kill_register_kernel)
+        const uint32_t g_kill = counted_kill ? 256u : 0u;   // the occupants that lost: how many is only known on the device
+        hipLaunchKernelGGL(inc_kill_register_kernel, dim3(g_kill + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_dead, (uint32_t)dead_cap, g_kill);
+        hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+        hipLaunchKernelGGL(inc_relocate_fill_kernel, dim3(g_rel + g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_reloc,
+                           (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
+        hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
+        hipLaunchKernelGGL(inc_place_commit_kernel, dim3(g_rep + g_grp), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank, g_rep);
+    } else {
+    if (counted_kill) hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(256), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
     hipLaunchKernelGGL(inc_register_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
-    {   // at most one run per (group, target) of this batch can be listed; 2048 workgroups walk longer lists in strides
-        const uint64_t t_need = t_grp * RELOC_LANES < t_rel ? t_grp * RELOC_LANES : t_rel;
-        const uint64_t g_need = (t_need + B - 1) / B;
-        hipLaunchKernelGGL(inc_relocate_kernel, dim3((uint32_t)(g_need < 2048 ? g_need : 2048)), dim3(B), 0, stream, M, d_reloc,
-                           (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
-    }
+    hipLaunchKernelGGL(inc_relocate_kernel, dim3(g_rel), dim3(B), 0, stream, M, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
     hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
     hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_commit_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
+    }
     LV_HIP(hipGetLastError());
     // the insert's outcome (ids handed out, occupants that lost, overflow) is read back WITHOUT waiting for it: settle() picks
     // it up when the map's bookkeeping is needed next (the following search or insert), by which time it has long arrived

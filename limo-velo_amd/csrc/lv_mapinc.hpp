@@ -337,11 +337,14 @@ __global__ void inc_kill_kernel(MapRW M, const float4* __restrict__ dead, uint32
     inc_kill_slot(M, dead, j, w);
 }
 // the same with the length of the list read on the device (small batches: no host round trip for it), grid-stride
-__global__ void inc_kill_counted_kernel(MapRW M, const float4* __restrict__ dead, uint32_t dead_cap) {
+__device__ __forceinline__ void inc_kill_counted_item(const MapRW& M, const float4* __restrict__ dead, uint32_t dead_cap, uint32_t t0, uint32_t n_threads) {
     const uint32_t n_dead = M.cnt->n_dead < dead_cap ? M.cnt->n_dead : dead_cap;
     const uint64_t total = (uint64_t)n_dead * (uint32_t)INC_SLOTS_PER_POINT;
-    for (uint64_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
+    for (uint64_t t = t0; t < total; t += (uint64_t)n_threads)
         inc_kill_slot(M, dead, (uint32_t)(t / (uint32_t)INC_SLOTS_PER_POINT), (int)(t % (uint32_t)INC_SLOTS_PER_POINT));
+}
+__global__ void inc_kill_counted_kernel(MapRW M, const float4* __restrict__ dead, uint32_t dead_cap) {
+    inc_kill_counted_item(M, dead, dead_cap, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 __device__ __forceinline__ void inc_kill_slot(const MapRW& M, const float4* __restrict__ dead, uint32_t j, int w) {
     const float4 p = dead[j];
@@ -464,8 +467,7 @@ __device__ __forceinline__ bool inc_group_leader(const GroupRW& G, const uint32_
 }
 
 // pass 2: per (voxel group, target): find / create the target's slot and take the group's share of its batch tail
-__global__ void inc_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void inc_register_item(const MapRW& M, const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint32_t t) {
     int l, c;
     uint32_t gs;
     if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
@@ -495,13 +497,15 @@ __global__ void inc_register_kernel(MapRW M, GroupRW G, const uint32_t* __restri
     G.gbase[l][r] = atomicAdd(&L.aux[slot].pending, n_v);
     G.gslot[l][r] = slot;
 }
+__global__ void inc_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
+    inc_register_item(M, G, alive, k, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // pass 3: the group that took offset 0 of a target's tail makes room for the whole batch: a run that cannot take
 // its pending entries gets fresh space at the end of the pool (1.5x the new size); the move itself is listed for
 // inc_relocate_kernel
-__global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
-                                   uint32_t reloc_cap, uint32_t* __restrict__ n_reloc) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
+                                   uint32_t reloc_cap, uint32_t* __restrict__ n_reloc, uint32_t t) {
     int l, c;
     uint32_t gs;
     if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
@@ -537,17 +541,21 @@ __global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restric
     }
     L.aux[slot].tail0 = e.w;
 }
+__global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
+                                   uint32_t reloc_cap, uint32_t* __restrict__ n_reloc) {
+    inc_reserve_item(M, G, alive, k, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // pass 3b: the listed runs move, 32 threads per run
 constexpr int RELOC_LANES = 32;
-__global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc) {
+__device__ __forceinline__ void inc_relocate_item(const MapRW& M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc,
+                                                  uint32_t t, uint32_t n_threads) {
     if (M.cnt->overflow) return;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = t % (uint32_t)RELOC_LANES;
     const uint32_t n = *n_reloc < reloc_cap ? *n_reloc : reloc_cap;
     // (grid-stride over the listed runs: how many there are is only known here, and a launch sized for the list's capacity
     // spent 23 us of a small batch on workgroups that had nothing to move)
-    for (uint32_t r = t / (uint32_t)RELOC_LANES; r < n; r += gridDim.x * blockDim.x / (uint32_t)RELOC_LANES) {
+    for (uint32_t r = t / (uint32_t)RELOC_LANES; r < n; r += n_threads / (uint32_t)RELOC_LANES) {
         const uint4 m = reloc[r];   // {level, old start, new start, count}
         if ((int)m.x < SORTED_LEVELS) {
             float* xs = M.bxyz[m.x];
@@ -564,6 +572,9 @@ __global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, ui
         }
     }
 }
+__global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc) {
+    inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 // where new point j goes in target (l, c): its table slot and the position inside the run
 __device__ __forceinline__ bool inc_place_of(const MapRW& M, const GroupRW& G, uint32_t j, int w, int& tl, uint32_t& slot, uint32_t& pos) {
@@ -579,10 +590,9 @@ __device__ __forceinline__ bool inc_place_of(const MapRW& M, const GroupRW& G, u
 
 // pass 4: ids into the tails of the sorted levels (arbitrary order inside a tail); the unordered runs (level-2 buckets,
 // voxel lists) take the whole record at once
-__global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
-                                const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base) {
+__device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, uint32_t t) {
     if (M.cnt->overflow) return;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
     const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
     if (j >= k || !alive[j]) return;
@@ -602,12 +612,15 @@ __global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ n
         M.cellpos[id] = pos;
     }
 }
+__global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base) {
+    inc_fill_item(M, G, newp, alive, apos, k, id_base, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // pass 5: rank of every new bucket entry among the ids of its tail (levels 0, 1)
-__global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
-                                uint32_t id_base, uint32_t* __restrict__ rank) {
+__device__ __forceinline__ void inc_rank_item(const MapRW& M, const GroupRW& G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                uint32_t id_base, uint32_t* __restrict__ rank, uint32_t t) {
     if (M.cnt->overflow) return;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
     if (j >= k || !alive[j]) return;
@@ -621,12 +634,15 @@ __global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__
     for (uint32_t i = 0; i < a.pending; ++i) r += ids[i] < id ? 1u : 0u;
     rank[t] = r;
 }
+__global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
+                                uint32_t id_base, uint32_t* __restrict__ rank) {
+    inc_rank_item(M, G, alive, apos, k, id_base, rank, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // pass 6: every new bucket entry goes to its ranked place (all reads of pass 5 are done: kernel boundary)
-__global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
-                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {
+__device__ __forceinline__ void inc_place_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank, uint32_t t) {
     if (M.cnt->overflow) return;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
     if (j >= k || !alive[j]) return;
@@ -640,10 +656,13 @@ __global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ 
     M.bxyz[tl][at * 3 + 2] = p.z;
     M.bidx[tl][at] = id_base + apos[j];
 }
+__global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
+                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {
+    inc_place_item(M, G, newp, alive, apos, k, id_base, rank, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // pass 7: the owner of every touched target takes the batch tail in
-__global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void inc_commit_item(const MapRW& M, const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint32_t t) {
     int l, c;
     uint32_t gs;
     if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
@@ -654,6 +673,9 @@ __global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict
     if (M.cnt->overflow == 0u) L.table[slot].w += L.aux[slot].pending;
     L.aux[slot].pending = 0u;
     L.aux[slot].fill = 0u;
+}
+__global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
+    inc_commit_item(M, G, alive, k, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- eviction --------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 // stays coherent for every IKFoM pass).  Results are always reported in ORIGINAL scan order: each
 // record carries its original index in .w.
 #include "lv_host.hpp"
+#include "lv_ldssort.hpp"
 
 #include <cstring>
 
@@ -198,19 +199,7 @@ __global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint64_
 constexpr int SMALL_WINDOW = 2048;
 constexpr int SW_THREADS = 1024;
 __device__ __forceinline__ void lds_bitonic_u64(uint64_t* s_key, uint32_t n, int tid) {
-    uint32_t len = 64;
-    while (len < n) len <<= 1;
-    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < len / 2; t += SW_THREADS) {
-                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
-                const bool up = (lo & k2) == 0;
-                const uint64_t a = s_key[lo], b = s_key[hi];
-                if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    lds_bitonic_sort_u64<SW_THREADS>(s_key, lds_sort_len(n), tid);   // (padding sorts last; lv_ldssort.hpp)
 }
 __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* __restrict__ raw, const double* __restrict__ times,
                                                                   uint32_t n_in, const MotionState* __restrict__ states,
@@ -390,18 +379,25 @@ __global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* 
     }
 }
 
-// ---- larger windows (a 0.01 s window of a 64-ring sensor holds ~13 k raw points): four launches + the library sort ----------
+// ---- larger windows (a 0.01 s window of a 64-ring sensor holds ~13 k raw points): two launches + the library sort -------------
 // The general chain below is thirteen launches and two host round trips for ~40 us of work.  Here: (1) de-skew straight from the
-// LiDAR buffer + bounds, (2) leaf keys, (3) the library's stable sort, (4) ONE workgroup for everything behind the sort — leaf
+// LiDAR buffer + bounds + sort keys, (2) the library's stable sort, (3) ONE workgroup for everything behind the sort — leaf
 // heads, their scan, the centroids (one leaf per thread: the sequential f32 sum in input order, eight loads in flight), the
 // Morton order of the few hundred output points, tile ranges and tile order — which posts (points out, status) as a note
 // (lv_note.hpp).  Every stage computes what its stand-alone kernel computes, in the same order: bit-identical results
-// (tests/test_gpu_deskew.py runs both).  Limit: WT_OUT output points; beyond it the tail declines (status 1) and the caller
-// continues with the general chain from the sorted keys.
+// (tests/test_gpu_cloud.py runs both).  Limits: WT_IN points in, WT_OUT out; beyond them the tail declines (status 1) and the
+// caller takes the general chain.
 constexpr int WT_OUT = 4096;
-__global__ __launch_bounds__(256) void deskew_bounds_kernel(const CloudPoint* __restrict__ cloud, uint32_t n, const MotionState* __restrict__ states,
-                                                            uint32_t n_states, MotionState xt2, float4* __restrict__ out,
-                                                            unsigned* __restrict__ bounds) {
+constexpr int WT_IN = 16384;
+constexpr long long WT_HALF = 1ll << 20;   // leaf coordinates of a window are taken relative to -2^20 (21-bit fields of the sort key)
+// (1) de-skew + bounds + sort keys.  The voxel grid's leaf index i0 + i1 * div0 + i2 * div0 * div1 (vg_keys_kernel) orders the
+// leaves exactly like the triple (i2, i1, i0) does — a mixed-radix number — and subtracting the grid's minimum from every
+// coordinate changes neither order nor equality: the key (i2, i1, i0) in three 21-bit fields relative to a FIXED offset gives
+// the same sorted sequence and the same leaf boundaries without knowing the bounds first, which is what cost a launch of its
+// own.  A coordinate outside the fields (|x| >= 2^20 leaves: 500 km at 0.5 m) raises bounds[7]: the tail then declines.
+__global__ __launch_bounds__(256) void deskew_keys_kernel(const CloudPoint* __restrict__ cloud, uint32_t n, const MotionState* __restrict__ states,
+                                                          uint32_t n_states, MotionState xt2, float inv_leaf, float4* __restrict__ out,
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, unsigned* __restrict__ bounds) {
     __shared__ unsigned s_b[6];
     if (threadIdx.x < 3) s_b[threadIdx.x] = 0xFFFFFFFFu;
     else if (threadIdx.x < 6) s_b[threadIdx.x] = 0u;
@@ -412,9 +408,16 @@ __global__ __launch_bounds__(256) void deskew_bounds_kernel(const CloudPoint* __
         const CloudPoint c = cloud[i];
         const float4 o = deskew_point(make_float4(c.x, c.y, c.z, 0.f), c.time, i, states, n_states, xt2);
         out[i] = o;
+        uint64_t key = ~0ull >> 1;   // dropped (sorted last): vg_keys_kernel
         if (isfinite(o.x) && isfinite(o.y) && isfinite(o.z)) {
             lo[0] = hi[0] = flip_f32(o.x); lo[1] = hi[1] = flip_f32(o.y); lo[2] = hi[2] = flip_f32(o.z);
+            const long long i0 = (long long)floorf(o.x * inv_leaf), i1 = (long long)floorf(o.y * inv_leaf), i2 = (long long)floorf(o.z * inv_leaf);
+            const long long lim = WT_HALF - 2;
+            if (i0 < -lim || i0 > lim || i1 < -lim || i1 > lim || i2 < -lim || i2 > lim) atomicOr(&bounds[7], 1u);
+            else key = ((uint64_t)(i2 + WT_HALF) << 42) | ((uint64_t)(i1 + WT_HALF) << 21) | (uint64_t)(i0 + WT_HALF);
         }
+        keys[i] = key;
+        idx[i] = i;
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -431,35 +434,42 @@ __global__ __launch_bounds__(256) void deskew_bounds_kernel(const CloudPoint* __
     if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s_b[threadIdx.x]);
     else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s_b[threadIdx.x]);
 }
+// (3) everything behind the sort, by one workgroup.  The sorted keys are only needed to tell where a leaf begins: they are read
+// once, coalesced, and what stays in LDS is one word per sorted element — its input index, bit 31 set on the first element of
+// a leaf (all ones: a dropped point) — from which the heads are counted and scanned (a run of consecutive elements per thread)
+// and the leaves' members are walked.
 __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* __restrict__ desk, const uint64_t* __restrict__ keys_sorted,
                                                                  const uint32_t* __restrict__ idx_sorted, uint32_t n_in, float inv_sort_cell,
                                                                  uint32_t tile_points, float4* __restrict__ out_raw,
                                                                  float4* __restrict__ out_sorted, uint32_t* __restrict__ tile_order,
                                                                  unsigned* __restrict__ bounds, unsigned long long* __restrict__ note,
                                                                  uint32_t seq) {
-    __shared__ float4 s_out[WT_OUT];
-    __shared__ uint64_t s_mkey[WT_OUT];
-    __shared__ float s_r2[WT_OUT];
+    __shared__ __attribute__((aligned(16))) unsigned char s_region[WT_OUT * (sizeof(float4) + sizeof(uint64_t) + sizeof(float))];
     __shared__ uint32_t s_headpos[WT_OUT];
     __shared__ uint32_t s_wsum[SW_THREADS / 64 + 1];
+    static_assert(sizeof(s_region) >= WT_IN * sizeof(uint32_t), "the element words overlay the output region");
+    uint32_t* s_hi = reinterpret_cast<uint32_t*>(s_region);
     const int tid = threadIdx.x;
     auto report = [&](uint32_t n_out, uint32_t status) {
         if (tid == 0) { bounds[6] = n_out; bounds[7] = status; note_post(note, seq, n_out); note_post(note + 1, seq, status); }
     };
-    if (bounds[0] == 0xFFFFFFFFu) { report(0u, 0u); return; }   // no finite point: nothing to match
-    constexpr uint64_t DROPPED = ~0ull >> 1;                     // (vg_keys_kernel's key of a dropped point: sorted last)
+    if (bounds[7] != 0u || n_in > (uint32_t)WT_IN) { report(0u, 1u); return; }   // (a coordinate outside the key's fields; too many points)
+    if (bounds[0] == 0xFFFFFFFFu) { report(0u, 0u); return; }                     // no finite point: nothing to match
+    constexpr uint64_t DROPPED = ~0ull >> 1;
+    constexpr uint32_t HEAD = 0x80000000u, GONE = 0xFFFFFFFFu;
+#pragma unroll 4
+    for (uint32_t i = tid; i < n_in; i += SW_THREADS) {
+        const uint64_t k = keys_sorted[i];
+        const uint64_t kp = i ? keys_sorted[i - 1] : 0ull;
+        const uint32_t id = idx_sorted[i];
+        s_hi[i] = k == DROPPED ? GONE : ((i == 0 || k != kp) ? (HEAD | id) : id);
+    }
+    __syncthreads();
     // ---- leaf heads (vg_heads_kernel) of this thread's run of consecutive sorted elements, then their exclusive scan
     const uint32_t per = (n_in + SW_THREADS - 1) / SW_THREADS;
     const uint32_t b0 = per * (uint32_t)tid, b1 = b0 + per < n_in ? b0 + per : n_in;
     uint32_t hcnt = 0;
-    {
-        uint64_t prev = b0 > 0 && b0 < n_in ? keys_sorted[b0 - 1] : 0ull;
-        for (uint32_t i = b0; i < b1; ++i) {
-            const uint64_t k = keys_sorted[i];
-            hcnt += (k != DROPPED && (i == 0 || k != prev)) ? 1u : 0u;
-            prev = k;
-        }
-    }
+    for (uint32_t i = b0; i < b1; ++i) { const uint32_t v = s_hi[i]; hcnt += (v & HEAD) && v != GONE ? 1u : 0u; }
     uint32_t incl = hcnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -478,52 +488,56 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
     if (n_out > (uint32_t)WT_OUT) { report(0u, 1u); return; }
     {
         uint32_t o = s_wsum[tid >> 6] + incl - hcnt;
-        uint64_t prev = b0 > 0 && b0 < n_in ? keys_sorted[b0 - 1] : 0ull;
-        for (uint32_t i = b0; i < b1; ++i) {
-            const uint64_t k = keys_sorted[i];
-            if (k != DROPPED && (i == 0 || k != prev)) s_headpos[o++] = i;
-            prev = k;
-        }
+        for (uint32_t i = b0; i < b1; ++i) { const uint32_t v = s_hi[i]; if ((v & HEAD) && v != GONE) s_headpos[o++] = i; }
     }
     __syncthreads();
-    // ---- centroid per leaf (vg_centroid_kernel), one leaf per thread at a time
-    for (uint32_t o = tid; o < n_out; o += SW_THREADS) {
+    // ---- centroid per leaf (vg_centroid_kernel): the sequential f32 sum of its points in input order, one leaf per thread at a time
+    constexpr int OPT = WT_OUT / SW_THREADS;
+    float4 cen[OPT];
+#pragma unroll
+    for (int r = 0; r < OPT; ++r) {
+        const uint32_t o = (uint32_t)tid + (uint32_t)r * SW_THREADS;
+        cen[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o >= n_out) continue;
         const uint32_t i = s_headpos[o];
-        const uint64_t k = keys_sorted[i];
         float sx = 0.f, sy = 0.f, sz = 0.f;
         constexpr int C = 8;
         uint32_t j = i;
         bool more = true;
         while (more) {
-            uint64_t kk[C];
-            uint32_t id[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const uint32_t jj = j + c < n_in ? j + c : n_in - 1;
-                kk[c] = keys_sorted[jj];
-                id[c] = idx_sorted[jj];
-            }
+            uint32_t e[C];
             float4 pp[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) pp[c] = desk[id[c]];
+            for (int c = 0; c < C; ++c) {
+                e[c] = j + c < n_in ? s_hi[j + c] : GONE;
+                const uint32_t id = e[c] & ~HEAD;
+                pp[c] = desk[id < n_in ? id : 0u];
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                if (more && j + c < n_in && kk[c] == k) { sx += pp[c].x; sy += pp[c].y; sz += pp[c].z; }
+                const bool member = (j + c == i) || !(e[c] & HEAD);   // (the head itself, then elements without the head bit)
+                if (more && member) { sx += pp[c].x; sy += pp[c].y; sz += pp[c].z; }
                 else if (more) { more = false; j += c; }
             }
             if (more) j += C;
         }
         const float cnt = (float)(j - i);
-        const float4 cen = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
-        s_out[o] = cen;
-        out_raw[o] = cen;
+        cen[r] = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
+    }
+    __syncthreads();   // nobody reads the element words any more: the region becomes output points | Morton keys | ranges
+    float4* s_out = reinterpret_cast<float4*>(s_region);
+    uint64_t* s_mkey = reinterpret_cast<uint64_t*>(s_region + WT_OUT * sizeof(float4));
+    float* s_r2 = reinterpret_cast<float*>(s_region + WT_OUT * (sizeof(float4) + sizeof(uint64_t)));
+#pragma unroll
+    for (int r = 0; r < OPT; ++r) {
+        const uint32_t o = (uint32_t)tid + (uint32_t)r * SW_THREADS;
+        if (o < n_out) { s_out[o] = cen[r]; out_raw[o] = cen[r]; }
     }
     __syncthreads();
     if (n_out == 0) { report(0u, 0u); return; }
     // ---- Morton order of the output, tile ranges, tile order (scan_sort_small_kernel)
     const float ox = unflip_f32(bounds[0]), oy = unflip_f32(bounds[1]), oz = unflip_f32(bounds[2]);
-    uint32_t len2 = 64;
-    while (len2 < n_out) len2 <<= 1;
+    const uint32_t len2 = lds_sort_len(n_out);
     for (uint32_t i = tid; i < len2; i += SW_THREADS) {
         uint64_t k = ~0ull;
         if (i < n_out) {
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
         s_mkey[i] = k;
     }
     __syncthreads();
-    lds_bitonic_u64(s_mkey, n_out, tid);
+    lds_bitonic_sort_u64<SW_THREADS>(s_mkey, len2, tid);
     for (uint32_t i = tid; i < n_out; i += SW_THREADS) {
         const float4 p = s_out[(uint32_t)s_mkey[i]];
         out_sorted[i] = p;
@@ -649,10 +663,10 @@ int ScanStore::window_small(hipStream_t stream, const float4* src, uint32_t n_in
 }
 
 bool ScanStore::large_window_applies(uint32_t n_in, uint32_t n_states, float leaf) const {
-    return large_enabled && n_in > 0 && leaf > 0.f && tile_points >= 4 && n_states >= 2;
+    return large_enabled && n_in > 0 && n_in <= (uint32_t)WT_IN && leaf > 0.f && tile_points >= 4 && n_states >= 2;
 }
 
-// windows beyond SMALL_WINDOW points, straight from the LiDAR buffer (cloud = its first point): deskew_bounds_kernel, leaf keys,
+// windows beyond SMALL_WINDOW points (up to WT_IN), straight from the LiDAR buffer (cloud = its first point): deskew_keys_kernel,
 // the library sort, window_tail_kernel.  d_bounds must hold "nothing seen" (CloudStore::window resets it when asked to).
 // *fell_back: the tail declined (more than WT_OUT points out): nothing was produced, d_desk holds the de-skewed points.
 int ScanStore::window_large(hipStream_t stream, const CloudPoint* cloud, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf,
@@ -667,8 +681,8 @@ int ScanStore::window_large(hipStream_t stream, const CloudPoint* cloud, uint32_
     const uint32_t seq = notes.next();
     const int B = 256;
     const uint32_t grid = (n_in + B - 1) / B;
-    hipLaunchKernelGGL(deskew_bounds_kernel, dim3(grid), dim3(B), 0, stream, cloud, n_in, d_states, n_states, xt2, d_desk, d_bounds);
-    hipLaunchKernelGGL(vg_keys_kernel, dim3(grid), dim3(B), 0, stream, d_desk, n_in, d_bounds, 1.0f / leaf, d_vkeys, d_vidx);
+    hipLaunchKernelGGL(deskew_keys_kernel, dim3(grid), dim3(B), 0, stream, cloud, n_in, d_states, n_states, xt2, 1.0f / leaf, d_desk, d_vkeys, d_vidx,
+                       d_bounds);
     size_t tmp = vsort_tmp_bytes;
     LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_vsort_tmp, tmp, d_vkeys, d_vkeys_sorted, d_vidx, d_vidx_sorted, (int)n_in, 0, 63,
                                                            stream));
@@ -778,19 +792,7 @@ __global__ __launch_bounds__(1024) void scan_sort_small_kernel(const float4* __r
     }
     __syncthreads();
     // bitonic network over the smallest power of two that holds n (padding sorts last)
-    uint32_t len = 64;
-    while (len < n) len <<= 1;
-    for (uint32_t k2 = 2; k2 <= len; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < len / 2; t += 1024) {
-                const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
-                const bool up = (lo & k2) == 0;
-                const uint64_t a = s_key[lo], b = s_key[hi];
-                if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    lds_bitonic_sort_u64<1024>(s_key, lds_sort_len(n), tid);
 #pragma unroll
     for (int h = 0; h < SMALL_SCAN / 1024; ++h) {
         const uint32_t i = (uint32_t)tid + (uint32_t)h * 1024u;

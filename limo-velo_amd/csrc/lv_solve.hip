@@ -36,16 +36,20 @@ struct StateArg {
     double v[NX];
     double P[NS * NS];
 };
-__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, int from_host, StateArg xin) {
+// filt != nullptr (lv_correct): the state and covariance come from the resident filter — or, when that filter is still the
+// posterior of the previous update and has not been copied out of kf yet (filt_in_kf), from kf->x / kf->P_post — and are
+// installed in kf->x / kf->P_prop as filter_to_kf_kernel would have done in a launch of its own.
+__global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, int from_host, StateArg xin, const FilterDev* filt, int filt_in_kf) {
     __shared__ double s_x[NX];
     __shared__ double s_rot[4][9];
     __shared__ float s_tmp[8];
     const int tid = threadIdx.x;
     double p = 0.0;
-    if (tid < NS * NS) p = from_host ? xin.P[tid] : kf->P_prop[tid];
+    const bool install = from_host || filt != nullptr;
+    if (tid < NS * NS) p = from_host ? xin.P[tid] : (filt ? (filt_in_kf ? kf->P_post[tid] : filt->P[tid]) : kf->P_prop[tid]);
     if (tid < NX) {
-        const double v = from_host ? xin.v[tid] : kf->x[tid];
-        if (from_host) kf->x[tid] = v;
+        const double v = from_host ? xin.v[tid] : ((filt && !filt_in_kf) ? filt->x[tid] : kf->x[tid]);
+        if (install) kf->x[tid] = v;
         kf->x_prop[tid] = v;
         io->x[tid] = v;
         s_x[tid] = v;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(576) void kf_begin_kernel(KfDev* kf, KfHostIO* io, 
     __syncthreads();
     if (tid >= 64 && tid < 128) pose_consts_stage_b(tid - 64, s_rot, &kf->pose, s_tmp);
     if (tid < NS * NS) {
-        if (from_host) kf->P_prop[tid] = p;
+        if (install) kf->P_prop[tid] = p;
         kf->P_post[tid] = p;
         io->P_post[tid] = p;   // an update without a terminal pass returns the propagated covariance
     }
@@ -394,11 +398,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(KfDev* kf, KfHostI
 #undef SV_STAMP
 }
 
-int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host) {
+int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host, const FilterDev* filt, int filt_in_kf) {
     StateArg xin;   // 4.4 KB of kernel arguments (copied into the kernarg buffer by the launch)
     if (x_host) { std::memcpy(xin.v, x_host, sizeof(xin.v)); std::memcpy(xin.P, x_host + NX, sizeof(xin.P)); }   // KfHostIO: x_in, P_in contiguous
     else std::memset(&xin, 0, sizeof(xin));
-    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, x_host ? 1 : 0, xin);
+    hipLaunchKernelGGL(kf_begin_kernel, dim3(1), dim3(576), 0, stream, kf, io, x_host ? 1 : 0, xin, filt, filt_in_kf);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }

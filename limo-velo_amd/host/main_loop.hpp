@@ -9,11 +9,22 @@
 // between the stages (same results, no host round trips) instead of the reference's by-value hand-overs.
 #pragma once
 
+#include <chrono>
+
 #include "limovelo_shim.hpp"
 
 struct LoopClock {      // the time variables of main.cpp:44-49
     double t1 = 0, t2 = 1e300, delta = 0;
 };
+
+// optional host wall-clock per stage of run_cycle (stream_demo: LV_DEMO_TIMING=1); no effect on the loop itself
+struct LoopTimes {
+    bool on = false;
+    double propagate = 0, window = 0, correct = 0, map_add = 0, clear = 0;
+    unsigned long cycles = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+inline LoopTimes& loop_times() { static LoopTimes t; return t; }
 
 // returns true if a localisation happened in this turn
 inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, Mapper& map, LoopClock& clk, bool on_device,
@@ -26,7 +37,11 @@ inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, M
     clk.t1 = std::max(clk.t2 - clk.delta, loc.last_time_updated);
     if (clk.t2 - clk.t1 < clk.delta - 1e-6) return false;
     // Step 1. LOCALIZATION (:75-93)
+    LoopTimes& lt = loop_times();
+    double tq = lt.on ? LoopTimes::now() : 0.0;
+    auto lap = [&](double& acc) { if (lt.on) { const double t = LoopTimes::now(); acc += t - tq; tq = t; } };
     loc.propagate_to(clk.t2);
+    lap(lt.propagate);
     State Xt2;
     if (!on_device) {
         Points compensated = comp.compensate(clk.t1, clk.t2);
@@ -41,11 +56,14 @@ inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, M
         if (n_points) *n_points = ds_compensated.size();
     } else {
         const size_t n_ds = comp.compensate_downsample_on_device(clk.t1, clk.t2);
+        lap(lt.window);
         if ((int)n_ds < Config.MAX_POINTS2MATCH) return false;
         loc.correct_current_scan(clk.t2);
         Xt2 = loc.latest_state();
         accum.add(Xt2, clk.t2);
+        lap(lt.correct);
         if (Config.mapping_online) map.add_current_scan(clk.t2, true);
+        lap(lt.map_add);
         if (n_points) *n_points = n_ds;
     }
     // Step 2, mapping offline (:105-116): once per full rotation the whole sweep [t2 - FULL_ROTATION_TIME, t2] is de-skewed
@@ -60,6 +78,8 @@ inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, M
     }
     // Step 3. ERASE OLD DATA (:116-118)
     accum.clear_lidar(clk.t2 - Config.empty_lidar_time);
+    lap(lt.clear);
+    ++lt.cycles;
     if (Xt2_out) *Xt2_out = Xt2;
     return true;
 }

@@ -58,3 +58,46 @@ def test_propagate_correct_cycles(lv, oracle, scene_small):
             assert np.abs(Pg - P).max() < 1e-8 * max(1.0, np.abs(P).max())
             x, P = xg, Pg  # continue from the device state so rounding does not accumulate in the comparison
     assert np.linalg.norm(x[:3] - sc["x_true"][:3]) < 5e-3
+
+
+def test_batched_predictions_and_lazy_filter_copies_change_no_bit(lv, scene_small):
+    """lv_predict calls are queued and launched up to eight steps at a time; after lv_correct the posterior stays in the update's
+    working copy until something needs it in the filter's own buffer (the next prediction reads it from there, the next
+    correct starts from there).  A propagate -> correct -> propagate sequence gives the same bits with one launch per
+    prediction, with the copies made eagerly (mail_filter = 0 reads the filter buffer), and with a changing Q in the queue."""
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    rng = np.random.default_rng(9)
+    steps = [(0.005 if i % 5 else 0.011, np.array([0.2, -0.1, 9.8]) + rng.normal(scale=0.2, size=3),
+              np.array([0.01, 0.02, 0.2]) + rng.normal(scale=0.05, size=3)) for i in range(23)]
+    Q2 = _Q() * 1.5
+    res = {}
+    for batch, mail in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        with capi.Context() as ctx:
+            ctx.set_option("batch_predict", batch)
+            ctx.set_option("mail_filter", mail)
+            ctx.map_build(sc["map_xyz"])
+            ctx.scan_set(sc["scan_xyz"][:5000])
+            ctx.filter_set(sc["x_init"], sc["P0"])
+            out = []
+            for i, (dt, a, g) in enumerate(steps):
+                ctx.predict(dt, Q2 if i in (11, 12) else _Q(), a, g)      # (a different Q in the middle of a queue)
+                if i in (2, 12, 13, 22):
+                    ctx.correct(want_passes=False)
+                    if i == 13:
+                        ctx.correct(want_passes=False)                      # two updates without a prediction in between
+                    if i != 12:
+                        out.append(ctx.filter_get())
+            # a by-value update in between must not disturb the resident filter
+            ctx.predict(0.004, _Q(), steps[0][1], steps[0][2])
+            ctx.correct(want_passes=False)
+            ctx.update(sc["x_init"], sc["P0"], want_trace=False)
+            ctx.predict(0.004, _Q(), steps[1][1], steps[1][2])
+            out.append(ctx.filter_get())
+            res[(batch, mail)] = out
+    ref = res[(0, 0)]
+    for key, out in res.items():
+        assert len(out) == len(ref)
+        for (xa, Pa), (xb, Pb) in zip(out, ref):
+            assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), key
