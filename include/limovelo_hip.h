@@ -227,6 +227,10 @@ int    lv_cloud_clear(lv_ctx* ctx, double t);
  * max_points_per_message records of point_step bytes and a LiDAR buffer of buffer_points points now, instead of on the first
  * message (pinned allocations take milliseconds: the first sweep of a stream otherwise pays them). */
 int    lv_cloud_reserve(lv_ctx* ctx, size_t max_points_per_message, size_t point_step, size_t buffer_points);
+/* Optional: size the work buffers of the 100 Hz cycle now — the de-skew / voxel-grid buffers for windows of up to
+ * max_window_points raw points, the scan / hand-over / insert buffers for scans of up to max_scan_points points — instead of
+ * growing them (allocate, synchronise, free) during the first cycles of a stream. */
+int    lv_reserve_stream(lv_ctx* ctx, size_t max_window_points, size_t max_scan_points);
 int    lv_scan_deskew_window(lv_ctx* ctx, double t1, double t2, const lv_motion_state* states, size_t n_states,
                              const lv_motion_state* Xt2, float downsample_prec, size_t* n_window);
 

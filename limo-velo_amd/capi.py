@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_last_passes", "lv_set_fused_pass", "lv_set_option", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather", "lv_comm_peer_export", "lv_comm_peer_init",
-    "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_cloud_reserve", "lv_scan_deskew_window",
+    "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_cloud_reserve", "lv_reserve_stream", "lv_scan_deskew_window",
 ]
 
 
@@ -295,6 +295,9 @@ class Context:
 
     def cloud_reserve(self, max_points_per_message: int, point_step: int, buffer_points: int):
         self._check(self.lib.lv_cloud_reserve(self.h, C.c_size_t(max_points_per_message), C.c_size_t(point_step), C.c_size_t(buffer_points)))
+
+    def reserve_stream(self, max_window_points: int, max_scan_points: int):
+        self._check(self.lib.lv_reserve_stream(self.h, C.c_size_t(max_window_points), C.c_size_t(max_scan_points)))
 
     def cloud_clear(self, t: float):
         self._check(self.lib.lv_cloud_clear(self.h, C.c_double(t)))

@@ -981,6 +981,38 @@ int lv_cloud_reserve(lv_ctx* c, size_t max_points_per_message, size_t point_step
     return buffer_points ? c->cloud.reserve_buffer(c->stream, (size_t)c->cloud.size + buffer_points) : LV_OK;
 }
 
+int lv_reserve_stream(lv_ctx* c, size_t max_window_points, size_t max_scan_points) {
+    LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
+    if (max_window_points > 0x7FFFFFF0ull || max_scan_points > 0x7FFFFFF0ull) { set_error("bad sizes"); return LV_EINVAL; }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    int rc = LV_OK;
+    if (max_window_points) {
+        rc = c->scan.reserve_raw(max_window_points, 64);
+        if (!rc) rc = c->scan.reserve(max_window_points);
+        if (!rc && c->scan.tile_points) rc = c->scan.reserve_tiles((uint32_t)((max_window_points + c->scan.tile_points - 1) / c->scan.tile_points));
+        if (rc) return rc;
+        LV_HIP(note_alloc(c->scan.notes));
+        if (!c->h_states_ring) LV_HIP(hipHostMalloc((void**)&c->h_states_ring, 8 * 64 * sizeof(MotionState), hipHostMallocDefault));
+    }
+    if (max_scan_points) {
+        rc = c->scan.reserve(max_scan_points);
+        if (!rc) rc = c->map.reserve_batch(max_scan_points);
+        if (rc) return rc;
+        LV_HIP(note_alloc(c->map.notes));
+        if ((uint32_t)max_scan_points > c->qstride) {
+            uint32_t cap = c->qstride ? c->qstride : 4096;
+            while (cap < (uint32_t)max_scan_points) cap *= 2;
+            hipFree(c->d_qrec);
+            c->d_qrec = nullptr;
+            c->qstride = 0;
+            LV_HIP(hipMalloc(&c->d_qrec, (size_t)cap * 8 * sizeof(float4)));
+            c->qstride = cap;
+        }
+    }
+    return LV_OK;
+}
+
 size_t lv_cloud_size(lv_ctx* c) {
     if (!c) return 0;
     c->cloud.settle();

@@ -71,7 +71,12 @@ int main(int argc, char** argv) {
         {   // a node sizes its LiDAR buffers when it starts, not when the first sweep arrives
             size_t max_n = 0;
             for (const auto& m : msgs) max_n = std::max(max_n, (size_t)m.n);
-            if (max_n && !getenv("LV_DEMO_NO_RESERVE")) lv_cloud_reserve(HipRuntime::ctx(), max_n, fmt.point_step, 4 * max_n);
+            if (max_n && !getenv("LV_DEMO_NO_RESERVE")) {
+                lv_cloud_reserve(HipRuntime::ctx(), max_n, fmt.point_step, 4 * max_n);
+                // a window of delta seconds holds delta / FULL_ROTATION_TIME of a sweep (twice that for slack); scans after the voxel grid are smaller
+                const size_t win = (size_t)(2.0 * (double)max_n * std::max(delta, 0.01) / std::max(Config.full_rotation_time, 0.01)) + 4096;
+                lv_reserve_stream(HipRuntime::ctx(), on_device ? win : 0, 8192);
+            }
         }
         loop_times().on = getenv("LV_DEMO_TIMING") != nullptr;
         double t_ingest = 0.0, t_imu = 0.0;
