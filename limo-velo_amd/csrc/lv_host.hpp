@@ -298,6 +298,7 @@ struct ScanStore {
     int window_large(hipStream_t stream, const struct CloudPoint* cloud, uint32_t n_in, uint32_t n_states, const MotionState& xt2, float leaf,
                      float sort_cell, bool* fell_back);
     NoteBoard notes;             // (points out, status) of the window kernels: lv_note.hpp
+    long long* d_tail_clk = nullptr;   // LV_TAIL_CLK=1: phase stamps of window_tail_kernel
     int sort(hipStream_t stream, const float bbox_min[3], float cell);
     int order_tiles(hipStream_t stream, uint32_t tile_points);
     int reserve_tiles(uint32_t nt);

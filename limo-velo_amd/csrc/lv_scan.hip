@@ -6,6 +6,7 @@
 #include "lv_host.hpp"
 #include "lv_ldssort.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <hipcub/hipcub.hpp>
@@ -443,12 +444,18 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
                                                                  uint32_t tile_points, float4* __restrict__ out_raw,
                                                                  float4* __restrict__ out_sorted, uint32_t* __restrict__ tile_order,
                                                                  unsigned* __restrict__ bounds, unsigned long long* __restrict__ note,
-                                                                 uint32_t seq) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_region[WT_OUT * (sizeof(float4) + sizeof(uint64_t) + sizeof(float))];
+                                                                 uint32_t seq, long long* __restrict__ clk) {
+#define WT_STAMP(i) do { if (clk && threadIdx.x == 0) { clk[i] = wall_clock64(); if ((i) == 4) clk[7] = clock64(); if ((i) == 5) clk[7] = clock64() - clk[7]; } } while (0)
+    WT_STAMP(0);
+    constexpr int WT_STAGE = 6144;   // sorted elements whose points are staged in LDS at a time (3 x 24 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char s_region[WT_IN * sizeof(uint32_t) + 3 * WT_STAGE * sizeof(float)];
     __shared__ uint32_t s_headpos[WT_OUT];
-    __shared__ uint32_t s_wsum[SW_THREADS / 64 + 1];
-    static_assert(sizeof(s_region) >= WT_IN * sizeof(uint32_t), "the element words overlay the output region");
+    __shared__ uint32_t s_wsum[SW_THREADS / 64 + 1], s_gsum[SW_THREADS / 64];
+    static_assert(sizeof(s_region) >= WT_OUT * (sizeof(float4) + sizeof(uint64_t) + sizeof(float)), "the output arrays overlay the element words and the stage");
     uint32_t* s_hi = reinterpret_cast<uint32_t*>(s_region);
+    float* s_px = reinterpret_cast<float*>(s_region + WT_IN * sizeof(uint32_t));
+    float* s_py = s_px + WT_STAGE;
+    float* s_pz = s_py + WT_STAGE;
     const int tid = threadIdx.x;
     auto report = [&](uint32_t n_out, uint32_t status) {
         if (tid == 0) { bounds[6] = n_out; bounds[7] = status; note_post(note, seq, n_out); note_post(note + 1, seq, status); }
@@ -465,65 +472,89 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
         s_hi[i] = k == DROPPED ? GONE : ((i == 0 || k != kp) ? (HEAD | id) : id);
     }
     __syncthreads();
+    WT_STAMP(1);
     // ---- leaf heads (vg_heads_kernel) of this thread's run of consecutive sorted elements, then their exclusive scan
     const uint32_t per = (n_in + SW_THREADS - 1) / SW_THREADS;
     const uint32_t b0 = per * (uint32_t)tid, b1 = b0 + per < n_in ? b0 + per : n_in;
-    uint32_t hcnt = 0;
-    for (uint32_t i = b0; i < b1; ++i) { const uint32_t v = s_hi[i]; hcnt += (v & HEAD) && v != GONE ? 1u : 0u; }
+    uint32_t hcnt = 0, gone = 0;
+    for (uint32_t i = b0; i < b1; ++i) { const uint32_t v = s_hi[i]; hcnt += (v & HEAD) && v != GONE ? 1u : 0u; gone += v == GONE ? 1u : 0u; }
     uint32_t incl = hcnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_up(incl, o);
         if ((tid & 63) >= o) incl += v;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gone += __shfl_xor(gone, o);
     if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    if ((tid & 63) == 0) s_gsum[tid >> 6] = gone;
     __syncthreads();
     if (tid == 0) {
-        uint32_t run = 0;
-        for (int w = 0; w < SW_THREADS / 64; ++w) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; }
+        uint32_t run = 0, g = 0;
+        for (int w = 0; w < SW_THREADS / 64; ++w) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; g += s_gsum[w]; }
         s_wsum[SW_THREADS / 64] = run;
+        s_gsum[0] = g;
     }
     __syncthreads();
     const uint32_t n_out = s_wsum[SW_THREADS / 64];
+    const uint32_t n_valid = n_in - s_gsum[0];   // (the dropped points sort last)
     if (n_out > (uint32_t)WT_OUT) { report(0u, 1u); return; }
     {
         uint32_t o = s_wsum[tid >> 6] + incl - hcnt;
         for (uint32_t i = b0; i < b1; ++i) { const uint32_t v = s_hi[i]; if ((v & HEAD) && v != GONE) s_headpos[o++] = i; }
     }
     __syncthreads();
-    // ---- centroid per leaf (vg_centroid_kernel): the sequential f32 sum of its points in input order, one leaf per thread at a time
+    WT_STAMP(2);
+    // ---- centroid per leaf (vg_centroid_kernel): the sequential f32 sum of its points in input order.  A leaf's members are
+    // consecutive sorted elements; their points are staged in LDS WT_STAGE elements at a time by the whole workgroup (six loads
+    // in flight per thread, one round trip per stage), and every thread adds up the members of its leaves that lie in the stage,
+    // in order, out of LDS — the longest leaf of a window (hundreds of points next to the sensor) was a chain of 8-load round
+    // trips of ONE thread before, most of this kernel's 25 us.
     constexpr int OPT = WT_OUT / SW_THREADS;
     float4 cen[OPT];
+    uint32_t lj[OPT], lend[OPT];
 #pragma unroll
     for (int r = 0; r < OPT; ++r) {
         const uint32_t o = (uint32_t)tid + (uint32_t)r * SW_THREADS;
         cen[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (o >= n_out) continue;
-        const uint32_t i = s_headpos[o];
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        constexpr int C = 8;
-        uint32_t j = i;
-        bool more = true;
-        while (more) {
-            uint32_t e[C];
-            float4 pp[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                e[c] = j + c < n_in ? s_hi[j + c] : GONE;
-                const uint32_t id = e[c] & ~HEAD;
-                pp[c] = desk[id < n_in ? id : 0u];
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const bool member = (j + c == i) || !(e[c] & HEAD);   // (the head itself, then elements without the head bit)
-                if (more && member) { sx += pp[c].x; sy += pp[c].y; sz += pp[c].z; }
-                else if (more) { more = false; j += c; }
-            }
-            if (more) j += C;
-        }
-        const float cnt = (float)(j - i);
-        cen[r] = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(o));
+        lj[r] = lend[r] = 0u;
+        if (o < n_out) { lj[r] = s_headpos[o]; lend[r] = o + 1u < n_out ? s_headpos[o + 1u] : n_valid; }
     }
+    for (uint32_t base = 0; base < n_valid; base += (uint32_t)WT_STAGE) {
+        const uint32_t top = base + (uint32_t)WT_STAGE < n_valid ? base + (uint32_t)WT_STAGE : n_valid;
+#pragma unroll 6
+        for (uint32_t e = base + (uint32_t)tid; e < top; e += SW_THREADS) {
+            const float4 p = desk[s_hi[e] & ~HEAD];
+            s_px[e - base] = p.x; s_py[e - base] = p.y; s_pz[e - base] = p.z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < OPT; ++r) {
+            const uint32_t stop = lend[r] < top ? lend[r] : top;
+            float sx = cen[r].x, sy = cen[r].y, sz = cen[r].z;
+            uint32_t j = lj[r];
+            // (eight members' coordinates read ahead of the adds: one LDS latency per eight members instead of per member)
+            for (; j + 8u <= stop; j += 8u) {
+                float vx[8], vy[8], vz[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { vx[c] = s_px[j - base + c]; vy[c] = s_py[j - base + c]; vz[c] = s_pz[j - base + c]; }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { sx += vx[c]; sy += vy[c]; sz += vz[c]; }
+            }
+            for (; j < stop; ++j) { sx += s_px[j - base]; sy += s_py[j - base]; sz += s_pz[j - base]; }
+            cen[r].x = sx; cen[r].y = sy; cen[r].z = sz;
+            lj[r] = j;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < OPT; ++r) {
+        const uint32_t o = (uint32_t)tid + (uint32_t)r * SW_THREADS;
+        if (o >= n_out) continue;
+        const float cnt = (float)(lend[r] - s_headpos[o]);
+        cen[r] = make_float4(cen[r].x / cnt, cen[r].y / cnt, cen[r].z / cnt, __uint_as_float(o));
+    }
+    WT_STAMP(3);
     __syncthreads();   // nobody reads the element words any more: the region becomes output points | Morton keys | ranges
     float4* s_out = reinterpret_cast<float4*>(s_region);
     uint64_t* s_mkey = reinterpret_cast<uint64_t*>(s_region + WT_OUT * sizeof(float4));
@@ -551,7 +582,9 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
         s_mkey[i] = k;
     }
     __syncthreads();
+    WT_STAMP(4);
     lds_bitonic_sort_u64<SW_THREADS>(s_mkey, len2, tid);
+    WT_STAMP(5);
     for (uint32_t i = tid; i < n_out; i += SW_THREADS) {
         const float4 p = s_out[(uint32_t)s_mkey[i]];
         out_sorted[i] = p;
@@ -576,7 +609,9 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
             tile_order[rank] = (uint32_t)tid;
         }
     }
+    WT_STAMP(6);
     report(n_out, 0u);
+#undef WT_STAMP
 }
 
 int ScanStore::reserve_raw(size_t cap, size_t n_states) {
@@ -678,6 +713,7 @@ int ScanStore::window_large(hipStream_t stream, const CloudPoint* cloud, uint32_
     if (rc) return rc;
     n_tiles = 0;
     LV_HIP(note_alloc(notes));
+    if (!d_tail_clk && getenv("LV_TAIL_CLK")) { LV_HIP(hipMalloc(&d_tail_clk, 8 * sizeof(long long))); LV_HIP(hipMemset(d_tail_clk, 0, 8 * sizeof(long long))); }
     const uint32_t seq = notes.next();
     const int B = 256;
     const uint32_t grid = (n_in + B - 1) / B;
@@ -687,10 +723,16 @@ int ScanStore::window_large(hipStream_t stream, const CloudPoint* cloud, uint32_
     LV_HIP((hipError_t)hipcub::DeviceRadixSort::SortPairs(d_vsort_tmp, tmp, d_vkeys, d_vkeys_sorted, d_vidx, d_vidx_sorted, (int)n_in, 0, 63,
                                                            stream));
     hipLaunchKernelGGL(window_tail_kernel, dim3(1), dim3(SW_THREADS), 0, stream, d_desk, d_vkeys_sorted, d_vidx_sorted, n_in, 1.0f / sort_cell,
-                       tile_points, d_raw, d_sorted, d_tile_order, d_bounds, notes.d, seq);
+                       tile_points, d_raw, d_sorted, d_tile_order, d_bounds, notes.d, seq, d_tail_clk);
     LV_HIP(hipGetLastError());
     uint32_t v[2] = {0, 0};
     if (!note_wait(notes, 0, 2, seq, v, stream)) { set_error("window kernel did not report"); return LV_EHIP; }
+    if (d_tail_clk) {   // LV_TAIL_CLK=1: phase stamps of the tail kernel (100 MHz wall clock), printed
+        long long h[8];
+        LV_HIP(hipMemcpy(h, d_tail_clk, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "window_tail us: keys->words %.2f  heads+scan %.2f  centroids %.2f  morton keys %.2f  sort %.2f  gather+tiles %.2f  (n_in %u, out %u; the sort: %lld shader cycles = %.0f MHz)\n",
+                (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0, (h[5] - h[4]) / 100.0, (h[6] - h[5]) / 100.0, n_in, v[0], h[7], h[7] / ((h[5] - h[4]) / 100.0 + 1e-9));
+    }
     if (v[1]) { *fell_back = true; return LV_OK; }
     n = v[0];
     n_tiles = n ? (n + tile_points - 1) / tile_points : 0;
@@ -761,7 +803,7 @@ void ScanStore::release() {
     hipFree(d_sort_tmp);
     hipFree(d_in); hipFree(d_times); hipFree(d_desk); hipFree(d_vkeys); hipFree(d_vkeys_sorted); hipFree(d_vidx);
     hipFree(d_vidx_sorted); hipFree(d_heads); hipFree(d_hpos); hipFree(d_vsort_tmp); hipFree(d_vscan_tmp); hipFree(d_states);
-    hipFree(d_bounds); hipFree(d_tile_order);
+    hipFree(d_bounds); hipFree(d_tile_order); hipFree(d_tail_clk);
     note_free(notes);
     *this = ScanStore();
 }
