@@ -554,6 +554,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_OVERLAP_INSERT")) c->overlap_insert = atoi(e) != 0;
     if (const char* e = getenv("LV_BATCH_PREDICT")) c->batch_predict = atoi(e) != 0;
     if (const char* e = getenv("LV_MERGED_INSERT")) c->map.merged_back = atoi(e) != 0;
+    if (const char* e = getenv("LV_SWEEP_EVICT")) c->map.sweep_evict = atoi(e) != 0;
     LV_HIP(hipMalloc(&c->d_kf, sizeof(KfDev)));
     LV_HIP(hipMemset(c->d_kf, 0, sizeof(KfDev)));
     LV_HIP(hipMalloc(&c->d_filter, sizeof(FilterDev)));
@@ -1135,6 +1136,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "overlap_insert")) c->overlap_insert = on;
     else if (!std::strcmp(name, "batch_predict")) { int rp = flush_predicts(c); if (rp) return rp; c->batch_predict = on; }
     else if (!std::strcmp(name, "merged_insert")) c->map.merged_back = on;
+    else if (!std::strcmp(name, "sweep_evict")) c->map.sweep_evict = on;
     else if (!std::strcmp(name, "small_window")) c->scan.small_enabled = on;
     else if (!std::strcmp(name, "large_window")) c->scan.large_enabled = on;
     else if (!std::strcmp(name, "small_insert")) c->map.small_front = on;

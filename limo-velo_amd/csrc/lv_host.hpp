@@ -116,6 +116,7 @@ struct MapStore {
 
     // the tail of an incremental insert (new ids / living points / overflow, read from the device counters) is settled by the
     // next call that needs the map's bookkeeping, not by a wait at the end of the insert
+    bool sweep_evict = true;     // lv_map_evict_box tests runs, not points (inc_evict_sweep_kernel; LV_SWEEP_EVICT=0 / lv_set_option: the per-point search)
     bool merged_back = true;     // independent stages of the insert's back half share launches (LV_MERGED_INSERT=0 / lv_set_option: off)
     bool small_front = true;     // batches of up to 2048 points: the insert's front half in one workgroup launch (LV_SMALL_INSERT=0: off)
     NoteBoard notes;             // the insert's counters come back as a note (lv_note.hpp): n_new, n_dead, dropped, overflow

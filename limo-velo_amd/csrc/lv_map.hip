@@ -989,6 +989,96 @@ __global__ __launch_bounds__(256) void inc_place_commit_kernel(MapRW M, GroupRW 
     else inc_commit_item(M, G, alive, k, (blockIdx.x - g_place) * blockDim.x + threadIdx.x);
 }
 
+// ---- lv_map_evict_box without a per-point search ---------------------------------------------------------------------------------
+// Every evicted point lives in 81 runs (27 neighbourhood buckets on three levels + its voxel list).  Finding them point by point
+// (inc_kill_kernel: a table probe and, on the sorted levels, a binary search over the run's ids per (point, run)) cost 8.3 ms per
+// million evicted points.  The box test can be applied to the RUNS instead: a run of table `ti` holds only points of the voxel
+// block around its voxel (27 voxels of its level; the voxel itself for the lists), so its bounding box — widened by one cell
+// against rounding — is either entirely in the region that stays (nothing to do), entirely in the region that goes (the run's
+// count drops to zero: its space is reused by later inserts, and the next sweep skips it), or cut by the box: only then are its
+// entries tested one by one, with the predicate of inc_evict_mark_kernel on the very same coordinates.  One pass over the four
+// tables, 64 slots per wavefront step; a cut run is walked by the whole wavefront.
+__global__ __launch_bounds__(256) void inc_evict_mark_kernel(float4* __restrict__ orig, uint32_t n_ids, float lx, float ly, float lz, float hx, float hy,
+                                                             float hz, int keep_inside, MapCounters* cnt) {
+    // (grid-stride, ONE atomic per workgroup: a count per point — or per wavefront — on one address serialises in the L2's
+    // atomic unit: 0.55 ms for 3.4 M evicted points, more than the sweep of every table)
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n_ids; id += gridDim.x * blockDim.x) {
+        const float4 p = orig[id];
+        if (!pt_alive(p)) continue;
+        const bool inside = p.x >= lx && p.x <= hx && p.y >= ly && p.y <= hy && p.z >= lz && p.z <= hz;
+        if (inside != (keep_inside != 0)) { orig[id].x = pos_inf(); ++mine; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(&cnt->n_dead, s_n);
+}
+__global__ __launch_bounds__(256) void inc_evict_sweep_kernel(MapRW M, int ti, float lx, float ly, float lz, float hx, float hy, float hz,
+                                                              int keep_inside) {
+    const LevelRW& L = M.lv[ti];
+    const uint32_t n_slots = L.mask + 1u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int lvl = ti == CELL_SLOT ? CELL_LEVEL : ti;
+    const int reach = ti == CELL_SLOT ? 0 : 1;
+    const float cell = 1.0f / M.inv_cell;
+    const float blo[3] = {lx, ly, lz}, bhi[3] = {hx, hy, hz};
+    for (uint32_t s0 = wave * 64u; s0 < n_slots; s0 += n_waves * 64u) {
+        const uint32_t slot = s0 + lane;
+        uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+        if (slot < n_slots) e = L.table[slot];
+        const uint64_t key = entry_key(e);
+        int action = 0;   // 0: untouched, 1: everything goes, 2: cut by the box
+        if (slot < n_slots && key != EMPTY_KEY && e.w > 0u) {
+            const int v[3] = {(int)(key & 0x1fffff), (int)((key >> 21) & 0x1fffff), (int)((key >> 42) & 0x1fffff)};
+            bool all_in = true, disjoint = false, clamped = false;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int c0 = ((v[a] - reach) << lvl) - CELL_OFFSET - 1, c1 = ((v[a] + 1 + reach) << lvl) - CELL_OFFSET + 1;
+                clamped = clamped || c0 <= -1047990 || c1 >= 1047990;   // (cell_coord clamps: the outermost cells hold points from anywhere beyond)
+                const float w0 = M.origin[a] + (float)c0 * cell, w1 = M.origin[a] + (float)c1 * cell;
+                all_in = all_in && w0 >= blo[a] && w1 <= bhi[a];
+                disjoint = disjoint || w1 < blo[a] || w0 > bhi[a];
+            }
+            const bool none_goes = keep_inside ? all_in : disjoint, all_go = keep_inside ? disjoint : all_in;
+            action = clamped ? 2 : (none_goes ? 0 : (all_go ? 1 : 2));
+        }
+        if (action == 1) L.table[slot].w = 0u;
+        unsigned long long cut = __ballot(action == 2);
+        while (cut) {
+            const int src = __ffsll((long long)cut) - 1;
+            cut &= cut - 1;
+            const uint32_t start = (uint32_t)__shfl((int)e.z, src), count = (uint32_t)__shfl((int)e.w, src);
+            bool survivor = false;
+            for (uint32_t i = lane; i < count; i += 64u) {
+                const size_t at = (size_t)start + i;
+                float x, y, z;
+                if (ti < SORTED_LEVELS) { x = M.bxyz[ti][at * 3 + 0]; y = M.bxyz[ti][at * 3 + 1]; z = M.bxyz[ti][at * 3 + 2]; }
+                else { const float4 p = ti < REPL_LEVELS ? M.bucket4[at] : M.cell4[at]; x = p.x; y = p.y; z = p.z; }
+                const bool inside = x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz;
+                const bool alive = x < pos_inf() && x > -pos_inf();
+                if (inside != (keep_inside != 0)) {   // (an entry that is dead already stays dead either way)
+                    if (alive) {
+                        if (ti < SORTED_LEVELS) M.bxyz[ti][at * 3 + 0] = pos_inf();
+                        else if (ti < REPL_LEVELS) M.bucket4[at].x = pos_inf();
+                        else M.cell4[at].x = pos_inf();
+                    }
+                } else {
+                    survivor = survivor || alive;
+                }
+            }
+            // a run without a living entry left is dropped like one that lies outside altogether: later sweeps (a rolling window
+            // cuts the same neighbourhood again and again) and searches skip it, later inserts reuse its space
+            if (!__any(survivor) && lane == 0u) L.table[s0 + (uint32_t)src].w = 0u;
+        }
+    }
+}
+
 // the outcome of an insert for the host (MapStore::settle), as a note
 __global__ void inc_post_counters_kernel(const MapCounters* __restrict__ cnt, unsigned long long* __restrict__ note, uint32_t seq) {
     if (threadIdx.x != 0) return;
@@ -1226,15 +1316,33 @@ int MapStore::evict_box(hipStream_t stream, const float lo[3], const float hi[3]
     if (!built || m == 0) return LV_OK;
     int rc = reset_batch_counters(*this, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(inc_evict_box_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, d_orig, n_ids, lo[0], lo[1], lo[2], hi[0],
-                       hi[1], hi[2], keep_inside, d_dead, (uint32_t)dead_cap, d_cnt);
-    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    const uint32_t n_dead = h_cnt->n_dead;
-    rc = kill_dead_list(stream, n_dead);
-    if (rc) return rc;
-    LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
+    uint32_t n_dead = 0;
+    if (sweep_evict) {   // (see inc_evict_sweep_kernel)
+        const uint32_t g_mark = (n_ids + 255) / 256;
+        hipLaunchKernelGGL(inc_evict_mark_kernel, dim3(g_mark < 2048u ? g_mark : 2048u), dim3(256), 0, stream, d_orig, n_ids, lo[0], lo[1], lo[2], hi[0],
+                           hi[1], hi[2], keep_inside, d_cnt);
+        const MapRW M = rw();
+        for (int ti = 0; ti < INC_LEVELS; ++ti) {
+            const uint64_t slots = (uint64_t)M.lv[ti].mask + 1u;
+            const uint64_t wgs = (slots + 255) / 256;   // 64 slots per wavefront step, four wavefronts per workgroup
+            hipLaunchKernelGGL(inc_evict_sweep_kernel, dim3((uint32_t)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, stream, M, ti, lo[0], lo[1], lo[2],
+                               hi[0], hi[1], hi[2], keep_inside);
+        }
+        LV_HIP(hipGetLastError());
+        LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        n_dead = h_cnt->n_dead;
+    } else {
+        hipLaunchKernelGGL(inc_evict_box_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, d_orig, n_ids, lo[0], lo[1], lo[2], hi[0],
+                           hi[1], hi[2], keep_inside, d_dead, (uint32_t)dead_cap, d_cnt);
+        LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+        n_dead = h_cnt->n_dead;
+        rc = kill_dead_list(stream, n_dead);
+        if (rc) return rc;
+        LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipStreamSynchronize(stream));
+    }
     m -= n_dead;
     tombstones += (uint64_t)n_dead * INC_SLOTS_PER_POINT;
     if (n_evicted) *n_evicted = n_dead;

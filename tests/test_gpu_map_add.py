@@ -257,3 +257,41 @@ def test_small_batch_front_kernel_equals_the_separate_launches(lv, scene_small):
     assert np.array_equal(maps[1][0].view(np.uint32), maps[0][0].view(np.uint32))
     assert np.array_equal(maps[1][2], maps[0][2]) and np.array_equal(maps[1][3].view(np.uint32), maps[0][3].view(np.uint32))
     assert maps[1][4] == maps[0][4] and np.array_equal(maps[1][5], maps[0][5])
+
+
+def test_eviction_by_runs_equals_eviction_by_points(lv, scene_small):
+    """lv_map_evict_box applies the box test to the RUNS (bucket / list bounding boxes: untouched, dropped whole, or walked entry
+    by entry) instead of searching every evicted point's 81 runs: the same living points, the same search results and the
+    same behaviour of later inserts, for both senses of the box, a box that cuts nothing, and one that takes everything."""
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    rng = np.random.default_rng(21)
+    batches = [(sc["map_xyz"][rng.integers(0, len(sc["map_xyz"]), n)] + rng.normal(0, 0.05, (n, 3))).astype(np.float32) for n in (3000, 900)]
+    res = {}
+    for sweep in (1, 0):
+        with capi.Context() as ctx:
+            ctx.set_option("sweep_evict", sweep)
+            ctx.map_build(sc["map_xyz"])
+            out = []
+            out.append(ctx.map_evict_box([-14.0, -17.5, -1.0], [16.25, 12.0, 9.0], keep_inside=True))
+            ctx.map_add(batches[0], downsample=True)
+            out.append(ctx.map_evict_box([-2.5, -3.0, -5.0], [3.5, 2.0, 5.0], keep_inside=False))
+            out.append(ctx.map_evict_box([-1e4] * 3, [1e4] * 3, keep_inside=True))      # cuts nothing
+            ctx.map_add(batches[1], downsample=True)
+            out.append(ctx.map_evict_box([100.0] * 3, [101.0] * 3, keep_inside=False))  # nothing inside
+            out.append(ctx.map_size())
+            ctx.scan_set(sc["scan_xyz"])
+            g = ctx.iterate(sc["x_init"])
+            idx, d2 = ctx.fetch_knn()
+            x, P, passes, _, sums = ctx.update(sc["x_init"], sc["P0"])
+            living = ctx.map_fetch()
+            out.append(ctx.map_evict_box([-1e4] * 3, [1e4] * 3, keep_inside=False))     # takes everything
+            out.append(ctx.map_size())
+            res[sweep] = (out, living, idx, d2, g["n_valid"], x, P, passes, [s["n_valid"] for s in sums])
+    a, b = res[1], res[0]
+    assert a[0] == b[0] and a[0][0] > 0 and a[0][1] > 0 and a[0][2] == 0 and a[0][3] == 0 and a[0][-1] == 0
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
+    assert a[4] == b[4] and a[7] == b[7] and a[8] == b[8]
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
