@@ -660,6 +660,14 @@ static int check_map_points(const void* points, size_t stride, size_t n) {
     return LV_OK;
 }
 
+// the stream an incremental insert runs on: the context's side stream, ordered behind what the context's stream holds so far
+// (the staged points), whenever the overlap applies (see lv_map_add_scan); the context's stream otherwise
+static hipStream_t insert_stream(lv_ctx* c) {
+    if (!(c->overlap_insert && c->side_stream && c->stream == c->own_stream && c->map.built && c->map.m > 0)) return c->stream;
+    if (hipEventRecord(c->ev_staged, c->stream) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_staged, 0) != hipSuccess) return c->stream;
+    return c->side_stream;
+}
+
 int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
     LV_CHECK_CTX(c);
     LV_SETTLE_MAP(c);
@@ -691,7 +699,7 @@ int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downs
     if (rc) return rc;
     rc = stage_map_points(c, points, stride, n, c->map.d_new);
     if (rc) return rc;
-    return c->map.add_staged(c->stream, (uint32_t)n, downsample, 0.2f, false);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
+    return c->map.add_staged(insert_stream(c), (uint32_t)n, downsample, 0.2f, false);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
 }
 
 namespace {
@@ -730,13 +738,7 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     // of ~150 us occupies a handful of CUs).  Everything that touches the map settles the insert first (LV_SETTLE_MAP: the
     // host waits for the note the chain's last kernel posts), so no other ordering is needed.  Only with the context's own
     // stream: a caller-provided stream keeps everything on that stream.
-    hipStream_t ms = c->stream;
-    if (c->overlap_insert && c->side_stream && c->stream == c->own_stream && c->map.built && c->map.m > 0) {
-        LV_HIP(hipEventRecord(c->ev_staged, c->stream));
-        LV_HIP(hipStreamWaitEvent(c->side_stream, c->ev_staged, 0));
-        ms = c->side_stream;
-    }
-    return c->map.add_staged(ms, n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
+    return c->map.add_staged(insert_stream(c), n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
 }
 
 int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_inside, size_t* n_evicted) {
