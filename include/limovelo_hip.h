@@ -132,7 +132,9 @@ int    lv_map_add(lv_ctx* ctx, const void* points, size_t stride, size_t n, int 
  * the current scan (lv_scan_set / lv_scan_deskew*) is moved to the world with the state the device holds — the
  * resident filter's (lv_filter_set / lv_predict / lv_correct) if there is one, otherwise the result of the last
  * lv_update — in f32 exactly as State::State(const state_ikfom&) + RotTransl do (rows a-1), and inserted in scan
- * order.  Non-finite points are skipped. */
+ * order.  Non-finite points are skipped.  The insert is enqueued and runs BESIDE whatever the caller enqueues next (on a
+ * second stream of the context, when the context owns its stream): every call that touches the map waits for it first, so
+ * the only visible effect is that lv_map_add / lv_map_add_scan return before the map has changed. */
 int    lv_map_add_scan(lv_ctx* ctx, int downsample);
 /* Rolling window (BASELINE configs[4]; ikd-Tree's Delete_Point_Boxes, which the reference never calls —
  * README.md:127 — but a bounded map needs): keep_inside != 0 removes every point OUTSIDE the axis-aligned box
@@ -192,7 +194,8 @@ int lv_scan_downsample(lv_ctx* ctx, const void* points, size_t stride, size_t n,
  * field offsets come from msg.fields, lv_cloud_format_preset gives the PCL in-memory layouts of
  * include/Headers/Common.hpp:109-221).  lv_cloud_fetch = Accumulator::get_points(t1, t2) (t1 <= time <= t2, oldest
  * first; records are the reference's 32-byte Point: x,y,z floats, double time at 16, intensity, range);
- * lv_cloud_clear = Accumulator::clear_lidar(t) (drops time <= t from the old end);
+ * lv_cloud_clear = Accumulator::clear_lidar(t) (drops time <= t from the old end; applied by the next window kernel, or by
+ * whatever needs the buffer's true extent first);
  * lv_scan_deskew_window = the point half of Compensator::compensate(t1, t2) (src/Modules/Compensator.cpp:18-35):
  * the buffered points of [t1, t2] are de-skewed exactly as lv_scan_deskew does, without leaving the device. */
 enum { LV_LIDAR_VELODYNE = 0, LV_LIDAR_HESAI = 1, LV_LIDAR_OUSTER = 2, LV_LIDAR_CUSTOM = 3 };
@@ -254,7 +257,13 @@ int lv_update(lv_ctx* ctx, lv_state* x, double* P, int* passes, lv_sums* per_pas
  * lv_filter_set / lv_filter_get     = esekf::change_x + change_P / get_x + get_P (src/Modules/Localizator.cpp:136-152)
  * lv_predict(dt, Q, acc, gyro)      = esekf::predict(dt, Q, in) as called by Localizator::propagate
  *                                     (Localizator.cpp:159-173; Q row-major 12x12, acc = imu.a, gyro = imu.w)
- * lv_correct(passes)                = lv_update on the resident state; asynchronous when passes == NULL. */
+ * lv_correct(passes)                = lv_update on the resident state; asynchronous when passes == NULL.
+ * Nothing here waits for the device except lv_filter_get and lv_correct with passes != NULL: lv_predict calls are queued (up to
+ * eight steps with the same Q go out as one launch when something needs the filter: lv_correct, lv_filter_get, lv_map_add_scan,
+ * lv_synchronize, an update by value); after lv_correct the posterior stays in the update's working copy until something needs
+ * it elsewhere, and lv_filter_get reads it — and the pass count, lv_last_passes — from the host-mapped mailbox the update's
+ * finishing pass writes (a poll, no copy).  The results are bit-identical to one launch per call with eager copies
+ * (tests/test_gpu_filter.py). */
 int lv_filter_set(lv_ctx* ctx, const lv_state* x, const double* P);
 int lv_filter_get(lv_ctx* ctx, lv_state* x, double* P);
 int lv_predict(lv_ctx* ctx, double dt, const double* Q, const double acc[3], const double gyro[3]);
