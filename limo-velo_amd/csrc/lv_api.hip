@@ -1412,6 +1412,8 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     c->state_src = 2;
     if (c->map.view.m == 0) {  // Localizator::correct returns without a map (Localizator.cpp:24)
         // ... but the state the caller propagated is the one the first map is built with (main.cpp:92,102 -> lv_map_add_scan)
+        LV_FLUSH_PREDICTS(c);                        // (a resident filter that still lives in kf moves out before kf->x is overwritten)
+        { int rm = materialise_filter(c); if (rm) return rm; }
         LV_HIP(hipStreamSynchronize(c->stream));   // (x_in of an earlier update may still be in flight)
         std::memcpy(c->h_io->x_in, x, sizeof(double) * NX);
         LV_HIP(hipMemcpyAsync(c->d_kf->x, c->h_io->x_in, sizeof(double) * NX, hipMemcpyHostToDevice, c->stream));
