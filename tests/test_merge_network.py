@@ -41,3 +41,36 @@ def test_merge_of_two_sorted_top5_lists_with_ties():
         b = sorted(rng.choice([rng.random(), rng.randint(0, 4)]) for _ in range(8))   # (the chunk side: 8 sorted, its 5 smallest are used)
         merged = _apply(net, [min(a[i], b[4 - i]) for i in range(5)])
         assert merged == sorted(a + b)[:5]
+
+
+def test_lds_bitonic_network_steps_and_the_wave_local_claim():
+    """lv_ldssort.hpp: pair t of step (k2, j = 1 << lj) is lo = ((t >> lj) << (lj + 1)) | (t & (j - 1)), hi = lo | j, ascending iff
+    (lo & k2) == 0; steps whose j and whose successor's j are <= 64 are separated by a wavefront fence only, which is sound iff
+    the 64 pairs of a wavefront (t in [64 w, 64 w + 64)) stay inside elements [128 w, 128 w + 128) in both steps."""
+    rng = random.Random(11)
+    for length in (64, 128, 1024, 2048):
+        keys = [rng.randrange(1 << 20) for _ in range(length)]
+        want = sorted(keys)
+        steps = []
+        k2, lk = 2, 1
+        while k2 <= length:
+            for lj in range(lk - 1, -1, -1):
+                steps.append((k2, lj))
+            k2, lk = k2 << 1, lk + 1
+        for si, (k2, lj) in enumerate(steps):
+            j = 1 << lj
+            touched = {}
+            for t in range(length // 2):
+                lo = ((t >> lj) << (lj + 1)) | (t & (j - 1))
+                hi = lo | j
+                assert hi == lo + j and hi < length
+                up = (lo & k2) == 0
+                if (keys[lo] > keys[hi]) == up:
+                    keys[lo], keys[hi] = keys[hi], keys[lo]
+                touched.setdefault(t // 64, set()).update((lo, hi))
+            next_j = (j >> 1) if lj > 0 else k2
+            last = si == len(steps) - 1
+            workgroup_barrier = j > 64 or next_j > 64 or last
+            if not workgroup_barrier:   # wave-local: every wavefront stayed inside its own 128 elements
+                assert all(min(e) >= 128 * w and max(e) < 128 * w + 128 for w, e in touched.items()), (length, k2, j)
+        assert keys == want
