@@ -356,6 +356,9 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     uint32_t bcount = 0;
     for (;;) {
         const uint4 e = g.table[slot];
+        // (all four words are wanted NOW: left alone the compiler fetches the key's 8 bytes, compares, and only then goes back
+        // for {start, count} — a second dependent trip to memory on the hit path of every probe)
+        asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
         const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
         if (ek == key) { bstart = e.z; bcount = e.w; break; }
         if (ek == EMPTY_KEY) break;
@@ -410,6 +413,7 @@ __device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl,
     uint32_t bstart = 0, bcount = 0;
     for (;;) {
         const uint4 e = g.table[slot];
+        asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));   // (one 16-byte load: see bucket_attempt)
         const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
         if (ek == key) { bstart = e.z; bcount = e.w; break; }
         if (ek == EMPTY_KEY) break;
@@ -481,6 +485,7 @@ __device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& g
                 uint32_t slot = hash_cell(key, g.shift) & g.mask;
                 for (;;) {
                     const uint4 e = g.table[slot];
+                    asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));   // (one 16-byte load: see bucket_attempt)
                     const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
                     if (ek == key) { start = e.z; cnt = e.w; break; }
                     if (ek == EMPTY_KEY) break;
