@@ -48,7 +48,7 @@ def test_lds_bitonic_network_steps_and_the_wave_local_claim():
     (lo & k2) == 0; steps whose j and whose successor's j are <= 64 are separated by a wavefront fence only, which is sound iff
     the 64 pairs of a wavefront (t in [64 w, 64 w + 64)) stay inside elements [128 w, 128 w + 128) in both steps."""
     rng = random.Random(11)
-    for length in (64, 128, 1024, 2048):
+    for length in (64, 128, 1024, 2048, 4096):   # (4096: two pairs per thread of a 1024-thread workgroup)
         keys = [rng.randrange(1 << 20) for _ in range(length)]
         want = sorted(keys)
         steps = []
