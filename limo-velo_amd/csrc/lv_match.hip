@@ -43,8 +43,8 @@ __device__ __forceinline__ kkey make_key(float d, uint32_t low) {
 }
 // the key of a candidate slot that may lie behind the end of its run: selects, not a branch around the distance arithmetic (the
 // compiler turns `ok ? make_key(calc_dist(...), j) : none_key()` into an exec-mask region per candidate: save / branch / wait /
-// restore around eight instructions).  Used for the level-0 stream only (search phase 13.4 -> 13.2 us per launch, A/B in one
-// box): on level 1 and the coarse levels the same change made the first launch 38 -> 59 us — there the masked regions pay.
+// restore around eight instructions).  Level-0 stream: search phase 13.4 -> 13.2 us per launch; level 1: see bucket_attempt
+// (the loads have to be pinned in front of the arithmetic there).
 __device__ __forceinline__ kkey make_key_if(bool ok, float d, uint32_t low) {
     const uint32_t hi = ok ? __float_as_uint(d) : 0x7FEFFFFFu;
     const uint32_t lo = ok ? low : 0xFFFFFFFFu;
@@ -380,10 +380,15 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
             for (int u = 0; u < U; ++u) stage[u * LANES + tl] = mpt[u];
         }
         kkey ck[U];
+        // Keys by selects on every level (make_key_if).  Behind level 0 the eight loads of a chunk are pinned in front of the
+        // arithmetic: left to the scheduler, the select form gets them ONE AT A TIME there (`s_waitcnt vmcnt(0)` after each
+        // load, to stay inside 128 registers) — eight dependent round trips per chunk, the first launch 38 -> 59 us; pinned,
+        // it beats the exec-mask form: first launch 37.6 -> 35.8 us, second 28.2 -> 26.5 (29.0 -> 29.7 k it/s, A/B in one box).
+        if (bl != 0) asm volatile("" :: "v"(mpt[0].x), "v"(mpt[1].x), "v"(mpt[2].x), "v"(mpt[3].x), "v"(mpt[4].x), "v"(mpt[5].x), "v"(mpt[6].x), "v"(mpt[7].x));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = base + (uint32_t)(u * LANES + tl);
-            ck[u] = bl == 0 ? make_key_if(j < bcount, calc_dist(qx, qy, qz, mpt[u]), j) : (j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), j) : none_key());
+            ck[u] = make_key_if(j < bcount, calc_dist(qx, qy, qz, mpt[u]), j);
         }
         sort8(ck);
         if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
@@ -435,7 +440,7 @@ __device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = base + (uint32_t)(u * LANES + tl);
-            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();
+            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();   // (selects + pinned loads: no difference here)
         }
         sort8(ck);
         merge5(k, ck);
