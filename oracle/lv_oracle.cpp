@@ -1337,6 +1337,28 @@ static void sincos_f32(float xf, float& sn, float& cs) {
     cs = (float)cd;
 }
 
+extern "C" void lvo_sincos_f32(const float* x, size_t n, float* sn, float* cs) {
+    for (size_t i = 0; i < n; ++i) sincos_f32(x[i], sn[i], cs[i]);
+}
+// How far the pinned polynomial is from THIS platform's libm: the reference evaluates std::sin(float) / std::cos(float)
+// (include/Headers/Utils.hpp:46), i.e. glibc's sinf / cosf on its x86-64 build.  Counts the arguments whose f32 result differs
+// and the largest difference in ulps — a measurement for DESIGN.md section 6 f-2, not a parity claim.
+extern "C" void lvo_sincos_vs_libm(const float* x, size_t n, int64_t* n_sin_diff, int64_t* n_cos_diff, int32_t* max_ulp) {
+    int64_t ds = 0, dc = 0;
+    int32_t mu = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float sn, cs;
+        sincos_f32(x[i], sn, cs);
+        const float ls = std::sin(x[i]), lc = std::cos(x[i]);   // float overloads: sinf / cosf
+        int32_t a, b;
+        std::memcpy(&a, &sn, 4); std::memcpy(&b, &ls, 4);
+        if (a != b) { ++ds; const int32_t u = a > b ? a - b : b - a; if ((a ^ b) >= 0 && u > mu) mu = u; }
+        std::memcpy(&a, &cs, 4); std::memcpy(&b, &lc, 4);
+        if (a != b) { ++dc; const int32_t u = a > b ? a - b : b - a; if ((a ^ b) >= 0 && u > mu) mu = u; }
+    }
+    *n_sin_diff = ds; *n_cos_diff = dc; *max_ulp = mu;
+}
+
 // SO3Math::Exp<float,float>(ang_vel, dt) — include/Headers/Utils.hpp:30-53
 static void so3_exp_f32(const float w[3], float dt, float E[9]) {
     const float nrm = std::sqrt(dot3f(w[0], w[0], w[1], w[1], w[2], w[2]));

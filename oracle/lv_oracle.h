@@ -161,6 +161,11 @@ typedef struct lvo_motion_state {
 
 /* State::operator+=(IMU(a, w, t)) = State::update -> propagate_f (State.cpp:94-121), f32. */
 void lvo_state_integrate(lvo_motion_state* s, const float a[3], const float w[3], double t);
+/* sin / cos of f32 arguments as rows f-2 / f-3 evaluate them (one fixed f64 polynomial, rounded to f32) */
+void lvo_sincos_f32(const float* x, size_t n, float* sn, float* cs);
+/* The pinned sin / cos polynomial of row f-2 against this platform's sinf / cosf (what the reference calls,
+ * include/Headers/Utils.hpp:46): how many of the n arguments differ, and by how many ulps at most. */
+void lvo_sincos_vs_libm(const float* x, size_t n, int64_t* n_sin_diff, int64_t* n_cos_diff, int32_t* max_ulp);
 
 /* Compensator::compensate(states, Xt2, points) (src/Modules/Compensator.cpp:123-146): for every point (xyz +
  * time, time-sorted) take the surrounding state, integrate it to the point's time with its own last IMU, move

@@ -301,6 +301,22 @@ def state_integrate(state, a, w, t):
     return s
 
 
+def sincos_f32(x):
+    v = _f32(x).ravel()
+    sn, cs = np.empty_like(v), np.empty_like(v)
+    lib().lvo_sincos_f32(_p(v, C.c_float), C.c_size_t(len(v)), _p(sn, C.c_float), _p(cs, C.c_float))
+    return sn, cs
+
+
+def sincos_vs_libm(x):
+    """(arguments whose sin differs, whose cos differs, largest difference in ulps) between the pinned polynomial of row
+    f-2 and this platform's sinf / cosf."""
+    v = _f32(x).ravel()
+    ns, nc, mu = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    lib().lvo_sincos_vs_libm(_p(v, C.c_float), C.c_size_t(len(v)), C.byref(ns), C.byref(nc), C.byref(mu))
+    return int(ns.value), int(nc.value), int(mu.value)
+
+
 def deskew(xyz, times, states, Xt2):
     p = _f32(xyz).reshape(-1, 3)
     t = _f64(times)

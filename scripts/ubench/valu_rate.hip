@@ -31,6 +31,19 @@ __global__ void k(double* out, long long* clk, double seed) {
             } else if (MODE == 3) {  // f64 fma
                 asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a[i]) : "v"(a[i + 1]));
                 asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a[i + 1]) : "v"(a[i]));
+            } else if (MODE == 5) {  // two DPP moves (quad_perm) of 32-bit words
+                int x = (int)u[i], y = (int)u[i + 1];
+                x = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, true);
+                y = __builtin_amdgcn_update_dpp(y, y, 0x141, 0xF, 0xF, true);
+                asm volatile("" : "+v"(x), "+v"(y));
+                u[i] = (uint32_t)x; u[i + 1] = (uint32_t)y;
+            } else if (MODE == 6) {  // two packed f32 multiplies
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[i + 1]));
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i + 1]) : "v"(a[i]));
+            } else if (MODE == 7) {  // two cndmask
+                uint32_t x = u[i], y = u[i + 1];
+                asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(y) : "vcc");
+                u[i] = x;
             } else if (MODE == 4) {  // f32 fma
                 float x = (float)u[i], y = (float)u[i+1];
                 asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(y));
@@ -60,7 +73,7 @@ void run(const char* name, int threads) {
 }
 int main() {
     for (int th : {64, 256, 1024}) {
-        run<0>("f64 min+max", th); run<1>("u32 min+max", th); run<2>("u64 cmp + 4 cndmask", th); run<3>("2x f64 fma", th); run<4>("2x f32 fma (+cvt)", th);
+        run<0>("f64 min+max", th); run<1>("u32 min+max", th); run<2>("u64 cmp + 4 cndmask", th); run<3>("2x f64 fma", th); run<4>("2x f32 fma (+cvt)", th); run<5>("2x dpp mov", th); run<6>("2x v_pk_mul_f32", th); run<7>("cmp + cndmask", th);
     }
     // clock64 rate vs wall clock
     return 0;

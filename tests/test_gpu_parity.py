@@ -435,6 +435,7 @@ def test_timed_build_is_pinned_per_pass(capi, oracle, lv, m, n):
         assert np.abs(g["HTH"] - o["HTH"]).max() <= TOL_SUMS_REL * scale, f"pass {i}"
         assert np.abs(g["HTh"] - o["HTh"]).max() <= TOL_SUMS_REL * max(np.abs(o["HTh"]).max(), 1.0), f"pass {i}"
         assert abs(g["sum_h2"] - o["sum_h2"]) <= TOL_SUMS_REL * max(o["sum_h2"], 1.0), f"pass {i}"
+    max_d2 = float(capi.default_params().MAX_DIST_PLANE) ** 2   # the gate of the configuration under test (Plane.cpp:40-43)
     for k in range(passes):
         with capi.Context(capi.default_params(MAX_NUM_ITERS=k)) as ctx:
             ctx.map_build(sc["map_xyz"])
@@ -450,9 +451,9 @@ def test_timed_build_is_pinned_per_pass(capi, oracle, lv, m, n):
         have = o["knn_idx"] != 0xFFFFFFFF
         # the timed launches are BOUNDED: a point whose 5th neighbour is not closer than MAX_DIST_PLANE (the reference
         # drops it at Plane.cpp:40-43) may be reported without neighbours; every other record is the exact answer
-        near = have.all(axis=1) & (o["knn_d2"][:, 4].astype(np.float64) < 4.0)
+        near = have.all(axis=1) & (o["knn_d2"][:, 4].astype(np.float64) < max_d2)
         assert near.mean() > 0.9
-        rejected = (found < 5) | ~(d2[:, 4].astype(np.float64) < 4.0)
+        rejected = (found < 5) | ~(d2[:, 4].astype(np.float64) < max_d2)
         assert rejected[~near].all(), f"pass {k}"
         assert np.array_equal(found[near], have.sum(axis=1)[near]), f"pass {k}"
         exp = np.where(have[..., None], sc["map_xyz"][np.where(have, o["knn_idx"], 0)], np.float32(0))
