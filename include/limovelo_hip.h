@@ -245,6 +245,19 @@ int    lv_scan_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
  * H^T H / H^T h on the GPU.  Synchronous. */
 int lv_iterate(lv_ctx* ctx, const lv_state* x, lv_sums* out);
 
+/* The Eigen-free half of IKFoM::h_share_model for an UNMODIFIED esekf loop (src/Modules/Localizator.cpp:105-117: the callback
+ * update_iterated_dyn_share_modified calls; :132 the update): esekf depends on the N x 12 Jacobian and the residuals only
+ * through H^T H and H^T h, so the callback hands it a pseudo measurement of *rows <= 12 rows with
+ *     h_x^T h_x = sums->HTH      h_x^T h = sums->HTh
+ * (h_x row-major, 12 columns = the first 12 tangent coordinates, rows >= *rows zero).  Without estimate_extrinsics: the upper
+ * Cholesky factor of the leading 6 x 6 block padded with zero columns (6 rows; Localizator.cpp:52 zeroes columns 6..11);
+ * with it, or if that block is not positive definite: the rank-revealing factor sqrt(lam) V^T of the symmetric eigen-
+ * decomposition (12 / 6 rows, the rows of vanished eigenvalues zero).  sums->n_valid == 0 (dyn_share.valid = false) gives
+ * *rows = 0.  Host arithmetic only: needs no context and no device.  The maintainer's h_share_model is then
+ *     lv_iterate(ctx, &x, &sums); lv_pseudo_measurement(&sums, ext, hx, h, &rows); copy hx / h into dyn_share.h_x / .h
+ * (both esekf gain branches checked in tests/test_hshare.py). */
+int lv_pseudo_measurement(const lv_sums* sums, int estimate_extrinsics, double h_x[144], double h[12], int* rows);
+
 /* esekf::update_iterated_dyn_share_modified(R, degeneracy_threshold, solve_time, print)
  *                                                 — call site src/Modules/Localizator.cpp:132.
  * Runs the whole iterated update on the device.  x and P (23x23 row-major) are updated in place.
