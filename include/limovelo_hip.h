@@ -341,16 +341,20 @@ typedef int (*lv_gather_fn)(void* user, void* slots, size_t bytes_per_rank, int 
 int lv_comm_set_host_gather(lv_ctx* ctx, int rank, int world, lv_gather_fn fn, void* user);
 
 /* The same one-launch-per-pass multi-rank form over PEER-MAPPED memory (HIP IPC over xGMI), no collective library: every
- * rank exports the handle of its gather buffers (lv_comm_peer_export: 64 bytes, LV_PEER_HANDLE_BYTES), the caller carries
- * the handles of all ranks to every rank by whatever means it has (they are plain bytes), and lv_comm_peer_init maps them.
- * After each pass one small kernel publishes "my partials of this launch are in memory" and pulls the other ranks' slots
- * straight out of their buffers — a one-shot peer read instead of a ring collective.  Tell the largest shard
- * with lv_comm_set_shard_max as above; ranks end bitwise equal.  A rank that never publishes ends the others' wait after
- * 50 ms: lv_update then returns LV_ESTATE.  At most 8 ranks (one node); HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in the
- * environment of every rank.  Opt-in: verified with two processes on one GPU, not yet across GPUs.  Not combinable with
- * lv_comm_init / lv_comm_set_host_gather. */
-#define LV_PEER_HANDLE_BYTES 64
-int lv_comm_peer_export(lv_ctx* ctx, void* handle64);
+ * rank exports the handles of its gather buffers and of its flag word (lv_comm_peer_export: LV_PEER_HANDLE_BYTES = 128 bytes,
+ * two HIP IPC handles), the caller carries the blobs of all ranks to every rank by whatever means it has (they are plain
+ * bytes), and lv_comm_peer_init maps them.  After each pass one small kernel publishes "my partials of this launch are in
+ * memory" and pulls the other ranks' slots straight out of their buffers — a one-shot peer read instead of a ring collective
+ * (SURVEY 8e).  Tell the largest shard with lv_comm_set_shard_max as above; ranks end bitwise equal.
+ * Failure: a rank that does not publish within the give-up time (LV_PEER_TIMEOUT_MS in the environment, default 2000 ms —
+ * far above ordinary host skew between processes) ends the others' wait; the rank that gave up poisons its own flag, so
+ * every rank of the node fails the SAME update.  lv_update then returns LV_ESTATE with x and P untouched; the resident
+ * filter (lv_correct) is declared unset and every later call fails with LV_ESTATE until lv_comm_destroy + lv_filter_set.
+ * At most 8 ranks (one node); HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in the environment of every rank.
+ * EXPERIMENTAL and opt-in: verified with two processes on one GPU (shared L2), not yet across GPUs; a second
+ * lv_comm_peer_init on the same context returns LV_ESTATE.  Not combinable with lv_comm_init / lv_comm_set_host_gather. */
+#define LV_PEER_HANDLE_BYTES 128
+int lv_comm_peer_export(lv_ctx* ctx, void* handles /* LV_PEER_HANDLE_BYTES */);
 int lv_comm_peer_init(lv_ctx* ctx, int rank, int world, const void* handles /* world x LV_PEER_HANDLE_BYTES, in rank order */);
 
 /* ---- API-parity / debug fetches (results of the most recent CAPTURED pass; original scan order) --

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LV_LIB_PATH") or os.path.join(_HERE, "liblimovelo_hip.so")
 
 LV_OK = 0
+PEER_HANDLE_BYTES = 128   # LV_PEER_HANDLE_BYTES: two HIP IPC handles (gather buffers, flag word)
 SUMS_LEN = 96
 NS = 23
 
@@ -530,13 +531,13 @@ class Context:
         self._gather_cb = cb   # (keeps the trampoline alive as long as the library may call it)
 
     def comm_peer_export(self) -> bytes:
-        buf = (C.c_ubyte * 64)()
+        buf = (C.c_ubyte * PEER_HANDLE_BYTES)()
         self._check(self.lib.lv_comm_peer_export(self.h, buf))
         return bytes(buf)
 
     def comm_peer_init(self, rank: int, world: int, handles):
         blob = b"".join(handles)
-        assert len(blob) == 64 * world
+        assert len(blob) == PEER_HANDLE_BYTES * world
         self._check(self.lib.lv_comm_peer_init(self.h, int(rank), int(world), blob))
 
     def set_fused_pass(self, on=True):

@@ -144,6 +144,27 @@ namespace {
         }                                        \
     } while (0)
 
+// The peer-mapped exchange (lv_peer.hip) failed in an earlier launch of this context (a rank of the node gave up waiting for
+// another, or met a rank that had): whatever those launches computed is built on stale partials.  Nothing of it is adopted
+// — the resident filter is declared unset — and every later call of the data path fails until the exchange is torn down
+// (lv_comm_destroy) and the filter re-seeded.
+static int peer_poisoned(lv_ctx* c) {
+    if (!c->peer.active || !peer_failed(c->peer)) return LV_OK;
+    c->filter_set = false;
+    c->filter_in_kf = false;
+    c->filter_in_mailbox = false;
+    c->pred_n = 0;
+    c->in_update = false;
+    set_error("peer-mapped gather: a rank of the node did not publish its partials in time (or reported a failed exchange): the update "
+              "was not adopted; lv_comm_destroy, then lv_filter_set / a new exchange");
+    return LV_ESTATE;
+}
+#define LV_CHECK_PEER(c)                 \
+    do {                                 \
+        int _rq = peer_poisoned(c);      \
+        if (_rq) return _rq;             \
+    } while (0)
+
 // an incremental insert leaves its outcome in flight (MapStore::settle): pick it up before the map's bookkeeping is used
 #define LV_SETTLE_MAP(c)                               \
     do {                                               \
@@ -605,7 +626,10 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_sums) hipHostFree(c->h_sums);
     hipFree(c->d_cpart[0]); hipFree(c->d_cpart[1]); hipFree(c->d_pclk); hipFree(c->d_wgcost[0]); hipFree(c->d_wgcost[1]);
     if (c->h_gather) hipHostFree(c->h_gather);
-    if (c->peer.local_alloc) { c->d_gather[0] = c->d_gather[1] = nullptr; peer_close(c->peer); }   // (the gather buffers were the peer allocation)
+    if (c->peer.local_alloc) {   // (once lv_comm_peer_init succeeded the gather buffers ARE the peer allocation: freed by peer_close alone)
+        if (c->peer.active) c->d_gather[0] = c->d_gather[1] = nullptr;
+        peer_close(c->peer);
+    }
     hipFree(c->d_gather[0]); hipFree(c->d_gather[1]);
     hipFree(c->d_qrec); hipFree(c->d_clk); hipFree(c->d_kf); hipFree(c->d_partials); hipFree(c->d_groups); hipFree(c->d_sums_own);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
@@ -621,6 +645,10 @@ void lv_destroy(lv_ctx* c) {
 int lv_set_stream(lv_ctx* c, void* hip_stream) {
     LV_CHECK_CTX(c);
     LV_FLUSH_PREDICTS(c);
+    // whatever is still tied to the OLD stream is settled on it: a remembered Buffer::clear (CloudStore keeps the stream it was
+    // issued on: the caller may destroy that stream after this call) and the outcome of an incremental map insert
+    { int rs = c->cloud.settle(); if (rs) return rs; }
+    LV_SETTLE_MAP(c);
     LV_HIP(hipStreamSynchronize(c->stream));
     if (c->side_stream) LV_HIP(hipStreamSynchronize(c->side_stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -1223,6 +1251,15 @@ int lv_comm_init(lv_ctx* c, const char* rccl_library, const void* id128, int ran
 
 int lv_comm_destroy(lv_ctx* c) {
     LV_CHECK_CTX(c);
+    if (c->in_update) { set_error("lv_comm_destroy inside an update"); return LV_ESTATE; }
+    if (c->peer.local_alloc) {   // the peer-mapped exchange: unmap the other ranks' buffers, free this rank's (the gather buffers WERE that allocation)
+        LV_HIP(hipStreamSynchronize(c->stream));
+        if (c->peer.active) { c->d_gather[0] = c->d_gather[1] = nullptr; c->gather_cap = 0; }
+        peer_close(c->peer);
+        c->comm_world = 1;
+        c->comm_rank = 0;
+        c->comm_shard_max = 0;
+    }
     if (!c->comm) return LV_OK;
     LV_HIP(hipStreamSynchronize(c->stream));
     int rc = comm_destroy(c->comm);
@@ -1247,16 +1284,16 @@ int lv_comm_set_host_gather(lv_ctx* c, int rank, int world, lv_gather_fn fn, voi
     return LV_OK;
 }
 
-int lv_comm_peer_export(lv_ctx* c, void* handle64) {
+int lv_comm_peer_export(lv_ctx* c, void* handle_blob) {
     LV_CHECK_CTX(c);
-    if (!handle64) { set_error("null argument"); return LV_EINVAL; }
+    if (!handle_blob) { set_error("null argument"); return LV_EINVAL; }
     if (c->in_update) { set_error("lv_comm_peer_export inside an update"); return LV_ESTATE; }
     if (c->comm || c->gather_cb) { set_error("another multi-rank transport is in place"); return LV_ESTATE; }
     LV_HIP(hipStreamSynchronize(c->stream));
     // sized once for the largest case (every CU a workgroup, 96-double partials, LV_PEER_MAX ranks): the other ranks map this
     // allocation, so it never moves
     const size_t cap = (size_t)(c->pass_max_wg + 8) * 96u * (size_t)LV_PEER_MAX;
-    return peer_export(c->peer, cap, handle64);
+    return peer_export(c->peer, cap, handle_blob);
 }
 
 int lv_comm_peer_init(lv_ctx* c, int rank, int world, const void* handles) {
@@ -1420,6 +1457,13 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
         return LV_OK;
     }
     const int npass = c->prm.MAX_NUM_ITERS + 1;
+    LV_CHECK_PEER(c);
+    lv_state x_prior;
+    std::vector<double> P_prior;
+    if (c->peer.active) {   // (a failed exchange must hand the caller's buffers back untouched: lv_update_end writes into them)
+        x_prior = *x;
+        P_prior.assign(P, P + NS * NS);
+    }
     int rc = lv_update_begin(c, x, P);
     if (rc) return rc;
     if (c->profiling) LV_HIP(hipEventRecord(c->ev_begin, c->stream));
@@ -1451,11 +1495,15 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     rc = lv_update_end(c, x, P, &np);
     c->want_log = false;
     if (rc) return rc;
-    if (c->peer.active) {   // a rank of the node that never published its partials ends the wait (50 ms) instead of hanging the GPU
-        int timed_out = 0;
-        rc = peer_status(c->peer, c->stream, &timed_out);
-        if (rc) return rc;
-        if (timed_out) { set_error("peer-mapped gather: a rank of the node did not publish its partials within 50 ms"); return LV_ESTATE; }
+    if (c->peer.active) {
+        // lv_update_end has waited for the update's last launch, so every pull of this update has run: a pull that gave up on a
+        // peer (or met a poisoned flag) has set the sticky status word.  The caller gets its prior back, nothing is adopted.
+        LV_HIP(hipStreamSynchronize(c->stream));
+        if (peer_failed(c->peer)) {
+            *x = x_prior;
+            std::memcpy(P, P_prior.data(), sizeof(double) * NS * NS);
+            return peer_poisoned(c);
+        }
     }
     if (passes) *passes = np;
     if (per_pass)
@@ -1552,31 +1600,38 @@ int lv_correct(lv_ctx* c, int* passes) {
     c->state_src = 1;
     if (passes) *passes = 0;
     if (c->map.view.m == 0) return LV_OK;  // Localizator::correct returns without a map (Localizator.cpp:24)
+    LV_CHECK_PEER(c);   // (a failed exchange of an EARLIER, asynchronous lv_correct surfaces here at the latest)
+    if (gather_only(c) && !pass_fused_applies(c)) {   // (before anything is enqueued: the filter stays exactly where it was)
+        set_error("host-staged / peer-mapped gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
+        return LV_ESTATE;
+    }
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;   // (the finishing pass echoes it into the mailbox: lv_filter_get polls for it)
     int rc = begin_device(c, nullptr, false, true);       // (kf_begin_kernel installs the filter in kf: no launch of its own)
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     c->last_update_fused = false;
-    if (gather_only(c) && !pass_fused_applies(c)) {
-        c->in_update = false;
-        set_error("host-staged / peer-mapped gather: this scan does not take the one-launch-per-pass form (largest shard told? size? options?)");
-        return LV_ESTATE;
-    }
     if (pass_fused_applies(c)) {
         rc = update_fused(c);
-        if (rc) { c->in_update = false; return rc; }
     } else {
-        for (int i = 0; i < npass; ++i) {
-            rc = pass_full(c);
-            if (rc) { c->in_update = false; return rc; }
-        }
+        for (int i = 0; i < npass && !rc; ++i) rc = pass_full(c);
     }
     c->in_update = false;
+    if (rc) {
+        // an enqueue failed part of the way: kf_begin_kernel has installed the prior in kf->x / kf->P_post (P_post is only
+        // rewritten by the pass that ends an update), but passes that did run may have moved kf->x.  Neither "the filter is
+        // d_filter" (possibly older than the prior) nor "the filter is kf" (possibly a half-iterated state) is right:
+        // the filter is declared unset and the caller re-seeds it.
+        c->filter_set = false;
+        c->filter_in_kf = false;
+        c->filter_in_mailbox = false;
+        return rc;
+    }
     c->filter_in_kf = true;        // (the posterior stays where the update left it: materialise_filter)
     c->filter_in_mailbox = true;
     if (passes) {  // optional: the only synchronisation point
         LV_HIP(hipStreamSynchronize(c->stream));
+        LV_CHECK_PEER(c);
         *passes = c->h_io->passes;   // stored by solve_kernel into the pinned mailbox
     }
     return LV_OK;

@@ -170,22 +170,32 @@ int comm_allgather_inplace(void* comm, double* buf, size_t count_per_rank, int r
 // lv_peer.hip — the same exchange by peer-mapped memory (HIP IPC), no collective library
 constexpr int LV_PEER_MAX = 8;
 struct PeerSet {
-    void* local_alloc = nullptr;                 // [gather buffer 0 | gather buffer 1 | flag word | status word]
+    void* local_alloc = nullptr;                 // [gather buffer 0 | gather buffer 1]: coarse-grained; written by pass kernels, read by
+                                                 // the peers only AFTER the kernel that wrote them has ended (a kernel boundary publishes it)
+    void* flag_alloc = nullptr;                  // [flag word]: its own FINE-GRAINED allocation — polled across devices in the middle of a
+                                                 // kernel, which coarse-grained memory does not guarantee to be coherent for
+    bool flag_fine = false;                      // (false: the runtime refused a fine-grained IPC allocation; the flag lives in a plain one)
     double* buf[2] = {nullptr, nullptr};
     unsigned long long* flag = nullptr;
-    uint32_t* status = nullptr;
-    void* mapped[LV_PEER_MAX] = {};              // the other ranks' allocations as mapped here
+    uint32_t* h_status = nullptr;                // pinned, host-mapped: set by a pull that gave up (or met a poisoned flag); sticky
+    uint32_t* d_status = nullptr;                // ... its device address
+    void* mapped[LV_PEER_MAX] = {};              // the other ranks' gather allocations as mapped here
+    void* mapped_flag[LV_PEER_MAX] = {};         // ... and their flag allocations
     double* peer_buf[2][LV_PEER_MAX] = {};
     unsigned long long* peer_flag[LV_PEER_MAX] = {};
     size_t cap = 0;                              // doubles per gather buffer
     int rank = 0, world = 1;
     unsigned long long seq = 0;                  // launches published so far (every rank counts alike)
+    long long timeout_ticks = 0;                 // give-up time of a pull's wait, 100 MHz ticks (LV_PEER_TIMEOUT_MS, default 2000 ms)
     bool active = false;
 };
-int peer_export(PeerSet& P, size_t cap_doubles, void* handle64);
+constexpr int LV_PEER_BLOB = 128;               // two HIP IPC handles: gather buffers, flag word (= LV_PEER_HANDLE_BYTES of the ABI)
+int peer_export(PeerSet& P, size_t cap_doubles, void* handle_blob);
 int peer_init(PeerSet& P, int rank, int world, const void* handles);
 int peer_gather(PeerSet& P, int parity, size_t slot_doubles, hipStream_t stream);
-int peer_status(PeerSet& P, hipStream_t stream, int* timed_out);
+// true once a pull of this context gave up on a peer or met a poisoned flag (a plain read of the host-mapped word: meaningful
+// for the launches that have completed)
+bool peer_failed(const PeerSet& P);
 void peer_close(PeerSet& P);
 
 // lv_match.hip

@@ -8,10 +8,19 @@
 // Why a rank may overwrite its slot: its slot of buffer (p & 1) is rewritten by ITS launch p + 2, which is enqueued behind
 // its pull #(p + 1), which waits for every peer's flag #(p + 1), which a peer publishes in its own pull #(p + 1) — a kernel
 // that runs after that peer's pull #p, the last reader of the slot.  Flags only grow (one counter per context).
-// A peer that never shows up (crashed rank) ends the wait after 50 ms of wall clock with the status word set: the update
-// then fails with LV_ESTATE instead of hanging the GPU.
-// Opt-in (lv_comm_peer_export / lv_comm_peer_init): proven with two processes on ONE GPU (tests/test_gpu_distributed.py);
-// not yet run across GPUs — no multi-GPU node was available to rounds 1-3.
+// A pull that waits longer than the give-up time (LV_PEER_TIMEOUT_MS in the environment, default 2000 ms: ordinary host skew
+// between processes — a first-touch allocation, Python's collector, a 20 ms note fallback — must never trip it) sets the
+// context's sticky status word (pinned host memory: the host reads it without a copy) AND poisons this rank's own flag (top
+// bit), so that every rank waiting for this one stops as well: all ranks fail the same update instead of diverging.  The host
+// side (lv_api.hip) then refuses to adopt that update's posterior and fails every later call with LV_ESTATE.
+// Memory: the gather slots live in a plain (coarse-grained) allocation — they are written by a pass kernel and read by peers
+// only after that kernel has ended and a LATER kernel of the same stream has published the flag, i.e. across a kernel boundary;
+// the flag word itself is polled across devices in the middle of a kernel and therefore lives in its own fine-grained
+// allocation (hipExtMallocWithFlags; a plain one only if the runtime refuses to export a fine-grained one).
+// EXPERIMENTAL, opt-in (lv_comm_peer_export / lv_comm_peer_init): proven with two processes on ONE GPU
+// (tests/test_gpu_distributed.py), where both ranks share one L2; not yet run across GPUs — no multi-GPU node was available to
+// rounds 1-4.
+#include <cstdlib>
 #include <cstring>
 
 #include "lv_host.hpp"
@@ -19,6 +28,7 @@
 namespace lv {
 
 namespace {
+constexpr unsigned long long PEER_POISON = 1ull << 63;
 struct PeerArgs {
     double* local;                          // this rank's gather buffer (parity of the launch)
     const double* peer[LV_PEER_MAX];        // the same buffer of every rank (self: local)
@@ -27,24 +37,35 @@ struct PeerArgs {
     unsigned long long seq;
     size_t slot;                            // doubles per rank
     int rank, world;
-    uint32_t* status;
+    uint32_t* status;                       // host-mapped, sticky
+    long long timeout_ticks;
 };
 
 __global__ __launch_bounds__(256) void peer_gather_kernel(PeerArgs a) {
     const int b = blockIdx.x;   // one workgroup per rank of the node
     if (b == a.rank) {          // publish: this rank's partials of launch #seq are complete (the pass kernel ended before this one began)
-        if (threadIdx.x == 0) __hip_atomic_store(a.my_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            // (a context that has already failed keeps telling its peers so)
+            const unsigned long long bad = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? PEER_POISON : 0ull;
+            __hip_atomic_store(a.my_flag, a.seq | bad, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
         int ok = 1;
-        while (__hip_atomic_load(a.pflag[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-            if (wall_clock64() - t0 > 5000000ll) { ok = 0; break; }   // 50 ms at 100 MHz: the peer is gone
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(a.pflag[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v & PEER_POISON) { ok = 0; break; }                     // that rank failed: so does this one, in the same update
+            if (v >= a.seq) break;
+            if (wall_clock64() - t0 > a.timeout_ticks) { ok = 0; break; }   // the peer is gone
             __builtin_amdgcn_s_sleep(8);
         }
-        if (!ok) atomicExch(a.status, 1u);
+        if (!ok) {
+            __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_or(a.my_flag, PEER_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         s_ok = ok;
     }
     __syncthreads();
@@ -56,42 +77,64 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerArgs a) {
 }
 }  // namespace
 
-int peer_export(PeerSet& P, size_t cap_doubles, void* handle64) {
+int peer_export(PeerSet& P, size_t cap_doubles, void* handle_blob) {
     if (P.local_alloc) { set_error("peer buffers already exported"); return LV_ESTATE; }
-    const size_t bytes = (2 * cap_doubles + 16) * sizeof(double);
+    const size_t bytes = 2 * cap_doubles * sizeof(double);
     LV_HIP(hipMalloc(&P.local_alloc, bytes));
     LV_HIP(hipMemset(P.local_alloc, 0, bytes));
+    hipIpcMemHandle_t h[2];
+    static_assert(sizeof(h) == LV_PEER_BLOB, "two 64-byte HIP IPC handles");
+    // the flag word: fine-grained if the runtime can allocate AND export such memory
+    P.flag_fine = false;
+    if (hipExtMallocWithFlags(&P.flag_alloc, 4096, hipDeviceMallocFinegrained) == hipSuccess && P.flag_alloc) {
+        if (hipIpcGetMemHandle(&h[1], P.flag_alloc) == hipSuccess) P.flag_fine = true;
+        else { hipFree(P.flag_alloc); P.flag_alloc = nullptr; }
+    }
+    (void)hipGetLastError();
+    if (!P.flag_fine) {
+        LV_HIP(hipMalloc(&P.flag_alloc, 4096));
+        LV_HIP(hipIpcGetMemHandle(&h[1], P.flag_alloc));
+    }
+    LV_HIP(hipMemset(P.flag_alloc, 0, 4096));
+    LV_HIP(hipHostMalloc((void**)&P.h_status, 64, hipHostMallocMapped));
+    *P.h_status = 0u;
+    LV_HIP(hipHostGetDevicePointer((void**)&P.d_status, P.h_status, 0));
     LV_HIP(hipDeviceSynchronize());
     P.cap = cap_doubles;
     P.buf[0] = static_cast<double*>(P.local_alloc);
     P.buf[1] = P.buf[0] + cap_doubles;
-    P.flag = reinterpret_cast<unsigned long long*>(P.buf[1] + cap_doubles);
-    P.status = reinterpret_cast<uint32_t*>(P.flag + 8);
-    hipIpcMemHandle_t h;
-    LV_HIP(hipIpcGetMemHandle(&h, P.local_alloc));
-    static_assert(sizeof(h) == 64, "HIP IPC handles are 64 bytes");
-    std::memcpy(handle64, &h, sizeof(h));
+    P.flag = static_cast<unsigned long long*>(P.flag_alloc);
+    LV_HIP(hipIpcGetMemHandle(&h[0], P.local_alloc));
+    std::memcpy(handle_blob, h, sizeof(h));
+    double ms = 2000.0;
+    if (const char* e = getenv("LV_PEER_TIMEOUT_MS")) { const double v = atof(e); if (v > 0.0) ms = v; }
+    P.timeout_ticks = (long long)(ms * 1e5);   // wall_clock64: 100 MHz
     return LV_OK;
 }
 
 int peer_init(PeerSet& P, int rank, int world, const void* handles) {
     if (!P.local_alloc) { set_error("lv_comm_peer_export first"); return LV_ESTATE; }
+    if (P.active) { set_error("the peer exchange of this context is already set up (lv_comm_destroy first)"); return LV_ESTATE; }
     if (world < 1 || world > LV_PEER_MAX || rank < 0 || rank >= world) { set_error("peer exchange: rank %d of %d (at most %d ranks)", rank, world, LV_PEER_MAX); return LV_EINVAL; }
     P.rank = rank;
     P.world = world;
     for (int r = 0; r < world; ++r) {
         void* base = P.local_alloc;
+        void* fbase = P.flag_alloc;
         if (r != rank) {
-            hipIpcMemHandle_t h;
-            std::memcpy(&h, static_cast<const char*>(handles) + (size_t)r * sizeof(h), sizeof(h));
+            hipIpcMemHandle_t h[2];
+            std::memcpy(h, static_cast<const char*>(handles) + (size_t)r * sizeof(h), sizeof(h));
             base = nullptr;
-            LV_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+            LV_HIP(hipIpcOpenMemHandle(&base, h[0], hipIpcMemLazyEnablePeerAccess));
             P.mapped[r] = base;
+            fbase = nullptr;
+            LV_HIP(hipIpcOpenMemHandle(&fbase, h[1], hipIpcMemLazyEnablePeerAccess));
+            P.mapped_flag[r] = fbase;
         }
         double* b0 = static_cast<double*>(base);
         P.peer_buf[0][r] = b0;
         P.peer_buf[1][r] = b0 + P.cap;
-        P.peer_flag[r] = reinterpret_cast<unsigned long long*>(b0 + 2 * P.cap);
+        P.peer_flag[r] = static_cast<unsigned long long*>(fbase);
     }
     P.active = true;
     return LV_OK;
@@ -108,26 +151,25 @@ int peer_gather(PeerSet& P, int parity, size_t slot_doubles, hipStream_t stream)
     a.slot = slot_doubles;
     a.rank = P.rank;
     a.world = P.world;
-    a.status = P.status;
+    a.status = P.d_status;
+    a.timeout_ticks = P.timeout_ticks;
     hipLaunchKernelGGL(peer_gather_kernel, dim3(P.world), dim3(256), 0, stream, a);
     LV_HIP(hipGetLastError());
     return LV_OK;
 }
 
-// 0: every pull so far found its peers; 1: a wait timed out (cleared by the read)
-int peer_status(PeerSet& P, hipStream_t stream, int* timed_out) {
-    uint32_t st = 0;
-    LV_HIP(hipMemcpyAsync(&st, P.status, sizeof(st), hipMemcpyDeviceToHost, stream));
-    LV_HIP(hipStreamSynchronize(stream));
-    if (st) LV_HIP(hipMemsetAsync(P.status, 0, sizeof(st), stream));
-    *timed_out = st ? 1 : 0;
-    return LV_OK;
+bool peer_failed(const PeerSet& P) {
+    return P.h_status && __atomic_load_n(P.h_status, __ATOMIC_ACQUIRE) != 0u;
 }
 
 void peer_close(PeerSet& P) {
-    for (int r = 0; r < LV_PEER_MAX; ++r)
+    for (int r = 0; r < LV_PEER_MAX; ++r) {
         if (P.mapped[r]) { hipIpcCloseMemHandle(P.mapped[r]); P.mapped[r] = nullptr; }
+        if (P.mapped_flag[r]) { hipIpcCloseMemHandle(P.mapped_flag[r]); P.mapped_flag[r] = nullptr; }
+    }
     if (P.local_alloc) hipFree(P.local_alloc);
+    if (P.flag_alloc) hipFree(P.flag_alloc);
+    if (P.h_status) hipHostFree(P.h_status);
     P = PeerSet();
 }
 

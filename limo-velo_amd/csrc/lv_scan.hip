@@ -202,11 +202,15 @@ constexpr int SW_THREADS = 1024;
 __device__ __forceinline__ void lds_bitonic_u64(uint64_t* s_key, uint32_t n, int tid) {
     lds_bitonic_sort_u64<SW_THREADS>(s_key, lds_sort_len(n), tid);   // (padding sorts last; lv_ldssort.hpp)
 }
-__global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* __restrict__ raw, const double* __restrict__ times,
+// raw and out_raw are NOT restrict-qualified: lv_scan_downsample with leaf <= 0 hands the same buffer in for both (every read
+// of raw precedes the barriers in front of the first store to out_raw, but `restrict` would promise the compiler more).
+// LDS: 88 KB static here, 156 KB in window_tail_kernel — more than the 64 KB of older CDNA parts: this file is gfx950 code.
+static_assert(sizeof(float4) * 2 * 2048 + sizeof(uint64_t) * 2048 + sizeof(float) * 2048 <= 160 * 1024, "window_small_kernel: one workgroup's LDS (gfx950: 160 KB per CU)");
+__global__ __launch_bounds__(SW_THREADS) void window_small_kernel(const float4* raw, const double* __restrict__ times,
                                                                   uint32_t n_in, const MotionState* __restrict__ states,
                                                                   uint32_t n_states, MotionState xt2, int do_deskew, float leaf,
                                                                   float inv_sort_cell, uint32_t tile_points,
-                                                                  float4* __restrict__ out_raw, float4* __restrict__ out_sorted,
+                                                                  float4* out_raw, float4* __restrict__ out_sorted,
                                                                   uint32_t* __restrict__ tile_order, unsigned* __restrict__ bounds,
                                                                   unsigned long long* __restrict__ note, uint32_t seq) {
     __shared__ float4 s_pt[SMALL_WINDOW];       // de-skewed input
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(SW_THREADS) void window_tail_kernel(const float4* _
     __shared__ uint32_t s_headpos[WT_OUT];
     __shared__ uint32_t s_wsum[SW_THREADS / 64 + 1], s_gsum[SW_THREADS / 64];
     static_assert(sizeof(s_region) >= WT_OUT * (sizeof(float4) + sizeof(uint64_t) + sizeof(float)), "the output arrays overlay the element words and the stage");
+    static_assert(sizeof(s_region) + sizeof(uint32_t) * WT_OUT <= 160 * 1024 - 1024, "window_tail_kernel: one workgroup's LDS (gfx950: 160 KB per CU)");
     uint32_t* s_hi = reinterpret_cast<uint32_t*>(s_region);
     float* s_px = reinterpret_cast<float*>(s_region + WT_IN * sizeof(uint32_t));
     float* s_py = s_px + WT_STAGE;

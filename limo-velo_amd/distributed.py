@@ -66,7 +66,7 @@ def init_host_gather(ctx, dist, torch, rank: int, world: int):
 
 def init_peer_gather(ctx, dist, rank: int, world: int):
     """The one-launch-per-pass multi-rank form over peer-mapped memory (lv_comm_peer_export / lv_comm_peer_init): every rank
-    exports the HIP IPC handle of its gather buffers, `dist` (any backend: the handles are 64 plain bytes) carries them to
+    exports the HIP IPC handle of its gather buffers, `dist` (any backend: the handles are 128 plain bytes) carries them to
     all ranks, every rank maps the others'.  After this, plain ctx.update() on every rank is the multi-GPU update with a
     one-shot peer read per pass instead of a collective."""
     mine = ctx.comm_peer_export()

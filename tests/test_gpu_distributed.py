@@ -305,6 +305,8 @@ def _world2_peer_worker(rank, world, port, n_scan, out_q, ext=0, absent_peer=Fal
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if absent_peer:
+        os.environ["LV_PEER_TIMEOUT_MS"] = "200"
     import torch
     import torch.distributed as dist
 
@@ -325,15 +327,30 @@ def _world2_peer_worker(rank, world, port, n_scan, out_q, ext=0, absent_peer=Fal
                 ctx.set_option("fused_ext", 1)
             ctx.map_build(sc["map_xyz"])
             init_peer_gather(ctx, dist, rank, world)
+            ctx_handles = bytes(capi.PEER_HANDLE_BYTES)
             upd = ShardedUpdater(HipEngine(ctx, torch, multi=False, library_comm=True), rank, world, dist, torch)
             upd.scan_set(scan)
             if absent_peer:
                 err = None
                 if rank == 0:
                     try:
-                        upd.update(sc["x_init"], sc["P0"])
+                        ctx.comm_peer_init(rank, world, [ctx_handles] * world)   # a second init on a live exchange: refused
+                        err = "second lv_comm_peer_init was accepted"
                     except Exception as e:  # noqa: BLE001
-                        err = str(e)
+                        assert "already set up" in str(e), str(e)
+                    import ctypes as C
+
+                    x0, P0, np_ = np.ascontiguousarray(sc["x_init"]).copy(), np.ascontiguousarray(sc["P0"]).copy(), C.c_int(0)
+                    rc = ctx.lib.lv_update(ctx.h, x0.ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), C.byref(np_), None, None)
+                    if rc != 0:
+                        err = err or ctx.lib.lv_last_error().decode()
+                    assert np.array_equal(x0, sc["x_init"]) and np.array_equal(P0, sc["P0"])   # nothing of the failed update came back
+                    try:                      # sticky: the context refuses further work until the exchange is torn down
+                        ctx.filter_set(sc["x_init"], sc["P0"])
+                        ctx.correct()
+                        err = "lv_correct after a failed exchange was accepted"
+                    except Exception as e:  # noqa: BLE001
+                        assert "peer-mapped gather" in str(e), str(e)
                 dist.barrier()
                 out_q.put((rank, err))
                 return
@@ -387,7 +404,8 @@ def test_world2_peer_mapped_gather_on_one_gpu(lv, n_scan, ext):
 
 def test_peer_mapped_gather_times_out_instead_of_hanging(lv):
     """A rank that never publishes its partials (here: it simply does not run the update) must not hang the others: the pull
-    kernel gives up after 50 ms per launch and lv_update reports LV_ESTATE."""
+    kernel gives up after LV_PEER_TIMEOUT_MS (default 2 s; 200 ms here) and lv_update reports LV_ESTATE with the caller's state untouched; a
+    second lv_comm_peer_init on a live exchange is refused."""
     import torch.multiprocessing as mp
 
     mpc = mp.get_context("spawn")
