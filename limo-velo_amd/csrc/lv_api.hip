@@ -556,6 +556,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_LARGE_WINDOW")) c->scan.large_enabled = atoi(e) != 0;
     if (const char* e = getenv("LV_MAIL_FILTER")) c->mail_filter = atoi(e) != 0;
     if (const char* e = getenv("LV_SMALL_INSERT")) c->map.small_front = atoi(e) != 0;
+    if (const char* e = getenv("LV_SURV_LIST")) c->map.surv_list = atoi(e) != 0;
     // (the stamp buffer below is strided by pass_max_wg + 1 workgroup slots: fix the grid limit first)
     c->pass_max_wg = prop.multiProcessorCount;
     if (const char* e = getenv("LV_PASS_WG")) c->pass_max_wg = atoi(e) > 0 ? atoi(e) : c->pass_max_wg;
@@ -1170,6 +1171,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "small_window")) c->scan.small_enabled = on;
     else if (!std::strcmp(name, "large_window")) c->scan.large_enabled = on;
     else if (!std::strcmp(name, "small_insert")) c->map.small_front = on;
+    else if (!std::strcmp(name, "survivor_list")) c->map.surv_list = on;
     else { set_error("lv_set_option: unknown option '%s'", name); return LV_EINVAL; }
     return LV_OK;
 }

@@ -88,6 +88,9 @@ struct MapStore {
     uint32_t* d_nidx_sorted = nullptr;
     uint32_t* d_nalive = nullptr;
     uint32_t* d_napos = nullptr;
+    uint32_t* d_nsurv = nullptr;       // the batch's survivors in sorted-batch (Morton box) order, + the flags / positions that build it
+    uint32_t* d_nsflag = nullptr;
+    uint32_t* d_nspos = nullptr;
     uint32_t* d_rank = nullptr;
     void* d_ntmp = nullptr;
     size_t ntmp_bytes = 0, batch_cap = 0;
@@ -118,6 +121,7 @@ struct MapStore {
     // next call that needs the map's bookkeeping, not by a wait at the end of the insert
     bool sweep_evict = true;     // lv_map_evict_box tests runs, not points (inc_evict_sweep_kernel; LV_SWEEP_EVICT=0 / lv_set_option: the per-point search)
     bool merged_back = true;     // independent stages of the insert's back half share launches (LV_MERGED_INSERT=0 / lv_set_option: off)
+    bool surv_list = true;       // large down-sampling batches: the append passes walk a survivor list in Morton (box sort) order (LV_SURV_LIST=0 / "survivor_list": off)
     bool small_front = true;     // batches of up to 2048 points: the insert's front half in one workgroup launch (LV_SMALL_INSERT=0: off)
     NoteBoard notes;             // the insert's counters come back as a note (lv_note.hpp): n_new, n_dead, dropped, overflow
     uint32_t counters_seq = 0;

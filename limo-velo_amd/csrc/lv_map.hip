@@ -469,7 +469,7 @@ void MapStore::release() {
     hipFree(d_cnt);
     if (h_cnt) hipHostFree(h_cnt);
     hipFree(d_new); hipFree(d_nkeys); hipFree(d_nkeys_sorted); hipFree(d_nidx); hipFree(d_nidx_sorted); hipFree(d_nalive);
-    hipFree(d_napos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
+    hipFree(d_napos); hipFree(d_nsurv); hipFree(d_nsflag); hipFree(d_nspos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_box); hipFree(d_box_next);
     for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_gtab[l]); hipFree(d_gbase[l]); hipFree(d_gslot[l]); }
     note_free(notes);
@@ -808,6 +808,9 @@ int MapStore::reserve_batch(size_t k) {
     LV_REALLOC(d_nidx_sorted, uint32_t, ncap);
     LV_REALLOC(d_nalive, uint32_t, ncap);
     LV_REALLOC(d_napos, uint32_t, ncap);
+    LV_REALLOC(d_nsurv, uint32_t, ncap);
+    LV_REALLOC(d_nsflag, uint32_t, ncap);
+    LV_REALLOC(d_nspos, uint32_t, ncap);
     LV_REALLOC(d_rank, uint32_t, ncap * 27 * SORTED_LEVELS);
     gtab_size = next_pow2((uint64_t)ncap * 4);
     for (int l = 0; l < REPL_LEVELS; ++l) {
@@ -973,20 +976,20 @@ __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx
 __global__ __launch_bounds__(256) void inc_kill_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k,
                                                                 const float4* __restrict__ dead, uint32_t dead_cap, uint32_t g_kill) {
     if (blockIdx.x < g_kill) inc_kill_counted_item(M, dead, dead_cap, blockIdx.x * blockDim.x + threadIdx.x, g_kill * blockDim.x);
-    else inc_register_item(M, G, alive, k, (blockIdx.x - g_kill) * blockDim.x + threadIdx.x);
+    else inc_register_item(M, G, alive, k, inc_block_of(blockIdx.x - g_kill, gridDim.x - g_kill) * blockDim.x + threadIdx.x);
 }
 __global__ __launch_bounds__(256) void inc_relocate_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
                                                                 const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
                                                                 uint32_t id_base, const uint4* __restrict__ reloc, uint32_t reloc_cap,
                                                                 const uint32_t* __restrict__ n_reloc, uint32_t g_rel) {
     if (blockIdx.x < g_rel) inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, g_rel * blockDim.x);
-    else inc_fill_item(M, G, newp, alive, apos, k, id_base, (blockIdx.x - g_rel) * blockDim.x + threadIdx.x);
+    else inc_fill_item(M, G, newp, alive, apos, k, id_base, inc_block_of(blockIdx.x - g_rel, gridDim.x - g_rel) * blockDim.x + threadIdx.x);
 }
 __global__ __launch_bounds__(256) void inc_place_commit_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
                                                                const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
                                                                uint32_t id_base, const uint32_t* __restrict__ rank, uint32_t g_place) {
-    if (blockIdx.x < g_place) inc_place_item(M, G, newp, alive, apos, k, id_base, rank, blockIdx.x * blockDim.x + threadIdx.x);
-    else inc_commit_item(M, G, alive, k, (blockIdx.x - g_place) * blockDim.x + threadIdx.x);
+    if (blockIdx.x < g_place) inc_place_item(M, G, newp, alive, apos, k, id_base, rank, inc_block_of(blockIdx.x, g_place) * blockDim.x + threadIdx.x);
+    else inc_commit_item(M, G, alive, k, inc_block_of(blockIdx.x - g_place, gridDim.x - g_place) * blockDim.x + threadIdx.x);
 }
 
 // ---- lv_map_evict_box without a per-point search ---------------------------------------------------------------------------------
@@ -1211,6 +1214,10 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     G.size = gtab_size;
     G.prank = d_prank;
     G.pslot = d_pslot;
+    // large down-sampling batches walk their survivors in the order of the box sort (Morton): see inc_box_key
+    const bool listed = downsample && !(small_front && k <= (uint32_t)SMALL_BATCH) && k > (uint32_t)SMALL_BATCH && surv_list;
+    G.surv = listed ? d_nsurv : nullptr;
+    G.n_live = &d_cnt->n_new;
     hipLaunchKernelGGL(inc_clear_groups_kernel, dim3((uint32_t)(((uint64_t)gtab_size * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, G,
                        d_gcnt, reset_early ? nullptr : d_cnt);
     const bool fused_front = small_front && k <= (uint32_t)SMALL_BATCH;
@@ -1237,6 +1244,12 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     }
     hipLaunchKernelGGL(inc_commit_points_kernel, dim3(gk), dim3(B), 0, stream, M, Bx, have_boxes ? 1 : 0, d_new, d_nalive, d_napos, k,
                        n_ids);
+    if (listed) {   // the survivor list in sorted-batch order (flags -> scan -> scatter: three small launches)
+        hipLaunchKernelGGL(inc_surv_flag_kernel, dim3(gk), dim3(B), 0, stream, d_nidx_sorted, d_nalive, k, d_nsflag);
+        size_t tmp = ntmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ntmp, tmp, d_nsflag, d_nspos, (int)k, stream));
+        hipLaunchKernelGGL(inc_surv_list_kernel, dim3(gk), dim3(B), 0, stream, d_nidx_sorted, d_nsflag, d_nspos, k, d_nsurv);
+    }
     // voxel groups of the survivors on every level
     hipLaunchKernelGGL(inc_group_kernel, dim3((uint32_t)(((uint64_t)k * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, M, G, d_new,
                        d_nalive, k);
@@ -1249,8 +1262,11 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         rc = kill_dead_list(stream, n_dead);
         if (rc) return rc;
     }
-    const uint64_t t_grp = (uint64_t)k * REPL_LEVELS * GROUP_TARGETS;
-    const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
+    // work items of the append passes: with a survivor list (and the counters just read) one per SURVIVOR and slot, else one per
+    // point of the batch and slot (the dead leave at once)
+    const uint64_t kk = (listed && !counted_kill) ? (uint64_t)(h_cnt->n_new > 0 ? h_cnt->n_new : 1u) : (uint64_t)k;
+    const uint64_t t_grp = kk * REPL_LEVELS * GROUP_TARGETS;
+    const uint64_t t_all = kk * INC_SLOTS_PER_POINT, t_rep = kk * 27 * SORTED_LEVELS;
     const uint32_t g_grp = (uint32_t)((t_grp + B - 1) / B), g_all = (uint32_t)((t_all + B - 1) / B), g_rep = (uint32_t)((t_rep + B - 1) / B);
     const uint64_t t_rel = (uint64_t)(reloc_cap < (1u << 18) ? reloc_cap : (1u << 18)) * RELOC_LANES;   // runs moved per batch (more: re-linearise)
     // at most one run per (group, target) of this batch can be listed; 2048 workgroups walk longer lists in strides

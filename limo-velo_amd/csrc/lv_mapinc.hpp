@@ -89,6 +89,16 @@ struct BoxRW {
 // defines LV_MAPINC_KERNELS before including this header; everybody else only sees the types above.
 #ifdef LV_MAPINC_KERNELS
 
+// XCD-aware work order.  Consecutive workgroup indices are dealt round-robin to the eight XCDs, each with its own L2; the work
+// items of the append / tombstone passes are spatially ordered (inc_box_key), so workgroup b takes the block of items that
+// keeps every XCD on ONE contiguous stretch of the list — neighbours that share table slots, run tails and id arrays then
+// share an L2 as well.  A bijection of [0, n) for every n.
+__device__ __forceinline__ uint32_t inc_block_of(uint32_t b, uint32_t n) {
+    const uint32_t q = n / 8u, r = n % 8u, x = b % 8u;
+    return x * q + (x < r ? x : r) + b / 8u;
+}
+__device__ __forceinline__ uint32_t inc_thread_id() { return inc_block_of(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; }
+
 __device__ __forceinline__ bool pt_alive(const float4& p) { return p.x < __uint_as_float(0x7F800000u) && p.x > -__uint_as_float(0x7F800000u); }
 __device__ __forceinline__ float pos_inf() { return __uint_as_float(0x7F800000u); }
 
@@ -139,8 +149,23 @@ __device__ __forceinline__ int inc_box_coord(float v, float len) {
     f = fminf(fmaxf(f, -1048000.0f), 1048000.0f);
     return (int)f + CELL_OFFSET;
 }
+// The key of a box interleaves the bits of its three 21-bit coordinates (Morton order).  Any injective key serves the box
+// table and the grouping sort; this one makes the SORTED batch spatially coherent, and with it everything that is issued in
+// that order: the box rule's dead list and the survivor list the append passes walk (round 4: neighbours in the list share
+// their 27-blocks, so the table slots, run tails and id arrays a thread touches are the ones its neighbours just touched —
+// the append / tombstone kernels were bound by random 64-byte transactions, not by arithmetic).
+__device__ __forceinline__ uint64_t inc_spread21(uint32_t v) {
+    uint64_t x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x001f00000000ffffull;
+    x = (x | (x << 16)) & 0x001f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
 __device__ __forceinline__ uint64_t inc_box_key(const float4& p, float len) {
-    return pack_cell((uint32_t)inc_box_coord(p.x, len), (uint32_t)inc_box_coord(p.y, len), (uint32_t)inc_box_coord(p.z, len));
+    return inc_spread21((uint32_t)inc_box_coord(p.x, len)) | (inc_spread21((uint32_t)inc_box_coord(p.y, len)) << 1) |
+           (inc_spread21((uint32_t)inc_box_coord(p.z, len)) << 2);
 }
 // calc_dist(point, centre of its box) [UPSTREAM-RECALL ikd-Tree Add_Points]: f32, centre = min + (max - min) / 2 with the
 // division in double as upstream writes it
@@ -330,7 +355,7 @@ __global__ void inc_commit_points_kernel(MapRW M, BoxRW B, int have_boxes, const
 // dead[j] = {x, y, z, id} of a point that left the map: one thread per (point, slot that holds it)
 __device__ __forceinline__ void inc_kill_slot(const MapRW& M, const float4* __restrict__ dead, uint32_t j, int w);
 __global__ void inc_kill_kernel(MapRW M, const float4* __restrict__ dead, uint32_t n_dead) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = inc_thread_id();
     const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
     const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
     if (j >= n_dead) return;
@@ -390,7 +415,39 @@ struct GroupRW {
     uint32_t* pslot;               // [j * REPL_LEVELS + l]: scratch-table slot of that group
     uint32_t* gbase[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: offset of the group's points in the batch tail of target c
     uint32_t* gslot[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: table slot of target c (ID_NONE: outside the range)
+    const uint32_t* surv;          // optional: the batch's survivors (indices into the batch) in the order the passes walk them —
+                                   // the box sort's, i.e. Morton — and their number n_live (device word); nullptr: every point of
+                                   // the batch is visited in input order and the dead leave at once
+    const uint32_t* n_live;
 };
+// work item s of a per-point pass -> the new point j it stands for (false: nothing to do)
+__device__ __forceinline__ bool inc_item_point(const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint32_t s, uint32_t& j) {
+    if (G.surv) {
+        if (s >= *G.n_live) return false;
+        j = G.surv[s];
+        return true;
+    }
+    if (s >= k || !alive[s]) return false;
+    j = s;
+    return true;
+}
+// the survivors in sorted-batch order: flag of sorted position i ...
+__device__ __forceinline__ void inc_surv_flag_item(const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ alive, uint32_t k,
+                                                   uint32_t* __restrict__ flag, uint32_t i) {
+    if (i < k) flag[i] = alive[idx_sorted[i]];
+}
+__global__ void inc_surv_flag_kernel(const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ alive, uint32_t k, uint32_t* __restrict__ flag) {
+    inc_surv_flag_item(idx_sorted, alive, k, flag, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// ... and, after an exclusive scan of the flags, the list itself
+__device__ __forceinline__ void inc_surv_list_item(const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ flag,
+                                                   const uint32_t* __restrict__ fpos, uint32_t k, uint32_t* __restrict__ surv, uint32_t i) {
+    if (i < k && flag[i]) surv[fpos[i]] = idx_sorted[i];
+}
+__global__ void inc_surv_list_kernel(const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ fpos,
+                                     uint32_t k, uint32_t* __restrict__ surv) {
+    inc_surv_list_item(idx_sorted, flag, fpos, k, surv, blockIdx.x * blockDim.x + threadIdx.x);
+}
 constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + (level 2 only) the voxel's own list
 // (No global work lists or group counters: an atomic whose result is needed costs ~10 ns when every thread of a
 // launch hits the same address — 400 000 list appends were 4 ms of a 6 ms insert.  The group that reserves the
@@ -399,9 +456,9 @@ constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + (level 2 only) the
 // pass 1: every surviving new point joins its voxel group on each level
 __device__ __forceinline__ void inc_group_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp,
                                                const uint32_t* __restrict__ alive, uint32_t k, uint32_t t) {
-    const uint32_t j = t / (uint32_t)REPL_LEVELS;
+    uint32_t j;
     const int l = (int)(t % (uint32_t)REPL_LEVELS);
-    if (j >= k || !alive[j]) return;
+    if (!inc_item_point(G, alive, k, t / (uint32_t)REPL_LEVELS, j)) return;
     const float4 p = newp[j];
     const int cx = cell_coord(p.x, M.origin[0], M.inv_cell) >> l, cy = cell_coord(p.y, M.origin[1], M.inv_cell) >> l,
               cz = cell_coord(p.z, M.origin[2], M.inv_cell) >> l;
@@ -425,7 +482,7 @@ __device__ __forceinline__ void inc_group_item(const MapRW& M, const GroupRW& G,
     atomicExch(&M.cnt->overflow, 1u);
 }
 __global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive, uint32_t k) {
-    inc_group_item(M, G, newp, alive, k, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_group_item(M, G, newp, alive, k, inc_thread_id());
 }
 
 // slot of `key` in a bucket / list table, inserting it if absent (plain probe first: most slots exist)
@@ -456,11 +513,11 @@ __device__ __forceinline__ uint32_t table_get_slot(const LevelRW& L, uint64_t ke
 // first point (rank 0) acts, the others leave at once.
 __device__ __forceinline__ bool inc_group_leader(const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint32_t t, int& l,
                                                  int& c, uint32_t& gs) {
-    const uint32_t j = t / (uint32_t)(REPL_LEVELS * GROUP_TARGETS);
+    uint32_t j;
     const uint32_t r = t % (uint32_t)(REPL_LEVELS * GROUP_TARGETS);
     l = (int)(r / (uint32_t)GROUP_TARGETS);
     c = (int)(r % (uint32_t)GROUP_TARGETS);
-    if (j >= k || !alive[j]) return false;
+    if (!inc_item_point(G, alive, k, t / (uint32_t)(REPL_LEVELS * GROUP_TARGETS), j)) return false;
     if (G.prank[(size_t)j * REPL_LEVELS + l] != 0u) return false;
     gs = G.pslot[(size_t)j * REPL_LEVELS + l];
     return true;
@@ -498,7 +555,7 @@ __device__ __forceinline__ void inc_register_item(const MapRW& M, const GroupRW&
     G.gslot[l][r] = slot;
 }
 __global__ void inc_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    inc_register_item(M, G, alive, k, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_register_item(M, G, alive, k, inc_thread_id());
 }
 
 // pass 3: the group that took offset 0 of a target's tail makes room for the whole batch: a run that cannot take
@@ -543,7 +600,7 @@ __device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& 
 }
 __global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
                                    uint32_t reloc_cap, uint32_t* __restrict__ n_reloc) {
-    inc_reserve_item(M, G, alive, k, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_reserve_item(M, G, alive, k, reloc, reloc_cap, n_reloc, inc_thread_id());
 }
 
 // pass 3b: the listed runs move, 32 threads per run
@@ -593,9 +650,9 @@ __device__ __forceinline__ bool inc_place_of(const MapRW& M, const GroupRW& G, u
 __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, uint32_t t) {
     if (M.cnt->overflow) return;
-    const uint32_t j = t / (uint32_t)INC_SLOTS_PER_POINT;
+    uint32_t j;
     const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
-    if (j >= k || !alive[j]) return;
+    if (!inc_item_point(G, alive, k, t / (uint32_t)INC_SLOTS_PER_POINT, j)) return;
     int tl;
     uint32_t slot, pos;
     if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
@@ -614,16 +671,16 @@ __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, 
 }
 __global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base) {
-    inc_fill_item(M, G, newp, alive, apos, k, id_base, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_fill_item(M, G, newp, alive, apos, k, id_base, inc_thread_id());
 }
 
 // pass 5: rank of every new bucket entry among the ids of its tail (levels 0, 1)
 __device__ __forceinline__ void inc_rank_item(const MapRW& M, const GroupRW& G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
                                 uint32_t id_base, uint32_t* __restrict__ rank, uint32_t t) {
     if (M.cnt->overflow) return;
-    const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
+    uint32_t j;
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
-    if (j >= k || !alive[j]) return;
+    if (!inc_item_point(G, alive, k, t / (uint32_t)(27 * SORTED_LEVELS), j)) return;
     int tl;
     uint32_t slot, pos;
     if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
@@ -636,16 +693,16 @@ __device__ __forceinline__ void inc_rank_item(const MapRW& M, const GroupRW& G, 
 }
 __global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
                                 uint32_t id_base, uint32_t* __restrict__ rank) {
-    inc_rank_item(M, G, alive, apos, k, id_base, rank, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_rank_item(M, G, alive, apos, k, id_base, rank, inc_thread_id());
 }
 
 // pass 6: every new bucket entry goes to its ranked place (all reads of pass 5 are done: kernel boundary)
 __device__ __forceinline__ void inc_place_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                  const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank, uint32_t t) {
     if (M.cnt->overflow) return;
-    const uint32_t j = t / (uint32_t)(27 * SORTED_LEVELS);
+    uint32_t j;
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
-    if (j >= k || !alive[j]) return;
+    if (!inc_item_point(G, alive, k, t / (uint32_t)(27 * SORTED_LEVELS), j)) return;
     int tl;
     uint32_t slot, pos;
     if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
@@ -658,7 +715,7 @@ __device__ __forceinline__ void inc_place_item(const MapRW& M, const GroupRW& G,
 }
 __global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                  const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {
-    inc_place_item(M, G, newp, alive, apos, k, id_base, rank, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_place_item(M, G, newp, alive, apos, k, id_base, rank, inc_thread_id());
 }
 
 // pass 7: the owner of every touched target takes the batch tail in
@@ -675,7 +732,7 @@ __device__ __forceinline__ void inc_commit_item(const MapRW& M, const GroupRW& G
     L.aux[slot].fill = 0u;
 }
 __global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    inc_commit_item(M, G, alive, k, blockIdx.x * blockDim.x + threadIdx.x);
+    inc_commit_item(M, G, alive, k, inc_thread_id());
 }
 
 // ---- eviction --------------------------------------------------------------------------------------------------

@@ -77,6 +77,7 @@ struct Emu {
     bool have_boxes = false, built = false;
     uint32_t pool_reserve = 4096;       // small on purpose: relocation / overflow paths get exercised
     uint64_t relinearisations = 0, relocations = 0, n_killed = 0;
+    uint32_t batch_no = 0;
     std::string err;
 
     void cell_of(const float4& p, int c[3]) const {
@@ -348,11 +349,24 @@ struct Emu {
         G.size = gsize;
         G.prank = prank.data();
         G.pslot = pslot.data();
+        // every other down-sampling batch walks its survivors through the list in sorted-batch order, as the product's large
+        // batches do (twin of the listed path of MapStore::add_staged); the others visit every point in input order
+        std::vector<uint32_t> sflag(k), spos(k), surv(k, 0xDEADBEEFu);
+        const bool listed = downsample && (batch_no++ & 1u);
+        if (listed) {
+            launch(inc_surv_flag_kernel, k, (const uint32_t*)idx_sorted.data(), (const uint32_t*)alive.data(), k, sflag.data());
+            uint32_t r2 = 0;
+            for (uint32_t i = 0; i < k; ++i) { spos[i] = r2; r2 += sflag[i]; }
+            launch(inc_surv_list_kernel, k, (const uint32_t*)idx_sorted.data(), (const uint32_t*)sflag.data(), (const uint32_t*)spos.data(), k, surv.data());
+            G.surv = surv.data();
+            G.n_live = &cnt.n_new;
+        }
+        const uint64_t kk = listed ? (uint64_t)(cnt.n_new ? cnt.n_new : 1u) : (uint64_t)k;
         launch(inc_group_kernel, (uint64_t)k * REPL_LEVELS, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), k);
         std::vector<uint32_t> rank((size_t)k * 27 * SORTED_LEVELS, 0u);
         std::vector<uint4> reloc((size_t)k * 27 + 64);
-        const uint64_t t_grp = (uint64_t)k * REPL_LEVELS * GROUP_TARGETS;
-        const uint64_t t_all = (uint64_t)k * INC_SLOTS_PER_POINT, t_rep = (uint64_t)k * 27 * SORTED_LEVELS;
+        const uint64_t t_grp = kk * REPL_LEVELS * GROUP_TARGETS;
+        const uint64_t t_all = kk * INC_SLOTS_PER_POINT, t_rep = kk * 27 * SORTED_LEVELS;
         launch(inc_register_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
         launch(inc_reserve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k, reloc.data(), (uint32_t)reloc.size(), gcnt.data());
         // (the product launches a grid for the runs a batch can list, at most 2048 workgroups, and walks longer lists in strides:
