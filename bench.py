@@ -267,6 +267,9 @@ def main() -> None:
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (GPU results of this run vs the CPU oracle)")
     ap.add_argument("--no-cycle", action="store_true", help="skip the whole-cycle leg (message in -> de-skew -> correct -> map insert)")
+    ap.add_argument("--same-device", action="store_true", help="FUNCTIONAL leg, not a measurement of scaling: the N ranks all use GPU 0 and "
+                    "exchange their partials through the peer-mapped buffers (HIP IPC; RCCL refuses two ranks on one device) — exercises "
+                    "the self-launch, sharding, forms and watchdog logic of an N > 1 run on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -293,6 +296,9 @@ def main() -> None:
     os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    same_dev = bool(args.same_device) and world > 1
+    if same_dev:
+        local_rank = 0                      # every rank on GPU 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -300,7 +306,16 @@ def main() -> None:
 
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if same_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: the data path is the peer exchange
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def reduce_over_ranks(values, op):
+        """MAX / MIN of a list of numbers over the ranks (device tensors with RCCL, host tensors with gloo)."""
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if same_dev else "cuda")
+        dist.all_reduce(t, op=op)
+        return [float(v) for v in t.tolist()]
 
     import lvamd
 
@@ -321,7 +336,13 @@ def main() -> None:
     ctx.map_build(sc["map_xyz"])
     collective = "none"
     engine = ctx
-    if world > 1:
+    if same_dev:
+        from limo_velo_amd.distributed import init_peer_gather
+
+        init_peer_gather(ctx, dist, rank, world)
+        engine = HipEngine(ctx, torch, multi=False, library_comm=True)
+        collective = "peer-mapped exchange (HIP IPC), all ranks on ONE GPU [functional leg]"
+    elif world > 1:
         # preferred: RCCL issued by the library itself on its stream (no host round trip per pass); if the
         # communicator cannot be created, the same all-reduce goes through torch.distributed pass by pass
         try:
@@ -331,9 +352,8 @@ def main() -> None:
         except Exception as e:  # noqa: BLE001
             print(f"[bench] library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
             collective = "rccl (torch.distributed, per pass from the host)"
-        flag = torch.tensor([1 if collective.startswith("rccl (library") else 0], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and engine is not ctx:   # not every rank got a communicator: all fall back together
+        all_have = int(reduce_over_ranks([1 if collective.startswith("rccl (library") else 0], dist.ReduceOp.MIN)[0])
+        if all_have == 0 and engine is not ctx:   # not every rank got a communicator: all fall back together
             ctx.comm_destroy()
             engine = ctx
             collective = "rccl (torch.distributed, per pass from the host)"
@@ -343,6 +363,11 @@ def main() -> None:
     upd = ShardedUpdater(engine, rank, world, dist, torch)
     upd.scan_set(sc["scan_xyz"])
     n_local = upd.n_local
+    if same_dev:
+        from limo_velo_amd.distributed import shard_bounds
+
+        lo0, hi0 = shard_bounds(N_POINTS, 0, world)
+        ctx.comm_set_shard_max(hi0 - lo0)
     if collective.startswith("rccl (library"):
         # With the library's communicator a pass is ONE launch + ONE collective: every rank's workgroup partials are
         # all-gathered (in place, on the context stream) and every rank's next launch folds them itself.  Checked here, on
@@ -364,9 +389,7 @@ def main() -> None:
             print(f"[bench] all-gather form failed on rank {rank}: {e}", file=sys.stderr)
             ok = 0
         if dist is not None:
-            flag = torch.tensor([ok], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
+            ok = int(reduce_over_ranks([ok], dist.ReduceOp.MIN)[0])
         if ok:
             collective += ": one launch per pass, ncclAllGather of the workgroup partials"
         else:
@@ -377,7 +400,10 @@ def main() -> None:
         ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if same_dev:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         ctx.synchronize()
         torch.cuda.synchronize()
 
@@ -398,16 +424,14 @@ def main() -> None:
         region_dt.append(time.perf_counter() - t0)
         region_passes.append(tp)
     if dist is not None:   # a region lasts as long as its slowest rank
-        t = torch.tensor(region_dt, dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        region_dt = [float(v) for v in t.tolist()]
+        region_dt = reduce_over_ranks(region_dt, dist.ReduceOp.MAX)
     order = sorted(range(len(region_dt)), key=lambda i: region_passes[i] / region_dt[i])
     mid = order[(len(order) - 1) // 2]          # the median region (the lower of the two middle ones for an even count)
     dt, total_passes = region_dt[mid], region_passes[mid]
     # ---- the same K steps again with HIP events around the dominant kernel (ctx stream) --------------
     # (event records between kernels add ~5 us gaps each, so they are kept out of the timed region; kernel
     # durations themselves are unaffected and must agree with the rocprofv3 summary under profiles/)
-    lib_comm = collective.startswith("rccl (library")
+    lib_comm = collective.startswith("rccl (library") or same_dev   # (lv_update itself runs the passes and the exchange)
 
     def events_leg(steps):
         """steps profiled updates: average device time of the dominant kernel, of the rest of a pass, and — with a library
@@ -432,7 +456,15 @@ def main() -> None:
     # that the first run on a node yields the breakdown of both: "allgather_one_launch" = one launch per pass + ncclAllGather
     # of the workgroup partials, "allreduce_three_kernel" = search / fit / reduce -> ncclAllReduce of 768 bytes -> solve
     forms = None
-    if lib_comm and (world > 1 or args.force_comm):   # (--force-comm: the same legs with one rank, to exercise this code on one GPU)
+    if same_dev:
+        # the one form this leg has: the peer-mapped one-launch pass; ranks must end bitwise equal
+        objs = [None] * world
+        dist.all_gather_object(objs, (x.tobytes(), P.tobytes()))
+        forms = {"peer_mapped_one_launch": {"avg_kernel_us": kern_ms / max(kern_cnt, 1) * 1e3,
+                                             "exchange_kernel_us_per_pass": [round(float(v), 2) for v in coll_us[:4]],
+                                             "ranks_bitwise_equal": bool(all(o == objs[0] for o in objs)),
+                                             "one_launch_per_pass": bool(fused_main)}}
+    elif lib_comm and (world > 1 or args.force_comm):   # (--force-comm: the same legs with one rank, to exercise this code on one GPU)
         def timed_form():
             barrier_sync()
             a, tp = time.perf_counter(), 0
@@ -441,9 +473,7 @@ def main() -> None:
             barrier_sync()
             d = time.perf_counter() - a
             if dist is not None:
-                t = torch.tensor([d], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                d = float(t.item())
+                d = reduce_over_ranks([d], dist.ReduceOp.MAX)[0]
             return tp / d, d / args.steps * 1e3
 
         def describe(rate_ms, ev):
@@ -453,8 +483,10 @@ def main() -> None:
 
         main_name = "allgather_one_launch" if fused_main else "allreduce_three_kernel"
         forms = {main_name: describe((None, None), (kern_ms, solve_ms, kern_cnt, coll_us))}   # (its rate = the headline value, filled in below)
-        if os.environ.get("LV_BENCH_PEER") == "1" and dist is not None:
-            # opt-in (not yet run across GPUs): the same one-launch form with the partials pulled out of peer-mapped buffers
+        if os.environ.get("LV_BENCH_PEER", "1") != "0" and dist is not None:
+            # (on by default with N > 1 — LV_BENCH_PEER=0 skips it — so that ONE run on a node yields all three forms; it has not run
+            # across GPUs yet: a failure stays inside this try and inside the second context, a lost rank ends a wait after
+            # LV_PEER_TIMEOUT_MS) the same one-launch form with the partials pulled out of peer-mapped buffers
             # (lv_comm_peer_export / _init) by a second context per rank
             try:
                 from limo_velo_amd.distributed import init_peer_gather
@@ -472,9 +504,8 @@ def main() -> None:
                         tp2 += u2.update(sc["x_init"], sc["P0"])[2]
                     c2.synchronize(); barrier_sync()
                     d2 = time.perf_counter() - a2
-                    t = torch.tensor([d2], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    forms["peer_mapped_one_launch"] = {"iters_per_s": tp2 / float(t.item()), "ms_per_step": float(t.item()) / args.steps * 1e3,
+                    d2 = reduce_over_ranks([d2], dist.ReduceOp.MAX)[0]
+                    forms["peer_mapped_one_launch"] = {"iters_per_s": tp2 / d2, "ms_per_step": d2 / args.steps * 1e3,
                                                        "agrees_with_headline_form": bool(np.abs(x2 - x).max() < 1e-9)}
             except Exception as e:  # noqa: BLE001
                 forms["peer_mapped_one_launch"] = {"error": str(e)}
@@ -573,13 +604,15 @@ def main() -> None:
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         traffic, traffic_file = pmc_traffic_bytes(kname) if world == 1 else (None, None)
         rp_us, rp_file = rocprof_kernel_avg_us("lv::pass_kernel<true, false>" if prm.estimate_extrinsics else "lv::pass_kernel<false, false>")
-        if forms:
+        if forms and same_dev:
+            forms["peer_mapped_one_launch"].update(iters_per_s=value, ms_per_step=dt / args.steps * 1e3)
+        elif forms:
             forms["allgather_one_launch" if fused else "allreduce_three_kernel"].update(iters_per_s=value, ms_per_step=dt / args.steps * 1e3)
         out = {
             "metric": "KF-update iters/sec, 64k-pt scan vs 1M-pt map",
             "value": value,
             "unit": "KF-update iters/s",
-            "n_gpus": world,
+            "n_gpus": 1 if same_dev else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -647,8 +680,13 @@ def main() -> None:
             "state_check": {"pos_err_m_from_ground_truth": float(np.linalg.norm(x[:3] - sc["x_true"][:3]))},
         }
         if world > 1 or forms:
-            out["multi_gpu"] = {"measured_on": f"{world} ranks", "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]],
-                                "forms": forms}
+            out["multi_gpu"] = {"measured_on": f"{world} ranks" + (" on ONE GPU (--same-device)" if same_dev else ""),
+                                "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]], "forms": forms}
+            if same_dev:
+                out["multi_gpu"]["same_device"] = True
+                out["multi_gpu"]["note"] = ("FUNCTIONAL leg: the ranks share one GPU (and its L2) and time-slice it — value is NOT a "
+                                            "scaling measurement; what it shows: self-launch, sharding, the peer-mapped exchange kernel's "
+                                            "time per pass, bitwise-equal ranks")
         if cycle is not None:
             out["cycle_ms_64k"] = cycle
         if gate is not None:

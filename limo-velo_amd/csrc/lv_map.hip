@@ -621,7 +621,9 @@ int MapStore::rebuild(hipStream_t stream) {
     for (int l = 0; l < n_levels; ++l) {
         // the level-2 table lives on as the voxel-list table of incremental inserts: give it room to grow
         uint32_t size = next_pow2((uint64_t)counts[l] * (l == CELL_LEVEL ? 8 : 4));
-        if (size > table_size[l]) {
+        // (re)builds also give memory BACK: a table 8x larger than this map wants — a rolling window that shrank from its
+        // initial extent — is re-allocated (hysteresis: growth doubles, so 8x cannot oscillate)
+        if (size > table_size[l] || ((uint64_t)size * 8 <= table_size[l] && table_size[l] > (1u << 20))) {
             if (d_tables[l]) hipFree(d_tables[l]);
             d_tables[l] = nullptr;
             LV_HIP(hipMalloc(&d_tables[l], (size_t)size * sizeof(uint4)));
@@ -663,9 +665,10 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
     GridLevelW occ{d_tables[level], table_size[level] - 1, (uint32_t)(64 - log2u(table_size[level]))};
     const uint32_t occ_slots = table_size[level];
     uint32_t size = next_pow2((uint64_t)n_occupied * 16);  // dilation factor <= 8 keeps the load <= 0.5
-    if (size < btable_size[level]) size = btable_size[level];
+    const bool give_back = (uint64_t)size * 8 <= btable_size[level] && btable_size[level] > (1u << 20);   // (see build_tables)
+    if (size < btable_size[level] && !give_back) size = btable_size[level];
     for (;;) {
-        if (size > btable_size[level] || !d_btable[level]) {
+        if (size != btable_size[level] || !d_btable[level]) {
             LV_REALLOC(d_btable[level], uint4, size);
             LV_REALLOC(d_baux[level], SlotAux, size);
             btable_size[level] = size;
@@ -719,7 +722,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
                 LV_REALLOC(d_bucket_tmp, float4, total + total / 8);
                 bucket_tmp_cap = total + total / 8;
             }
-            if (want > pool_cap[level]) {
+            if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {   // (grow, or give back: see build_tables)
                 pool_cap[level] = 0;
                 LV_REALLOC(d_bxyz[level], float, want * 3 + 4);
                 LV_REALLOC(d_bidx[level], uint32_t, want);
@@ -733,7 +736,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
                 hipLaunchKernelGGL(bucket_pack_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_bucket_tmp,
                                    (uint32_t)total, d_bxyz[level], d_bidx[level]);
         } else {                       // level 2: unordered records, every point remembers where it sits (deletions)
-            if (want > pool_cap[level]) {
+            if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {
                 pool_cap[level] = 0;
                 LV_REALLOC(d_bucket4, float4, want);
                 pool_cap[level] = (size_t)want;

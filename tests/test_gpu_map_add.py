@@ -295,3 +295,39 @@ def test_eviction_by_runs_equals_eviction_by_points(lv, scene_small):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
     assert a[4] == b[4] and a[7] == b[7] and a[8] == b[8]
     assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+
+
+def test_rebuild_gives_memory_back_after_the_map_shrank(lv):
+    """A rolling window that shrank far below its initial extent (configs[4]: a 10 M-point map cut to the 2.4 M points around the
+    sensor) must not keep pools and tables sized for the old map for ever: the (re)build that a re-linearisation runs re-allocates
+    pools 3x / tables 8x larger than the map now wants.  The search on the shrunk structure = the search on a fresh build of the
+    same points, bit for bit."""
+    from limo_velo_amd import capi, synth
+
+    sc = synth.make_scene(4_000_000, 8_192)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        st0 = ctx.map_stats()
+        c = sc["x_init"][:3].astype(np.float32)
+        gone = ctx.map_evict_box(c - np.float32([18, 18, 10]), c + np.float32([18, 18, 10]), keep_inside=True)
+        living = ctx.map_size()
+        assert gone > 0 and living * 5 < 4_000_000, (gone, living)
+        ctx.map_relinearise()
+        st1 = ctx.map_stats()
+        assert st1["living"] == living and st1["ids"] == living
+        for l in range(3):
+            assert st1["pool_cap"][l] * 2 < st0["pool_cap"][l], (l, st0["pool_cap"], st1["pool_cap"])
+        assert st1["bytes"] < 0.6 * st0["bytes"], (st0["bytes"], st1["bytes"])
+        pts = ctx.map_fetch()
+        ctx.scan_set(sc["scan_xyz"])
+        xa, Pa, pa, tra, sa = ctx.update(sc["x_init"], sc["P0"])
+        # ... and it still takes inserts (the pools' free part was laid out for the new size)
+        ctx.map_add_scan(downsample=True)
+        assert ctx.map_size() > living
+        ctx.update(sc["x_init"], sc["P0"])
+    with capi.Context() as ctx:
+        ctx.map_build(pts)
+        ctx.scan_set(sc["scan_xyz"])
+        xb, Pb, pb, trb, sb = ctx.update(sc["x_init"], sc["P0"])
+    assert pa == pb and np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+    assert [s["n_valid"] for s in sa] == [s["n_valid"] for s in sb]
