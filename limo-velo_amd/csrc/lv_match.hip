@@ -1201,9 +1201,11 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         if (CLOSING) {   // the terminal pass: what it needs besides the solve, fetched while the prologue's own loads are in flight
             for (int e = tid; e < NS * NS; e += PK_THREADS) Bk.P[e / NS][e % NS] = ps_in->prep_P[e];
             if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
+            set_identity<PK_THREADS>(Bk.J, tid);   // (the projection blocks are filled in by solve_core, beside the boxplus)
         }
         const bool choose = !CLOSING && !dedicated && a.cost_in != nullptr;
-        if (!solve_core<W, !CLOSING>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk, choose ? a.cost_in : nullptr, choose ? (int)nwg : 0))
+        if (!solve_core<W, !CLOSING>(L, kf, ps_in, a.recs_in, a.nrec, a.sp, &s_pose, tid, clk, choose ? a.cost_in : nullptr, choose ? (int)nwg : 0,
+                                     CLOSING ? &Bk : nullptr))
             return;   // the update ended in an earlier launch
         if (choose && L.cheapest >= 0) keeper = (int)bid == L.cheapest;
         if (keeper) {   // region 0 is about to become the candidate stage: remember what the books need
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             WgBar bar;
             const bool closing = a.rounds == 0;
             bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, closing ? kf->P_prop : K.Pprop,
-                                       closing ? kf->x_prop : K.xp, closing, tid, bar, clk);
+                                       closing ? kf->x_prop : K.xp, closing, tid, bar, clk, CLOSING);
             PK_STAMP(10, tid == 0);
             return;
         }

@@ -110,7 +110,11 @@ struct BookLds {
 template <int NW, bool WITH_POSE = true>
 __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
                                   const double* __restrict__ recs, int nrec, const SolveParams& prm, PoseConsts* pose, int tid,
-                                  long long* clk, const uint32_t* __restrict__ cost_in = nullptr, int ncost = 0) {
+                                  long long* clk, const uint32_t* __restrict__ cost_in = nullptr, int ncost = 0, BookLds* term = nullptr) {
+    // term (closing launch only): the terminal books' scratch, with J = identity and xp = the propagated state already in it:
+    // the three projection blocks of the terminal pass (A-matrix of dx_ on the two SO3 blocks, Nx / Mx on S2) depend on dx_ —
+    // and the S2 one on the new gravity direction — only, so they are computed HERE, beside the boxplus, by lanes that would
+    // idle, instead of behind two more barriers in the books (round 4: the closing launch's serial chain is shorter by them)
     // cost_in (optional): how long each of the ncost searching workgroups of the PREVIOUS launch took; L.cheapest = the
     // quickest one (ties: the highest index), -1 without a history
     constexpr int T = PK_THREADS;
@@ -236,7 +240,14 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
         }
         __syncthreads();
         // x_.boxplus(dx_)
-        if (wave < 3 && lane == 0) boxplus_block(wave, L.x, L.dxo);
+        // (round 4, measured and dropped: the two rotation lanes going straight on to their matrices and the conjugates' instead
+        // of a barrier and four other lanes — two more serial f64 chains per lane cost more than the barrier they replace:
+        // prologue 6.16 -> 6.25 us)
+        if (wave < 3 && lane == 0) {
+            boxplus_block(wave, L.x, L.dxo);
+            if (term && wave == 2) manifold_block(2, 1, L.x, term->xp, L.dxo, nullptr, term->J);   // (after its boxplus: needs the new gravity)
+        }
+        if (term && (wave == 4 || wave == 5) && lane == 0) manifold_block(wave - 4, 1, L.x, term->xp, L.dxo, nullptr, term->J);
         if (wave == 3 && lane < 15) {
             const int dof = lane < 3 ? lane : lane + 6;
             L.x[vect_state_index(dof)] += L.dxo[dof];
@@ -248,21 +259,28 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
             L.last = (t > 1 || kf_iter == prm.maximum_iter - 1) ? 1 : 0;
         }
     }
+    if (!WITH_POSE) { __syncthreads(); return true; }   // (closing launch: no pass follows)
     __syncthreads();
-    if (!WITH_POSE) return true;   // (closing launch: no pass follows)
-    // the constants of the coming pass: four rotation matrices, one lane each, then the composed transforms spread over
-    // one wavefront (same operations, same order as compute_pose_consts => same bits)
-    if (tid >= 320 && tid < 324) {
-        const int w = tid - 320;               // 0: rot, 1: offset_R_L_I, 2: conj(rot), 3: conj(offset_R_L_I)
-        const int q = (w & 1) ? 7 : 3;
-        const double sg = (w & 2) ? -1.0 : 1.0;
-        const double qq[4] = {sg * L.x[q], sg * L.x[q + 1], sg * L.x[q + 2], L.x[q + 3]};
-        quat_to_rot(qq, &L.Rot[w][0]);
+    // the constants of the coming pass by ONE wavefront: four rotation matrices, one lane each, then the composed transforms
+    // spread over its lanes in two stages — wavefront-local fences between the three steps instead of the two workgroup
+    // barriers of rounds 2-3 (same operations, same order as compute_pose_consts => same bits)
+    if (tid >= 64 && tid < 128) {
+        if (tid < 68) {
+            const int w = tid - 64;                // 0: rot, 1: offset_R_L_I, 2: conj(rot), 3: conj(offset_R_L_I)
+            const int q = (w & 1) ? 7 : 3;
+            const double sg = (w & 2) ? -1.0 : 1.0;
+            const double qq[4] = {sg * L.x[q], sg * L.x[q + 1], sg * L.x[q + 2], L.x[q + 3]};
+            quat_to_rot(qq, &L.Rot[w][0]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pose_consts_stage_a(tid - 64, L.x, L.Rot, pose, L.ptmp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pose_consts_stage_b(tid - 64, L.Rot, pose, L.ptmp);
     }
-    __syncthreads();
-    if (tid >= 64 && tid < 128) pose_consts_stage_a(tid - 64, L.x, L.Rot, pose, L.ptmp);
-    __syncthreads();
-    if (tid >= 64 && tid < 128) pose_consts_stage_b(tid - 64, L.Rot, pose, L.ptmp);
     __syncthreads();
     return true;
 }
@@ -383,7 +401,8 @@ template <int NW, int T, class Bar>
 __device__ __forceinline__ void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev* __restrict__ kf, const KfDev::PassState* __restrict__ in,
                                    KfDev::PassState* __restrict__ out, KfHostIO* io, double* __restrict__ sums_out,
                                    double prm_R_inv, int prm_seq, const PoseConsts* pose, const double* Pprop, const double* xprop,
-                                   bool prep_preloaded, int tid, Bar& bar, long long* clk) {
+                                   bool prep_preloaded, int tid, Bar& bar, long long* clk, bool blocks_ready = false) {
+    // blocks_ready: Bk.J already holds the terminal pass' projection (solve_core computed its three blocks: closing launch)
     const int wave = tid >> 6, lane = tid & 63;
     const int pass = K.pass, last = K.last, kf_iter = K.kf_iter;
     if (tid < SUMS_LEN) {
@@ -435,9 +454,11 @@ __device__ __forceinline__ void bookkeeping(const KeepLds& K, BookLds& Bk, KfDev
         if (tid < NX) Bk.xp[tid] = xprop[tid];
     }
     if (tid == 0) Bk.chk = 0u;
-    set_identity<T>(Bk.J, tid);
-    bar();
-    if (wave < 3 && lane == 0) manifold_block(wave, 1, K.x, Bk.xp, K.dxo, nullptr, Bk.J);
+    if (!blocks_ready) {
+        set_identity<T>(Bk.J, tid);
+        bar();
+        if (wave < 3 && lane == 0) manifold_block(wave, 1, K.x, Bk.xp, K.dxo, nullptr, Bk.J);
+    }
     bar();
     congruence<T>(Bk.B, Bk.J, Bk.P, tid);  // B = L_ = J2 P_ J2^T
     for (int e = tid; e < NS * NS; e += T) {   // A = P_ J2^T (J2 = identity outside its three blocks: at most 3 terms each)

@@ -2,7 +2,7 @@
 # Round artefacts: bench line + rocprofv3 kernel stats + PMC traffic for the same command.
 set -u
 export TMPDIR=/tmp
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
