@@ -109,6 +109,10 @@ struct lv_ctx {
     bool qrec_valid = false;       // d_qrec holds the records of a pass over the CURRENT scan (lv_fetch_neighbors)
 
     bool begin_pending = false;    // the update's state waits in h_begin for the first search launch (no begin kernel)
+    bool filter_host = false;      // lv_filter_set just wrote the filter: it lives in h_filter (pinned) until something needs it on the
+                                   // device — the next lv_correct does not: the prior rides in its first launch's arguments
+    bool filter_up_pending = false;   // an upload out of h_filter may still be in flight (ev_filter_up)
+    hipEvent_t ev_filter_up = nullptr;
     BeginArg h_begin;
     int fallback_base = 0;         // device counter value before the update in flight (the device never resets it)
     long mailbox_resyncs = 0;      // updates whose mailbox checksum did not match at first sight (stream synchronised instead)
@@ -234,8 +238,20 @@ void unpack_sums(const double* rec, lv_sums* out) {
 // The resident filter after lv_correct IS kf->x / kf->P_post (filter_in_kf): the next lv_predict reads it from there and the
 // next lv_correct starts from there; only something that needs it in d_filter, or that is about to overwrite kf (an update
 // by value, lv_iterate), copies it out first — in the 100 Hz cycle that launch never happens.
+// The filter as lv_filter_set left it (pinned host memory) goes to d_filter: needed by whatever reads the resident filter on
+// the device other than an lv_correct that starts right from it.
+static int filter_to_device(lv_ctx* c) {
+    if (!c->filter_host) return LV_OK;
+    c->filter_host = false;
+    LV_HIP(hipMemcpyAsync(c->d_filter, c->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, c->stream));
+    if (!c->ev_filter_up) LV_HIP(hipEventCreateWithFlags(&c->ev_filter_up, hipEventDisableTiming));
+    LV_HIP(hipEventRecord(c->ev_filter_up, c->stream));
+    c->filter_up_pending = true;
+    return LV_OK;
+}
 static int flush_predicts(lv_ctx* c) {
     if (c->pred_n == 0) return LV_OK;
+    { int ru = filter_to_device(c); if (ru) return ru; }
     const int n = c->pred_n;
     c->pred_n = 0;
     const KfDev* src = c->pred_src_kf ? c->d_kf : nullptr;
@@ -256,6 +272,10 @@ static int materialise_filter(lv_ctx* c) {
 
 int begin_device(lv_ctx* c, const double* x_host, bool defer, bool from_filter) {
     LV_FLUSH_PREDICTS(c);   // (a queued prediction may still have to read the posterior from kf, which this update is about to overwrite)
+    // a filter that still waits on the host goes to d_filter now: kf_begin_kernel reads it there (from_filter), and an update by
+    // value / lv_iterate / lv_calculate_H uses kf as its working copy but leaves the resident filter alone (the lv_correct that
+    // CONSUMES the host copy through its launch arguments has cleared filter_host before it calls)
+    { int ru = filter_to_device(c); if (ru) return ru; }
     if (!from_filter) { int rm = materialise_filter(c); if (rm) return rm; }
     c->begin_pending = false;
     c->filter_in_mailbox = false;   // (the mailbox is about to receive this update's results)
@@ -621,6 +641,7 @@ void lv_destroy(lv_ctx* c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_kf) hipHostFree(c->h_kf);
     if (c->h_io) hipHostFree(c->h_io);
+    if (c->ev_filter_up) hipEventDestroy(c->ev_filter_up);
     if (c->h_filter) hipHostFree(c->h_filter);
     if (c->h_states_ring) hipHostFree(c->h_states_ring);
     hipFree(c->d_filter);
@@ -758,6 +779,7 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     if (rc) return rc;
     // the state of whichever path ran last (main.cpp:92,102: Xt2 = the state the update just produced — or, before the first
     // map exists, the propagated state the caller handed to lv_update)
+    { int ru = filter_to_device(c); if (ru) return ru; }
     const double* x = (c->state_src == 2 || !c->filter_set || c->filter_in_kf) ? c->d_kf->x : c->d_filter->x;
     hipLaunchKernelGGL(scan_to_world_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, c->scan.d_raw, n, c->map.d_new);
     LV_HIP(hipGetLastError());
@@ -1542,10 +1564,17 @@ int lv_filter_set(lv_ctx* c, const lv_state* x, const double* P) {
     if (!x || !P) { set_error("null argument"); return LV_EINVAL; }
     c->pred_n = 0;   // (queued predictions of a filter that is being replaced)
     c->pred_src_kf = false;
-    LV_HIP(hipStreamSynchronize(c->stream));  // staging reuse
+    // Nothing goes to the device here (round 4; rounds 1-3 synchronised the stream and uploaded): the filter waits in pinned host
+    // memory.  An lv_correct that follows takes it along in its first launch's kernel arguments — exactly as lv_update takes its
+    // x / P — so "set the prior, correct" enqueues without a copy, a begin kernel or a wait; anything else that needs the
+    // filter on the device (lv_predict, lv_map_add_scan, a correct on a route without the argument hand-over) uploads it first.
+    if (c->filter_up_pending) {   // (h_filter is about to be overwritten: an upload out of it must have completed)
+        LV_HIP(hipEventSynchronize(c->ev_filter_up));
+        c->filter_up_pending = false;
+    }
     std::memcpy(c->h_filter->x, x, sizeof(double) * NX);
     std::memcpy(c->h_filter->P, P, sizeof(double) * NS * NS);
-    LV_HIP(hipMemcpyAsync(c->d_filter, c->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, c->stream));
+    c->filter_host = true;
     c->filter_set = true;
     c->filter_in_mailbox = false;
     c->filter_in_kf = false;
@@ -1557,6 +1586,11 @@ int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
     LV_CHECK_CTX(c);
     if (!c->filter_set) { set_error("lv_filter_get before lv_filter_set"); return LV_ESTATE; }
     LV_FLUSH_PREDICTS(c);
+    if (c->filter_host) {   // (set and never touched since: it is still where lv_filter_set put it)
+        if (x) std::memcpy(x, c->h_filter->x, sizeof(double) * NX);
+        if (P) std::memcpy(P, c->h_filter->P, sizeof(double) * NS * NS);
+        return LV_OK;
+    }
     if (c->filter_in_mailbox && c->mail_filter) {
         // the resident filter is the posterior of the lv_correct just enqueued: its finishing pass stores x, P (and the pass count)
         // into the host-mapped mailbox as well — wait for THAT (a poll) instead of a copy + stream synchronise (~30 us of wake-up,
@@ -1608,7 +1642,16 @@ int lv_correct(lv_ctx* c, int* passes) {
         return LV_ESTATE;
     }
     c->update_seq = (c->update_seq + 1) & 0x3fffffff;   // (the finishing pass echoes it into the mailbox: lv_filter_get polls for it)
-    int rc = begin_device(c, nullptr, false, true);       // (kf_begin_kernel installs the filter in kf: no launch of its own)
+    int rc;
+    if (c->filter_host) {
+        // the prior was just set by the host: it rides in the first launch's arguments (x followed by P: FilterDev = the layout
+        // begin_device expects), like an update by value — no upload, no begin kernel
+        static_assert(offsetof(FilterDev, P) == sizeof(double) * NX, "x followed by P");
+        c->filter_host = false;
+        rc = begin_device(c, reinterpret_cast<const double*>(c->h_filter), true, false);
+    } else {
+        rc = begin_device(c, nullptr, false, true);       // (kf_begin_kernel installs the filter in kf: no launch of its own)
+    }
     if (rc) return rc;
     c->in_update = true;
     const int npass = c->prm.MAX_NUM_ITERS + 1;

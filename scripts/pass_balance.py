@@ -40,6 +40,9 @@ for li in range(ends.shape[1]):
     print(f"      search phase alone: min {np.median(se, axis=0).min():.2f} med {np.median(se):.2f} max {np.median(se, axis=0).max():.2f}")
     print(f"      corr(end, bid) {np.corrcoef(m, bid)[0, 1]:+.2f}; by XCD {[round(x, 2) for x in xcd]}; jitter of one workgroup (std) {resid.std():.2f} us,"
           f" spread of the typical ends (std) {m.std():.2f} us")
+    stm = np.median(st, axis=0)                 # a workgroup's typical start after the launch's first
+    print("      typical START by XCD (bid % 8):", [round(float(np.median(stm[bid % 8 == x])), 2) for x in range(8)],
+          " by bid octile:", [round(float(stm[i].mean()), 2) for i in np.array_split(np.argsort(bid), 8)], f" max {stm.max():.2f}")
     q = np.array_split(np.argsort(bid), 8)
     print("      typical end by bid octile:", [round(float(m[i].mean()), 2) for i in q])
     slow = np.argsort(-m)[:8]
