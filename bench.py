@@ -272,6 +272,8 @@ def main() -> None:
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (GPU results of this run vs the CPU oracle)")
     ap.add_argument("--no-cycle", action="store_true", help="skip the whole-cycle leg (message in -> de-skew -> correct -> map insert)")
+    ap.add_argument("--resident-only", action="store_true", help="profiling aid (scripts/gpu_profile.sh): only the timed resident steps — no "
+                    "by-value legs, no event-instrumented repetition — so that a rocprofv3 run of this command sees the timed step alone")
     ap.add_argument("--same-device", action="store_true", help="FUNCTIONAL leg, not a measurement of scaling: the N ranks all use GPU 0 and "
                     "exchange their partials through the peer-mapped buffers (HIP IPC; RCCL refuses two ranks on one device) — exercises "
                     "the self-launch, sharding, forms and watchdog logic of an N > 1 run on a one-GPU box")
@@ -472,7 +474,9 @@ def main() -> None:
     dt, total_passes = region_dt[mid], region_passes[mid]
     by_value_sync = None
     x_res = P_res = None
-    if resident:
+    if resident and args.resident_only:
+        x_res, P_res = ctx.filter_get()
+    elif resident:
         x_res, P_res = ctx.filter_get()          # the posterior the last resident step left on the device
         bv_dt, bv_p = timed_regions(min(args.regions, 3), by_value=True)
         bm = median_region(bv_dt, bv_p)
@@ -501,7 +505,7 @@ def main() -> None:
         return k_ms, s_ms, cnt, (c_us / max(steps, 1))
 
     kern_ms, kern_cnt, solve_ms, coll_us = 0.0, 0, 0.0, np.zeros(8)
-    if world == 1 or lib_comm:   # lv_update itself runs the passes: per-kernel events exist
+    if (world == 1 or lib_comm) and not args.resident_only:   # lv_update itself runs the passes: per-kernel events exist
         kern_ms, solve_ms, kern_cnt, coll_us = events_leg(args.steps)
     fused_main = bool(ctx.last_update_fused())
     # ---- N > 1: the OTHER form of the multi-GPU pass, the same K steps (timed like the headline region, then with events), so
