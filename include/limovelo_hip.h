@@ -271,6 +271,9 @@ int lv_update(lv_ctx* ctx, lv_state* x, double* P, int* passes, lv_sums* per_pas
  * lv_predict(dt, Q, acc, gyro)      = esekf::predict(dt, Q, in) as called by Localizator::propagate
  *                                     (Localizator.cpp:159-173; Q row-major 12x12, acc = imu.a, gyro = imu.w)
  * lv_correct(passes)                = lv_update on the resident state; asynchronous when passes == NULL.
+ * lv_filter_set itself neither uploads nor waits (round 4): the filter stays in pinned host memory until something needs it on the
+ * device; an lv_correct that follows takes it along in its first launch's kernel arguments (as lv_update takes its x / P), so "set
+ * the prior, correct" is two enqueue-only calls — bench.py's timed step.
  * Nothing here waits for the device except lv_filter_get and lv_correct with passes != NULL: lv_predict calls are queued (up to
  * eight steps with the same Q go out as one launch when something needs the filter: lv_correct, lv_filter_get, lv_map_add_scan,
  * lv_synchronize, an update by value); after lv_correct the posterior stays in the update's working copy until something needs
