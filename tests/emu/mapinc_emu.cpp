@@ -562,6 +562,9 @@ uint32_t emu_size(void* h) { return static_cast<Emu*>(h)->m; }
 uint32_t emu_ids(void* h) { return static_cast<Emu*>(h)->n_ids; }
 uint64_t emu_relinearisations(void* h) { return static_cast<Emu*>(h)->relinearisations; }
 uint64_t emu_relocations(void* h) { return static_cast<Emu*>(h)->relocations; }
+// the pure helpers of the insert's work order (lv_mapinc.hpp), exposed for tests/test_mapinc_emulation.py
+uint32_t emu_block_of(uint32_t b, uint32_t n) { return inc_block_of(b, n); }
+uint64_t emu_box_key(float x, float y, float z, float len) { return inc_box_key(float4{x, y, z, 0.f}, len); }
 uint32_t emu_tombstones(void* h) { return (uint32_t)static_cast<Emu*>(h)->n_killed; }
 uint32_t emu_fetch(void* h, float* out) {
     Emu* e = static_cast<Emu*>(h);

@@ -101,3 +101,49 @@ def test_batched_predictions_and_lazy_filter_copies_change_no_bit(lv, scene_smal
         assert len(out) == len(ref)
         for (xa, Pa), (xb, Pb) in zip(out, ref):
             assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), key
+
+
+def test_filter_set_hands_over_lazily_and_is_never_lost(lv, oracle, scene_small):
+    """lv_filter_set (round 4) neither uploads nor waits: the filter stays in pinned host memory until something needs it on
+    the device.  Whatever comes next must see exactly the filter that was set: lv_filter_get (no device involved), lv_correct
+    (the prior rides in its first launch's arguments: same result as the update by value), lv_predict (uploaded first), an
+    lv_update / lv_iterate by value in between (they use the device's working copy but leave the resident filter alone), a second
+    lv_filter_set (replaces the first)."""
+    from limo_velo_amd import capi
+
+    sc = scene_small
+    x0, P0 = sc["x_init"].copy(), sc["P0"].copy()
+    x1 = oracle.boxplus(x0, np.r_[0.02, -0.01, 0.015, 0.003, -0.002, 0.004, np.zeros(17)])
+    acc, gyro = np.array([0.1, -0.05, 9.81]), np.array([0.01, 0.02, -0.01])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        xu, Pu, pu, _, _ = ctx.update(x0, P0)                    # the reference result: update by value from (x0, P0)
+        # set -> get
+        ctx.filter_set(x1, P0)
+        xg, Pg = ctx.filter_get()
+        assert np.array_equal(xg, x1) and np.array_equal(Pg, P0)
+        # set (replaces) -> correct: the by-value update, bit for bit
+        ctx.filter_set(x0, P0)
+        assert ctx.correct() == pu
+        xg, Pg = ctx.filter_get()
+        assert np.array_equal(xg, xu) and np.array_equal(Pg, Pu)
+        # set -> an update by value and a capturing pass in between -> correct still starts from the filter that was set
+        ctx.filter_set(x0, P0)
+        ctx.update(x1, P0)
+        ctx.iterate(x1)
+        assert ctx.correct() == pu
+        xg, Pg = ctx.filter_get()
+        assert np.array_equal(xg, xu) and np.array_equal(Pg, Pu)
+        # set -> predict (needs the filter on the device) -> get
+        ctx.filter_set(x0, P0)
+        ctx.predict(0.01, _Q(), acc, gyro)
+        xg, Pg = ctx.filter_get()
+        xo, Po = oracle.predict(x0, P0, 0.01, _Q(), acc, gyro)
+        assert np.abs(xg - xo).max() < 1e-12 and np.abs(Pg - Po).max() < 1e-12 * max(1.0, np.abs(Po).max())
+        # many set + correct pairs enqueued without waiting (bench.py's timed step), one wait at the end
+        for _ in range(20):
+            ctx.filter_set(x0, P0)
+            ctx.correct(want_passes=False)
+        xg, Pg = ctx.filter_get()
+        assert np.array_equal(xg, xu) and np.array_equal(Pg, Pu) and ctx.last_passes() == pu

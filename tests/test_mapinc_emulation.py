@@ -208,3 +208,40 @@ def test_non_finite_points_are_dropped(emu, oracle):
     mp.check()
     assert np.array_equal(mp.fetch().view(np.uint32), ref.view(np.uint32))
     mp.close()
+
+
+def test_work_order_helpers_of_the_insert(emu):
+    """inc_block_of: the XCD-aware workgroup -> item-block map must be a bijection of [0, n) for every grid size (a hole would
+    skip work items, a collision would run them twice) that keeps the workgroups of one XCD (b % 8) on one contiguous stretch;
+    inc_box_key: the Morton key of a 0.2 m box must be injective on the boxes (it is the key of the box table and of the
+    grouping sort) and order boxes along the Z-curve."""
+    import ctypes as C
+
+    emu.emu_block_of.argtypes = [C.c_uint32, C.c_uint32]
+    emu.emu_block_of.restype = C.c_uint32
+    emu.emu_box_key.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float]
+    emu.emu_box_key.restype = C.c_uint64
+    for n in list(range(1, 70)) + [255, 256, 257, 1000, 4099]:
+        img = [emu.emu_block_of(b, n) for b in range(n)]
+        assert sorted(img) == list(range(n)), n
+        for x in range(min(8, n)):
+            mine = sorted(img[b] for b in range(x, n, 8))
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (n, x)      # contiguous per XCD
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-300.0, 300.0, (20_000, 3)).astype(np.float32)
+    box = np.floor(pts / np.float32(0.2)).astype(np.int64)
+    keys = np.array([emu.emu_box_key(float(p[0]), float(p[1]), float(p[2]), 0.2) for p in pts], np.uint64)
+    # same box <=> same key
+    _, inv_b = np.unique(box, axis=0, return_inverse=True)
+    _, inv_k = np.unique(keys, return_inverse=True)
+    assert len(np.unique(inv_b)) == len(np.unique(inv_k))
+    assert len(np.unique(np.stack([inv_b.ravel(), inv_k.ravel()], 1), axis=0)) == len(np.unique(inv_k))
+    # Z-curve: de-interleaving the key gives back the (offset) box coordinates
+    def compact(k, shift):
+        v = np.zeros(len(k), np.int64)
+        for bit in range(21):
+            v |= ((k >> np.uint64(3 * bit + shift)) & np.uint64(1)).astype(np.int64) << bit
+        return v
+    off = 1 << 20
+    assert np.array_equal(compact(keys, 0) - off, box[:, 0]) and np.array_equal(compact(keys, 1) - off, box[:, 1])
+    assert np.array_equal(compact(keys, 2) - off, box[:, 2])
