@@ -822,6 +822,10 @@ int lv_map_get_stats(lv_ctx* c, lv_map_stats* out) {
     if (!out) { set_error("null argument"); return LV_EINVAL; }
     static_assert(sizeof(lv_map_stats) == sizeof(MapStats), "lv_map_stats layout");
     MapStats st;
+    if (c->map.h_cnt && c->map.d_cnt && c->map.built) {   // (the pools' cursors live on the device: fetch them for the statistics)
+        LV_HIP(hipMemcpyAsync(c->map.h_cnt, c->map.d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, c->stream));
+        LV_HIP(hipStreamSynchronize(c->stream));
+    }
     c->map.stats(&st);
     std::memcpy(out, &st, sizeof(st));
     return LV_OK;

@@ -1259,8 +1259,17 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     }   // !fused_front
     const bool counted_kill = downsample && k <= (uint32_t)SMALL_BATCH;
     if (!counted_kill && downsample) {
-        LV_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(MapCounters), hipMemcpyDeviceToHost, stream));
-        LV_HIP(hipStreamSynchronize(stream));
+        // the counters of the front half (survivors, occupants that lost) size the launches that follow: fetched as a NOTE (a
+        // one-thread kernel posts them into pinned memory, the host polls: lv_note.hpp) instead of a copy + stream synchronise,
+        // whose wake-up leaves the device idle for ~30 us in the middle of the insert (round 4)
+        LV_HIP(note_alloc(notes));
+        const uint32_t mid_seq = notes.next();
+        hipLaunchKernelGGL(inc_post_counters_kernel, dim3(1), dim3(64), 0, stream, d_cnt, notes.d, mid_seq);
+        LV_HIP(hipGetLastError());
+        uint32_t mv[4] = {0, 0, 0, 0};   // n_new, n_dead, dropped, overflow
+        if (!note_wait(notes, 0, 4, mid_seq, mv, stream)) { set_error("map insert: the front half's counters never arrived"); return LV_EHIP; }
+        h_cnt->n_new = mv[0];
+        h_cnt->n_dead = mv[1];
         n_dead = h_cnt->n_dead < dead_cap ? h_cnt->n_dead : (uint32_t)dead_cap;
         rc = kill_dead_list(stream, n_dead);
         if (rc) return rc;
