@@ -101,6 +101,7 @@ struct MapStore {
     uint32_t* d_pslot = nullptr;
     uint32_t* d_gbase[REPL_LEVELS] = {};
     uint32_t* d_gslot[REPL_LEVELS] = {};
+    uint2* d_gdst[REPL_LEVELS] = {};
     uint32_t* d_gcnt = nullptr;        // [0] relocations of the batch
     uint4* d_reloc = nullptr;
     uint32_t reloc_cap = 0;

@@ -471,7 +471,7 @@ void MapStore::release() {
     hipFree(d_new); hipFree(d_nkeys); hipFree(d_nkeys_sorted); hipFree(d_nidx); hipFree(d_nidx_sorted); hipFree(d_nalive);
     hipFree(d_napos); hipFree(d_nsurv); hipFree(d_nsflag); hipFree(d_nspos); hipFree(d_rank); hipFree(d_ntmp); hipFree(d_dead); hipFree(d_alive); hipFree(d_apos); hipFree(d_ascan_tmp);
     hipFree(d_box); hipFree(d_box_next);
-    for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_gtab[l]); hipFree(d_gbase[l]); hipFree(d_gslot[l]); }
+    for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_gtab[l]); hipFree(d_gbase[l]); hipFree(d_gslot[l]); hipFree(d_gdst[l]); }
     note_free(notes);
     hipFree(d_prank); hipFree(d_pslot); hipFree(d_gcnt); hipFree(d_reloc);
     *this = MapStore();
@@ -820,6 +820,7 @@ int MapStore::reserve_batch(size_t k) {
         LV_REALLOC(d_gtab[l], uint4, gtab_size);
         LV_REALLOC(d_gbase[l], uint32_t, (size_t)gtab_size * GROUP_TARGETS);
         LV_REALLOC(d_gslot[l], uint32_t, (size_t)gtab_size * GROUP_TARGETS);
+        LV_REALLOC(d_gdst[l], uint2, (size_t)gtab_size * GROUP_TARGETS);
     }
     LV_REALLOC(d_prank, uint32_t, ncap * REPL_LEVELS);
     LV_REALLOC(d_pslot, uint32_t, ncap * REPL_LEVELS);
@@ -981,12 +982,13 @@ __global__ __launch_bounds__(256) void inc_kill_register_kernel(MapRW M, GroupRW
     if (blockIdx.x < g_kill) inc_kill_counted_item(M, dead, dead_cap, blockIdx.x * blockDim.x + threadIdx.x, g_kill * blockDim.x);
     else inc_register_item(M, G, alive, k, inc_block_of(blockIdx.x - g_kill, gridDim.x - g_kill) * blockDim.x + threadIdx.x);
 }
-__global__ __launch_bounds__(256) void inc_relocate_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
-                                                                const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
-                                                                uint32_t id_base, const uint4* __restrict__ reloc, uint32_t reloc_cap,
-                                                                const uint32_t* __restrict__ n_reloc, uint32_t g_rel) {
+// (round 4: the listed runs move while every (group, target) notes where its target's batch tail lies — inc_resolve — and the new
+// entries go to the tails in a launch of their own behind it)
+__global__ __launch_bounds__(256) void inc_relocate_resolve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k,
+                                                                   const uint4* __restrict__ reloc, uint32_t reloc_cap,
+                                                                   const uint32_t* __restrict__ n_reloc, uint32_t g_rel) {
     if (blockIdx.x < g_rel) inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, g_rel * blockDim.x);
-    else inc_fill_item(M, G, newp, alive, apos, k, id_base, inc_block_of(blockIdx.x - g_rel, gridDim.x - g_rel) * blockDim.x + threadIdx.x);
+    else inc_resolve_item(M, G, alive, k, inc_block_of(blockIdx.x - g_rel, gridDim.x - g_rel) * blockDim.x + threadIdx.x);
 }
 __global__ __launch_bounds__(256) void inc_place_commit_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
                                                                const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
@@ -1211,6 +1213,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         G.table[l] = d_gtab[l];
         G.gbase[l] = d_gbase[l];
         G.gslot[l] = d_gslot[l];
+        G.gdst[l] = d_gdst[l];
     }
     G.mask = gtab_size - 1;
     G.shift = (uint32_t)(64 - log2u(gtab_size));
@@ -1289,8 +1292,9 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         const uint32_t g_kill = counted_kill ? 256u : 0u;   // the occupants that lost: how many is only known on the device
         hipLaunchKernelGGL(inc_kill_register_kernel, dim3(g_kill + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_dead, (uint32_t)dead_cap, g_kill);
         hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
-        hipLaunchKernelGGL(inc_relocate_fill_kernel, dim3(g_rel + g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_reloc,
+        hipLaunchKernelGGL(inc_relocate_resolve_kernel, dim3(g_rel + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc,
                            (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
+        hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
         hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
         hipLaunchKernelGGL(inc_place_commit_kernel, dim3(g_rep + g_grp), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank, g_rep);
     } else {
@@ -1298,6 +1302,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     hipLaunchKernelGGL(inc_register_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
     hipLaunchKernelGGL(inc_relocate_kernel, dim3(g_rel), dim3(B), 0, stream, M, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+    hipLaunchKernelGGL(inc_resolve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
     hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank);

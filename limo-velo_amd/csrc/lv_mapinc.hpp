@@ -415,6 +415,9 @@ struct GroupRW {
     uint32_t* pslot;               // [j * REPL_LEVELS + l]: scratch-table slot of that group
     uint32_t* gbase[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: offset of the group's points in the batch tail of target c
     uint32_t* gslot[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: table slot of target c (ID_NONE: outside the range)
+    uint2* gdst[REPL_LEVELS];      // [slot * GROUP_TARGETS + c]: {absolute pool index of target c's batch tail, entries the batch appends
+                                   // to it} (x = ID_NONE: no such target), written once per (group, target) after the room is made
+                                   // (inc_resolve): the per-point passes then need neither the table nor the aux record of the target
     const uint32_t* surv;          // optional: the batch's survivors (indices into the batch) in the order the passes walk them —
                                    // the box sort's, i.e. Morton — and their number n_live (device word); nullptr: every point of
                                    // the batch is visited in input order and the dead leave at once
@@ -603,6 +606,24 @@ __global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restric
     inc_reserve_item(M, G, alive, k, reloc, reloc_cap, n_reloc, inc_thread_id());
 }
 
+// pass 3a: every (voxel group, target) notes where the target's batch tail starts in the pool and how long it is — table slot and
+// aux record are read ONCE per (group, target) here instead of once per (point, target) in each of the three passes below
+// (round 4: those passes are bound by the requests they issue)
+__device__ __forceinline__ void inc_resolve_item(const MapRW& M, const GroupRW& G, const uint32_t* __restrict__ alive, uint32_t k, uint32_t t) {
+    int l, c;
+    uint32_t gs;
+    if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
+    const size_t r = (size_t)gs * GROUP_TARGETS + (size_t)c;
+    const uint32_t slot = G.gslot[l][r];
+    if (slot == ID_NONE) { G.gdst[l][r] = uint2{ID_NONE, 0u}; return; }
+    const LevelRW& L = M.lv[c < 27 ? l : CELL_SLOT];
+    const SlotAux a = L.aux[slot];
+    G.gdst[l][r] = uint2{L.table[slot].z + a.tail0, a.pending};
+}
+__global__ void inc_resolve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
+    inc_resolve_item(M, G, alive, k, inc_thread_id());
+}
+
 // pass 3b: the listed runs move, 32 threads per run
 constexpr int RELOC_LANES = 32;
 __device__ __forceinline__ void inc_relocate_item(const MapRW& M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc,
@@ -633,15 +654,15 @@ __global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, ui
     inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-// where new point j goes in target (l, c): its table slot and the position inside the run
-__device__ __forceinline__ bool inc_place_of(const MapRW& M, const GroupRW& G, uint32_t j, int w, int& tl, uint32_t& slot, uint32_t& pos) {
-    int l, c;
+// where new point j goes in target w: the level's table index, the absolute pool index of the target's batch tail, the tail's
+// length and the point's offset inside it (arbitrary order: its group's share + its rank in the group); c = target of its level
+__device__ __forceinline__ bool inc_dst_of(const GroupRW& G, uint32_t j, int w, int& tl, int& l, int& c, size_t& r, uint2& dst, uint32_t& off) {
     if (w < 27 * REPL_LEVELS) { l = w / 27; c = w % 27; tl = l; }
     else { l = CELL_LEVEL; c = 27; tl = CELL_SLOT; }
-    const size_t r = (size_t)G.pslot[(size_t)j * REPL_LEVELS + l] * GROUP_TARGETS + (size_t)c;
-    slot = G.gslot[l][r];
-    if (slot == ID_NONE) return false;
-    pos = M.lv[tl].aux[slot].tail0 + G.gbase[l][r] + G.prank[(size_t)j * REPL_LEVELS + l];
+    r = (size_t)G.pslot[(size_t)j * REPL_LEVELS + l] * GROUP_TARGETS + (size_t)c;
+    dst = G.gdst[l][r];
+    if (dst.x == ID_NONE) return false;
+    off = G.gbase[l][r] + G.prank[(size_t)j * REPL_LEVELS + l];
     return true;
 }
 
@@ -653,20 +674,27 @@ __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, 
     uint32_t j;
     const int w = (int)(t % (uint32_t)INC_SLOTS_PER_POINT);
     if (!inc_item_point(G, alive, k, t / (uint32_t)INC_SLOTS_PER_POINT, j)) return;
-    int tl;
-    uint32_t slot, pos;
-    if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
-    const float4 p = newp[j];
+    int tl, l, c;
+    size_t r;
+    uint2 dst;
+    uint32_t off;
+    if (!inc_dst_of(G, j, w, tl, l, c, r, dst, off)) return;
     const uint32_t id = id_base + apos[j];
-    const size_t at = (size_t)M.lv[tl].table[slot].z + pos;
+    const size_t at = (size_t)dst.x + off;
     if (tl < SORTED_LEVELS) {
         M.bidx[tl][at] = id;
-    } else if (tl < REPL_LEVELS) {
-        M.bucket4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
-        M.backptr[(size_t)id * 27 + (uint32_t)(w % 27)] = pos;
     } else {
-        M.cell4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
-        M.cellpos[id] = pos;
+        // the unordered runs remember positions RELATIVE to the run's start (a run may move): that needs the count before
+        // the batch, i.e. the aux record after all (28 of a point's 82 targets)
+        const float4 p = newp[j];
+        const uint32_t pos = M.lv[tl].aux[G.gslot[l][r]].tail0 + off;
+        if (tl < REPL_LEVELS) {
+            M.bucket4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+            M.backptr[(size_t)id * 27 + (uint32_t)c] = pos;
+        } else {
+            M.cell4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+            M.cellpos[id] = pos;
+        }
     }
 }
 __global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
@@ -681,14 +709,15 @@ __device__ __forceinline__ void inc_rank_item(const MapRW& M, const GroupRW& G, 
     uint32_t j;
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
     if (!inc_item_point(G, alive, k, t / (uint32_t)(27 * SORTED_LEVELS), j)) return;
-    int tl;
-    uint32_t slot, pos;
-    if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
-    const SlotAux a = M.lv[tl].aux[slot];
-    const uint32_t* ids = M.bidx[tl] + (size_t)M.lv[tl].table[slot].z + a.tail0;
+    int tl, l, c;
+    size_t rr;
+    uint2 dst;
+    uint32_t off;
+    if (!inc_dst_of(G, j, w, tl, l, c, rr, dst, off)) return;
+    const uint32_t* ids = M.bidx[tl] + (size_t)dst.x;
     const uint32_t id = id_base + apos[j];
     uint32_t r = 0;
-    for (uint32_t i = 0; i < a.pending; ++i) r += ids[i] < id ? 1u : 0u;
+    for (uint32_t i = 0; i < dst.y; ++i) r += ids[i] < id ? 1u : 0u;
     rank[t] = r;
 }
 __global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
@@ -703,11 +732,13 @@ __device__ __forceinline__ void inc_place_item(const MapRW& M, const GroupRW& G,
     uint32_t j;
     const int w = (int)(t % (uint32_t)(27 * SORTED_LEVELS));
     if (!inc_item_point(G, alive, k, t / (uint32_t)(27 * SORTED_LEVELS), j)) return;
-    int tl;
-    uint32_t slot, pos;
-    if (!inc_place_of(M, G, j, w, tl, slot, pos)) return;
+    int tl, l, c;
+    size_t rr;
+    uint2 dst;
+    uint32_t off;
+    if (!inc_dst_of(G, j, w, tl, l, c, rr, dst, off)) return;
     const float4 p = newp[j];
-    const size_t at = (size_t)M.lv[tl].table[slot].z + M.lv[tl].aux[slot].tail0 + rank[t];
+    const size_t at = (size_t)dst.x + rank[t];
     M.bxyz[tl][at * 3 + 0] = p.x;
     M.bxyz[tl][at * 3 + 1] = p.y;
     M.bxyz[tl][at * 3 + 2] = p.z;

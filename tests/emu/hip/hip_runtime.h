@@ -20,6 +20,7 @@
 
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned int x, y, z, w; };
+struct uint2 { unsigned int x, y; };
 struct emu_dim3 { unsigned int x = 1, y = 1, z = 1; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 

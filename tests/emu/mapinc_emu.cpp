@@ -336,13 +336,15 @@ struct Emu {
         const uint32_t gsize = next_pow2((uint64_t)k * 4);
         std::vector<uint4> gtab[REPL_LEVELS];
         std::vector<uint32_t> gbase[REPL_LEVELS], gslot[REPL_LEVELS];
+        std::vector<uint2> gdst[REPL_LEVELS];
         std::vector<uint32_t> prank((size_t)k * REPL_LEVELS, 0u), pslot((size_t)k * REPL_LEVELS, 0u), gcnt(4, 0u);
         GroupRW G{};
         for (int l = 0; l < REPL_LEVELS; ++l) {
             gtab[l].assign(gsize, uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
             gbase[l].assign((size_t)gsize * GROUP_TARGETS, 0xDEADBEEFu);
             gslot[l].assign((size_t)gsize * GROUP_TARGETS, 0xDEADBEEFu);
-            G.table[l] = gtab[l].data(); G.gbase[l] = gbase[l].data(); G.gslot[l] = gslot[l].data();
+            gdst[l].assign((size_t)gsize * GROUP_TARGETS, uint2{0xDEADBEEFu, 0xDEADBEEFu});
+            G.table[l] = gtab[l].data(); G.gbase[l] = gbase[l].data(); G.gslot[l] = gslot[l].data(); G.gdst[l] = gdst[l].data();
         }
         G.mask = gsize - 1;
         G.shift = (uint32_t)(64 - log2u(gsize));
@@ -372,6 +374,7 @@ struct Emu {
         // (the product launches a grid for the runs a batch can list, at most 2048 workgroups, and walks longer lists in strides:
         // 16 runs per sweep here, so that the stride loop is exercised)
         launch(inc_relocate_kernel, (uint64_t)16 * RELOC_LANES, M, (const uint4*)reloc.data(), (uint32_t)reloc.size(), (const uint32_t*)gcnt.data());
+        launch(inc_resolve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
         launch(inc_fill_kernel, t_all, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids);
         launch(inc_rank_kernel, t_rep, M, G, (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids, rank.data());
         launch(inc_place_kernel, t_rep, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
