@@ -375,7 +375,7 @@ int lv_fetch_knn(lv_ctx* ctx, uint32_t* idx, float* d2);
  * needs a capturing launch). */
 int lv_fetch_neighbors(lv_ctx* ctx, float* nbr_xyz, float* d2, float* p_world, int32_t* found);
 /* The single-GPU lv_update / lv_correct run ONE launch per pass (pass_kernel: the solve of the previous pass in every
- * workgroup, the search, the plane fits; no capture, degeneracy_mode 0, lanes_per_query 8, up to 196 608 scan points) and keep the
+ * workgroup, the search, the plane fits; no capture, degeneracy_mode 0, lanes_per_query 8, up to 16 rounds per workgroup = 1 M scan points on a 256-CU part) and keep the
  * hand-over records in LDS (also with estimate_extrinsics since round 3).  lv_set_record_dump(ctx, 1) makes that same kernel also store them to memory so that
  * lv_fetch_neighbors can pin it (one uniform branch; off by default).  lv_last_update_fused: 1 if the most recent
  * lv_update / lv_correct took the one-launch-per-pass route, 0 if the three-kernel pass (search / fit / solve). */
@@ -388,13 +388,13 @@ int lv_last_passes(lv_ctx* ctx);
 /* Geometry of the one-launch-per-pass kernel for an n_scan-point scan on a part with n_cus compute units (pure host
  * logic, no GPU needed): out = {searching workgroups, search steps per round (1 or 2), rounds per workgroup,
  * 1 if one more workgroup only keeps the books (a CU is left over) else 0}.  A workgroup searches 4 tiles of 32 points
- * per step; lv_update takes this route up to 3 rounds (196 608 points on a 256-CU part). */
+ * per step; lv_update takes this route up to 16 rounds (1 M points on a 256-CU part; 3 rounds with estimate_extrinsics). */
 int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]);
 /* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);
 /* Tuning / test knobs by name (the environment variables LV_<NAME> set the defaults at lv_create): "fused_pass",
- * "fused_ext" (one launch per pass also with estimate_extrinsics), "fused_multi_round" (... also for scans of more than two
- * rounds per workgroup), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused", "small_window" / "small_insert" (windows /
+ * "fused_ext" (one launch per pass also with estimate_extrinsics), "fused_multi_round" (1: ... whatever the rounds per workgroup, 0: up to three — the rule of
+ * round 3; default: up to 16), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused", "small_window" / "small_insert" (windows /
  * insert batches of up to 2048 points take their one-launch forms).  None of them changes a result beyond
  * the summation order of the workgroup partials.  LV_EINVAL for an unknown name. */
 int lv_set_option(lv_ctx* ctx, const char* name, int value);

@@ -98,7 +98,8 @@ struct lv_ctx {
     long long* d_pclk = nullptr;   // LV_PASS_CLK=1: phase stamps of pass_kernel's workgroups (lv_get_pass_clocks)
     int pclk_wg = 0;
     bool keeper_by_cost = true;       // LV_KEEPER_BY_COST=0: the last searching workgroup always keeps the books (A/B knob)
-    bool fused_multi_round = false;   // LV_FUSED_MULTI=1: pass_kernel also for scans that need more than two rounds per workgroup
+    int fused_multi_round = -1;       // LV_FUSED_MULTI: 1 = pass_kernel whatever the rounds per workgroup, 0 = up to three (the rule of
+                                      // round 3), -1 (default) = up to PK_DEFAULT_MAX_ROUNDS (three with estimate_extrinsics)
     bool fused_ext = true;         // LV_FUSED_EXT=0: the three-kernel pass with estimate_extrinsics (one launch per pass measured 22.1 k vs 21.4 k it/s, r03)
 
     // capture (debug / API-parity) buffers, sized for the current scan
@@ -405,9 +406,10 @@ static inline size_t partial_width(const lv_ctx* c) { return c->prm.estimate_ext
 uint32_t pass_geometry_points(const lv_ctx* c) { return multi_rank(c) ? (uint32_t)c->comm_shard_max : c->scan.n; }
 
 bool pass_fused_applies(const lv_ctx* c) {
-    // (scans of more than three rounds per workgroup — beyond 196 608 points on a 256-CU part — stay with the three-kernel
-    // pass: pass_kernel idles twelve of sixteen wavefronts during the plane fits of every round but the last; measured r03:
-    // 131 072 points 217 vs 230 us per update, 196 608 points 286 vs 294, 262 144 points 356 vs 352)
+    // (multi-round scans run pass_kernel<.., MULTI>: a round's plane fits run on four wavefronts beside the next round's search
+    // on the other twelve; measured r04 per update: 131 072 points 191.8 us, 196 608 249.1, 262 144 304.9 against 329.3 with
+    // three kernels.  The estimate_extrinsics build keeps round 3's form — a barrier either side of every round's fits — and
+    // its limit of three rounds: 262 144 points 356 vs 352 us)
     if (multi_rank(c)) {
         // with a communicator: the caller has told the largest shard of this scan (lv_comm_set_shard_max), librccl has
         // ncclAllGather (or the caller exchanges the partials itself: lv_comm_set_host_gather), the gather buffers are in
@@ -420,7 +422,8 @@ bool pass_fused_applies(const lv_ctx* c) {
     }
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
-    if (rounds > 3 && !c->fused_multi_round) return false;   // (measured r03: 196 608 points 286 vs 294 us, 262 144 points 356 vs 352)
+    const int max_rounds = c->fused_multi_round > 0 ? INT32_MAX : (c->fused_multi_round == 0 || c->prm.estimate_extrinsics) ? 3 : PK_DEFAULT_MAX_ROUNDS;
+    if (rounds > max_rounds) return false;
     if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * partial_width(c) > c->gather_cap) return false;
     return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;
@@ -569,7 +572,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
-    if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0;
+    if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
     if (const char* e = getenv("LV_SMALL_WINDOW")) c->scan.small_enabled = atoi(e) != 0;
@@ -1184,7 +1187,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     const bool on = value != 0;
     if (!std::strcmp(name, "fused_pass")) c->fused_pass = on;
     else if (!std::strcmp(name, "fused_ext")) c->fused_ext = on;
-    else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on;
+    else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on ? 1 : 0;
     else if (!std::strcmp(name, "keeper_by_cost")) c->keeper_by_cost = on;
     else if (!std::strcmp(name, "tile_lpt")) c->tile_lpt = on;
     else if (!std::strcmp(name, "spin_wait")) c->spin_wait = on;

@@ -258,6 +258,7 @@ struct PassLaunch {
     SolveParams sp;
 };
 void pass_grid_size(uint32_t n, int max_wg, int* nsearch, int* steps, int* rounds, int* dedicated);
+constexpr int PK_DEFAULT_MAX_ROUNDS = 16;   // rounds per workgroup up to which lv_update takes pass_kernel by default (1 M points on 256 CUs)
 int pass_clock_words();   // stamp words per workgroup (PassLaunch::clk)
 int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin);
 // lv_predict.hip

@@ -1083,7 +1083,7 @@ constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS 
 constexpr size_t PK_OFF_OUT = PK_OFF_POSE + ((sizeof(PoseConsts) + 15) / 16) * 16;
 constexpr size_t PK_OFF_KEEP = PK_OFF_OUT + sizeof(double) * PK_FITW * 2 * SUMS_LEN;
 constexpr size_t PK_OFF_QN = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
-constexpr size_t PK_OFF_QUEUE = PK_OFF_QN + 16;                              // float4 [256] + uint32 [256]: points left to the coarse levels
+constexpr size_t PK_OFF_QUEUE = PK_OFF_QN + 32;                              // float4 [256] + uint32 [256]: points left to the coarse levels
 constexpr size_t PK_OFF_QUEUEQ = PK_OFF_QUEUE + sizeof(float4) * PK_RPTS_MAX;
 constexpr size_t PK_LDS_BYTES = PK_OFF_QUEUEQ + sizeof(uint32_t) * PK_RPTS_MAX;
 constexpr size_t PK_OFF_BOOK = 32 * 1024;   // the books' scratch inside region 0: above the solve scratch and above the staged rows
@@ -1152,7 +1152,10 @@ constexpr int PK_BOOKW = PK_THREADS / 64 - PK_FITW;   // wavefronts of a workgro
 
 // CLOSING: the closing launch of an update as its own (search-free) kernel: the solve of the last pass and the terminal
 // books by one workgroup.
-template <bool EXT, bool CLOSING>
+// MULTI: the instantiation for scans of more than one round per workgroup (round 4): a round's plane fits run BESIDE the next
+// round's search instead of between two barriers.  Scans of one round — the headline — keep the instantiation without it: the same
+// source compiled with the overlap logic in place fitted planes 0.4 us slower per launch (register allocation / loop peeling).
+template <bool EXT, bool CLOSING, bool MULTI = false>
 __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
     constexpr int S = 8;
     constexpr int W = EXT ? 12 : 6;
@@ -1187,7 +1190,9 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     int* s_qn = reinterpret_cast<int*>(smem + PK_OFF_QN);   // entries in the queue of points left to the coarse levels
     float4* s_queue = reinterpret_cast<float4*>(smem + PK_OFF_QUEUE);
     uint32_t* s_queueq = reinterpret_cast<uint32_t*>(smem + PK_OFF_QUEUEQ);
-    if (threadIdx.x < 3) s_qn[threadIdx.x] = 0;   // [0] queue entries, [1] search-task counter, [2] the books' sub-barrier (the prologue's barriers publish them)
+    // [0] / [3] queue entries and [1] / [4] search-task counter of the even / odd rounds, [2] the books' sub-barrier, [5] fit
+    // wavefronts that have taken their records out of the buffer (multi-round scans) — the prologue's barriers publish them
+    if (threadIdx.x < 8) s_qn[threadIdx.x] = 0;
     bool books_done = false;
     constexpr int NW32 = (int)(sizeof(PoseConsts) / 4);
     long long* clk = a.clk ? a.clk + (size_t)bid * PK_CLK : nullptr;
@@ -1258,11 +1263,15 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     }
     for (int t = tid; t < PK_FITW * 2 * SUMS_LEN; t += PK_THREADS) (&s_out[0][0][0])[t] = 0.0;
     const DebugOut nodbg{};
-    auto do_fits = [&](bool stamp) __attribute__((always_inline)) {
+    auto do_fits = [&](bool stamp, bool release_records) __attribute__((always_inline)) {
         const float4* rec = s_rec + (size_t)fstep * QREC_SLOTS * PK_GROUPS + fbase;
         float4 r[QREC_SLOTS];
 #pragma unroll
         for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = rec[sl * PK_GROUPS + lane];
+        if (release_records) {   // (multi-round scans) the records are in registers: the buffer may take the next round's
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(s_qn + 5, 1);
+        }
         float P[KNN][3];
         uint32_t nidx[KNN], dbits[KNN];
 #pragma unroll
@@ -1292,12 +1301,23 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         // serves a task changes nothing: a task's points and record slots are fixed.  Measured (A/B of two builds in one
         // box): 148.3-150.2 -> 146.8-147.9 us per update, all of it in the first two passes (spans 41.3 -> 40.2, 31.9 -> 29.2).
         const int ntask = a.steps * (PK_THREADS / 64);
+        // (counters by round parity: the other parity's are reset while this round runs — see the end of the round)
+        int* const s_task = s_qn + ((MULTI && (round & 1)) ? 4 : 1);
+        int* const s_qcnt = s_qn + ((MULTI && (round & 1)) ? 3 : 0);
 #pragma unroll 1
         for (;;) {
             int task = 0;
-            if (lane == 0) task = atomicAdd(s_qn + 1, 1);
+            if (lane == 0) task = atomicAdd(s_task, 1);
             task = __builtin_amdgcn_readfirstlane(task);
             if (task >= ntask) break;
+            if (MULTI && !EXT && round > 0) {
+                // the previous round's fits may still be running beside this search (below): its records must have left the
+                // buffer before this round's are written — every fit wavefront counts itself in s_qn[5] once it holds its 64
+                // records in registers, microseconds before the first task of this round gets here (bounded: never a hang)
+                const int want = a.steps * (PK_GROUPS / 64) * round;
+                for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(s_qn + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)
+                    __builtin_amdgcn_s_sleep(1);
+            }
             const int step = task / (PK_THREADS / 64);
             const int gqv = (task % (PK_THREADS / 64)) * 8 + (lane >> 3);   // position among the step's 128 points
             // strided assignment: every workgroup gets far and near tiles
@@ -1329,7 +1349,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             knn_search<S, false>(a.map, kf, qx, qy, qz, gl, k, bstart, src, nullptr, false, live, s_stage[gq], a.mp.max_dist_plane_sq,
                                  s_pref[wave], s_start[wave], &open_pt);
             if (open_pt && gl == 0) {
-                const int qi = atomicAdd(s_qn, 1);
+                const int qi = atomicAdd(s_qcnt, 1);
                 s_queue[qi] = make_float4(qx, qy, qz, __int_as_float(step * PK_GROUPS + gqv));
                 s_queueq[qi] = q;
             }
@@ -1372,9 +1392,9 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         }
         if (round == 0) PK_STAMP(5, tid == 0);                    // (wavefront 0 has no task left)
         __syncthreads();   // the records of both steps are complete; nobody reads the candidate stage any more
-        if (tid == 0) s_qn[1] = 0;   // (next round's tasks; the barrier after the fits publishes it)
+        if (tid == 0) *s_task = 0;   // (this parity serves the round after next: published by the next round's barrier)
         if (round == 0) PK_STAMP(6, tid == 0);
-        const int nq = *s_qn;
+        const int nq = *s_qcnt;
         if (nq > 0) {   // (uniform) the open points, one per wavefront at a time: level-2 bucket / level-3 lists / every id
             for (int i = wave; i < nq; i += PK_THREADS / 64) {
                 const float4 e = s_queue[i];
@@ -1409,11 +1429,22 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
                 }
             }
             __syncthreads();
-            if (tid == 0) *s_qn = 0;   // (next round; the barrier after the fits publishes it)
+            if (tid == 0) *s_qcnt = 0;   // (this parity serves the round after next)
         }
         if (round + 1 < a.rounds) {   // (not the last round: its fits are part of the loop; the last round's follow the loop)
-            if (fitter) do_fits(false);
-            __syncthreads();   // the next round reuses the stage (under the rows) and the records
+            if constexpr (EXT || !MULTI) {
+                // (with estimate_extrinsics a fit wavefront's 64 rows of 14 doubles are 7 KB: more than its own 6 KB of candidate
+                // stage — the fourth one's rows reach into wavefront 4's stage — so there the fits finish before the search goes on)
+                if (fitter) do_fits(false, false);
+                __syncthreads();
+            } else if (fitter) {
+                // Round 4: NO barrier behind these fits — the twelve wavefronts that do not fit planes go straight on to the next
+                // round's search tasks while the four fit (rows staged in the fit wavefronts' OWN candidate-stage areas, region 0
+                // below 4 x 6 KB, which nobody else writes; the record buffer is released as soon as the records are in
+                // registers) and join the search when they are done.  Before, the twelve idled through every round's fits but
+                // the last: 131 072 points 202 us per update, 262 144 points 332.
+                do_fits(false, true);
+            }
         }
     }
     // ---- 3b. the fits of the last round — and, in the bookkeeping workgroup of a launch whose prologue solved a pass that does
@@ -1423,7 +1454,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     {
         const bool beside = a.mode == 1 && keeper;
         if (fitter) {
-            do_fits(true);
+            do_fits(true, false);
         } else if (beside && wave >= PK_FITW) {
             SubBar bar(s_qn + 2, PK_BOOKW);
             bookkeeping<W, 64 * PK_BOOKW>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, K.Pprop, K.xp, false,
@@ -1518,6 +1549,7 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
         else hipLaunchKernelGGL((pass_kernel<true, false>), grid, block, 0, stream, a, b);
     } else {
         if (closing) hipLaunchKernelGGL((pass_kernel<false, true>), grid, block, 0, stream, a, b);
+        else if (pl.rounds > 1) hipLaunchKernelGGL((pass_kernel<false, false, true>), grid, block, 0, stream, a, b);
         else hipLaunchKernelGGL((pass_kernel<false, false>), grid, block, 0, stream, a, b);
     }
     LV_HIP(hipGetLastError());

@@ -6,17 +6,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth
-sc = synth.make_scene(1_048_576, 262_144)
+SIZES = [int(v) for v in os.environ.get("SIZES", "512,2048,8192,16384,32768,65536,131072,196608,262144").split(",")]
+sc = synth.make_scene(1_048_576, max(262_144, max(SIZES)))
 ctx = capi.Context(); ctx.map_build(sc["map_xyz"])
 if len(sys.argv) > 1:
-    ctx.set_fused_pass(int(sys.argv[1]) != 0)   # 0: the three-kernel pass, 1: one launch per pass (the default), 2: ... also beyond two rounds
+    ctx.set_fused_pass(int(sys.argv[1]) != 0)   # 0: the three-kernel pass, 1: one launch per pass (the default), 2: ... whatever the rounds
     if int(sys.argv[1]) == 2:
         ctx.set_option("fused_multi_round", 1)
-for n in (512, 2048, 8192, 16384, 32768, 65536, 131072, 196608, 262144):
+for n in SIZES:
     ctx.scan_set(sc["scan_xyz"][:n])
     for _ in range(10):
         ctx.update(sc["x_init"], sc["P0"], want_trace=False)
-    reps = 100
+    reps = 100 if n <= 262144 else 30
     ctx.synchronize(); t0 = time.perf_counter(); p = 0
     for _ in range(reps):
         p += ctx.update(sc["x_init"], sc["P0"], want_trace=False)[2]

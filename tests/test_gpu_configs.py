@@ -197,15 +197,16 @@ def test_timed_build_is_pinned_with_the_yaml_keys(capi, oracle, lv, name, mdp, p
 @pytest.mark.parametrize("route", ["three-kernel", "one-launch-multi-round"])
 def test_cfg3_size_full_update(capi, oracle, lv, route):
     """260k-point scan vs 5M-point map (BASELINE configs[3], one GPU's worth): all four passes of the NON-capturing
-    update against the oracle — the default route at this size (three kernels: more than two rounds per workgroup) and the
-    one-launch form admitted for it (its hand-over records and the fit accumulators are reused across five rounds)."""
+    update against the oracle — the default route at this size (one launch per pass, five rounds per workgroup: a round's
+    plane fits beside the next round's search) and the three-kernel pass."""
     from limo_velo_amd import synth
 
     sc = synth.make_scene(5_000_000, 260_000)
     tree = oracle.KdTree(sc["map_xyz"])
     ref = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], tree=tree)
     with capi.Context() as ctx:
-        ctx.set_option("fused_multi_round", int(route != "three-kernel"))
+        if route == "three-kernel":
+            ctx.set_fused_pass(False)
         ctx.map_build(sc["map_xyz"])
         ctx.scan_set(sc["scan_xyz"])
         res = ctx.update(sc["x_init"], sc["P0"])

@@ -60,19 +60,32 @@ def test_geometries_match_the_three_kernel_pass(capi, lv, n):
         _agree(a, b)
 
 
-def test_larger_scans_take_the_three_kernel_pass(capi, lv):
+def test_multi_round_scans_keep_the_one_launch_pass(capi, lv):
+    """Beyond two steps a workgroup takes rounds; from the second round on the separate multi-round instantiation runs a
+    round's plane fits on four wavefronts beside the next round's search (task and queue counters alternate by round parity,
+    the fit wavefronts release the records before the searchers overwrite them).  Three, four and six rounds against the
+    three-kernel pass; estimate_extrinsics keeps round 3's barrier form and its limit of three rounds."""
     from limo_velo_amd import synth
 
-    sc = synth.make_scene(300_000, 200_000)
+    sc = synth.make_scene(300_000, 330_000)
     with capi.Context() as ctx:
         ctx.map_build(sc["map_xyz"])
-        ctx.scan_set(sc["scan_xyz"][:190_000])
-        a, b = _both(ctx, sc, sc["x_init"], sc["P0"])
-        assert a[5]                          # three rounds per workgroup: still one launch per pass ...
-        _agree(a, b)
-        ctx.scan_set(sc["scan_xyz"])
+        for n in (190_000, 200_000, 262_144, 330_000):
+            a, b = _both(ctx, sc, sc["x_init"], sc["P0"], sc["scan_xyz"][:n])
+            assert a[5], n                   # one launch per pass
+            _agree(a, b)
+        ctx.set_option("fused_multi_round", 0)   # round 3's rule: four rounds go to the three-kernel pass
+        ctx.scan_set(sc["scan_xyz"][:200_000])
         ctx.update(sc["x_init"], sc["P0"])
-        assert not ctx.last_update_fused()   # ... four: pass_kernel would idle twelve wavefronts during three rounds' fits
+        assert not ctx.last_update_fused()
+    with capi.Context(capi.default_params(estimate_extrinsics=True)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"][:190_000])
+        ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+        ctx.scan_set(sc["scan_xyz"][:200_000])
+        ctx.update(sc["x_init"], sc["P0"])
+        assert not ctx.last_update_fused()
 
 
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
