@@ -47,7 +47,9 @@ typedef struct lv_ctx lv_ctx;
  * config/params.yaml:32,46-53 and src/main.cpp:145), same names. */
 typedef struct lv_params {
     int    MAX_NUM_ITERS;        /* 3  -> esekf maximum_iter; up to MAX_NUM_ITERS+1 measurement passes */
-    int    NUM_MATCH_POINTS;     /* 5  (this build supports 5 only) */
+    int    NUM_MATCH_POINTS;     /* 5  (k of Nearest_Search and rows of the plane fit, Mapper.cpp:85-86, Utils.cpp:33; 3..8: every tuned
+                                  *     path — one launch per pass, the benchmark — is built for 5, other values run a general build of
+                                  *     the three-kernel pass with lanes_per_query 8; LV_EINVAL outside 3..8) */
     double MAX_DIST_PLANE;       /* 2.0 */
     float  PLANES_THRESHOLD;     /* 0.05 */
     int    estimate_extrinsics;  /* 0 */
@@ -365,11 +367,11 @@ int lv_comm_peer_init(lv_ctx* ctx, int rank, int world, const void* handles /* w
  * executed wins).  Capturing writes ~200 B per scan point and is off on the fast path. */
 int lv_set_capture(lv_ctx* ctx, int enabled);
 /* Nearest_Search outputs: idx N x k (index into the map in insertion order, 0xFFFFFFFF = none),
- * d2 N x k squared distances ascending (+inf = none). */
+ * d2 N x k squared distances ascending (+inf = none); k = NUM_MATCH_POINTS. */
 int lv_fetch_knn(lv_ctx* ctx, uint32_t* idx, float* d2);
 /* The same Nearest_Search outputs as the hand-over records of the most recent pass hold them, whatever build
  * ran it — in particular the NON-capturing kernels of lv_update / lv_correct / lv_pass_reduce (the timed path),
- * which carry no map indices: nbr_xyz N x 5 x 3 neighbour coordinates (zeros = none), d2 N x 5 (+inf = none),
+ * which carry no map indices: nbr_xyz N x k x 3 neighbour coordinates (zeros = none), d2 N x k (+inf = none; k = NUM_MATCH_POINTS),
  * p_world N x 3 (the transformed scan point, Mapper.cpp:51), found N.  Original scan order; any pointer may be
  * NULL.  Tests compare these with the oracle's neighbours to pin the fast build (the index-carrying lv_fetch_knn
  * needs a capturing launch). */

@@ -487,8 +487,9 @@ class Context:
     # --- fetches
     def fetch_knn(self):
         n = self._n
-        idx = np.empty((n, 5), np.uint32)
-        d2 = np.empty((n, 5), np.float32)
+        k = self.params.NUM_MATCH_POINTS
+        idx = np.empty((n, k), np.uint32)
+        d2 = np.empty((n, k), np.float32)
         self._check(self.lib.lv_fetch_knn(self.h, idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p)))
         return idx, d2
 
@@ -571,8 +572,9 @@ class Context:
         """Neighbour coordinates / squared distances / world points / found counts out of the hand-over records of
         the most recent pass (works for the non-capturing, timed kernels)."""
         n = self._n
-        nbr = np.empty((n, 5, 3), np.float32)
-        d2 = np.empty((n, 5), np.float32)
+        k = self.params.NUM_MATCH_POINTS
+        nbr = np.empty((n, k, 3), np.float32)
+        d2 = np.empty((n, k), np.float32)
         pw = np.empty((n, 3), np.float32)
         found = np.empty(n, np.int32)
         self._check(self.lib.lv_fetch_neighbors(self.h, nbr.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p),

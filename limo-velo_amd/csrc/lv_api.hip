@@ -209,8 +209,8 @@ int ensure_capture(lv_ctx* c, size_t n) {
     if (n <= c->cap_n && c->dbg.knn_idx) return LV_OK;
     free_capture(c);
     size_t cap = n ? n : 1;
-    LV_HIP(hipMalloc(&c->dbg.knn_idx, cap * KNN * sizeof(uint32_t)));
-    LV_HIP(hipMalloc(&c->dbg.knn_d2, cap * KNN * sizeof(float)));
+    LV_HIP(hipMalloc(&c->dbg.knn_idx, cap * c->prm.NUM_MATCH_POINTS * sizeof(uint32_t)));
+    LV_HIP(hipMalloc(&c->dbg.knn_d2, cap * c->prm.NUM_MATCH_POINTS * sizeof(float)));
     LV_HIP(hipMalloc(&c->dbg.valid, cap));
     LV_HIP(hipMalloc(&c->dbg.p_world, cap * 3 * sizeof(float)));
     LV_HIP(hipMalloc(&c->dbg.abcd, cap * 4 * sizeof(float)));
@@ -300,7 +300,7 @@ int begin_device(lv_ctx* c, const double* x_host, bool defer, bool from_filter) 
         hipFree(c->d_qrec);
         c->d_qrec = nullptr;
         c->qstride = 0;
-        LV_HIP(hipMalloc(&c->d_qrec, (size_t)cap * 8 * sizeof(float4)));
+        LV_HIP(hipMalloc(&c->d_qrec, (size_t)cap * qrec_slots(c->prm.NUM_MATCH_POINTS) * sizeof(float4)));
         c->qstride = cap;
     }
     return LV_OK;
@@ -343,12 +343,12 @@ int pass_reduce(lv_ctx* c, bool finalize) {
     if (c->scan.n > 0) {
         rc = launch_search(c->stream, c->prm.lanes_per_query, c->map.view, c->scan.d_sorted, c->scan.n, c->d_kf, c->d_qrec,
                            c->qstride, c->tile_lpt ? c->scan.d_tile_order : nullptr, c->scan.n_tiles, mp.max_dist_plane_sq, dbg,
-                           c->begin_pending ? &c->h_begin : nullptr, c->d_io);
+                           c->begin_pending ? &c->h_begin : nullptr, c->d_io, c->prm.NUM_MATCH_POINTS);
         c->begin_pending = false;
     }
     if (rc) return rc;
     if (c->ev_mid) LV_HIP(hipEventRecord(c->ev_mid, c->stream));   // profiled pass: brackets the search kernel
-    rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg);
+    rc = launch_fit_reduce(c->stream, c->d_qrec, c->qstride, c->scan.n, c->d_kf, mp, c->d_partials, c->grid, dbg, c->prm.NUM_MATCH_POINTS);
     if (rc) return rc;
     // few enough block partials (a 64k-point scan leaves 256): solve_kernel folds them itself in one memory
     // round trip; otherwise stage 1 of the reduction runs as its own kernel
@@ -425,7 +425,7 @@ bool pass_fused_applies(const lv_ctx* c) {
     const int max_rounds = c->fused_multi_round > 0 ? INT32_MAX : (c->fused_multi_round == 0 || c->prm.estimate_extrinsics) ? 3 : PK_DEFAULT_MAX_ROUNDS;
     if (rounds > max_rounds) return false;
     if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * partial_width(c) > c->gather_cap) return false;
-    return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 &&
+    return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 && c->prm.NUM_MATCH_POINTS == KNN &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;
 }
 
@@ -537,7 +537,14 @@ const char* lv_version(void) { return "limovelo_hip 0.1 (gfx950)"; }
 int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (!params || !out) { set_error("null argument"); return LV_EINVAL; }
     *out = nullptr;
-    if (params->NUM_MATCH_POINTS != KNN) { set_error("NUM_MATCH_POINTS=%d unsupported (this build: %d)", params->NUM_MATCH_POINTS, KNN); return LV_EINVAL; }
+    if (params->NUM_MATCH_POINTS < KNN_MIN || params->NUM_MATCH_POINTS > KNN_MAX) {
+        set_error("NUM_MATCH_POINTS=%d unsupported (%d..%d)", params->NUM_MATCH_POINTS, KNN_MIN, KNN_MAX);
+        return LV_EINVAL;
+    }
+    if (params->NUM_MATCH_POINTS != KNN && params->lanes_per_query != 8) {
+        set_error("NUM_MATCH_POINTS=%d runs the general build: lanes_per_query must be 8", params->NUM_MATCH_POINTS);
+        return LV_EINVAL;
+    }
     if (params->MAX_NUM_ITERS < 0 || params->MAX_NUM_ITERS + 1 > MAX_PASSES) { set_error("MAX_NUM_ITERS out of range"); return LV_EINVAL; }
     if (!(params->voxel_size > 0.f)) { set_error("voxel_size must be > 0"); return LV_EINVAL; }
     const int S = params->lanes_per_query;
@@ -1067,7 +1074,7 @@ int lv_reserve_stream(lv_ctx* c, size_t max_window_points, size_t max_scan_point
             hipFree(c->d_qrec);
             c->d_qrec = nullptr;
             c->qstride = 0;
-            LV_HIP(hipMalloc(&c->d_qrec, (size_t)cap * 8 * sizeof(float4)));
+            LV_HIP(hipMalloc(&c->d_qrec, (size_t)cap * qrec_slots(c->prm.NUM_MATCH_POINTS) * sizeof(float4)));
             c->qstride = cap;
         }
     }
@@ -1700,9 +1707,9 @@ int lv_fetch_knn(lv_ctx* c, uint32_t* idx, float* d2) {
     LV_SETTLE_MAP(c);
     int rc = fetch_check(c);
     if (rc) return rc;
-    const size_t n = c->scan.n;
+    const size_t n = c->scan.n, K = (size_t)c->prm.NUM_MATCH_POINTS;
     if (idx) {
-        LV_HIP(hipMemcpy(idx, c->dbg.knn_idx, n * KNN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        LV_HIP(hipMemcpy(idx, c->dbg.knn_idx, n * K * sizeof(uint32_t), hipMemcpyDeviceToHost));
         if (c->map.n_ids != c->map.m) {   // the kernels report point ids; the API's index space is the rank among the living
             const size_t ids = c->map.n_ids;
             std::vector<float4> pts(ids);
@@ -1710,11 +1717,11 @@ int lv_fetch_knn(lv_ctx* c, uint32_t* idx, float* d2) {
             std::vector<uint32_t> rank(ids);
             uint32_t r = 0;
             for (size_t i = 0; i < ids; ++i) { rank[i] = r; r += std::isfinite(pts[i].x) ? 1u : 0u; }
-            for (size_t i = 0; i < n * KNN; ++i)
+            for (size_t i = 0; i < n * K; ++i)
                 if (idx[i] != 0xFFFFFFFFu && idx[i] < ids) idx[i] = rank[idx[i]];
         }
     }
-    if (d2) LV_HIP(hipMemcpy(d2, c->dbg.knn_d2, n * KNN * sizeof(float), hipMemcpyDeviceToHost));
+    if (d2) LV_HIP(hipMemcpy(d2, c->dbg.knn_d2, n * K * sizeof(float), hipMemcpyDeviceToHost));
     return LV_OK;
 }
 
@@ -1736,27 +1743,32 @@ int lv_fetch_neighbors(lv_ctx* c, float* nbr_xyz, float* d2, float* p_world, int
     if (n == 0) return LV_OK;
     if (!c->qrec_valid || !c->d_qrec || c->qstride < n) { set_error("no pass has run on the current scan"); return LV_ESTATE; }
     LV_HIP(hipStreamSynchronize(c->stream));
-    std::vector<float4> rec((size_t)8 * n);
-    for (int sl = 0; sl < 8; ++sl)
+    const int K = c->prm.NUM_MATCH_POINTS, NSL = qrec_slots(K);
+    std::vector<float4> rec((size_t)NSL * n);
+    for (int sl = 0; sl < NSL; ++sl)
         LV_HIP(hipMemcpy(rec.data() + (size_t)sl * n, c->d_qrec + (size_t)sl * c->qstride, n * sizeof(float4), hipMemcpyDeviceToHost));
     const float inf = std::numeric_limits<float>::infinity();
-    for (size_t q = 0; q < n; ++q) {   // records are in the scan's Morton order: slot 5 carries the original index
+    const auto dword = [&](size_t q, int w) {   // word w of the distance slots: distance of neighbour w, then `found`
+        const float4& v = rec[(size_t)(K + 1 + w / 4) * n + q];
+        return (w & 3) == 0 ? v.x : (w & 3) == 1 ? v.y : (w & 3) == 2 ? v.z : v.w;
+    };
+    for (size_t q = 0; q < n; ++q) {   // records are in the scan's Morton order: slot K carries the original index
         uint32_t oq;
-        std::memcpy(&oq, &rec[5 * n + q].w, 4);
+        std::memcpy(&oq, &rec[(size_t)K * n + q].w, 4);
         if (oq >= n) { set_error("corrupt hand-over record %zu", q); return LV_ESTATE; }
         int32_t fnd;
-        std::memcpy(&fnd, &rec[7 * n + q].y, 4);
-        const float dd[5] = {rec[6 * n + q].x, rec[6 * n + q].y, rec[6 * n + q].z, rec[6 * n + q].w, rec[7 * n + q].x};
-        for (int j = 0; j < KNN; ++j) {
+        const float fw = dword(q, K);
+        std::memcpy(&fnd, &fw, 4);
+        for (int j = 0; j < K; ++j) {
             const bool have = j < fnd;
             if (nbr_xyz) {
-                nbr_xyz[((size_t)oq * KNN + j) * 3 + 0] = have ? rec[(size_t)j * n + q].x : 0.f;
-                nbr_xyz[((size_t)oq * KNN + j) * 3 + 1] = have ? rec[(size_t)j * n + q].y : 0.f;
-                nbr_xyz[((size_t)oq * KNN + j) * 3 + 2] = have ? rec[(size_t)j * n + q].z : 0.f;
+                nbr_xyz[((size_t)oq * K + j) * 3 + 0] = have ? rec[(size_t)j * n + q].x : 0.f;
+                nbr_xyz[((size_t)oq * K + j) * 3 + 1] = have ? rec[(size_t)j * n + q].y : 0.f;
+                nbr_xyz[((size_t)oq * K + j) * 3 + 2] = have ? rec[(size_t)j * n + q].z : 0.f;
             }
-            if (d2) d2[(size_t)oq * KNN + j] = have ? dd[j] : inf;
+            if (d2) d2[(size_t)oq * K + j] = have ? dword(q, j) : inf;
         }
-        if (p_world) { p_world[(size_t)oq * 3] = rec[5 * n + q].x; p_world[(size_t)oq * 3 + 1] = rec[5 * n + q].y; p_world[(size_t)oq * 3 + 2] = rec[5 * n + q].z; }
+        if (p_world) { const float4& w = rec[(size_t)K * n + q]; p_world[(size_t)oq * 3] = w.x; p_world[(size_t)oq * 3 + 1] = w.y; p_world[(size_t)oq * 3 + 2] = w.z; }
         if (found) found[oq] = fnd;
     }
     return LV_OK;

@@ -12,7 +12,10 @@
 
 namespace lv {
 
-constexpr int KNN = 5;              // NUM_MATCH_POINTS (config/params.yaml:48)
+constexpr int KNN = 5;              // NUM_MATCH_POINTS (config/params.yaml:48): the value every tuned path is built for
+constexpr int KNN_MIN = 3, KNN_MAX = 8;   // other values take the general-K build of the three-kernel pass (lv_match.hip)
+// search -> fit hand-over record of a scan point, in float4 slots: K neighbours, the world point, K distances + `found`
+constexpr int qrec_slots(int k) { return k + 1 + (k + 1 + 3) / 4; }
 constexpr int NS = 23;              // state dof
 constexpr int NX = 26;              // state doubles (lv_state)
 constexpr int SUMS_LEN = 96;        // per-pass reduction record (include/limovelo_hip.h)

@@ -204,15 +204,15 @@ bool peer_failed(const PeerSet& P);
 void peer_close(PeerSet& P);
 
 // lv_match.hip
-// search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries);
+// search_kernel writes one 128-byte record per scan point (8 float4 planes of qstride entries; qrec_slots(K) planes with K neighbours);
 // fit_reduce_kernel turns them into `grid` block partials (and one extra workgroup runs solve_prep)
 // begin != nullptr: the first launch of an update (no begin kernel ran): the state / covariance / pass constants
 // travel as kernel arguments and one extra workgroup installs them in kf and the mailbox io
 int launch_search(hipStream_t stream, int lanes_per_query, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf,
                   float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg,
-                  const BeginArg* begin, KfHostIO* io);
+                  const BeginArg* begin, KfHostIO* io, int num_match = KNN);
 int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
-                      double* partials, int grid, const DebugOut& dbg);
+                      double* partials, int grid, const DebugOut& dbg, int num_match = KNN);   // num_match: NUM_MATCH_POINTS (3..8; 5 = the tuned build)
 int fit_grid_size(uint32_t n, int max_blocks);
 // lv_solve.hip
 int launch_kf_begin(hipStream_t stream, KfDev* kf, KfHostIO* io, const double* x_host, const FilterDev* filt = nullptr, int filt_in_kf = 0);  // io: device pointer of the pinned mailbox;

@@ -81,25 +81,36 @@ __device__ __forceinline__ void sort8(kkey (&c)[8]) {
     cswap(c[2], c[4]); cswap(c[3], c[5]);
     cswap(c[1], c[2]); cswap(c[3], c[4]); cswap(c[5], c[6]);
 }
-// optimal 5-key sorter, 9 comparators
-__device__ __forceinline__ void sort5(kkey (&c)[KNN]) {
-    cswap(c[0], c[1]); cswap(c[3], c[4]); cswap(c[2], c[4]); cswap(c[2], c[3]); cswap(c[1], c[4]);
-    cswap(c[0], c[3]); cswap(c[0], c[2]); cswap(c[1], c[3]); cswap(c[1], c[2]);
-}
 // k, o sorted ascending (o: at least 5 entries) -> k = the 5 smallest of the union, sorted:
 // min(k[i], o[4-i]) selects exactly the 5 smallest (bitonic halving).  The selection is UNIMODAL — it follows the ascending k
 // while k[i] is the smaller one, then the descending o[4-i] — and a unimodal sequence of 5 needs 5 comparators, not the 9 of
 // a general sort5: (0,4) (1,3) (1,4) (2,4) (3,4), minimal by exhaustive search over all networks on the 0^p 1^m 0^q images
 // (0-1 principle restricted to unimodal inputs; scripts/merge5_network.py re-derives and checks it).  Round 3: the search
 // phase is 55 % VALU and the three DPP merge rounds were 99 of a task's ~450 instructions; they are 75 now.
-__device__ __forceinline__ void order_unimodal5(kkey (&c)[KNN]) {
+__device__ __forceinline__ void order_unimodal5(kkey (&c)[5]) {
     cswap(c[0], c[4]); cswap(c[1], c[3]); cswap(c[1], c[4]); cswap(c[2], c[4]); cswap(c[3], c[4]);
 }
-template <typename T>
-__device__ __forceinline__ void merge5(kkey (&k)[KNN], const T& o) {
+// NUM_MATCH_POINTS other than 5 (3..8, the general-K build of the three-kernel pass: not a tuned path): the K selected keys
+// padded with NONE to eight and sorted by the 19-comparator network
+template <int K>
+__device__ __forceinline__ void order_selected(kkey (&c)[K]) {
+    if constexpr (K == 5) {
+        order_unimodal5(c);
+    } else {
+        kkey t[8];
 #pragma unroll
-    for (int i = 0; i < KNN; ++i) k[i] = kmin(o[KNN - 1 - i], k[i]);
-    order_unimodal5(k);
+        for (int i = 0; i < 8; ++i) t[i] = i < K ? c[i < K ? i : 0] : none_key();
+        sort8(t);
+#pragma unroll
+        for (int i = 0; i < K; ++i) c[i] = t[i];
+    }
+}
+// k, o sorted ascending (o: at least K entries) -> k = the K smallest of the union, sorted (K = 5: see above)
+template <int K, typename T>
+__device__ __forceinline__ void merge5(kkey (&k)[K], const T& o) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) k[i] = kmin(o[K - 1 - i], k[i]);
+    order_selected<K>(k);
 }
 // cross-lane exchange of a key through DPP (VALU data path, no LDS round trip):
 //   0xB1 quad_perm(1,0,3,2) = lane ^ 1, 0x4E quad_perm(2,3,0,1) = lane ^ 2,
@@ -113,15 +124,15 @@ __device__ __forceinline__ kkey dpp_key(kkey v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-template <int CTRL>
-__device__ __forceinline__ void merge_round(kkey (&k)[KNN]) {
-    kkey o[KNN];
+template <int CTRL, int K>
+__device__ __forceinline__ void merge_round(kkey (&k)[K]) {
+    kkey o[K];
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) o[j] = dpp_key<CTRL>(k[j]);
+    for (int j = 0; j < K; ++j) o[j] = dpp_key<CTRL>(k[j]);
     merge5(k, o);
 }
-template <int S>
-__device__ __forceinline__ void merge_group(kkey (&k)[KNN]) {
+template <int S, int K>
+__device__ __forceinline__ void merge_group(kkey (&k)[K]) {
     if (S >= 2) merge_round<0xB1>(k);
     if (S >= 4) merge_round<0x4E>(k);
     if (S >= 8) merge_round<0x141>(k);
@@ -144,11 +155,12 @@ __device__ __forceinline__ float calc_dist(float qx, float qy, float qz, float4 
     return s + sz;
 }
 
-// Column-pivoted Householder QR least squares for the 5 x 3 system A n = -1, f32.  Same operation
+// Column-pivoted Householder QR least squares for the K x 3 system A n = -1 (K = NUM_MATCH_POINTS: 5 on the tuned paths), f32.  Same operation
 // sequence as the oracle's restatement of R3Math::estimate_plane's
 // `A.colPivHouseholderQr().solve(b)` (reference src/Utils/Utils.cpp:47).
-__device__ inline void plane_qr_solve(float (&A)[KNN][3], float (&x)[3]) {
-    constexpr int rows = KNN, cols = 3, size = 3;
+template <int K>
+__device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
+    constexpr int rows = K, cols = 3, size = 3;
     const float eps = 1.1920928955078125e-07f;
     float hC[3];
     int perm[3] = {0, 1, 2};
@@ -244,7 +256,7 @@ __device__ inline void plane_qr_solve(float (&A)[KNN][3], float (&x)[3]) {
     }
     x[0] = x[1] = x[2] = 0.f;
     if (nonzero_pivots == 0) return;
-    float c[KNN];
+    float c[K];
 #pragma unroll
     for (int i = 0; i < rows; ++i) c[i] = -1.0f;
 #pragma unroll
@@ -319,17 +331,17 @@ __device__ __forceinline__ kkey shfl_xor_key(kkey v, int mask) {
 }
 // all-reduce of the sorted top-5 lists over a team of LANES consecutive lanes (LANES <= 16: merge_group over
 // DPP; 64: the whole wavefront, the two cross-row rounds go through ds_bpermute)
-template <int LANES>
-__device__ __forceinline__ void merge_team(kkey (&k)[KNN]) {
+template <int LANES, int K>
+__device__ __forceinline__ void merge_team(kkey (&k)[K]) {
     if (LANES <= 16) {
         merge_group<LANES>(k);
     } else {
         merge_group<16>(k);
 #pragma unroll
         for (int mask = 16; mask < LANES; mask <<= 1) {
-            kkey o[KNN];
+            kkey o[K];
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) o[j] = shfl_xor_key(k[j], mask);
+            for (int j = 0; j < K; ++j) o[j] = shfl_xor_key(k[j], mask);
             merge5(k, o);
         }
     }
@@ -345,9 +357,9 @@ __device__ __forceinline__ bool key_real(kkey k) { return key_hi(k) < 0x7F800000
 // positions inside the bucket starting at bstart) iff 5 candidates were found inside the guaranteed radius,
 // otherwise false with k reset to NONE.  Deleted entries stay in place with x = +inf: their distance is +inf,
 // which loses against every real candidate and fails the radius test.
-template <int LANES>
+template <int LANES, int K>
 __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
-                                               kkey (&k)[KNN], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
+                                               kkey (&k)[K], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
     // stage (LDS, LANES * 8 entries of this team, or nullptr): the first chunk's candidates are kept there by
     // position, so that the caller can pick the winners up without another trip to memory
     const GridLevel g = map.bt[bl];
@@ -365,7 +377,7 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
         slot = (slot + 1) & g.mask;
     }
     if (clk) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
-    if (bcount < KNN) return false;
+    if (bcount < K) return false;
     constexpr int U = 8;
     const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
     for (uint32_t base = 0; base < bcount; base += LANES * U) {
@@ -393,25 +405,25 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
         sort8(ck);
         if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
 #pragma unroll
-            for (int i = 0; i < KNN; ++i) k[i] = ck[i];
+            for (int i = 0; i < K; ++i) k[i] = ck[i];
         } else {
             merge5(k, ck);
         }
     }
     merge_team<LANES>(k);
     const float r = search_radius(map, geo, bl);
-    const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-    if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) return true;
+    const float d5 = __uint_as_float(key_hi(k[K - 1]));
+    if (!is_none(k[K - 1]) && r > 0.f && d5 < r * r) return true;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int j = 0; j < K; ++j) k[j] = none_key();
     return false;
 }
 
 // The same for a level whose buckets are UNORDERED runs of {x, y, z, id} records (level 2): the key's low word is the
 // point id, so the reference's (distance, index) order needs no ordered bucket; the winners are read from map.orig.
-template <int LANES>
+template <int LANES, int K>
 __device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
-                                                     kkey (&k)[KNN]) {
+                                                     kkey (&k)[K]) {
     const GridLevel g = map.bt[bl];
     const uint64_t key = pack_cell((uint32_t)(geo.c0x >> bl), (uint32_t)(geo.c0y >> bl), (uint32_t)(geo.c0z >> bl));
     uint32_t slot = hash_cell(key, g.shift) & g.mask;
@@ -425,8 +437,8 @@ __device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl,
         slot = (slot + 1) & g.mask;
     }
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
-    if (bcount < KNN) return false;
+    for (int j = 0; j < K; ++j) k[j] = none_key();
+    if (bcount < K) return false;
     constexpr int U = 8;
     const float4* __restrict__ bp = map.bucket4 + bstart;
     for (uint32_t base = 0; base < bcount; base += LANES * U) {
@@ -447,10 +459,10 @@ __device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl,
     }
     merge_team<LANES>(k);
     const float r = search_radius(map, geo, bl);
-    const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-    if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) return true;
+    const float d5 = __uint_as_float(key_hi(k[K - 1]));
+    if (!is_none(k[K - 1]) && r > 0.f && d5 < r * r) return true;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int j = 0; j < K; ++j) k[j] = none_key();
     return false;
 }
 
@@ -466,9 +478,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // flight (each load finds its list by a 6-step binary search over the prefix sums in LDS).  Keys are
 // (distance, id); on success k holds the sorted result on every lane.  s_pref / s_start: 64 words each, private
 // to this wavefront.
-template <int LVL>
+template <int LVL, int K>
 __device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& geo, float qx, float qy, float qz, int lane,
-                                              kkey (&k)[KNN], uint32_t* s_pref, uint32_t* s_start) {
+                                              kkey (&k)[K], uint32_t* s_pref, uint32_t* s_start) {
     static_assert(LVL == CELL_LEVEL || LVL == CELL_LEVEL + 1, "the level-2 block = 27 lists, the level-3 block = 216");
     constexpr int SIDE = LVL == CELL_LEVEL ? 3 : 6;
     constexpr int NC = SIDE * SIDE * SIDE;
@@ -478,7 +490,7 @@ __device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& g
     const int bz = LVL == CELL_LEVEL ? (geo.c0z >> 2) - 1 : ((geo.c0z >> 3) - 1) * 2;
     const GridLevel g = map.ct;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int j = 0; j < K; ++j) k[j] = none_key();
     for (int r0 = 0; r0 < NC; r0 += 64) {
         const int ci = r0 + lane;
         uint32_t start = 0, cnt = 0;
@@ -534,18 +546,19 @@ __device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& g
     }
     merge_team<64>(k);
     const float r = search_radius(map, geo, LVL);
-    const float d5 = __uint_as_float(key_hi(k[KNN - 1]));
-    if (!is_none(k[KNN - 1]) && r > 0.f && d5 < r * r) return true;
+    const float d5 = __uint_as_float(key_hi(k[K - 1]));
+    if (!is_none(k[K - 1]) && r > 0.f && d5 < r * r) return true;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int j = 0; j < K; ++j) k[j] = none_key();
     return false;
 }
 
 // exhaustive scan of every id by a whole wavefront, (distance, id) keys; deleted ids sit at +inf
-__device__ __forceinline__ void brute_attempt(const MapView& map, float qx, float qy, float qz, int lane, kkey (&k)[KNN]) {
+template <int K>
+__device__ __forceinline__ void brute_attempt(const MapView& map, float qx, float qy, float qz, int lane, kkey (&k)[K]) {
     constexpr int U = 8;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int j = 0; j < K; ++j) k[j] = none_key();
     for (uint32_t base = 0; base < map.n_ids; base += 64 * U) {
         float4 mpt[U];
 #pragma unroll
@@ -568,13 +581,13 @@ __device__ __forceinline__ void brute_attempt(const MapView& map, float qx, floa
 // One scan point that the per-lane-group bucket levels left undecided, searched by a WHOLE wavefront: level-2 bucket, the
 // level-3 block as 216 voxel lists, finally every id (see knn_search).  On return every lane holds the sorted result in kw
 // (keys carry point ids); returns what decided (2, 3 voxel levels; 4 every id; 5 bounded stop: no neighbours reported).
-template <bool DBG>
-__device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict__ kf, float wx, float wy, float wz, int lane, kkey (&kw)[KNN],
+template <bool DBG, int K>
+__device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict__ kf, float wx, float wy, float wz, int lane, kkey (&kw)[K],
                                           double max_dist_sq, uint32_t* s_pref, uint32_t* s_start) {
     const QGeom wgeo = make_geom(map, wx, wy, wz);
     const bool w_in_range = wgeo.amax < CELL_FAR;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) kw[j] = none_key();
+    for (int j = 0; j < K; ++j) kw[j] = none_key();
     int wbin = 5;
     bool done = false;
     if (w_in_range) {
@@ -611,9 +624,9 @@ __device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict_
 // so the point is reported without neighbours (found = 0) and the update is unchanged; capturing launches (API
 // parity: lv_iterate / lv_fetch_knn) always continue to the exact answer.
 // clk != nullptr (DBG builds): phase-stamp slot of this workgroup.
-template <int S, bool DBG>
+template <int S, bool DBG, int K>
 __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
-                                           kkey (&k)[KNN], uint32_t& bstart, int& src, long long* clk, bool hist,
+                                           kkey (&k)[K], uint32_t& bstart, int& src, long long* clk, bool hist,
                                            bool live, Xyz* stage0, double max_dist_sq, uint32_t* s_pref, uint32_t* s_start,
                                            bool* undecided = nullptr) {
     // undecided != nullptr: stop after the bucket levels 0 / 1 and report whether the point is still open (the caller
@@ -647,11 +660,11 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
         const int L = __ffsll((long long)pending) - 1;   // leader lane of the scan point served now
         pending &= pending - 1;
         const float wx = __shfl(qx, L), wy = __shfl(qy, L), wz = __shfl(qz, L);
-        kkey kw[KNN];
+        kkey kw[K];
         const int wbin = knn_coarse<DBG>(map, kf, wx, wy, wz, lane, kw, max_dist_sq, s_pref, s_start);
         if (lane / S == L / S) {   // (keys carry point ids: src stays -1)
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) k[j] = kw[j];
+            for (int j = 0; j < K; ++j) k[j] = kw[j];
             hist_bin = wbin;
             decided = true;
         }
@@ -662,9 +675,9 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
 // Plane fit + gates + Jacobian row of ONE scan point (one lane): Plane.cpp:19-55, Utils.cpp:32-66,
 // Match.cpp:18-22, Localizator.cpp:36-56.  P / nidx / dbits: the 5 nearest map points in (distance, index)
 // order; found < 0 marks a padding lane.  The row {J[0..W), h, valid} goes to srow (LDS).
-template <int W, bool EXT, bool DBG>
+template <int W, bool EXT, bool DBG, int K>
 __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams& prm, const DebugOut& dbg, int found,
-                                        const float (&P)[KNN][3], const uint32_t (&nidx)[KNN], const uint32_t (&dbits)[KNN],
+                                        const float (&P)[K][3], const uint32_t (&nidx)[K], const uint32_t (&dbits)[K],
                                         float qx, float qy, float qz, uint32_t oq, double* srow) {
     double row[W];
 #pragma unroll
@@ -673,12 +686,12 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
     bool chosen = false;
     float abcd[4] = {0.f, 0.f, 0.f, 0.f};
     float dist = 0.f;
-    if (found >= KNN) {                                                   // Plane.cpp:36-38
-        const float d5 = __uint_as_float(dbits[KNN - 1]);
+    if (found >= K) {                                                   // Plane.cpp:36-38
+        const float d5 = __uint_as_float(dbits[K - 1]);
         if ((double)d5 < prm.max_dist_plane_sq) {                         // Plane.cpp:40-43
-            float A[KNN][3];
+            float A[K][3];
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) { A[j][0] = P[j][0]; A[j][1] = P[j][1]; A[j][2] = P[j][2]; }
+            for (int j = 0; j < K; ++j) { A[j][0] = P[j][0]; A[j][1] = P[j][1]; A[j][2] = P[j][2]; }
             float nv[3];
             plane_qr_solve(A, nv);                                        // Utils.cpp:47
             const float nrm = sqrtf(dot3f(nv[0], nv[0], nv[1], nv[1], nv[2], nv[2]));  // Utils.cpp:50
@@ -686,7 +699,7 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
             const float e3 = (float)(1.0 / (double)nrm);                  // Utils.cpp:54
             bool ok = true;                                               // Utils.cpp:59-66
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) {
+            for (int j = 0; j < K; ++j) {
                 const float res = e0 * P[j][0] + e1 * P[j][1] + e2 * P[j][2] + e3;
                 if (fabsf(res) > prm.planes_threshold) ok = false;
             }
@@ -732,10 +745,10 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
     if (DBG && found >= 0) {
         if (dbg.knn_idx) {
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) {
+            for (int j = 0; j < K; ++j) {
                 const bool have = j < found;
-                dbg.knn_idx[(size_t)oq * KNN + j] = have ? nidx[j] : 0xFFFFFFFFu;
-                dbg.knn_d2[(size_t)oq * KNN + j] = have ? __uint_as_float(dbits[j]) : __uint_as_float(0x7f800000u);
+                dbg.knn_idx[(size_t)oq * K + j] = have ? nidx[j] : 0xFFFFFFFFu;
+                dbg.knn_d2[(size_t)oq * K + j] = have ? __uint_as_float(dbits[j]) : __uint_as_float(0x7f800000u);
             }
         }
         if (dbg.valid) dbg.valid[oq] = chosen ? 1 : 0;
@@ -761,7 +774,10 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
 //   slots 0-4  the 5 nearest map points {x, y, z, original index}   (fetched here, while L2-hot)
 //   slot  5    {world x, y, z, original scan index}
 //   slot  6    squared distances 0..3 (bits)      slot 7  {distance 4 (bits), found, -, -}
-constexpr int QREC_SLOTS = 8;
+// General K (NUM_MATCH_POINTS 3..8, three-kernel pass only): slots 0..K-1 the neighbours, slot K the world point, then the K
+// distance bits followed by `found`, four words to a slot — the layout above for K = 5.
+constexpr int QREC_SLOTS = qrec_slots(KNN);
+static_assert(QREC_SLOTS == 8, "the K = 5 record is 128 bytes");
 #ifdef LV_SEARCH_WAVES
 #define LV_SEARCH_BOUNDS __launch_bounds__(256, LV_SEARCH_WAVES)
 #else
@@ -771,7 +787,7 @@ constexpr int QREC_SLOTS = 8;
 // FIRST: the update starts here (no begin kernel): the pass constants come with the kernel arguments, and one extra
 // workgroup (the last) installs the state, covariance, constants and loop counters in kf / the mailbox for the kernels
 // that follow.
-template <int S, bool DBG, bool FIRST>
+template <int S, bool DBG, bool FIRST, int K = KNN>
 __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __restrict__ scan, uint32_t n,
                                                      KfDev* __restrict__ kf, float4* __restrict__ qrec, uint32_t qstride,
                                                      const uint32_t* __restrict__ tile_order, uint32_t n_tiles, double max_dist_sq,
@@ -820,9 +836,9 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     // no lane leaves early: the coarse levels are searched by whole wavefronts (knn_search);
     // padding lanes (q >= n) carry a copy of the last point, lend a hand and store nothing
     const bool live = q < n;
-    kkey k[KNN];
+    kkey k[K];
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) k[j] = none_key();
+    for (int j = 0; j < K; ++j) k[j] = none_key();
     uint32_t bstart = 0;
     int src = -1;
     const float4 sp = scan[live ? q : n - 1];
@@ -834,17 +850,17 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
     if (DBG && stamp_slot) { asm volatile("" :: "v"(k[0]), "v"(k[4])); stamp_slot[3] = clock64(); }
     int found = 0;
 #pragma unroll
-    for (int j = 0; j < KNN; ++j) found += key_real(k[j]) ? 1 : 0;
+    for (int j = 0; j < K; ++j) found += key_real(k[j]) ? 1 : 0;
     if (live) {
 #pragma unroll
-        for (int slot0 = 0; slot0 < QREC_SLOTS; slot0 += S) {
+        for (int slot0 = 0; slot0 < qrec_slots(K); slot0 += S) {
             const int slot = slot0 + gl;
-            if (slot >= QREC_SLOTS) break;
+            if (slot >= qrec_slots(K)) break;
             float4 v;
-            if (slot < KNN) {
+            if (slot < K) {
                 kkey kk = k[0];
 #pragma unroll
-                for (int j = 1; j < KNN; ++j) kk = (slot == j) ? k[j] : kk;
+                for (int j = 1; j < K; ++j) kk = (slot == j) ? k[j] : kk;
                 v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
                 if (key_real(kk)) {
                     const uint32_t pos = key_lo(kk);
@@ -862,13 +878,26 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
                         v.w = __uint_as_float(pos);
                     }
                 }
-            } else if (slot == 5) {
+            } else if (slot == K) {
                 v = make_float4(qx, qy, qz, sp.w);
-            } else if (slot == 6) {
-                v = make_float4(__uint_as_float(key_hi(k[0])), __uint_as_float(key_hi(k[1])), __uint_as_float(key_hi(k[2])),
-                                __uint_as_float(key_hi(k[3])));
-            } else {
-                v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(found), 0.f, 0.f);
+            } else if constexpr (K == KNN) {
+                if (slot == 6) {
+                    v = make_float4(__uint_as_float(key_hi(k[0])), __uint_as_float(key_hi(k[1])), __uint_as_float(key_hi(k[2])),
+                                    __uint_as_float(key_hi(k[3])));
+                } else {
+                    v = make_float4(__uint_as_float(key_hi(k[4])), __int_as_float(found), 0.f, 0.f);
+                }
+            } else {   // word w of the distance slots: distance bits of neighbour w, then `found`
+                float wv[4];
+#pragma unroll
+                for (int cw = 0; cw < 4; ++cw) {
+                    const int w = (slot - K - 1) * 4 + cw;
+                    float val = w == K ? __int_as_float(found) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) val = (w == j) ? __uint_as_float(key_hi(k[j])) : val;
+                    wv[cw] = val;
+                }
+                v = make_float4(wv[0], wv[1], wv[2], wv[3]);
             }
             qrec[(size_t)slot * qstride + q] = v;
         }
@@ -881,7 +910,7 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
 // staged rows in f64, and the 4 wave sums are combined in a fixed order into the block partial: FIT_POINTS
 // scan points per workgroup iteration, so a 64k-point scan leaves 256 partials that solve_kernel folds itself.
 constexpr int FIT_POINTS = 256;
-template <bool EXT, bool DBG>
+template <bool EXT, bool DBG, int K = KNN>
 __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __restrict__ qrec, uint32_t qstride, uint32_t n,
                                                                 KfDev* __restrict__ kf, MatchParams prm,
                                                                 double* __restrict__ partials, DebugOut dbg) {
@@ -922,23 +951,24 @@ __global__ __launch_bounds__(FIT_POINTS) void fit_reduce_kernel(const float4* __
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t q = (it * nfit + vb) * (uint32_t)G + (uint32_t)tid;
         if (DBG && stamp_slot && it == 0) stamp_slot[5] = clock64();
-        float P[KNN][3];
-        uint32_t nidx[KNN], dbits[KNN];
+        float P[K][3];
+        uint32_t nidx[K], dbits[K];
         float qx = 0.f, qy = 0.f, qz = 0.f;
         uint32_t oq = 0;
         int found = -1;
 #pragma unroll
-        for (int j = 0; j < KNN; ++j) { P[j][0] = P[j][1] = P[j][2] = 0.f; nidx[j] = 0xFFFFFFFFu; dbits[j] = 0x7f800000u; }
+        for (int j = 0; j < K; ++j) { P[j][0] = P[j][1] = P[j][2] = 0.f; nidx[j] = 0xFFFFFFFFu; dbits[j] = 0x7f800000u; }
         if (q < n) {
-            float4 r[QREC_SLOTS];
+            float4 r[qrec_slots(K)];
 #pragma unroll
-            for (int sl = 0; sl < QREC_SLOTS; ++sl) r[sl] = qrec[(size_t)sl * qstride + q];
+            for (int sl = 0; sl < qrec_slots(K); ++sl) r[sl] = qrec[(size_t)sl * qstride + q];
 #pragma unroll
-            for (int j = 0; j < KNN; ++j) { P[j][0] = r[j].x; P[j][1] = r[j].y; P[j][2] = r[j].z; nidx[j] = __float_as_uint(r[j].w); }
-            qx = r[5].x; qy = r[5].y; qz = r[5].z; oq = __float_as_uint(r[5].w);
-            dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
-            dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
-            found = __float_as_int(r[7].y);
+            for (int j = 0; j < K; ++j) { P[j][0] = r[j].x; P[j][1] = r[j].y; P[j][2] = r[j].z; nidx[j] = __float_as_uint(r[j].w); }
+            qx = r[K].x; qy = r[K].y; qz = r[K].z; oq = __float_as_uint(r[K].w);
+            const auto dword = [&](int w) { const float4 v = r[K + 1 + w / 4]; return (w & 3) == 0 ? v.x : (w & 3) == 1 ? v.y : (w & 3) == 2 ? v.z : v.w; };
+#pragma unroll
+            for (int j = 0; j < K; ++j) dbits[j] = __float_as_uint(dword(j));
+            found = __float_as_int(dword(K));
         }
         fit_row<W, EXT, DBG>(pc, prm, dbg, found, P, nidx, dbits, qx, qy, qz, oq, s_rows[tid]);
         __syncthreads();
@@ -977,7 +1007,7 @@ int fit_grid_size(uint32_t n, int max_blocks) {
     return (int)grid;
 }
 
-template <int S>
+template <int S, int K = KNN>
 static void launch_search(hipStream_t stream, bool dbg_on, const MapView& map, const float4* scan, uint32_t n, KfDev* kf,
                           float4* qrec, uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq,
                           const DebugOut& dbg, const BeginArg* begin, KfHostIO* io) {
@@ -986,13 +1016,13 @@ static void launch_search(hipStream_t stream, bool dbg_on, const MapView& map, c
     grid = (grid + 7u) & ~7u;
     if (grid == 0) grid = 8;
     if (begin) {   // first launch of an update: one more workgroup installs the state
-        if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true, true>), dim3(grid + 1), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, *begin, io);
-        else hipLaunchKernelGGL((search_kernel<S, false, true>), dim3(grid + 1), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, *begin, io);
+        if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true, true, K>), dim3(grid + 1), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, *begin, io);
+        else hipLaunchKernelGGL((search_kernel<S, false, true, K>), dim3(grid + 1), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, *begin, io);
         return;
     }
     static const BeginArg none{};
-    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, none, io);
-    else hipLaunchKernelGGL((search_kernel<S, false, false>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, none, io);
+    if (dbg_on) hipLaunchKernelGGL((search_kernel<S, true, false, K>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, none, io);
+    else hipLaunchKernelGGL((search_kernel<S, false, false, K>), dim3(grid), dim3(256), 0, stream, map, scan, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, none, io);
 }
 
 static bool debug_requested(const DebugOut& dbg) {
@@ -1003,8 +1033,18 @@ static bool debug_requested(const DebugOut& dbg) {
 // which a non-capturing launch may stop — see knn_search)
 int launch_search(hipStream_t stream, int S, const MapView& map, const float4* scan_sorted, uint32_t n, KfDev* kf, float4* qrec,
                   uint32_t qstride, const uint32_t* tile_order, uint32_t n_tiles, double max_dist_sq, const DebugOut& dbg,
-                  const BeginArg* begin, KfHostIO* io) {
+                  const BeginArg* begin, KfHostIO* io, int num_match) {
     const bool dbg_on = debug_requested(dbg);
+    if (num_match != KNN) {   // NUM_MATCH_POINTS other than 5: the general-K build, eight lanes per point
+#define LV_K(K_) case K_: launch_search<8, K_>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break
+        switch (num_match) {
+            LV_K(3); LV_K(4); LV_K(6); LV_K(7); LV_K(8);
+            default: set_error("NUM_MATCH_POINTS must be 3..8 (got %d)", num_match); return LV_EINVAL;
+        }
+#undef LV_K
+        LV_HIP(hipGetLastError());
+        return LV_OK;
+    }
     switch (S) {
         case 1: launch_search<1>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
         case 2: launch_search<2>(stream, dbg_on, map, scan_sorted, n, kf, qrec, qstride, tile_order, n_tiles, max_dist_sq, dbg, begin, io); break;
@@ -1019,13 +1059,24 @@ int launch_search(hipStream_t stream, int S, const MapView& map, const float4* s
 
 // split form, kernel 2: qrec -> plane fits, Jacobian rows, `grid` block partials
 int launch_fit_reduce(hipStream_t stream, const float4* qrec, uint32_t qstride, uint32_t n, KfDev* kf, const MatchParams& prm,
-                      double* partials, int grid, const DebugOut& dbg) {
+                      double* partials, int grid, const DebugOut& dbg, int num_match) {
     const bool dbg_on = debug_requested(dbg);
     const bool ext = prm.estimate_extrinsics != 0;
-#define LV_LAUNCH(EXT_, DBG_) \
-    hipLaunchKernelGGL((fit_reduce_kernel<EXT_, DBG_>), dim3(grid + 1), dim3(FIT_POINTS), 0, stream, qrec, qstride, n, kf, prm, partials, dbg)
-    if (ext) { if (dbg_on) LV_LAUNCH(true, true); else LV_LAUNCH(true, false); }
-    else { if (dbg_on) LV_LAUNCH(false, true); else LV_LAUNCH(false, false); }
+#define LV_LAUNCH(EXT_, DBG_, K_) \
+    hipLaunchKernelGGL((fit_reduce_kernel<EXT_, DBG_, K_>), dim3(grid + 1), dim3(FIT_POINTS), 0, stream, qrec, qstride, n, kf, prm, partials, dbg)
+#define LV_LAUNCH_K(K_) \
+    do { if (ext) { if (dbg_on) LV_LAUNCH(true, true, K_); else LV_LAUNCH(true, false, K_); } \
+         else { if (dbg_on) LV_LAUNCH(false, true, K_); else LV_LAUNCH(false, false, K_); } } while (0)
+    switch (num_match) {
+        case 3: LV_LAUNCH_K(3); break;
+        case 4: LV_LAUNCH_K(4); break;
+        case KNN: LV_LAUNCH_K(KNN); break;
+        case 6: LV_LAUNCH_K(6); break;
+        case 7: LV_LAUNCH_K(7); break;
+        case 8: LV_LAUNCH_K(8); break;
+        default: set_error("NUM_MATCH_POINTS must be 3..8 (got %d)", num_match); return LV_EINVAL;
+    }
+#undef LV_LAUNCH_K
 #undef LV_LAUNCH
     LV_HIP(hipGetLastError());
     return LV_OK;

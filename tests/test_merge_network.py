@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def _network_in_the_kernel():
     src = (ROOT / "limo-velo_amd" / "csrc" / "lv_match.hip").read_text()
-    body = re.search(r"void order_unimodal5\(kkey \(&c\)\[KNN\]\) \{(.*?)\n\}", src, re.S).group(1)
+    body = re.search(r"void order_unimodal5\(kkey \(&c\)\[5\]\) \{(.*?)\n\}", src, re.S).group(1)
     return [(int(a), int(b)) for a, b in re.findall(r"cswap\(c\[(\d)\], c\[(\d)\]\)", body)]
 
 
@@ -74,3 +74,21 @@ def test_lds_bitonic_network_steps_and_the_wave_local_claim():
             if not workgroup_barrier:   # wave-local: every wavefront stayed inside its own 128 elements
                 assert all(min(e) >= 128 * w and max(e) < 128 * w + 128 for w, e in touched.items()), (length, k2, j)
         assert keys == want
+
+
+def test_the_eight_key_network_sorts(  ):
+    """sort8 (every chunk of eight candidates; also the ordering step of the general-K merge, NUM_MATCH_POINTS 3..8:
+    order_selected pads the K selected keys with NONE and sorts them with it): 0-1 principle over all 256 images."""
+    src = (ROOT / "limo-velo_amd" / "csrc" / "lv_match.hip").read_text()
+    body = re.search(r"void sort8\(kkey \(&c\)\[8\]\) \{(.*?)\n\}", src, re.S).group(1)
+    net = [(int(a), int(b)) for a, b in re.findall(r"cswap\(c\[(\d)\], c\[(\d)\]\)", body)]
+    assert len(net) == 19 and all(i < j for i, j in net)
+    assert all(_apply(net, im) == sorted(im) for im in itertools.product((0, 1), repeat=8))
+    # the general-K merge: the K smallest of two sorted lists = min(k[i], o[K-1-i]), then any sorter
+    rng = random.Random(5)
+    for K in (3, 4, 6, 7, 8):
+        for _ in range(200):
+            k = sorted(rng.sample(range(1000), K))
+            o = sorted(rng.sample(range(1000, 2000), 8)) if rng.random() < 0.3 else sorted(rng.sample(range(1000), 8))
+            sel = [min(k[i], o[K - 1 - i]) for i in range(K)]
+            assert sorted(sel) == sorted(k + o)[:K]
