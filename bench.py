@@ -64,7 +64,7 @@ def pmc_traffic_bytes(kernel="search"):
     return fetch + write, os.path.basename(files[-1])
 
 
-def rocprof_kernel_avg_us(kernel="lv::pass_kernel<false, false>"):
+def rocprof_kernel_avg_us(kernel="lv::pass_kernel<false, false"):
     """Average duration (us) of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
     (profiles/rNN_rocprofv3_kernel_stats.csv, produced by scripts/gpu_profile.sh; the latest round wins) and the file's name.
     (None, None) without one.  Like roofline.traffic it is NOT a measurement of this run: rocprofv3 wraps a process."""
@@ -660,7 +660,7 @@ def main() -> None:
         alg_bytes = b_alg(M_POINTS) * n_local
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         traffic, traffic_file = pmc_traffic_bytes(kname) if world == 1 else (None, None)
-        rp_us, rp_file = rocprof_kernel_avg_us("lv::pass_kernel<true, false>" if prm.estimate_extrinsics else "lv::pass_kernel<false, false>")
+        rp_us, rp_file = rocprof_kernel_avg_us("lv::pass_kernel<true, false" if prm.estimate_extrinsics else "lv::pass_kernel<false, false")   # (name prefixes: the instantiation has a third argument since round 4)
         if forms and same_dev:
             forms["peer_mapped_one_launch"].update(iters_per_s=value, ms_per_step=dt / args.steps * 1e3)
         elif forms:

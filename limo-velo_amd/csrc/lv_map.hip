@@ -984,10 +984,11 @@ __global__ __launch_bounds__(256) void inc_kill_register_kernel(MapRW M, GroupRW
 }
 // (round 4: the listed runs move while every (group, target) notes where its target's batch tail lies — inc_resolve — and the new
 // entries go to the tails in a launch of their own behind it)
+template <int LANES>
 __global__ __launch_bounds__(256) void inc_relocate_resolve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k,
                                                                    const uint4* __restrict__ reloc, uint32_t reloc_cap,
                                                                    const uint32_t* __restrict__ n_reloc, uint32_t g_rel) {
-    if (blockIdx.x < g_rel) inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, g_rel * blockDim.x);
+    if (blockIdx.x < g_rel) inc_relocate_item<LANES>(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, g_rel * blockDim.x);
     else inc_resolve_item(M, G, alive, k, inc_block_of(blockIdx.x - g_rel, gridDim.x - g_rel) * blockDim.x + threadIdx.x);
 }
 __global__ __launch_bounds__(256) void inc_place_commit_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
@@ -1292,8 +1293,12 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         const uint32_t g_kill = counted_kill ? 256u : 0u;   // the occupants that lost: how many is only known on the device
         hipLaunchKernelGGL(inc_kill_register_kernel, dim3(g_kill + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_dead, (uint32_t)dead_cap, g_kill);
         hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
-        hipLaunchKernelGGL(inc_relocate_resolve_kernel, dim3(g_rel + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc,
-                           (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
+        if (k <= (uint32_t)SMALL_BATCH)   // few runs move: a workgroup each
+            hipLaunchKernelGGL(inc_relocate_resolve_kernel<RELOC_LANES_SMALL>, dim3(g_rel + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc,
+                               (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
+        else
+            hipLaunchKernelGGL(inc_relocate_resolve_kernel<RELOC_LANES>, dim3(g_rel + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc,
+                               (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
         hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
         hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
         hipLaunchKernelGGL(inc_place_commit_kernel, dim3(g_rep + g_grp), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank, g_rep);

@@ -624,29 +624,45 @@ __global__ void inc_resolve_kernel(MapRW M, GroupRW G, const uint32_t* __restric
     inc_resolve_item(M, G, alive, k, inc_thread_id());
 }
 
-// pass 3b: the listed runs move, 32 threads per run
-constexpr int RELOC_LANES = 32;
+// pass 3b: the listed runs move, one wavefront per run — a whole workgroup per run for small batches (LANES = 256: few runs, and
+// the longest one is the launch's duration).  (Round 4: four independent copies in flight per lane instead of 32 lanes with one —
+// a level-2 run of ~1000 entries was 31 dependent trips to memory, ~30 us of a small batch's insert; source and destination never
+// overlap: the new place is a fresh allocation at the end of the pool.)
+constexpr int RELOC_LANES = 64, RELOC_LANES_SMALL = 256, RELOC_UNROLL = 4;
+template <int LANES, typename T>
+__device__ __forceinline__ void inc_copy_run(T* __restrict__ dst, const T* __restrict__ src, uint32_t n, uint32_t lane) {
+    for (uint32_t base = 0; base < n; base += (uint32_t)(LANES * RELOC_UNROLL)) {
+        T v[RELOC_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RELOC_UNROLL; ++u) {
+            const uint32_t i = base + (uint32_t)(u * LANES) + lane;
+            if (i < n) v[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < RELOC_UNROLL; ++u) {
+            const uint32_t i = base + (uint32_t)(u * LANES) + lane;
+            if (i < n) dst[i] = v[u];
+        }
+    }
+}
+template <int LANES = RELOC_LANES>
 __device__ __forceinline__ void inc_relocate_item(const MapRW& M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc,
                                                   uint32_t t, uint32_t n_threads) {
     if (M.cnt->overflow) return;
-    const uint32_t lane = t % (uint32_t)RELOC_LANES;
+    const uint32_t lane = t % (uint32_t)LANES;
     const uint32_t n = *n_reloc < reloc_cap ? *n_reloc : reloc_cap;
     // (grid-stride over the listed runs: how many there are is only known here, and a launch sized for the list's capacity
     // spent 23 us of a small batch on workgroups that had nothing to move)
-    for (uint32_t r = t / (uint32_t)RELOC_LANES; r < n; r += n_threads / (uint32_t)RELOC_LANES) {
+    for (uint32_t r = t / (uint32_t)LANES; r < n; r += n_threads / (uint32_t)LANES) {
         const uint4 m = reloc[r];   // {level, old start, new start, count}
         if ((int)m.x < SORTED_LEVELS) {
             float* xs = M.bxyz[m.x];
             uint32_t* is = M.bidx[m.x];
-            for (uint32_t i = lane; i < m.w; i += RELOC_LANES) {
-                xs[((size_t)m.z + i) * 3 + 0] = xs[((size_t)m.y + i) * 3 + 0];
-                xs[((size_t)m.z + i) * 3 + 1] = xs[((size_t)m.y + i) * 3 + 1];
-                xs[((size_t)m.z + i) * 3 + 2] = xs[((size_t)m.y + i) * 3 + 2];
-                is[(size_t)m.z + i] = is[(size_t)m.y + i];
-            }
+            inc_copy_run<LANES>(xs + (size_t)m.z * 3, xs + (size_t)m.y * 3, m.w * 3u, lane);   // (12-byte points as plain words: coalesced)
+            inc_copy_run<LANES>(is + (size_t)m.z, is + (size_t)m.y, m.w, lane);
         } else {
             float4* run = (int)m.x < REPL_LEVELS ? M.bucket4 : M.cell4;
-            for (uint32_t i = lane; i < m.w; i += RELOC_LANES) run[(size_t)m.z + i] = run[(size_t)m.y + i];
+            inc_copy_run<LANES>(run + (size_t)m.z, run + (size_t)m.y, m.w, lane);
         }
     }
 }

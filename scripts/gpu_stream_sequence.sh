@@ -35,7 +35,7 @@ for f in glob.glob(out + "/t/**/*memory_copy_trace.csv", recursive=True):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", r.get("Name", ""))))
 ev.sort()
 # cycles are delimited by the closing launch of the update
-idx = [i for i, e in enumerate(ev) if "pass_kernel<false, true>" in e[2]]
+idx = [i for i, e in enumerate(ev) if "pass_kernel<false, true" in e[2]]
 print("events", len(ev), "updates", len(idx))
 a, b = idx[len(idx) // 2], idx[len(idx) // 2 + 2]
 lines = []

@@ -1,6 +1,8 @@
 """What one rank of an N-GPU run sees: the 64k-point scan cut to 64k / N points against the full 1M-point map
 (no collective: an upper bound for the strong-scaling run), plus larger scans."""
 import sys, time
+import ctypes as C
+import numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
@@ -22,4 +24,12 @@ for n in SIZES:
     for _ in range(reps):
         p += ctx.update(sc["x_init"], sc["P0"], want_trace=False)[2]
     dt = time.perf_counter() - t0
-    print("fused" if ctx.last_update_fused() else "3-kernel", "scan %7d points: %.1f us per update, %.0f iterations/s, %.2f Gpoint-passes/s" % (n, dt / reps * 1e6, p / dt, p * n / reps / (dt / reps) / 1e9 / (p / reps) * (p / reps)))
+    # the same update on the device-resident filter, enqueued back to back (one synchronisation per region: bench.py's step)
+    x0 = np.ascontiguousarray(sc["x_init"], np.float64); P0 = np.ascontiguousarray(sc["P0"], np.float64)
+    x0p, P0p = x0.ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p)
+    ctx.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        if ctx.lib.lv_filter_set(ctx.h, x0p, P0p) or ctx.lib.lv_correct(ctx.h, None):
+            raise RuntimeError(ctx.lib.lv_last_error().decode())
+    ctx.synchronize(); dr = time.perf_counter() - t0
+    print("fused" if ctx.last_update_fused() else "3-kernel", "scan %7d points: %.1f us per update, %.0f iterations/s, %.2f Gpoint-passes/s; resident, back to back: %.1f us per update" % (n, dt / reps * 1e6, p / dt, p * n / reps / (dt / reps) / 1e9 / (p / reps) * (p / reps), dr / reps * 1e6))
