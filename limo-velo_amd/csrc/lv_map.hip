@@ -922,32 +922,35 @@ __global__ __launch_bounds__(1024) void inc_sort_small_kernel(const uint64_t* __
 // microseconds of work each otherwise; the stages are the *_item functions of lv_mapinc.hpp, separated by workgroup barriers
 // (one workgroup: a barrier also orders its global-memory traffic).
 __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx, int have_boxes, GroupRW G, const float4* __restrict__ newp,
-                                                               uint32_t k, float len, int downsample, uint64_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ idx, uint64_t* __restrict__ keys_sorted,
-                                                               uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ alive,
+                                                               uint32_t k, float len, int downsample, uint32_t* __restrict__ alive,
                                                                uint32_t* __restrict__ apos, float4* __restrict__ dead, uint32_t dead_cap,
                                                                uint32_t id_base) {
+    // (round 4: the stages hand their keys, flags and positions to each other in LDS — the *_item functions take generic pointers —
+    // instead of through global memory: every such hand-over was a write, a barrier and a read of ~1.5 us; `alive` and `apos`, which
+    // the back half reads, leave for global memory once, at the end)
     __shared__ uint64_t s_key[SMALL_BATCH];
     __shared__ uint32_t s_idx[SMALL_BATCH];
+    __shared__ uint32_t s_alive[SMALL_BATCH], s_apos[SMALL_BATCH];
     __shared__ uint32_t s_wsum[1024 / 64 + 1];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t j = tid; j < k; j += 1024) inc_box_keys_item(M, newp, k, len, keys, idx, alive, downsample, 1, j);
+    for (uint32_t i = tid; i < (uint32_t)SMALL_BATCH; i += 1024) {
+        if (i < k) {
+            inc_box_keys_item(M, newp, k, len, s_key, s_idx, s_alive, downsample, 1, i);
+        } else {
+            s_key[i] = ~0ull;
+            s_idx[i] = 0xFFFFFFFFu;
+            s_alive[i] = 0u;
+        }
+    }
     __syncthreads();
     if (downsample) {
-        for (uint32_t i = tid; i < (uint32_t)SMALL_BATCH; i += 1024) {
-            s_key[i] = i < k ? keys[i] : ~0ull;
-            s_idx[i] = i < k ? idx[i] : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        lds_bitonic_sort_u64_u32<1024>(s_key, s_idx, lds_sort_len(k), (int)tid);
-        for (uint32_t i = tid; i < k; i += 1024) { keys_sorted[i] = s_key[i]; idx_sorted[i] = s_idx[i]; }
-        __syncthreads();
-        for (uint32_t i = tid; i < k; i += 1024) inc_box_rule_item(Bx, M.orig, newp, keys_sorted, idx_sorted, k, alive, dead, dead_cap, M.cnt, i);
+        lds_bitonic_sort_u64_u32<1024>(s_key, s_idx, lds_sort_len(k), (int)tid);   // (ends with a barrier of its own)
+        for (uint32_t i = tid; i < k; i += 1024) inc_box_rule_item(Bx, M.orig, newp, s_key, s_idx, k, s_alive, dead, dead_cap, M.cnt, i);
         __syncthreads();
     }
     {   // exclusive scan of alive[0 .. k) (k <= 2048: two elements per thread)
         const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
-        const uint32_t a0 = i0 < k ? alive[i0] : 0u, a1 = i1 < k ? alive[i1] : 0u;
+        const uint32_t a0 = s_alive[i0], a1 = s_alive[i1];
         uint32_t incl = a0 + a1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -962,12 +965,14 @@ __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx
         }
         __syncthreads();
         const uint32_t excl = s_wsum[tid >> 6] + incl - (a0 + a1);
-        if (i0 < k) apos[i0] = excl;
-        if (i1 < k) apos[i1] = excl + a0;
+        s_apos[i0] = excl;
+        s_apos[i1] = excl + a0;
+        if (i0 < k) { alive[i0] = a0; apos[i0] = excl; }
+        if (i1 < k) { alive[i1] = a1; apos[i1] = excl + a0; }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < k; j += 1024) inc_commit_points_item(M, Bx, have_boxes, newp, alive, apos, k, id_base, j);
-    for (uint32_t t = tid; t < k * (uint32_t)REPL_LEVELS; t += 1024) inc_group_item(M, G, newp, alive, k, t);
+    for (uint32_t j = tid; j < k; j += 1024) inc_commit_points_item(M, Bx, have_boxes, newp, s_alive, s_apos, k, id_base, j);
+    for (uint32_t t = tid; t < k * (uint32_t)REPL_LEVELS; t += 1024) inc_group_item(M, G, newp, s_alive, k, t);
 }
 
 // ---- the back half of a small batch's insert in four launches instead of eight ---------------------------------------------------
@@ -1231,7 +1236,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     uint32_t n_dead = 0;
     if (fused_front) {
         hipLaunchKernelGGL(inc_small_front_kernel, dim3(1), dim3(1024), 0, stream, M, Bx, have_boxes ? 1 : 0, G, d_new, k, box_length,
-                           downsample, d_nkeys, d_nidx, d_nkeys_sorted, d_nidx_sorted, d_nalive, d_napos, d_dead, (uint32_t)dead_cap, n_ids);
+                           downsample, d_nalive, d_napos, d_dead, (uint32_t)dead_cap, n_ids);
     } else {
     hipLaunchKernelGGL(inc_box_keys_kernel, dim3(gk), dim3(B), 0, stream, M, d_new, k, box_length, d_nkeys, d_nidx, d_nalive, downsample, 1);
     if (downsample) {
