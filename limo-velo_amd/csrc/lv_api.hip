@@ -1461,6 +1461,7 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
         if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
     }
     const KfHostIO* io = c->h_io;
+    if ((unsigned)io->fallback_queries & KF_FAULT_BIT) { set_error("a bounded wait inside pass_kernel expired: the update's results are invalid"); return LV_EHIP; }
     c->timing.fallback_queries = io->fallback_queries - c->fallback_base;
     c->fallback_base = io->fallback_queries;
     if (x) std::memcpy(x, io->x, sizeof(double) * NX);
@@ -1611,6 +1612,7 @@ int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
         // once per 100 Hz cycle: the reference's main loop reads the state after every correct, src/main.cpp:96-102)
         if (!mailbox_wait(c)) LV_HIP(hipStreamSynchronize(c->stream));
         const KfHostIO* io = c->h_io;
+        if ((unsigned)io->fallback_queries & KF_FAULT_BIT) { set_error("a bounded wait inside pass_kernel expired: the update's results are invalid"); return LV_EHIP; }
         if (x) std::memcpy(x, io->x, sizeof(double) * NX);
         if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
         return LV_OK;

@@ -105,6 +105,9 @@ struct KfHostIO {
     unsigned long long seqcheck;
 };
 constexpr uint32_t MAILBOX_UNCHECKED = 0xFFFFFFFFu;
+// KfDev::fallback_queries / KfHostIO::fallback_queries: bit 30 = a bounded wait inside a kernel expired (the update's results are
+// not to be trusted; sticky) — the counter proper stays far below it
+constexpr unsigned int KF_FAULT_BIT = 0x40000000u;
 __host__ __device__ __forceinline__ uint32_t mailbox_mix(double v, uint32_t idx) {
     unsigned long long b;
 #if defined(__HIP_DEVICE_COMPILE__)

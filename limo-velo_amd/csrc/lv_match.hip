@@ -1366,8 +1366,12 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
                 // buffer before this round's are written — every fit wavefront counts itself in s_qn[5] once it holds its 64
                 // records in registers, microseconds before the first task of this round gets here (bounded: never a hang)
                 const int want = a.steps * (PK_GROUPS / 64) * round;
-                for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(s_qn + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)
+                int spin = 0;
+                for (; spin < (1 << 20) && __hip_atomic_load(s_qn + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)
                     __builtin_amdgcn_s_sleep(1);
+                // (never seen; if it ever expires the records below overwrite ones still being read: tell the host — the flag rides
+                // in the counter the finishing pass posts, lv_update / lv_filter_get fail with LV_EHIP)
+                if (spin == (1 << 20) && lane == 0) atomicOr(reinterpret_cast<unsigned int*>(&kf->fallback_queries), KF_FAULT_BIT);
             }
             const int step = task / (PK_THREADS / 64);
             const int gqv = (task % (PK_THREADS / 64)) * 8 + (lane >> 3);   // position among the step's 128 points

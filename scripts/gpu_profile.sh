@@ -21,7 +21,7 @@ f = glob.glob("$OUT/stats/**/*kernel_trace.csv", recursive=True)
 rows = []
 for r in csv.DictReader(open(f[0])):
     if "pass_kernel" in r["Kernel_Name"]:
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "true>" in r["Kernel_Name"].split("(")[0]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("<")[1].split(">")[0].split(", ")[1] == "true"))   # pass_kernel<EXT, CLOSING, MULTI>
 rows.sort()
 ups, cur = [], []
 for s, e, closing in rows:
