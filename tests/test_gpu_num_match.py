@@ -86,3 +86,29 @@ def test_values_outside_the_range_are_refused(capi):
             capi.Context(capi.default_params(NUM_MATCH_POINTS=k))
     with pytest.raises(capi.LvError):      # the general build runs eight lanes per point
         capi.Context(capi.default_params(NUM_MATCH_POINTS=4, lanes_per_query=4))
+
+
+def test_resident_filter_and_map_insert_with_k4(capi, oracle, scene_small):
+    """The calls the reference's main loop makes (lv_filter_set / lv_predict / lv_correct / lv_filter_get, lv_map_add_scan) with
+    NUM_MATCH_POINTS = 4: the resident route equals the update by value bit for bit, and the posterior matches the oracle's."""
+    sc = scene_small
+    prm_o = oracle.default_params(num_match_points=4)
+    Q = np.diag([1e-4] * 3 + [1e-2] * 3 + [1e-5] * 3 + [1e-4] * 3)
+    with capi.Context(capi.default_params(NUM_MATCH_POINTS=4)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        ctx.filter_set(sc["x_init"], sc["P0"])
+        ctx.predict(0.005, Q, [0.1, -0.05, 9.81], [0.01, 0.02, -0.01])
+        xp, Pp = ctx.filter_get()
+        passes = ctx.correct()
+        xr, Pr = ctx.filter_get()
+        xv, Pv, pv, _, _ = ctx.update(xp, Pp)
+        assert passes == pv and np.array_equal(xr, xv) and np.array_equal(Pr, Pv)
+        n0 = ctx.map_size()
+        ctx.map_add_scan(True)          # the scan, transformed by the posterior, joins the map (Mapper::add, main.cpp:102)
+        assert ctx.map_size() > n0
+        g = ctx.iterate(xr)             # and the next search sees it
+        idx, d2 = ctx.fetch_knn()
+        assert idx.shape == (len(sc["scan_xyz"]), 4) and (d2[:, 0] == 0).mean() > 0.02     # (a survivor finds itself)
+    xo, Po, po, _, _ = oracle.update(xp, Pp, sc["map_xyz"], sc["scan_xyz"], params=prm_o)
+    assert po == passes and np.abs(xr - xo).max() < TOL_STATE and np.abs(Pr - Po).max() < 1e-10
