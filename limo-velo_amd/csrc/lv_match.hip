@@ -380,7 +380,36 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     if (bcount < K) return false;
     constexpr int U = 8;
     const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
-    for (uint32_t base = 0; base < bcount; base += LANES * U) {
+#ifndef LV_HALF_CHUNK
+#define LV_HALF_CHUNK 1
+#endif
+    uint32_t base = 0;
+    do {
+        // (round 4) A bucket of the benchmark's map holds 62 candidates on average and more than the 64 of a chunk one time in four:
+        // two in three of the 8-point tasks went through a second chunk for the handful of candidates beyond — at the full price of
+        // eight loads, eight distances and the 19-comparator sort.  When what is left fits (at most 4 per lane for every lane group
+        // of the wavefront) the tail takes HALF a chunk: four loads, four distances, a 5-comparator sort, the same merge.  Level 0
+        // only: on the level-1 stream (seven chunks) the wavefront-uniform loop it needs cost more than the half chunk saves.
+        if constexpr (LV_HALF_CHUNK && K == KNN) {
+            if (bl == 0 && base != 0 && __builtin_amdgcn_ballot_w64(base + (uint32_t)(LANES * 4) < bcount) == 0ull) {
+                Xyz mp4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                    mp4[u] = bp[j < bcount ? j : 0];
+                }
+                kkey c4[5];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                    c4[u] = make_key_if(j < bcount, calc_dist(qx, qy, qz, mp4[u]), j);
+                }
+                c4[4] = none_key();
+                cswap(c4[0], c4[1]); cswap(c4[2], c4[3]); cswap(c4[0], c4[2]); cswap(c4[1], c4[3]); cswap(c4[1], c4[2]);
+                merge5(k, c4);
+                break;   // (nothing is left behind a half chunk)
+            }
+        }
         Xyz mpt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -409,7 +438,8 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
         } else {
             merge5(k, ck);
         }
-    }
+        base += LANES * U;
+    } while ((LV_HALF_CHUNK && K == KNN && bl == 0) ? __builtin_amdgcn_ballot_w64(base < bcount) != 0ull : base < bcount);
     merge_team<LANES>(k);
     const float r = search_radius(map, geo, bl);
     const float d5 = __uint_as_float(key_hi(k[K - 1]));
