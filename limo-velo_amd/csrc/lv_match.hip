@@ -207,6 +207,25 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
         for (int i = k + 1; i < rows; ++i) tailSq += A[i][k] * A[i][k];
         float c0 = A[k][k];
         float tau, beta;
+#ifndef LV_QR_SELECT
+#define LV_QR_SELECT 1
+#endif
+#if LV_QR_SELECT
+        {   // both sides computed, selected (same operations on the side that counts => same bits; the discarded side may divide by zero)
+            const bool tiny = tailSq <= 1.17549435e-38f;
+            float b = sqrtf(c0 * c0 + tailSq);
+            if (c0 >= 0.f) b = -b;
+            const float den = c0 - b;
+#pragma unroll
+            for (int i = k + 1; i < rows; ++i) {
+                const float q = A[i][k] / den;
+                A[i][k] = tiny ? 0.f : q;
+            }
+            const float t = (b - c0) / b;
+            tau = tiny ? 0.f : t;
+            beta = tiny ? c0 : b;
+        }
+#else
         if (tailSq <= 1.17549435e-38f) {
             tau = 0.f;
             beta = c0;
@@ -220,6 +239,7 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
             for (int i = k + 1; i < rows; ++i) A[i][k] = A[i][k] / den;
             tau = (beta - c0) / beta;
         }
+#endif
         A[k][k] = beta;
         hC[k] = tau;
         if (tau != 0.f) {
@@ -236,6 +256,22 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
         }
 #pragma unroll
         for (int j = k + 1; j < cols; ++j) {
+#if LV_QR_SELECT
+            const bool nz = nU[j] != 0.f;
+            float temp = fabsf(A[k][j]) / nU[j];
+            temp = (1.f + temp) * (1.f - temp);
+            temp = temp < 0.f ? 0.f : temp;
+            const float r = nU[j] / nD[j];
+            const float temp2 = temp * (r * r);
+            const bool redo = temp2 <= norm_downdate_threshold;
+            float s = 0.f;
+#pragma unroll
+            for (int i = k + 1; i < rows; ++i) s += A[i][j] * A[i][j];
+            const float nd_new = sqrtf(s);
+            const float nu_scaled = nU[j] * sqrtf(temp);
+            nD[j] = (nz && redo) ? nd_new : nD[j];
+            nU[j] = nz ? (redo ? nd_new : nu_scaled) : nU[j];
+#else
             if (nU[j] != 0.f) {
                 float temp = fabsf(A[k][j]) / nU[j];
                 temp = (1.f + temp) * (1.f - temp);
@@ -252,6 +288,7 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
                     nU[j] *= sqrtf(temp);
                 }
             }
+#endif
         }
     }
     x[0] = x[1] = x[2] = 0.f;
