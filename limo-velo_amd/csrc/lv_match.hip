@@ -296,6 +296,35 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
     float c[K];
 #pragma unroll
     for (int i = 0; i < rows; ++i) c[i] = -1.0f;
+#if LV_QR_SELECT
+#pragma unroll
+    for (int k = 0; k < size; ++k) {   // c = Q^T c, selects instead of branches (see the Householder step)
+        const float tau = hC[k];
+        const bool on = k < nonzero_pivots && tau != 0.f;
+        float tmp = 0.f;
+#pragma unroll
+        for (int i = k + 1; i < rows; ++i) tmp += A[i][k] * c[i];
+        tmp += c[k];
+        const float ck = c[k] - tau * tmp;
+        c[k] = on ? ck : c[k];
+#pragma unroll
+        for (int i = k + 1; i < rows; ++i) {
+            const float ci = c[i] - tau * A[i][k] * tmp;
+            c[i] = on ? ci : c[i];
+        }
+    }
+#pragma unroll
+    for (int i = size - 1; i >= 0; --i) {
+        float sv = c[i];
+#pragma unroll
+        for (int j = i + 1; j < size; ++j) {
+            const float sj = sv - A[i][j] * c[j];
+            sv = (j < nonzero_pivots) ? sj : sv;
+        }
+        const float q = sv / A[i][i];
+        c[i] = (i < nonzero_pivots) ? q : c[i];
+    }
+#else
 #pragma unroll
     for (int k = 0; k < size; ++k) {
         if (k < nonzero_pivots) {
@@ -321,6 +350,7 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
             c[i] = s / A[i][i];
         }
     }
+#endif
 #pragma unroll
     for (int i = 0; i < size; ++i) {
         if (i < nonzero_pivots) {
