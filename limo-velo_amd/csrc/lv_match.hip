@@ -783,6 +783,11 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
     bool chosen = false;
     float abcd[4] = {0.f, 0.f, 0.f, 0.f};
     float dist = 0.f;
+    // the point in the LiDAR and IMU frames (Localizator.cpp:38-39): independent of the plane, so computed HERE, where the
+    // scheduler can slot it between the dependent steps of the QR (behind the `chosen` gate it was a serial tail of its own)
+    float plx, ply, plz, pix, piy, piz;
+    rt_apply(pc.back, qx, qy, qz, plx, ply, plz);                         // :38
+    rt_apply(pc.LI, plx, ply, plz, pix, piy, piz);                        // :39
     if (found >= K) {                                                   // Plane.cpp:36-38
         const float d5 = __uint_as_float(dbits[K - 1]);
         if ((double)d5 < prm.max_dist_plane_sq) {                         // Plane.cpp:40-43
@@ -809,9 +814,6 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
     }
     // ---- Localizator::calculate_H row (Localizator.cpp:36-56) ------------------------------
     if (chosen) {
-        float plx, ply, plz, pix, piy, piz;
-        rt_apply(pc.back, qx, qy, qz, plx, ply, plz);                     // :38
-        rt_apply(pc.LI, plx, ply, plz, pix, piy, piz);                    // :39
         const double n0 = (double)abcd[0], n1 = (double)abcd[1], n2 = (double)abcd[2];
         const double* Ri = pc.R_inv;
         const double C0 = dot3d(Ri[0], n0, Ri[1], n1, Ri[2], n2);         // :47
