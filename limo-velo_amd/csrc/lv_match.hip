@@ -28,6 +28,14 @@
 #include "lv_host.hpp"
 #include "lv_pass_dev.hpp"    // solve_prep / solve_core / out_pair (restores -ffp-contract=off for everything below)
 
+// A/B switches of two round-4 changes (scripts/build_variant.sh NAME -DLV_...=0 builds the form before them)
+#ifndef LV_HALF_CHUNK
+#define LV_HALF_CHUNK 1   // bucket_attempt: the tail of a level-0 bucket beyond its first chunk takes half a chunk when it fits
+#endif
+#ifndef LV_QR_SELECT
+#define LV_QR_SELECT 1    // plane_qr_solve: selects instead of branches (tiny-tail case, norm downdate, Q^T c, back substitution)
+#endif
+
 namespace lv {
 
 // Candidate keys.  A key packs (f32 distance bits << 32 | position) and is handled as an IEEE f64:
@@ -207,9 +215,6 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
         for (int i = k + 1; i < rows; ++i) tailSq += A[i][k] * A[i][k];
         float c0 = A[k][k];
         float tau, beta;
-#ifndef LV_QR_SELECT
-#define LV_QR_SELECT 1
-#endif
 #if LV_QR_SELECT
         {   // both sides computed, selected (same operations on the side that counts => same bits; the discarded side may divide by zero)
             const bool tiny = tailSq <= 1.17549435e-38f;
@@ -447,9 +452,6 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     if (bcount < K) return false;
     constexpr int U = 8;
     const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
-#ifndef LV_HALF_CHUNK
-#define LV_HALF_CHUNK 1
-#endif
     uint32_t base = 0;
     do {
         // (round 4) A bucket of the benchmark's map holds 62 candidates on average and more than the 64 of a chunk one time in four:
