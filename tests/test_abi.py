@@ -129,3 +129,7 @@ def test_pass_kernel_geometry_policy(capi):
     assert capi.pass_geometry(32_768, 256) == (256, 1, 1, 0)
     assert capi.pass_geometry(8_192, 256) == (64, 1, 1, 1)
     assert capi.pass_geometry(131_072, 256)[2] == 2 and capi.pass_geometry(131_073, 256)[2] == 3
+    # lv_update takes one launch per pass up to 16 rounds per workgroup (3 with estimate_extrinsics): the sizes of that rule
+    assert capi.pass_geometry(196_608, 256)[2] == 3 and capi.pass_geometry(196_609, 256)[2] == 4
+    assert capi.pass_geometry(262_144, 256)[2] == 4                      # configs[3]'s scan
+    assert capi.pass_geometry(1_048_576, 256)[2] == 16 and capi.pass_geometry(1_048_577, 256)[2] == 17
