@@ -88,6 +88,26 @@ def test_multi_round_scans_keep_the_one_launch_pass(capi, lv):
         assert not ctx.last_update_fused()
 
 
+def test_multi_round_scans_with_open_and_stray_points(capi, lv):
+    """The multi-round instantiation with every path of a round in play: a sparse map (many points need level 1, some the coarse
+    levels' queue) and stray points far from every surface (bounded stops), four and five rounds per workgroup, against the
+    three-kernel pass."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(60_000, 300_000)
+    rng = np.random.default_rng(3)
+    scan = sc["scan_xyz"].copy()
+    pick = rng.choice(len(scan), 3000, replace=False)
+    scan[pick] += rng.uniform(-4.0, 4.0, (3000, 3)).astype(np.float32)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        for n in (230_000, 300_000):
+            a, b = _both(ctx, sc, sc["x_init"], sc["P0"], scan[:n])
+            assert a[5]
+            _agree(a, b)
+            assert ctx.timing()["fallback_queries"] >= 0
+
+
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
 def test_pass_counts_and_oracle(capi, oracle, scene_small, iters):
     sc = scene_small
