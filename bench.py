@@ -271,6 +271,7 @@ def main() -> None:
     ap.add_argument("--no-phases", action="store_true", help="skip the in-kernel phase stamps leg (N=1, one launch per pass)")
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (GPU results of this run vs the CPU oracle)")
+    ap.add_argument("--no-large", action="store_true", help="skip the large-N leg (262 144-point scan vs 5 M-point map on one GPU)")
     ap.add_argument("--no-cycle", action="store_true", help="skip the whole-cycle leg (message in -> de-skew -> correct -> map insert)")
     ap.add_argument("--resident-only", action="store_true", help="profiling aid (scripts/gpu_profile.sh): only the timed resident steps — no "
                     "by-value legs, no event-instrumented repetition — so that a rocprofv3 run of this command sees the timed step alone")
@@ -419,15 +420,15 @@ def main() -> None:
     for _ in range(args.warmup):
         x, P, passes = upd.update(sc["x_init"], sc["P0"])
 
-    # ---- what a step is.  The hot path keeps its state ON THE DEVICE (the resident filter of row f-3: lv_filter_set /
-    # lv_predict / lv_correct — how the reference's loop src/main.cpp:75-103 drives it through the shim): a step = "set the
-    # prior, run the iterated update" = lv_filter_set + lv_correct, enqueued without waiting; K steps go out back to back and the
-    # region is synchronised at both ends.  Every step starts from the same prior (the 4.4 KB ride in the first launch's kernel
-    # arguments), so every step is the same four passes.  Rounds 1-3 timed lv_update BY VALUE instead — x / P handed over as host
-    # buffers and the posterior returned through the pinned mailbox, one host round trip per step: that rate (PCIe- and
-    # host-latency-inclusive: ~5 us of turnaround + up to 4.4 us of XCD wake-up skew on the launch that follows an empty queue,
-    # scripts/pass_balance.py) is reported beside `value` as value_by_value_sync.  Routes without the library's own collective
-    # (torch.distributed driving the all-reduce pass by pass) have no resident form: their step stays the by-value update.
+    # ---- what a step is.  The reference's loop reads the posterior after every correction (src/main.cpp:84-86: `correct` ->
+    # `latest_state`), so a STEP = "set the prior, run the iterated update, read the posterior back" with one host wait per step:
+    # lv_filter_set + lv_correct + lv_filter_get on the device-resident filter (row f-3; the state rides in the first launch's
+    # kernel arguments, the posterior comes back through the pinned mailbox).  Every step starts from the same prior, so every
+    # step is the same four passes.  That is `value` (round 5; rounds 1-3 timed lv_update by value — the same launches with x / P
+    # handed over as host buffers: `value_by_value_sync`, a top-level sibling; round 4 reported the PIPELINED rate as `value` —
+    # K steps enqueued back to back with no posterior read in between, which no caller of the reference's API can do: it is kept
+    # as `value_pipelined`).  Routes without the library's own collective (torch.distributed driving the all-reduce pass by pass)
+    # have no resident form: their step is the by-value update.
     import ctypes as C
 
     resident = (world == 1 or lib_comm_early) and not os.environ.get("LV_BENCH_BY_VALUE")
@@ -435,25 +436,35 @@ def main() -> None:
     P0c = np.ascontiguousarray(sc["P0"], np.float64)
     x0p, P0p = x0c.ctypes.data_as(C.c_void_p), P0c.ctypes.data_as(C.c_void_p)
 
-    def timed_regions(n_regions, by_value):
+    xg_buf, Pg_buf = np.zeros(26), np.zeros(23 * 23)
+    xgp, Pgp = xg_buf.ctypes.data_as(C.c_void_p), Pg_buf.ctypes.data_as(C.c_void_p)
+
+    def timed_regions(n_regions, form):
         """n_regions regions of exactly K steps each, no instrumentation on the stream, every region bracketed by barrier +
         synchronise on both sides (a region of 20 steps is 2.7 ms: a single one is at the mercy of whatever else the box does in
-        those milliseconds, so the median region is reported and the line carries the rest).  Returns (dt, passes) per region."""
+        those milliseconds, so the median region is reported and the line carries the rest).  form: "sync" = resident filter, the
+        posterior read back every step; "pipelined" = resident filter, steps enqueued back to back; "by_value" = lv_update.
+        Returns (dt, passes) per region."""
         dts, ps = [], []
+        lib, h = ctx.lib, ctx.h
         for _ in range(max(n_regions, 1)):
             tp = 0
             barrier_sync()
             t0 = time.perf_counter()
-            if by_value:
+            if form == "by_value":
                 for _ in range(args.steps):
                     tp += upd.update(sc["x_init"], sc["P0"])[2]
+            elif form == "sync":
+                for _ in range(args.steps):
+                    if lib.lv_filter_set(h, x0p, P0p) or lib.lv_correct(h, None) or lib.lv_filter_get(h, xgp, Pgp):
+                        raise RuntimeError(lib.lv_last_error().decode())
             else:
                 for _ in range(args.steps):
-                    if ctx.lib.lv_filter_set(ctx.h, x0p, P0p) or ctx.lib.lv_correct(ctx.h, None):
-                        raise RuntimeError(ctx.lib.lv_last_error().decode())
+                    if lib.lv_filter_set(h, x0p, P0p) or lib.lv_correct(h, None):
+                        raise RuntimeError(lib.lv_last_error().decode())
             barrier_sync()
             dts.append(time.perf_counter() - t0)
-            if not by_value:
+            if form != "by_value":
                 tp = ctx.last_passes() * args.steps      # (every step is the same update: the last one's pass count)
             ps.append(tp)
         if dist is not None:   # a region lasts as long as its slowest rank
@@ -469,20 +480,24 @@ def main() -> None:
             ctx.lib.lv_filter_set(ctx.h, x0p, P0p)
             ctx.lib.lv_correct(ctx.h, None)
         ctx.synchronize()
-    region_dt, region_passes = timed_regions(args.regions, by_value=not resident)
+    region_dt, region_passes = timed_regions(args.regions, "sync" if resident else "by_value")
     mid = median_region(region_dt, region_passes)
     dt, total_passes = region_dt[mid], region_passes[mid]
-    by_value_sync = None
+    by_value_sync = pipelined = None
     x_res = P_res = None
-    if resident and args.resident_only:
-        x_res, P_res = ctx.filter_get()
-    elif resident:
-        x_res, P_res = ctx.filter_get()          # the posterior the last resident step left on the device
-        bv_dt, bv_p = timed_regions(min(args.regions, 3), by_value=True)
-        bm = median_region(bv_dt, bv_p)
-        by_value_sync = {"value": bv_p[bm] / bv_dt[bm], "ms_per_step": bv_dt[bm] / args.steps * 1e3,
-                         "value_per_region": [round(p / d, 1) for p, d in zip(bv_p, bv_dt)],
-                         "note": "lv_update by value, one host round trip per step (the definition of `value` in rounds 1-3)"}
+    if resident:
+        x_res, P_res = xg_buf.copy(), Pg_buf.reshape(23, 23).copy()     # the posterior the last timed step read back
+
+        def side_leg(form, note):
+            d_, p_ = timed_regions(min(args.regions, 3) if not args.resident_only else 1, form)
+            m_ = median_region(d_, p_)
+            return {"value": p_[m_] / d_[m_], "ms_per_step": d_[m_] / args.steps * 1e3,
+                    "value_per_region": [round(p / d, 1) for p, d in zip(p_, d_)], "note": note}
+
+        pipelined = side_leg("pipelined", "lv_filter_set + lv_correct enqueued back to back, one synchronisation per region, no posterior "
+                             "read between steps (round 4's definition of `value`; not a call pattern the reference's loop has)")
+        if not args.resident_only:
+            by_value_sync = side_leg("by_value", "lv_update by value, one host round trip per step (the definition of `value` in rounds 1-3)")
     x, P, passes = upd.update(sc["x_init"], sc["P0"])
     # ---- the same K steps again with HIP events around the dominant kernel (ctx stream) --------------
     # (event records between kernels add ~5 us gaps each, so they are kept out of the timed region; kernel
@@ -500,11 +515,14 @@ def main() -> None:
             k_ms += tm["last_reduce_ms"] * p
             s_ms += tm["last_solve_ms"] * p
             c_us[:p] += np.array(tm["pass_collective_ms"][:p]) * 1e3
+            per_launch_us[:p] += np.array(tm["pass_match_ms"][:p]) * 1e3
+            per_launch_n[:p] += 1
             cnt += p
         ctx.set_profiling(False)
         return k_ms, s_ms, cnt, (c_us / max(steps, 1))
 
     kern_ms, kern_cnt, solve_ms, coll_us = 0.0, 0, 0.0, np.zeros(8)
+    per_launch_us, per_launch_n = np.zeros(8), np.zeros(8)     # the dominant kernel's HIP-event time by launch index within an update
     if (world == 1 or lib_comm) and not args.resident_only:   # lv_update itself runs the passes: per-kernel events exist
         kern_ms, solve_ms, kern_cnt, coll_us = events_leg(args.steps)
     fused_main = bool(ctx.last_update_fused())
@@ -625,6 +643,37 @@ def main() -> None:
                           "note": "medians over the workgroups (span: first start -> last search/fit end) and over 20 updates; wall clock inside the kernel"}
         finally:
             del os.environ["LV_PASS_CLK"]
+    # ---- the large-N figure, driver-timed (N=1 only): BASELINE configs[3]'s sizes on ONE GPU — 262 144-point scan against a
+    # 5 242 880-point map (B_alg 1328 B per point-pass), same synchronised step as `value`, in a context of its own
+    large = None
+    if world == 1 and not args.no_large and not args.resident_only:
+        try:
+            ML, NL = 5 * 1_048_576, 262_144
+            scl = synth.make_scene(ML, NL)
+            with capi.Context(prm, device=local_rank) as c3:
+                c3.map_build(scl["map_xyz"])
+                c3.scan_set(scl["scan_xyz"])
+                xl = np.ascontiguousarray(scl["x_init"], np.float64); Pl = np.ascontiguousarray(scl["P0"], np.float64)
+                xlp, Plp = xl.ctypes.data_as(C.c_void_p), Pl.ctypes.data_as(C.c_void_p)
+                for _ in range(5):
+                    c3.filter_set(xl, Pl); c3.correct(want_passes=False); c3.filter_get()
+                rates = []
+                for _ in range(3):
+                    c3.synchronize(); t0 = time.perf_counter()
+                    for _ in range(max(args.steps // 4, 5)):
+                        if c3.lib.lv_filter_set(c3.h, xlp, Plp) or c3.lib.lv_correct(c3.h, None) or c3.lib.lv_filter_get(c3.h, xgp, Pgp):
+                            raise RuntimeError(c3.lib.lv_last_error().decode())
+                    c3.synchronize()
+                    rates.append((time.perf_counter() - t0) / max(args.steps // 4, 5))
+                pl_ = c3.last_passes()
+                us = sorted(rates)[1] * 1e6
+                large = {"workload": f"{NL}-pt scan vs {ML}-pt map, k=5, 1 GPU (BASELINE configs[3] sizes un-sharded)", "passes_per_update": int(pl_),
+                         "us_per_update": us, "iters_per_s": pl_ / (us * 1e-6), "alg_bytes_per_point_pass": b_alg(ML),
+                         "whole_update_frac": b_alg(ML) * NL * pl_ / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "one_launch_per_pass": bool(c3.last_update_fused())}
+            del scl
+        except Exception as e:  # noqa: BLE001
+            large = {"error": str(e)}
     # ---- parity gate, GPU side (every rank: with a communicator the update is a collective): one capturing pass over this
     # rank's shard at the initial state + the timed build once more with its per-pass log; rank 0 then checks against the oracle
     gate = None
@@ -673,8 +722,14 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "step": ("lv_filter_set + lv_correct on the device-resident filter, K steps enqueued back to back (one synchronisation "
-                     "per region)" if resident else "lv_update by value (one host round trip per step)"),
+            "step": ("lv_filter_set + lv_correct + lv_filter_get on the device-resident filter: the posterior is read back after every "
+                     "update, one host wait per step (the reference's call pattern, src/main.cpp:84-86)" if resident
+                     else "lv_update by value (one host round trip per step)"),
+            "value_definition": "round 5: synchronised step (posterior read every step), like rounds 1-3 and unlike round 4, whose `value` "
+                                "was the pipelined rate now reported as value_pipelined",
+            "value_pipelined": None if not pipelined else pipelined["value"],
+            "value_by_value": None if not by_value_sync else by_value_sync["value"],
+            "value_pipelined_detail": pipelined,
             "value_by_value_sync": by_value_sync,
             # the R timed regions of K steps each: value / ms_per_step are the median region's
             "regions": len(region_dt),
@@ -720,6 +775,13 @@ def main() -> None:
                 "alg_bytes_per_launch": alg_bytes,
                 "alg_bytes_per_point_pass": b_alg(M_POINTS),
                 "avg_kernel_us": avg_kernel_s * 1e6,
+                # the same HIP-event durations by launch index within an update: the first launch (pose off by the perturbation: more
+                # open points, unbalanced tiles) and the converged ones are two regimes — rocprofv3's average mixes them
+                "kernel_us_by_launch": [round(float(u / max(n_, 1)), 2) for u, n_ in zip(per_launch_us[:4], per_launch_n[:4])],
+                "kernel_us_first": float(per_launch_us[0] / max(per_launch_n[0], 1)),
+                "kernel_us_converged": float(per_launch_us[1:4].sum() / max(per_launch_n[1:4].sum(), 1)),
+                "frac_converged": (alg_bytes / (per_launch_us[1:4].sum() / max(per_launch_n[1:4].sum(), 1) * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                if per_launch_n[1:4].sum() > 0 and per_launch_us[1:4].sum() > 0 else None,
                 "avg_fit_plus_solve_us": solve_ms / max(kern_cnt, 1) * 1e3,
                 "avg_solve_us": solve_ms / max(kern_cnt, 1) * 1e3,
                 "last_update_match_us_per_pass": [round(v * 1e3, 1) for v in ctx.timing()["pass_match_ms"][:4]],
@@ -749,6 +811,8 @@ def main() -> None:
                                             "time per pass, bitwise-equal ranks")
         if cycle is not None:
             out["cycle_ms_64k"] = cycle
+        if large is not None:
+            out["large_n"] = large
         if gate is not None:
             if "error" in gate:
                 out["parity"] = {"ok": False, "error": gate["error"]}

@@ -398,6 +398,20 @@ int pass_solve(lv_ctx* c, bool from_groups) {
 // communicator (the all-reduce sits between fit and solve), no degeneracy stage, 8 lanes per scan point.
 // the scan size that fixes pass_kernel's geometry: the local scan, or with a communicator the largest shard over the ranks
 // (every rank launches the same grid; workgroups without a tile contribute zero partials)
+// KF_FAULT_BIT (a bounded wait inside pass_kernel expired) rides in the device's fallback counter.  It fails the update that
+// raised it — and only that one: the host clears the bit on the device once it has reported it (the stream is idle at that
+// point), so the context stays usable, and everything that uses the word as a counter masks the bit out.
+static int report_kf_fault(lv_ctx* c, int raw) {
+    const int cnt = raw & (int)~KF_FAULT_BIT;
+    LV_HIP(hipStreamSynchronize(c->stream));
+    LV_HIP(hipMemcpy(&c->d_kf->fallback_queries, &cnt, sizeof(int), hipMemcpyHostToDevice));
+    c->h_io->fallback_queries = cnt;
+    c->fallback_base = cnt;
+    set_error("a bounded wait inside pass_kernel expired: this update's results are invalid (the flag has been cleared; the context stays usable)");
+    return LV_EHIP;
+}
+static inline int fallback_count(int raw) { return raw & (int)~KF_FAULT_BIT; }
+
 static inline bool multi_rank(const lv_ctx* c) { return c->comm != nullptr || c->gather_cb != nullptr || c->peer.active; }
 // transports that only carry the one-launch form's partials (no 96-double all-reduce behind them)
 static inline bool gather_only(const lv_ctx* c) { return c->gather_cb != nullptr || c->peer.active; }
@@ -1245,8 +1259,8 @@ int lv_iterate(lv_ctx* c, const lv_state* x, lv_sums* out) {
     LV_HIP(hipMemcpyAsync(&c->h_kf->fallback_queries, &c->d_kf->fallback_queries, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LV_HIP(hipStreamSynchronize(c->stream));
     unpack_sums(c->h_sums, out);
-    c->timing.fallback_queries = c->h_kf->fallback_queries - c->fallback_base;
-    c->fallback_base = c->h_kf->fallback_queries;
+    c->timing.fallback_queries = fallback_count(c->h_kf->fallback_queries) - c->fallback_base;
+    c->fallback_base = fallback_count(c->h_kf->fallback_queries);
     return LV_OK;
 }
 
@@ -1461,9 +1475,9 @@ int lv_update_end(lv_ctx* c, lv_state* x, double* P, int* passes) {
         if (!seen) LV_HIP(hipStreamSynchronize(c->stream));
     }
     const KfHostIO* io = c->h_io;
-    if ((unsigned)io->fallback_queries & KF_FAULT_BIT) { set_error("a bounded wait inside pass_kernel expired: the update's results are invalid"); return LV_EHIP; }
-    c->timing.fallback_queries = io->fallback_queries - c->fallback_base;
-    c->fallback_base = io->fallback_queries;
+    if ((unsigned)io->fallback_queries & KF_FAULT_BIT) { c->in_update = false; return report_kf_fault(c, io->fallback_queries); }
+    c->timing.fallback_queries = fallback_count(io->fallback_queries) - c->fallback_base;
+    c->fallback_base = fallback_count(io->fallback_queries);
     if (x) std::memcpy(x, io->x, sizeof(double) * NX);
     if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
     if (passes) *passes = io->passes;
@@ -1497,6 +1511,7 @@ int lv_update(lv_ctx* c, lv_state* x, double* P, int* passes, lv_sums* per_pass,
     }
     const int npass = c->prm.MAX_NUM_ITERS + 1;
     LV_CHECK_PEER(c);
+    if (!x || !P) { set_error("lv_update: null argument"); return LV_EINVAL; }   // (before the snapshot below dereferences them)
     lv_state x_prior;
     std::vector<double> P_prior;
     if (c->peer.active) {   // (a failed exchange must hand the caller's buffers back untouched: lv_update_end writes into them)
@@ -1612,7 +1627,7 @@ int lv_filter_get(lv_ctx* c, lv_state* x, double* P) {
         // once per 100 Hz cycle: the reference's main loop reads the state after every correct, src/main.cpp:96-102)
         if (!mailbox_wait(c)) LV_HIP(hipStreamSynchronize(c->stream));
         const KfHostIO* io = c->h_io;
-        if ((unsigned)io->fallback_queries & KF_FAULT_BIT) { set_error("a bounded wait inside pass_kernel expired: the update's results are invalid"); return LV_EHIP; }
+        if ((unsigned)io->fallback_queries & KF_FAULT_BIT) return report_kf_fault(c, io->fallback_queries);
         if (x) std::memcpy(x, io->x, sizeof(double) * NX);
         if (P) std::memcpy(P, io->P_post, sizeof(double) * NS * NS);
         return LV_OK;

@@ -179,6 +179,7 @@ struct PeerSet {
                                                  // the peers only AFTER the kernel that wrote them has ended (a kernel boundary publishes it)
     void* flag_alloc = nullptr;                  // [flag word]: its own FINE-GRAINED allocation — polled across devices in the middle of a
                                                  // kernel, which coarse-grained memory does not guarantee to be coherent for
+    bool buf_fine = false;                       // the gather slots are in fine-grained memory (false: plain allocation)
     bool flag_fine = false;                      // (false: the runtime refused a fine-grained IPC allocation; the flag lives in a plain one)
     double* buf[2] = {nullptr, nullptr};
     unsigned long long* flag = nullptr;

@@ -1319,7 +1319,12 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     SolveLds& L = *reinterpret_cast<SolveLds*>(smem);
     BookLds& Bk = *reinterpret_cast<BookLds*>(smem + PK_OFF_BOOK);
     Xyz (*s_stage)[PK_STAGE] = reinterpret_cast<Xyz (*)[PK_STAGE]>(smem);
-    double (*s_rows)[64][ROW_W] = reinterpret_cast<double (*)[64][ROW_W]>(smem);
+    // staged Jacobian rows of a fit wavefront.  Multi-round scans fit a round's planes BESIDE the next round's search (below), so
+    // there a fit wavefront's rows must lie inside its OWN candidate-stage area (wavefront w: [w * 6 KB, w * 6 KB + 4 KB)) — packed
+    // at a 4 KB stride, wavefront 1's rows would overlap wavefront 0's stage, which wavefront 0 refills as soon as it rejoins the
+    // search.  The single-round / EXT instantiations fit between two barriers and keep the packed layout.
+    constexpr size_t ROWS_STRIDE = (MULTI && !EXT) ? sizeof(Xyz) * 8 * PK_STAGE : sizeof(double) * 64 * ROW_W;
+    static_assert(sizeof(double) * 64 * ROW_W <= ROWS_STRIDE && ROWS_STRIDE * PK_FITW <= PK_OFF_BOOK, "staged rows: inside the stride, below the books");
     float4* s_rec = reinterpret_cast<float4*>(smem + PK_OFF_REC);
     uint32_t (*s_pref)[64] = reinterpret_cast<uint32_t (*)[64]>(smem + PK_OFF_PREF);
     uint32_t (*s_start)[64] = s_pref + PK_THREADS / 64;
@@ -1431,11 +1436,12 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         dbits[0] = __float_as_uint(r[6].x); dbits[1] = __float_as_uint(r[6].y); dbits[2] = __float_as_uint(r[6].z);
         dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
         const int found = __float_as_int(r[7].y);
-        double* srow = &s_rows[wave][lane][0];
+        double (*rows_w)[ROW_W] = reinterpret_cast<double (*)[ROW_W]>(smem + (size_t)wave * ROWS_STRIDE);
+        double* srow = &rows_w[lane][0];
         fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
         wave_lds_fence();   // this wavefront's 64 rows are staged
         if (stamp) PK_STAMP(7, tid == 0);
-        const double (*rows)[ROW_W] = s_rows[wave];
+        const double (*rows)[ROW_W] = rows_w;
 #pragma unroll
         for (int c = 0; c < NACC; ++c) {
             if (olane + c * 64 < NOUT) {
@@ -1664,6 +1670,10 @@ void pass_grid_size(uint32_t n, int max_wg, int* nsearch, int* steps, int* round
     const bool ded = g <= M - 1u;
     if (g > M) g = M;
     if (g < 1) g = 1;
+    // A/B knob (profiles/experiments_r05/half_rounds_ab.txt): a scan of ONE two-step round per workgroup as TWO one-step rounds
+    // through the MULTI instantiation, so that the first half's plane fits run beside the second half's search
+    static const bool split = [] { const char* e = getenv("LV_PASS_SPLIT"); return e && atoi(e) != 0; }();
+    if (split && st == (uint32_t)PK_STEPS && (nt + st * U * g - 1u) / (st * U * g) == 1u && nt > U * g) st = 1;
     *nsearch = (int)g;
     *steps = (int)st;
     *rounds = (int)((nt + st * U * g - 1u) / (st * U * g));

@@ -13,13 +13,16 @@
 // context's sticky status word (pinned host memory: the host reads it without a copy) AND poisons this rank's own flag (top
 // bit), so that every rank waiting for this one stops as well: all ranks fail the same update instead of diverging.  The host
 // side (lv_api.hip) then refuses to adopt that update's posterior and fails every later call with LV_ESTATE.
-// Memory: the gather slots live in a plain (coarse-grained) allocation — they are written by a pass kernel and read by peers
-// only after that kernel has ended and a LATER kernel of the same stream has published the flag, i.e. across a kernel boundary;
-// the flag word itself is polled across devices in the middle of a kernel and therefore lives in its own fine-grained
-// allocation (hipExtMallocWithFlags; a plain one only if the runtime refuses to export a fine-grained one).
-// EXPERIMENTAL, opt-in (lv_comm_peer_export / lv_comm_peer_init): proven with two processes on ONE GPU
-// (tests/test_gpu_distributed.py), where both ranks share one L2; not yet run across GPUs — no multi-GPU node was available to
-// rounds 1-4.
+// Memory: the gather slots are written by a pass kernel and read by peers only after that kernel has ended and a LATER kernel
+// of the same stream has published the flag, i.e. across a kernel boundary — correct in plain (coarse-grained) memory by the
+// argument written out in peer_gather_kernel; since round 5 they are nevertheless allocated fine-grained when the runtime can
+// export such memory (one assumption fewer on the first real multi-GPU run).  The flag word is polled across devices in the
+// middle of a kernel and lives in its own fine-grained allocation (hipExtMallocWithFlags; a plain one, with a warning on
+// stderr, only if the runtime refuses to export a fine-grained one; LV_PEER_REQUIRE_FINE=1 turns the warning into an error).
+// EXPERIMENTAL, opt-in (lv_comm_peer_export / lv_comm_peer_init): proven with two and four processes on ONE GPU
+// (tests/test_gpu_distributed.py), where all ranks share one L2; NOT yet run across GPUs — no multi-GPU node was available to
+// rounds 1-5, and no scaling curve exists.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -47,7 +50,12 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerArgs a) {
         if (threadIdx.x == 0) {
             // (a context that has already failed keeps telling its peers so)
             const unsigned long long bad = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? PEER_POISON : 0ull;
-            __hip_atomic_store(a.my_flag, a.seq | bad, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // fetch_max, not a store: a pulling workgroup of this or of the previous exchange kernel may have OR-ed PEER_POISON into
+            // this word already; a plain store landing after that would erase the poison until the next launch re-read the status
+            // word, and peers could adopt an update this rank has failed.  The poison is the top bit, so max() keeps it;
+            // flags only grow, so max() == store otherwise.  RELEASE at system scope: the write-back of this XCD's L2 precedes the
+            // flag (the pass kernel's own stores were written back from every XCD's L2 when THAT kernel ended — see below).
+            __hip_atomic_fetch_max(a.my_flag, a.seq | bad, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
@@ -70,6 +78,17 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerArgs a) {
     }
     __syncthreads();
     if (!s_ok) return;
+    // Why the slot reads below see the peer's partials (the argument the flag protocol rests on):
+    //  writer side — the slot was written by the peer's pass kernel with ordinary stores; that kernel ENDED before the peer's
+    //    exchange kernel (same stream) began, and the end-of-kernel release writes every XCD's dirty L2 lines back to memory;
+    //    the peer's publish is a system-scope RELEASE after that, so flag >= seq implies the slot is in the peer's HBM / MALL
+    //    (memory-side, coherent for every requester);
+    //  reader side — thread 0's ACQUIRE load of the flag at system scope orders (and the barrier above extends that to the
+    //    workgroup) the loads below, which are themselves system-scope atomic loads: they bypass this GPU's L2 / TCP (sc0 sc1),
+    //    so a line of the peer buffer cached from an earlier exchange can never be served.  Nothing here depends on the two ranks
+    //    sharing an L2 — that is merely the only configuration rounds 1-5 could run (one GPU per lease).
+    //  The slots are allocated fine-grained when the runtime exports such memory (peer_export), which removes the dependence on
+    //  the end-of-kernel write-back as well; coarse-grained is the fallback and is reported (PeerSet::buf_fine, stderr).
     const double* src = a.peer[b] + (size_t)b * a.slot;
     double* dst = a.local + (size_t)b * a.slot;
     for (size_t i = threadIdx.x; i < a.slot; i += blockDim.x)
@@ -80,10 +99,20 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerArgs a) {
 int peer_export(PeerSet& P, size_t cap_doubles, void* handle_blob) {
     if (P.local_alloc) { set_error("peer buffers already exported"); return LV_ESTATE; }
     const size_t bytes = 2 * cap_doubles * sizeof(double);
-    LV_HIP(hipMalloc(&P.local_alloc, bytes));
-    LV_HIP(hipMemset(P.local_alloc, 0, bytes));
     hipIpcMemHandle_t h[2];
     static_assert(sizeof(h) == LV_PEER_BLOB, "two 64-byte HIP IPC handles");
+    // the gather slots: fine-grained if the runtime can allocate AND export such memory (LV_PEER_COARSE_SLOTS=1 keeps round 4's
+    // plain allocation), else coarse-grained (correct across a kernel boundary: see peer_gather_kernel)
+    P.buf_fine = false;
+    const char* coarse_env = getenv("LV_PEER_COARSE_SLOTS");
+    if (!(coarse_env && atoi(coarse_env) != 0) && hipExtMallocWithFlags(&P.local_alloc, bytes, hipDeviceMallocFinegrained) == hipSuccess && P.local_alloc) {
+        hipIpcMemHandle_t probe;
+        if (hipIpcGetMemHandle(&probe, P.local_alloc) == hipSuccess) P.buf_fine = true;
+        else { hipFree(P.local_alloc); P.local_alloc = nullptr; }
+    }
+    (void)hipGetLastError();
+    if (!P.buf_fine) LV_HIP(hipMalloc(&P.local_alloc, bytes));
+    LV_HIP(hipMemset(P.local_alloc, 0, bytes));
     // the flag word: fine-grained if the runtime can allocate AND export such memory
     P.flag_fine = false;
     if (hipExtMallocWithFlags(&P.flag_alloc, 4096, hipDeviceMallocFinegrained) == hipSuccess && P.flag_alloc) {
@@ -92,6 +121,16 @@ int peer_export(PeerSet& P, size_t cap_doubles, void* handle_blob) {
     }
     (void)hipGetLastError();
     if (!P.flag_fine) {
+        // the flag is polled across devices in the MIDDLE of a kernel: in coarse-grained memory that is only coherent when the
+        // poller bypasses its caches (it does: system-scope atomic loads) and the writer's store reaches memory at once (a
+        // system-scope atomic does).  It has worked wherever it was tried, but it is outside what the memory model promises: say so.
+        fprintf(stderr, "[limovelo_hip] warning: the runtime exports no fine-grained memory; the peer exchange's flag word lives in "
+                        "coarse-grained memory (set LV_PEER_REQUIRE_FINE=1 to refuse instead)\n");
+        if (const char* e = getenv("LV_PEER_REQUIRE_FINE")) if (atoi(e) != 0) {
+            hipFree(P.local_alloc); P.local_alloc = nullptr;
+            set_error("lv_comm_peer_export: no exportable fine-grained allocation for the flag word (LV_PEER_REQUIRE_FINE)");
+            return LV_EHIP;
+        }
         LV_HIP(hipMalloc(&P.flag_alloc, 4096));
         LV_HIP(hipIpcGetMemHandle(&h[1], P.flag_alloc));
     }

@@ -108,6 +108,35 @@ def test_multi_round_scans_with_open_and_stray_points(capi, lv):
             assert ctx.timing()["fallback_queries"] >= 0
 
 
+def test_multi_round_sums_are_bitwise_stable_across_repetitions(capi, lv):
+    """in the multi-round instantiation a fit wavefront's staged rows used to overlap the candidate stage of
+    the fit wavefront before it, which refills that stage as soon as it rejoins the next round's search — a timing-dependent
+    corruption of H^T H / H^T h or of neighbour coordinates.  The rows now live inside the fit wavefront's own stage area.  This
+    is the stress test the finding asks for: many repetitions of multi-round updates (3 / 5 / 9 rounds per workgroup; a sparse map
+    so that search tasks differ wildly in length and fit wavefronts rejoin the search at different times), every per-pass sums
+    record, state and covariance compared BITWISE with the first repetition, and the first repetition with the three-kernel pass."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(80_000, 600_000)
+    rng = np.random.default_rng(11)
+    scan = sc["scan_xyz"].copy()
+    pick = rng.choice(len(scan), 6000, replace=False)
+    scan[pick] += rng.uniform(-3.0, 3.0, (6000, 3)).astype(np.float32)
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        for n, reps in ((150_000, 60), (300_000, 40), (600_000, 20)):
+            a, b = _both(ctx, sc, sc["x_init"], sc["P0"], scan[:n])
+            assert a[5], n
+            _agree(a, b)
+            x0, P0, p0, tr0, s0 = a[:5]
+            for r in range(reps):
+                x, P, p, tr, sm = ctx.update(sc["x_init"], sc["P0"])
+                assert ctx.last_update_fused()
+                assert p == p0 and np.array_equal(x, x0) and np.array_equal(P, P0), (n, r)
+                for u, v in zip(sm, s0):
+                    assert u["n_valid"] == v["n_valid"] and np.array_equal(u["HTH"], v["HTH"]) and np.array_equal(u["HTh"], v["HTh"]), (n, r)
+
+
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
 def test_pass_counts_and_oracle(capi, oracle, scene_small, iters):
     sc = scene_small
