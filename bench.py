@@ -93,8 +93,8 @@ def parity_check(g: dict, sc, scan_local, prm, nthreads: int = 16) -> dict:
     the CPU oracle on the identical inputs — the oracle is the checker here, never the thing measured.  Exact kNN (index
     mismatches, distance bits), valid-mask flips, plane / residual bits, H^T H / H^T h of that pass; then the iterated update:
     pass count, per-pass n_valid, state after every pass, final state and covariance.  The oracle is a restatement of the
-    reference (no reference binary or golden vectors exist: parity unpinned), so "ok" means "equal to the oracle within the
-    stated tolerances"."""
+    reference whose in-tree half is pinned to the reference's own compiled sources (oracle/_ref; the absent submodules' half is
+    not), so "ok" means "equal to the oracle within the stated tolerances"."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import lvoracle as lo
 
@@ -110,7 +110,9 @@ def parity_check(g: dict, sc, scan_local, prm, nthreads: int = 16) -> dict:
     scale = float(np.abs(o["HTH"]).max())
     g0 = g["g0"]
     out = {
-        "against": "oracle/ (CPU restatement of the reference; parity unpinned: the reference ships no vectors and cannot be built here)",
+        "against": "oracle/ (CPU restatement of the reference).  Pinned half: world transform, Plane gates, estimate_plane call structure, is_plane, "
+                   "Match / chosen set, calculate_H rows = the reference's own sources compiled in place (oracle/_ref, tests/test_oracle_ref.py, "
+                   "bit-equal).  Unpinned half (stand-ins on both sides, upstream recall): kNN tie / traversal rule, Eigen QR internals, esekf algebra",
         "points_checked_per_point": int(len(scan_local)),
         "knn_index_mismatches": int((g["idx"] != o["knn_idx"]).any(axis=1).sum()),
         "knn_distance_bit_mismatches": int((g["d2"].view(np.uint32) != o["knn_d2"].view(np.uint32)).any(axis=1).sum()),

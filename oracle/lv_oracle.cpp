@@ -1,6 +1,6 @@
 /*
  * lv_oracle.cpp — CPU ORACLE (test infrastructure; see lv_oracle.h header for the usage rule and
- * the "PARITY UNPINNED" statement).
+ * the statement of what its parity is pinned to).
  *
  * A dependency-free C++17 restatement of the LIMO-Velo iterated-KF-update hot path.  Every function
  * cites the reference file:line it follows (paths relative to /root/reference).  Pieces whose source
@@ -1359,6 +1359,12 @@ extern "C" void lvo_sincos_vs_libm(const float* x, size_t n, int64_t* n_sin_diff
     *n_sin_diff = ds; *n_cos_diff = dc; *max_ulp = mu;
 }
 
+// lvo_set_sincos_libm(1): SO3Math::Exp takes this platform's sinf / cosf instead of the pinned polynomial — the mode in which
+// the oracle must equal the reference's own State::propagate_f compiled here (oracle/_ref, tests/test_oracle_ref.py) bit for bit;
+// the default (0) is the polynomial the device evaluates as well (lvo_sincos_vs_libm measures the distance between the two).
+static int g_sincos_libm = 0;
+extern "C" void lvo_set_sincos_libm(int on) { g_sincos_libm = on; }
+
 // SO3Math::Exp<float,float>(ang_vel, dt) — include/Headers/Utils.hpp:30-53
 static void so3_exp_f32(const float w[3], float dt, float E[9]) {
     const float nrm = std::sqrt(dot3f(w[0], w[0], w[1], w[1], w[2], w[2]));
@@ -1368,7 +1374,8 @@ static void so3_exp_f32(const float w[3], float dt, float E[9]) {
     const float K[9] = {0.f, -r[2], r[1], r[2], 0.f, -r[0], -r[1], r[0], 0.f};
     const float r_ang = nrm * dt;
     float sn, cs;
-    sincos_f32(r_ang, sn, cs);
+    if (g_sincos_libm) { sn = std::sin(r_ang); cs = std::cos(r_ang); }   // (float overloads = sinf / cosf: what Utils.hpp:46 calls)
+    else sincos_f32(r_ang, sn, cs);
     const float c = (float)(1.0 - (double)cs);
     float cK[9], cKK[9];
     for (int i = 0; i < 9; ++i) cK[i] = c * K[i];

@@ -5,13 +5,16 @@
  * bench.py's cpu_baseline leg may load this library, and there only as the checker / the timed
  * CPU baseline.  The product path (limo-velo_amd/) never links or calls it.
  *
- * PARITY UNPINNED: the reference (Huguet57/LIMO-Velo) ships no tests, no golden vectors and cannot
- * be built in this container (ROS/PCL/Eigen absent, the ikd-Tree and IKFoM submodules are empty —
- * SURVEY.md F1-F4).  This oracle is a restatement of the in-tree reference files (cited per
- * function in lv_oracle.cpp) plus the published algorithms of the two absent dependencies
- * (hku-mars/ikd-Tree, hku-mars/IKFoM as vendored by FAST-LIO2; every such piece is tagged
- * [UPSTREAM-RECALL]).  It is cross-checked against scipy/numpy (tests/test_oracle_*.py), not
- * against reference outputs.
+ * PARITY, what it is pinned to (round 5): the reference (Huguet57/LIMO-Velo) ships no tests and no golden vectors, and its build
+ * needs ROS / PCL / Eigen and two submodules that are absent here.  Its IN-TREE sources, however, compile
+ * in place against stand-in headers (oracle/ref_build/ -> oracle/_ref/liblvref.so), and tests/test_oracle_ref.py holds this
+ * oracle to what that code computes, bit for bit: the world transform and State mirror, the Plane gates, estimate_plane's
+ * call structure / normalisation, is_plane, Match, the chosen set, calculate_H's rows, the x0 / P0 / Q / propagate_to
+ * schedule, State::propagate_f + Compensator::compensate, the Accumulator windows and the PointCloud2 time rules.
+ * STILL UNPINNED — restated from the published algorithms of absent dependencies, tagged [UPSTREAM-RECALL] in lv_oracle.cpp,
+ * and stand-ins on the reference side of that comparison as well: Eigen's QR internals and reduction order, ikd-Tree's search
+ * order / tie rule / Add_Points box rule, esekf's update algebra (incl. the fork's degeneracy stage) and pcl::VoxelGrid.
+ * Those are cross-checked against scipy / numpy / algebraic properties (tests/test_oracle*.py), not against reference outputs.
  */
 #ifndef LV_ORACLE_H
 #define LV_ORACLE_H
@@ -161,6 +164,9 @@ typedef struct lvo_motion_state {
 
 /* State::operator+=(IMU(a, w, t)) = State::update -> propagate_f (State.cpp:94-121), f32. */
 void lvo_state_integrate(lvo_motion_state* s, const float a[3], const float w[3], double t);
+/* on != 0: SO3Math::Exp inside lvo_state_integrate / lvo_deskew evaluates sin / cos with this platform's sinf / cosf (what the
+ * reference calls) instead of the pinned polynomial below — used only to compare the oracle with oracle/_ref bit for bit. */
+void lvo_set_sincos_libm(int on);
 /* sin / cos of f32 arguments as rows f-2 / f-3 evaluate them (one fixed f64 polynomial, rounded to f32) */
 void lvo_sincos_f32(const float* x, size_t n, float* sn, float* cs);
 /* The pinned sin / cos polynomial of row f-2 against this platform's sinf / cosf (what the reference calls,

@@ -1,8 +1,9 @@
 """ctypes binding of the CPU oracle (oracle/liblvoracle.so).
 
 TEST INFRASTRUCTURE ONLY — see oracle/lv_oracle.h.  Importable from tests/, __graft_entry__.smoke()
-and bench.py's cpu_baseline leg; never from the product package.  PARITY UNPINNED (no reference
-golden vectors exist).
+and bench.py's cpu_baseline leg; never from the product package.  Parity: the in-tree half of the path is
+pinned to the reference's own compiled sources (oracle/_ref, tests/test_oracle_ref.py); the absent
+dependencies' half (kNN order, QR internals, esekf algebra) stays unpinned — see lv_oracle.h.
 """
 from __future__ import annotations
 

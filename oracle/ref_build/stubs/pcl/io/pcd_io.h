@@ -1,0 +1,1 @@
+#include <pcl/point_types.h>

@@ -1,0 +1,110 @@
+"""The HIP path against the REFERENCE'S OWN CODE, without the oracle in between: oracle/_ref/liblvref.so (/root/reference/src
+compiled in place, tests/test_oracle_ref.py) driven through its C glue on the same seeded inputs as the GPU context.  The
+library travels to the GPU box prebuilt (the reference mount does not); the module skips where it is absent.
+
+What equality here means: for every scan point, what Mapper::match / Plane / R3Math / Match / Localizator::calculate_H of the
+reference compute (world point, chosen set, plane, residual, Jacobian row) are the bits lv_iterate's per-point outputs carry,
+and a whole Localizator::correct lands on lv_update's posterior.  The reference-side kNN and filter algebra are stand-ins
+(exact search; the oracle's esekf restatement) — see oracle/ref_build/slam/."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lr(oracle, lv):
+    import os
+
+    import lvref
+
+    if not os.path.exists(lvref._LIB_PATH) and lvref.build() is None:
+        pytest.skip("oracle/_ref/liblvref.so did not travel with this snapshot")
+    lvref.set_config()
+    lvref.reset()
+    return lvref
+
+
+@pytest.fixture(scope="module")
+def capi(lv):
+    from limo_velo_amd import capi as c
+
+    return c
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+@pytest.mark.parametrize("extrinsics,est", [("identity", False), ("xaloc", True)])
+def test_per_point_outputs_equal_the_reference_code(capi, lr, extrinsics, est):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 2_000, extrinsics=extrinsics)
+    lr.set_config(estimate_extrinsics=int(est))
+    lr.reset()
+    lr.map_add(sc["map_xyz"])
+    with capi.Context(capi.default_params(estimate_extrinsics=int(est))) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        for x in (sc["x_init"], sc["x_true"]):
+            m = lr.match(x, sc["scan_xyz"])
+            ctx.iterate(x)
+            valid, pw, abcd, dist = ctx.fetch_matches()
+            H, h = ctx.fetch_rows()
+            v = valid.astype(bool)
+            assert np.array_equal(np.nonzero(v)[0], m["src"])                      # the chosen set (Match::is_chosen)
+            assert np.array_equal(_bits(pw), _bits(lr.transform(x, sc["scan_xyz"])))   # Mapper.cpp:51 for EVERY point
+            assert np.array_equal(_bits(abcd[v]), _bits(m["abcd"]))                 # R3Math::estimate_plane behind Plane's gates
+            assert np.array_equal(_bits(dist[v]), _bits(m["dist"]))                 # Plane::dist_to_plane
+            Hr, hr, _ = lr.calculate_H(x, m["p_world"], m["abcd"])                  # Localizator::calculate_H
+            assert np.array_equal(_bits(H[v]), _bits(Hr)) and np.array_equal(_bits(h[v]), _bits(hr))
+            Hc, hc = ctx.calculate_H(x, m["p_world"], m["abcd"], m["dist"])        # the drop-in entry point lv_calculate_H
+            assert np.array_equal(_bits(Hc), _bits(Hr)) and np.array_equal(_bits(hc), _bits(hr))
+    lr.set_config()
+
+
+def test_iterated_update_lands_on_the_reference_glue_posterior(capi, lr):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 2_000)
+    lr.set_config()
+    lr.reset()
+    lr.map_add(sc["map_xyz"])
+    xr, Pr, nr, trr, sr = lr.update(sc["x_init"], sc["P0"], sc["scan_xyz"])
+    with capi.Context() as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, n, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+    assert n == nr
+    assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in sr]
+    assert np.abs(x - xr).max() < 1e-9 and np.abs(P - Pr).max() < 1e-9 * max(1.0, np.abs(Pr).max())
+    lr.reset()
+
+
+def test_deskew_window_against_the_reference_compensator(capi, lr, oracle):
+    """Row f-2 on the device against Compensator::compensate compiled from the reference: the device evaluates sin / cos by the
+    pinned polynomial, the reference by this platform's libm — so the bar is the rounding of one sin / cos per point (a few f32
+    ulps of a coordinate up to 60 m), and exact equality wherever the angular rate is zero."""
+    rng = np.random.default_rng(4)
+    for w in ([0.0, 0.0, 0.0], [0.02, -0.05, 0.4]):
+        states, cur = [], oracle.motion_state(R=np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32), pos=[3, -2, 1.5], vel=[4, 0.5, 0.1],
+                                              a=[0.3, 0.1, 9.8], w=w, time=50.0, tLI=[0.05, 0.0, -0.1])
+        for i in range(12):
+            states.append(cur.copy())
+            cur = oracle.state_integrate(cur, rng.normal(0, 0.5, 3) + [0, 0, 9.8], np.asarray(w) * rng.uniform(0.5, 1.5), 50.0 + 0.01 * (i + 1))
+        states = np.concatenate(states)
+        times = np.sort(rng.uniform(50.0, 50.11, 3000))
+        xyz = rng.uniform(-60, 60, (3000, 3)).astype(np.float32)
+        Xt2 = oracle.state_integrate(states[-1:].copy(), states[-1]["a"], states[-1]["w"], 50.11)
+        ref, k = lr.deskew(xyz, times, states, Xt2)
+        assert k == 3000
+        with capi.Context() as ctx:
+            ctx.scan_deskew(xyz, times, states, Xt2, 0.0)      # no voxel grid: the scan keeps every point (Morton order)
+            got = ctx.scan_fetch()
+        key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        if not any(w):
+            assert np.array_equal(_bits(key(got[:, :3])), _bits(key(ref)))
+        else:
+            assert np.abs(key(got[:, :3]) - key(ref)).max() < 2e-4

@@ -1,0 +1,329 @@
+"""The oracle pinned to the REFERENCE'S OWN CODE.  oracle/_ref/liblvref.so is /root/reference/src/{Utils,Objects,Modules}/*.cpp
+compiled in place (oracle/ref_build/Makefile; nothing copied) against stand-in headers for what this container lacks — ROS / PCL
+types, a minimal eager Eigen with Eigen 3.3's evaluation order, and the two absent submodules (exact kNN; the oracle's esekf
+algebra) — and driven through a thin C glue.  Every test below calls the reference's functions on seeded inputs and demands the
+bits of oracle/lv_oracle.cpp (the checker of every GPU parity test):
+
+  pinned by this file (the in-tree half of SURVEY §8a):  a-1 world transform / State(state_ikfom) · a-3 Plane gates · a-4
+  estimate_plane's call structure, normalisation and the f64 `1.0 / n` · a-5 is_plane · a-6 Match / dist_to_plane / the chosen
+  set · a-7 calculate_H rows (both extrinsics settings) · Localizator's x0 / P0 / Q / propagate_to schedule · f-2 State::
+  propagate_f + Compensator::compensate (with this platform's sinf / cosf on both sides) · f-3 Accumulator windows · f-4 the
+  per-sensor time rules, temporal down-sampling and time sort of PointCloudProcessor.
+  NOT pinned (stand-ins on the reference side, [UPSTREAM-RECALL] on both): Eigen's QR internals and reduction order, ikd-Tree's
+  search / insert rule, esekf's update algebra, pcl::VoxelGrid.
+
+Needs the built library: built here when /root/reference is mounted; on a box without the mount the prebuilt .so is used; with
+neither the module skips."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def lr(oracle, lv):
+    import lvref
+
+    if lvref.build() is None:
+        pytest.skip("oracle/_ref/liblvref.so is not built and /root/reference is not mounted")
+    lvref.set_config()
+    lvref.reset()
+    return lvref
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def _rand_state(rng, big=False):
+    from limo_velo_amd import synth
+
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    qo = synth.quat_from_rpy(*rng.uniform(-0.3, 0.3, 3))
+    x = np.zeros(26)
+    x[0:3] = rng.uniform(-200, 200, 3) if big else rng.uniform(-20, 20, 3)
+    x[3:7] = q
+    x[7:11] = qo
+    x[11:14] = rng.uniform(-0.5, 0.5, 3)
+    x[14:17] = rng.uniform(-3, 3, 3)
+    x[17:23] = rng.uniform(-0.01, 0.01, 6)
+    x[23:26] = [0, 0, -9.809]
+    return x
+
+
+def test_state_mirror_and_world_transform_bits(lr, oracle):
+    """a-1: State(const state_ikfom&, double) (State.cpp:51-62) and X * X.I_Rt_L() * p (Mapper.cpp:51, RotTransl.cpp:36-48)."""
+    rng = np.random.default_rng(5)
+    for k in range(40):
+        x = _rand_state(rng, big=k % 2 == 1)
+        assert np.array_equal(_bits(lr.state_to_pose(x)), _bits(oracle.state_to_pose(x)))
+        scan = (rng.uniform(-90, 90, (500, 3)) * rng.choice([1e-3, 1.0, 1.0, 1.0], (500, 1))).astype(np.float32)
+        assert np.array_equal(_bits(lr.transform(x, scan)), _bits(oracle.transform_scan(x, scan)))
+
+
+@pytest.mark.parametrize("extrinsics,est", [("identity", False), ("xaloc", False), ("xaloc", True)])
+def test_match_set_planes_residuals_and_rows_on_cfg0(lr, oracle, lv, extrinsics, est):
+    """configs[0] (2k-pt scan vs 50k-pt map): Mapper::match -> the chosen set, ABCD, distance, world point; then
+    Localizator::calculate_H on those matches -> H rows and h.  All bit-equal to the oracle (the kNN behind match is the
+    stand-in's exact search = the oracle's; what this pins is everything the reference does around it)."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(50_000, 2_000, extrinsics=extrinsics)
+    lr.set_config(estimate_extrinsics=int(est))
+    lr.reset()
+    lr.map_add(sc["map_xyz"])
+    assert lr.map_size() == 50_000
+    prm = oracle.default_params(estimate_extrinsics=int(est))
+    tree = oracle.KdTree(sc["map_xyz"])
+    for x in (sc["x_init"], sc["x_true"]):
+        m = lr.match(x, sc["scan_xyz"])
+        o = oracle.iterate(x, sc["map_xyz"], sc["scan_xyz"], params=prm, tree=tree)
+        valid = o["valid"].astype(bool)
+        assert 1000 < valid.sum() < 2000
+        assert np.array_equal(m["src"], np.nonzero(valid)[0])                       # a-3 / a-5 / a-6: the chosen set
+        assert np.array_equal(_bits(m["p_world"]), _bits(oracle.transform_scan(x, sc["scan_xyz"])[valid]))
+        assert np.array_equal(_bits(m["abcd"]), _bits(o["abcd"][valid]))            # a-4
+        assert np.array_equal(_bits(m["dist"]), _bits(o["dist"][valid]))            # a-6
+        H, h, d = lr.calculate_H(x, m["p_world"], m["abcd"])                        # a-7
+        assert np.array_equal(_bits(d), _bits(m["dist"]))
+        assert np.array_equal(_bits(H), _bits(o["Hrows"][valid])) and np.array_equal(_bits(h), _bits(o["h"][valid]))
+        if est:
+            assert np.abs(H[:, 6:]).max() > 0
+        else:
+            assert not H[:, 6:].any()
+    lr.set_config()
+
+
+def test_plane_gates_and_degenerate_fits(lr, oracle):
+    """a-3 / a-4 / a-5 one plane at a time, Plane(near, sq_dists) against lvo_plane_fit: too few neighbours, the far gate at
+    exactly MAX_DIST_PLANE^2 (f32 distance promoted against the f64 square, Plane.cpp:41), thick / curved neighbourhoods around
+    PLANES_THRESHOLD, collinear and coincident points (rank cut of the QR), large world coordinates."""
+    rng = np.random.default_rng(9)
+    lr.set_config()
+    n_plane = n_not = 0
+    for case in range(3000):
+        kind = case % 6
+        k = 5
+        c = rng.uniform(-150, 150, 3)
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        u = np.cross(nrm, [1, 0, 0.3]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+        ab = rng.uniform(-0.3, 0.3, (k, 2))
+        thick = [0.001, 0.03, 0.1, 0.25, 0.0, 0.01][kind]
+        pts = c + ab[:, :1] * u + ab[:, 1:] * v + rng.uniform(-thick, thick, (k, 1)) * nrm
+        if kind == 4:
+            pts = c + ab[:, :1] * u                      # collinear
+        if case % 97 == 0:
+            pts[:] = c                                   # coincident
+        if case % 53 == 0:
+            k = 4                                        # enough_points fails
+        near = pts[:k].astype(np.float32)
+        sq = np.sort(rng.uniform(0.01, 1.0, k)).astype(np.float32)
+        if case % 11 == 0:
+            sq[-1] = np.float32(4.0) if case % 22 == 0 else np.nextafter(np.float32(4.0), np.float32(0))
+        ok_r, abcd_r = lr.plane(near, sq)
+        ok_o, abcd_o = oracle.plane_fit(near, sq)
+        assert ok_r == bool(ok_o), case
+        if ok_r:
+            assert np.array_equal(_bits(abcd_r), _bits(np.asarray(abcd_o, np.float32))), case
+            n_plane += 1
+        else:
+            n_not += 1
+        if k == 5 and np.isfinite(lr.estimate_plane(near)).all():   # the raw QR solution, gates aside (NaN for rank-0 inputs on both)
+            prm1 = oracle.default_params(planes_threshold=np.float32(1e30), max_dist_plane=1e30)
+            ok2, abcd2 = oracle.plane_fit(near, sq, params=prm1)
+            if ok2:
+                assert np.array_equal(_bits(lr.estimate_plane(near)), _bits(np.asarray(abcd2, np.float32))), case
+    assert n_plane > 500 and n_not > 500, (n_plane, n_not)
+
+
+def test_iterated_update_through_the_reference_glue(lr, oracle, lv):
+    """Localizator::correct (Localizator.cpp:21-27,129-133) from a given prior: the measurement of every pass is the
+    reference's match + calculate_H, the algebra between passes the oracle's (the stand-in esekf) — so pass count, per-pass
+    n_valid and the state after every pass must follow lvo_update; H^T H is summed row by row here and in 1024-point chunks
+    there, hence 1e-13 relative on the sums and 1e-12 on the state."""
+    from limo_velo_amd import synth
+
+    for iters in (3, 1):
+        sc = synth.make_scene(50_000, 2_000)
+        lr.set_config(max_num_iters=iters)
+        lr.reset()
+        lr.map_add(sc["map_xyz"])
+        x, P, n, tr, sums = lr.update(sc["x_init"], sc["P0"], sc["scan_xyz"])
+        prm = oracle.default_params(max_num_iters=iters)
+        xo, Po, no, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=prm, tree=oracle.KdTree(sc["map_xyz"]))
+        assert n == no == iters + 1
+        assert [s["n_valid"] for s in sums] == [s["n_valid"] for s in so]
+        for a, b in zip(sums, so):
+            assert np.abs(a["HTH"] - b["HTH"]).max() <= 1e-13 * np.abs(b["HTH"]).max()
+        assert np.abs(tr - np.asarray(tro)[:, 23:]).max() < 1e-12
+        assert np.abs(x - xo).max() < 1e-12 and np.abs(P - Po).max() < 1e-12 * max(1.0, np.abs(Po).max())
+    lr.set_config()
+    lr.reset()
+    x, P, n, _, sums = lr.update(sc["x_init"], sc["P0"], sc["scan_xyz"])      # no map: Localizator::correct returns at once
+    assert n == 0
+    assert np.array_equal(x, sc["x_init"])
+
+
+def test_initial_state_covariance_and_imu_propagation(lr, oracle):
+    """f-3: Localizator::initialize (x0 from the first IMU's orientation, S2 gravity from initial_gravity, extrinsics from the
+    YAML lists; P0 = Localizator.cpp:144-150) and propagate_to (Q = Localizator.cpp:159-173; one predict per IMU + one to t with
+    the last IMU's controls) against the oracle's predict driven by the same schedule."""
+    rng = np.random.default_rng(2)
+    RLI = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]], np.float32)
+    cfg = lr.set_config(I_Rotation_L=RLI.ravel(), I_Translation_L=[0.1, -0.2, 0.3], initial_gravity=[0.0, 0.1, -9.8])
+    lr.reset()
+    q = np.array([0.1, -0.2, 0.3, 0.9], np.float32); q /= np.linalg.norm(q)
+    x0, P0 = lr.initialize([0, 0, 9.8], [0, 0, 0], q, 10.0)
+    assert np.array_equal(x0[3:7], q.astype(np.float64))                          # rot = imu.q.cast<double>() (not re-normalised)
+    g = -np.array([0.0, 0.1, -9.8], np.float32).astype(np.float64)
+    assert np.allclose(x0[23:26], g / np.linalg.norm(g) * 9.809, rtol=0, atol=1e-15)
+    # offset_R_L_I = SO3(Map<Matrix3f>(I_Rotation_L) COLUMN-major: the transpose of the row-major YAML list
+    from limo_velo_amd import synth
+    assert np.allclose(synth.quat_to_rot(x0[7:11]), RLI.T.astype(np.float64), atol=1e-15)
+    assert np.array_equal(x0[11:14], np.array([0.1, -0.2, 0.3], np.float32).astype(np.float64))
+    d = np.ones(23); d[6:12] = 1e-5; d[15:18] = 1e-4; d[18:21] = 1e-3; d[21:23] = 1e-5
+    assert np.array_equal(P0, np.diag(d))
+    # propagate_to: IMUs at 400 Hz between the last integration time and t
+    lr.set_config()
+    ts = 10.0 + 0.0025 * np.arange(1, 9)
+    a = (np.array([0.0, 0.0, 9.8]) + rng.normal(0, 0.2, (8, 3))).astype(np.float32)
+    w = rng.normal(0, 0.1, (8, 3)).astype(np.float32)
+    x = _rand_state(np.random.default_rng(3)); P = np.diag(d)
+    t_end = 10.0213
+    xr, Pr = lr.propagate(x, P, 10.0, a, w, ts, t_end)
+    Q = np.eye(12); Q[0:3, 0:3] *= cfg.cov_gyro; Q[3:6, 3:6] *= cfg.cov_acc; Q[6:9, 6:9] *= cfg.cov_bias_gyro; Q[9:12, 9:12] *= cfg.cov_bias_acc
+    xo, Po, last = x.copy(), P.copy(), 10.0
+    for i in range(8):
+        xo, Po = oracle.predict(xo, Po, ts[i] - last, Q, a[i].astype(np.float64), w[i].astype(np.float64))
+        last = ts[i]
+    xo, Po = oracle.predict(xo, Po, t_end - last, Q, a[-1].astype(np.float64), w[-1].astype(np.float64))
+    assert np.array_equal(xr, xo) and np.array_equal(Pr, Po)
+
+
+def test_state_integration_and_deskew_bits(lr, oracle):
+    """f-2: State::operator+=(IMU) (State.cpp:94-121: SO3Math::Exp in f32, the f64 literals 0.5 / 1.0 entering as the reference
+    writes them) and Compensator::compensate(states, Xt2, points) (Compensator.cpp:123-146).  The reference calls std::sin /
+    std::cos on floats (this platform's sinf / cosf); the oracle's default is a pinned polynomial (so that device and oracle
+    agree on every platform) — with lvo_set_sincos_libm(1) the oracle takes libm's too and must equal the reference bit for bit;
+    in its default mode the two differ by at most an ulp of sin / cos (counted)."""
+    rng = np.random.default_rng(4)
+    oracle.lib().lvo_set_sincos_libm(1)
+    try:
+        for k in range(200):
+            R = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+            s = oracle.motion_state(R=R, pos=rng.uniform(-50, 50, 3), vel=rng.uniform(-5, 5, 3), a=rng.normal(0, 3, 3) + [0, 0, 9.8],
+                                    w=rng.normal(0, 0.5 if k % 4 else 0.0, 3), time=100.0, bw=rng.normal(0, 0.01, 3), ba=rng.normal(0, 0.05, 3))
+            a, w, t = rng.normal(0, 3, 3).astype(np.float32), rng.normal(0, 0.5, 3).astype(np.float32), 100.0 + rng.uniform(0.0005, 0.11)
+            so, sr = oracle.state_integrate(s, a, w, t), lr.state_integrate(s, a, w, t)
+            for f in ("R", "pos", "vel", "a", "w"):
+                assert np.array_equal(_bits(so[f]), _bits(sr[f])), (k, f)
+            assert so["time"][0] == sr["time"][0] == t
+        # a window: 12 states 10 ms apart, 3000 stamped points, Xt2 = the state at the window's end
+        states = []
+        cur = oracle.motion_state(R=np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32), pos=[3, -2, 1.5], vel=[4, 0.5, 0.1], a=[0.3, 0.1, 9.8],
+                                  w=[0.02, -0.05, 0.4], time=50.0, tLI=[0.05, 0.0, -0.1])
+        for i in range(12):
+            states.append(cur.copy())
+            cur = oracle.state_integrate(cur, rng.normal(0, 0.5, 3) + [0, 0, 9.8], rng.normal(0, 0.3, 3), 50.0 + 0.01 * (i + 1))
+        states = np.concatenate(states)
+        times = np.sort(rng.uniform(50.0, 50.11, 3000))
+        xyz = rng.uniform(-60, 60, (3000, 3)).astype(np.float32)
+        Xt2 = oracle.state_integrate(states[-1:].copy(), states[-1]["a"], states[-1]["w"], 50.11)
+        do = oracle.deskew(xyz, times, states, Xt2)
+        dr, k = lr.deskew(xyz, times, states, Xt2)
+        assert k == 3000 and np.array_equal(_bits(do), _bits(dr))
+    finally:
+        oracle.lib().lvo_set_sincos_libm(0)
+    dp = oracle.deskew(xyz, times, states, Xt2)               # pinned polynomial: within rounding of the libm result
+    assert np.abs(dp - dr).max() < 2e-4 and (dp != dr).mean() < 0.9
+
+
+def test_compensator_path_upsamples_like_the_host_shim_expects(lr, oracle):
+    """f-3: Compensator::path (Compensator.cpp:35-49: get_states + get_prev_state + get_imus + get_next_imu) -> upsample (:69-102):
+    the times and count of the up-sampled states and their integration (each equals the oracle's state_integrate chain)."""
+    oracle.lib().lvo_set_sincos_libm(1)
+    try:
+        rng = np.random.default_rng(6)
+        imu_t = 20.0 + 0.005 * np.arange(60)
+        imu_a = (rng.normal(0, 0.3, (60, 3)) + [0, 0, 9.8]).astype(np.float32)
+        imu_w = rng.normal(0, 0.2, (60, 3)).astype(np.float32)
+        st = np.concatenate([oracle.motion_state(pos=[i, 0, 0], vel=[1, 0, 0], time=20.0 + 0.1 * i, a=imu_a[20 * i], w=imu_w[20 * i]) for i in range(3)])
+        p = lr.path(st, imu_a, imu_w, imu_t, 20.12, 20.2)
+        # expected by the reference's own rules: states in [t1, t2] plus the one before t1; IMUs from that state's time to t2 plus the next
+        assert p["time"][0] == 20.1 and len(p) >= 2
+        cur = st[1:2].copy()
+        k = 1
+        for t, a, w in zip(imu_t, imu_a, imu_w):
+            if 20.1 <= t < 20.2:
+                cur = oracle.state_integrate(cur, a, w, t)
+                assert p["time"][k] == t and np.array_equal(_bits(p["pos"][k]), _bits(cur["pos"][0])) and np.array_equal(_bits(p["R"][k]), _bits(cur["R"][0]))
+                k += 1
+    finally:
+        oracle.lib().lvo_set_sincos_libm(0)
+
+
+@pytest.mark.parametrize("kind", ["velodyne", "hesai", "ouster", "custom"])
+@pytest.mark.parametrize("stamp_beginning,offset_beginning", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_pointcloud2_ingest_against_the_reference_processor(lr, oracle, kind, stamp_beginning, offset_beginning):
+    """f-4: PointCloudProcessor::msg2points (per-sensor constructors of src/Objects/Point.cpp:37-111, get_begin_time of
+    PointCloudProcessor.cpp:43-91) -> temporal down-sampling + min_dist (:99-110) -> time sort (:112-121), on PCL-layout
+    messages of the four sensors x the four stamp conventions, against lvo_cloud_ingest.  Stamps are distinct (std::sort leaves
+    the order of equal stamps unspecified; the oracle's is stable)."""
+    import cloud_messages as cm
+
+    n = 4000
+    raw, fmt, stamp = cm.make_message(kind, n, seed=7, wire=False)
+    dt = cm._fields(kind, False)
+    rec = np.frombuffer(raw, dt).copy()
+    tf = {"velodyne": "time", "hesai": "timestamp", "ouster": "t", "custom": "timestamp"}[kind]
+    if kind == "ouster":
+        rec[tf] = (np.arange(n, dtype=np.uint64) * 25_000 + 17).astype(np.uint32)
+    else:
+        base = 0.0 if kind == "velodyne" else 1_700_000_000.25
+        rec[tf] = (base + np.arange(n) * (0.1 / n)).astype(rec[tf].dtype)
+    rng = np.random.default_rng(1)
+    rec = rec[rng.permutation(n)]
+    raw = rec.tobytes()
+    for rate, min_dist in ((1, 0.0), (4, 3.0)):
+        lr.set_config(lidar_type=kind, stamp_beginning=stamp_beginning, offset_beginning=offset_beginning, downsample_rate=rate, min_dist=min_dist)
+        got = lr.cloud_ingest(raw, n, dt, stamp)
+        f = oracle.CloudFormat(**fmt)
+        prm = oracle.IngestParams(stamp, stamp_beginning, offset_beginning, 0.1, rate, min_dist)
+        want = oracle.cloud_ingest(raw, n, f, prm)
+        assert len(got) == len(want) and len(got) > 0
+        for k in ("x", "y", "z", "time", "intensity", "range"):
+            assert np.array_equal(got[k], want[k]), (kind, k, rate)
+    lr.set_config()
+
+
+def test_accumulator_windows_and_clear(lr):
+    """f-3: Accumulator::get_points(t1, t2) over the newest-first buffer (Accumulator.hpp:73-87, binary search of Utils.hpp:9-23)
+    and Buffer::clear(t) (Buffer.cpp:61-66): the stamps returned = those with t1 <= time <= t2 (oldest first) that survive the
+    clear — the contract limo-velo_amd/host's Accumulator and lv_cloud_fetch / lv_cloud_clear implement."""
+    rng = np.random.default_rng(8)
+    times = np.sort(rng.uniform(0.0, 10.0, 500))
+    for t1, t2, clr in ((2.0, 3.0, None), (0.0, 10.0, None), (4.5, 4.5001, None), (2.0, 8.0, 5.0), (9.0, 20.0, 1.0), (-5.0, 0.5, None)):
+        got = lr.buffer_window(times, t1, t2, clr)
+        keep = times if clr is None else times[times > clr]
+        want = keep[(keep >= t1) & (keep <= t2)]
+        # the reference's walk starts at before_t(t2) and may miss the element AT that index boundary: compare as the reference behaves
+        assert set(got) <= set(want) and len(want) - len(got) <= 1, (t1, t2, clr, len(got), len(want))
+        assert np.all(np.diff(got) >= 0)
+
+
+def test_map_growth_through_mapper_add(lr, oracle):
+    """Mapper::add (Mapper.cpp:22-30): the first call builds, later calls add (with / without down-sampling) and move
+    last_map_time; contents = the oracle's Add_Points restatement (the stand-in tree calls it: this pins Mapper's plumbing — the
+    deque -> vector copies, the build-or-add decision — not the ikd-Tree rule)."""
+    rng = np.random.default_rng(12)
+    lr.reset()
+    a = rng.uniform(-5, 5, (3000, 3)).astype(np.float32)
+    b = rng.uniform(-5, 5, (2000, 3)).astype(np.float32)
+    lr.map_add(a, 1.0, True)                     # first add builds whatever `downsample` says
+    assert lr.map_size() == 3000
+    lr.map_add(b, 2.0, True)
+    want = oracle.map_add(a, b, downsample=True)
+    got = lr.map_fetch()
+    assert got.shape == want.shape and np.array_equal(_bits(got), _bits(want))
+    lr.map_add(np.zeros((0, 3), np.float32), 3.0, True)   # empty: returns before touching anything
+    assert lr.map_size() == len(want)
+    lr.reset()
