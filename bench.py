@@ -532,6 +532,20 @@ def main() -> None:
     # that the first run on a node yields the breakdown of both: "allgather_one_launch" = one launch per pass + ncclAllGather
     # of the workgroup partials, "allreduce_three_kernel" = search / fit / reduce -> ncclAllReduce of 768 bytes -> solve
     forms = None
+    # ---- N > 1: what every rank ended with, gathered so that the line can say so (a multi-GPU run must not be able to fail
+    # silently): the communicator's size as the LIBRARY sees it, every rank's shard, and whether all ranks hold the same bits
+    rank_report = None
+    if world > 1:
+        objs = [None] * world
+        try:
+            nranks_lib = int(ctx.comm_world())
+        except Exception:  # noqa: BLE001
+            nranks_lib = None
+        dist.all_gather_object(objs, (rank, int(n_local), nranks_lib, x.tobytes(), P.tobytes(), int(passes), bool(ctx.last_update_fused())))
+        rank_report = {"world": world, "library_comm_nranks": [o[2] for o in objs], "points_per_rank": [o[1] for o in objs],
+                       "passes_per_rank": [o[5] for o in objs], "one_launch_per_pass_per_rank": [o[6] for o in objs],
+                       "ranks_bitwise_equal": bool(all(o[3] == objs[0][3] and o[4] == objs[0][4] for o in objs)),
+                       "points_total": int(sum(o[1] for o in objs))}
     if same_dev:
         # the one form this leg has: the peer-mapped one-launch pass; ranks must end bitwise equal
         objs = [None] * world
@@ -805,6 +819,9 @@ def main() -> None:
         }
         if world > 1 or forms:
             out["multi_gpu"] = {"measured_on": f"{world} ranks" + (" on ONE GPU (--same-device)" if same_dev else ""),
+                                "ranks": rank_report,
+                                "note_scaling": "no scaling curve has been measured by the builder (one GPU per lease in rounds 1-5): the driver's "
+                                                "N = 1, 2, 4, 8 runs of this file are the first executions across xGMI",
                                 "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]], "forms": forms}
             if same_dev:
                 out["multi_gpu"]["same_device"] = True
@@ -829,6 +846,9 @@ def main() -> None:
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank_report is not None and rank == 0 and (not rank_report["ranks_bitwise_equal"] or rank_report["points_total"] != N_POINTS):
+        print("bench.py: RANKS DISAGREE (see multi_gpu.ranks in the JSON line)", file=sys.stderr)
+        rc = rc or 4
     if rc:
         print("bench.py: PARITY GATE FAILED (see \"parity\" in the JSON line)", file=sys.stderr)
         raise SystemExit(rc)

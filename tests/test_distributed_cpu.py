@@ -270,3 +270,71 @@ def test_two_rank_gloo_one_launch_form(oracle, lv, n_scan):
         assert passes == po
         assert np.abs(x - xo).max() < 1e-10 and np.abs(P - Po).max() < 1e-12
     assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])  # ranks agree bitwise
+
+
+def _run_world(target, world, args, timeout=300):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=timeout) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def _allreduce_worker_n(rank, world, port, n_scan, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    import torch
+    import torch.distributed as dist
+
+    import lvamd
+
+    lvamd.load()
+    from limo_velo_amd import synth
+    from limo_velo_amd.distributed import ShardedUpdater
+
+    import lvoracle as lo
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    upd = ShardedUpdater(OracleEngine(lo, torch, sc["map_xyz"]), rank, world, dist, torch)
+    upd.scan_set(sc["scan_xyz"][:n_scan])
+    x, P, passes = upd.update(sc["x_init"], sc["P0"])
+    out_q.put((rank, upd.n_local, x, P, passes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scan", [2001, 5])
+def test_eight_rank_gloo_both_forms(oracle, lv, n_scan):
+    """World size 8 (the node the north star names) on CPU over gloo, both multi-rank forms' protocols — the per-pass all-reduce
+    of the 96-double record (ShardedUpdater, what bench.py falls back to) and the one-launch form's gather of workgroup partials
+    (init_host_gather, the product's gather function; the same slots and fixed-order fold as the RCCL all-gather and the
+    peer-mapped pull) — with uneven shards (2001 = 251 x 1 + 250 x 7) and with EMPTY shards (5 points: ranks 5-7 hold none and
+    still take part in every exchange).  All eight ranks bitwise equal; the single-process update within 1e-10."""
+    from limo_velo_amd import synth
+    from limo_velo_amd.distributed import shard_bounds
+
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    tree = oracle.KdTree(sc["map_xyz"])
+    xo, Po, po, _, _ = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"][:n_scan], tree=tree)
+    tol_P = 1e-12 if n_scan > 100 else 1e-9     # (five matches: a barely determined solve, conditioning 1e3 worse)
+    want = [shard_bounds(n_scan, r, 8)[1] - shard_bounds(n_scan, r, 8)[0] for r in range(8)]
+    res = _run_world(_allreduce_worker_n, 8, (n_scan,))
+    assert [r[1] for r in res] == want and sum(want) == n_scan
+    for rank, n_local, x, P, passes in res:
+        assert passes == po and np.abs(x - xo).max() < 1e-10 and np.abs(P - Po).max() < tol_P
+        assert np.array_equal(x, res[0][2]) and np.array_equal(P, res[0][3])
+    res = _run_world(_gather_worker, 8, (n_scan,))
+    assert [r[1] for r in res] == want and len({r[2] for r in res}) == 1
+    for rank, n_local, nwg, x, P, passes in res:
+        assert passes == po and np.abs(x - xo).max() < 1e-10 and np.abs(P - Po).max() < tol_P
+        assert np.array_equal(x, res[0][3]) and np.array_equal(P, res[0][4])

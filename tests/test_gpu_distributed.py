@@ -419,3 +419,35 @@ def test_peer_mapped_gather_times_out_instead_of_hanging(lv):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res[0][1] is not None and "did not publish" in res[0][1]
+
+
+@pytest.mark.parametrize("n_scan", [2001, 3])
+def test_world4_peer_mapped_gather_on_one_gpu(lv, n_scan):
+    """Four ranks on ONE GPU over the peer-mapped exchange: every rank publishes once and pulls THREE
+    peers' slots per pass; with 3 points one rank holds none and still publishes / pulls.  All four ranks bitwise equal, within
+    1e-10 of the single-process update.  (Same device: the ranks share an L2 — the protocol and its bookkeeping are what this
+    exercises; no run across GPUs exists yet.)"""
+    import torch.multiprocessing as mp
+
+    from limo_velo_amd import capi, synth
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_world2_peer_worker, args=(r, 4, port, n_scan, q, 0)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = synth.make_scene(50_000, max(n_scan, 8))
+    with capi.Context() as ref:
+        ref.map_build(sc["map_xyz"])
+        ref.scan_set(sc["scan_xyz"][:n_scan])
+        x1, P1, p1, _, _ = ref.update(sc["x_init"], sc["P0"])
+    assert sum(r[1] for r in res) == n_scan and max(r[1] for r in res) - min(r[1] for r in res) <= 1
+    for _, _, x, P, passes, fused, same_filter in res:
+        assert fused and same_filter and passes == p1
+        assert np.array_equal(x, res[0][2]) and np.array_equal(P, res[0][3])
+        assert np.abs(x - x1).max() < 1e-10 and np.abs(P - P1).max() < 1e-10 * max(1.0, np.abs(P1).max())
