@@ -120,6 +120,7 @@ struct lv_ctx {
 
     int pass_index = -1;           // index of the pass being enqueued by lv_update's three-kernel loop (events of its collective)
     bool coll_timed = false;       // the last profiled update recorded events around its collectives
+    bool multi_overlap = true;   // multi-round scans: plane fits beside the next round's search (LV_MULTI_OVERLAP=0: round 3's barrier form)
     bool in_update = false;
     bool want_log = false;         // download trace / per-pass sums at lv_update_end
     int passes_issued = 0;
@@ -219,6 +220,38 @@ int ensure_capture(lv_ctx* c, size_t n) {
     LV_HIP(hipMalloc(&c->dbg.h, cap * sizeof(double)));
     c->cap_n = cap;
     return LV_OK;
+}
+
+// eigenvalues (cyclic Jacobi, 8 sweeps, unsorted: the order degeneracy_stage of lv_solve_dev.hpp leaves them in) of the 6 x 6
+// pose block of the H^T H packed in a 96-double sums record
+static void host_pose_eigenvalues(const double* rec, double eig[6]) {
+    double A[6][6];
+    int idx = 0;
+    for (int i = 0; i < 12; ++i)
+        for (int j = i; j < 12; ++j) {
+            if (j < 6) { A[i][j] = rec[idx]; A[j][i] = rec[idx]; }
+            ++idx;
+        }
+    for (int sweep = 0; sweep < 8; ++sweep)
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p][q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+            }
+    for (int i = 0; i < 6; ++i) eig[i] = A[i][i];
 }
 
 void unpack_sums(const double* rec, lv_sums* out) {
@@ -436,10 +469,13 @@ bool pass_fused_applies(const lv_ctx* c) {
     }
     int nwg = 0, rounds = 0, steps = 0, dedicated = 0;
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
-    const int max_rounds = c->fused_multi_round > 0 ? INT32_MAX : (c->fused_multi_round == 0 || c->prm.estimate_extrinsics) ? 3 : PK_DEFAULT_MAX_ROUNDS;
+    // (round 5: estimate_extrinsics takes the overlapped multi-round form as well — its rows staged in two halves — so the
+    // limit of three rounds it had is gone: xaloc.yaml's configuration stays on one launch per pass up to the same sixteen)
+    const int max_rounds = c->fused_multi_round > 0 ? INT32_MAX : c->fused_multi_round == 0 ? 3 : PK_DEFAULT_MAX_ROUNDS;
     if (rounds > max_rounds) return false;
     if (multi_rank(c) && (size_t)nwg * (size_t)c->comm_world * partial_width(c) > c->gather_cap) return false;
-    return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode == 0 && c->prm.NUM_MATCH_POINTS == KNN &&
+    // (degeneracy_mode 1 only REPORTS eigenvalues: derived on the host from the logged sums, lv_get_degeneracy_values)
+    return c->fused_pass && !c->capture && !c->phase_clocks && c->prm.degeneracy_mode <= 1 && c->prm.NUM_MATCH_POINTS == KNN &&
            c->prm.lanes_per_query == 8 && (c->prm.estimate_extrinsics == 0 || c->fused_ext) && c->map.view.m > 0;
 }
 
@@ -472,6 +508,7 @@ int update_fused(lv_ctx* c) {
     pass_grid_size(pass_geometry_points(c), c->pass_max_wg, &nwg, &steps, &rounds, &dedicated);
     const bool gathered = multi_rank(c);                      // multi-GPU: the partials of all ranks, gathered after every launch
     const size_t slot = (size_t)nwg * partial_width(c);       // doubles per rank in the gather buffers (compact records)
+    pl.multi_overlap = c->multi_overlap;
     pl.qrec = c->record_dump ? c->d_qrec : nullptr;
     c->pclk_wg = nwg + dedicated;   // (the last slot is the bookkeeping workgroup either way)
     pl.qstride = c->qstride;
@@ -594,6 +631,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("LV_MULTI_OVERLAP")) c->multi_overlap = atoi(e) != 0;   // A/B: 0 = every round's fits between two barriers
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
     if (const char* e = getenv("LV_SMALL_WINDOW")) c->scan.small_enabled = atoi(e) != 0;
@@ -1840,7 +1878,17 @@ int lv_get_degeneracy_values(lv_ctx* c, double* eig, int capacity_passes, int* n
     LV_HIP(hipMemcpy(&np, &c->d_kf->passes, sizeof(int), hipMemcpyDeviceToHost));
     if (np > MAX_PASSES) np = MAX_PASSES;
     if (np > capacity_passes) np = capacity_passes;
-    if (np > 0) LV_HIP(hipMemcpy(eig, c->d_kf->degen_eig, (size_t)np * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    if (np > 0 && c->last_update_fused) {
+        // degeneracy_mode 1 is a REPORT (print_degeneracy_values, config/params.yaml:53): nothing in the update depends on it, so
+        // the one-launch-per-pass form does not compute it on the device at all (a cyclic Jacobi is a serial f64 chain of ~75 us
+        // in one lane) — the eigenvalues of a pass' pose block are derived here, on demand, from the sums record that pass'
+        // bookkeeping logged (KfDev::sums_log), by the same fixed 8 sweeps as degeneracy_stage (lv_solve_dev.hpp)
+        std::vector<double> log((size_t)np * SUMS_LEN);
+        LV_HIP(hipMemcpy(log.data(), c->d_kf->sums_log, log.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int p = 0; p < np; ++p) host_pose_eigenvalues(&log[(size_t)p * SUMS_LEN], eig + 6 * p);
+    } else if (np > 0) {
+        LV_HIP(hipMemcpy(eig, c->d_kf->degen_eig, (size_t)np * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (n_passes) *n_passes = np;
     return LV_OK;
 }

@@ -774,10 +774,12 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
 // Plane fit + gates + Jacobian row of ONE scan point (one lane): Plane.cpp:19-55, Utils.cpp:32-66,
 // Match.cpp:18-22, Localizator.cpp:36-56.  P / nidx / dbits: the 5 nearest map points in (distance, index)
 // order; found < 0 marks a padding lane.  The row {J[0..W), h, valid} goes to srow (LDS).
-template <int W, bool EXT, bool DBG, int K>
+// KEEP: the row stays in the caller's registers (keep[0 .. W + 2)) instead of going to LDS — the multi-round
+// estimate_extrinsics pass stages a wavefront's 64 rows of 14 doubles in two halves (pass_kernel).
+template <int W, bool EXT, bool DBG, int K, bool KEEP = false>
 __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams& prm, const DebugOut& dbg, int found,
                                         const float (&P)[K][3], const uint32_t (&nidx)[K], const uint32_t (&dbits)[K],
-                                        float qx, float qy, float qz, uint32_t oq, double* srow) {
+                                        float qx, float qy, float qz, uint32_t oq, double* srow, double* keep = nullptr) {
     double row[W];
 #pragma unroll
     for (int i = 0; i < W; ++i) row[i] = 0.0;
@@ -839,10 +841,17 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
         }
         hres = -(double)dist;                                             // :55
     }
+    if constexpr (KEEP) {
 #pragma unroll
-    for (int j = 0; j < W; ++j) srow[j] = row[j];
-    srow[W] = hres;
-    srow[W + 1] = chosen ? 1.0 : 0.0;
+        for (int j = 0; j < W; ++j) keep[j] = row[j];
+        keep[W] = hres;
+        keep[W + 1] = chosen ? 1.0 : 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < W; ++j) srow[j] = row[j];
+        srow[W] = hres;
+        srow[W + 1] = chosen ? 1.0 : 0.0;
+    }
     if (DBG && found >= 0) {
         if (dbg.knn_idx) {
 #pragma unroll
@@ -1323,8 +1332,13 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     // there a fit wavefront's rows must lie inside its OWN candidate-stage area (wavefront w: [w * 6 KB, w * 6 KB + 4 KB)) — packed
     // at a 4 KB stride, wavefront 1's rows would overlap wavefront 0's stage, which wavefront 0 refills as soon as it rejoins the
     // search.  The single-round / EXT instantiations fit between two barriers and keep the packed layout.
-    constexpr size_t ROWS_STRIDE = (MULTI && !EXT) ? sizeof(Xyz) * 8 * PK_STAGE : sizeof(double) * 64 * ROW_W;
-    static_assert(sizeof(double) * 64 * ROW_W <= ROWS_STRIDE && ROWS_STRIDE * PK_FITW <= PK_OFF_BOOK, "staged rows: inside the stride, below the books");
+    // With estimate_extrinsics a wavefront's 64 rows of 14 doubles are 7 KB — more than its 6 KB of stage: the multi-round EXT
+    // instantiation (round 5) stages them in TWO HALVES of 32 rows (3.5 KB), the rows waiting in registers (fit_row<.., KEEP>);
+    // the contraction runs over rows 0..31, then 32..63: the same order, the same bits as the one-piece form.
+    constexpr bool TWO_PHASE = MULTI && EXT;
+    constexpr int ROWS_STAGED = TWO_PHASE ? 32 : 64;
+    constexpr size_t ROWS_STRIDE = MULTI ? sizeof(Xyz) * 8 * PK_STAGE : sizeof(double) * 64 * ROW_W;
+    static_assert(sizeof(double) * ROWS_STAGED * ROW_W <= ROWS_STRIDE && ROWS_STRIDE * PK_FITW <= PK_OFF_BOOK, "staged rows: inside the stride, below the books");
     float4* s_rec = reinterpret_cast<float4*>(smem + PK_OFF_REC);
     uint32_t (*s_pref)[64] = reinterpret_cast<uint32_t (*)[64]>(smem + PK_OFF_PREF);
     uint32_t (*s_start)[64] = s_pref + PK_THREADS / 64;
@@ -1437,11 +1451,34 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         dbits[3] = __float_as_uint(r[6].w); dbits[4] = __float_as_uint(r[7].x);
         const int found = __float_as_int(r[7].y);
         double (*rows_w)[ROW_W] = reinterpret_cast<double (*)[ROW_W]>(smem + (size_t)wave * ROWS_STRIDE);
+        const double (*rows)[ROW_W] = rows_w;
+        if constexpr (TWO_PHASE) {
+            double keep[ROW_W];
+            fit_row<W, EXT, false, KNN, true>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), nullptr, keep);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if ((lane >> 5) == half) {
+#pragma unroll
+                    for (int j = 0; j < ROW_W; ++j) rows_w[lane & 31][j] = keep[j];
+                }
+                wave_lds_fence();   // this half's 32 rows are staged
+                if (stamp && half == 1) PK_STAMP(7, tid == 0);
+#pragma unroll
+                for (int c = 0; c < NACC; ++c) {
+                    if (olane + c * 64 < NOUT) {
+                        double sacc = acc[c];
+#pragma unroll 8
+                        for (int p = 0; p < 32; ++p) sacc += rows[p][oa[c]] * rows[p][ob[c]];
+                        acc[c] = sacc;
+                    }
+                }
+                wave_lds_fence();   // every lane has read this half before the next one overwrites it
+            }
+        } else {
         double* srow = &rows_w[lane][0];
         fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
         wave_lds_fence();   // this wavefront's 64 rows are staged
         if (stamp) PK_STAMP(7, tid == 0);
-        const double (*rows)[ROW_W] = rows_w;
 #pragma unroll
         for (int c = 0; c < NACC; ++c) {
             if (olane + c * 64 < NOUT) {
@@ -1450,6 +1487,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
                 for (int p = 0; p < (HALVES ? 32 : 64); ++p) sacc += rows[prow0 + p][oa[c]] * rows[prow0 + p][ob[c]];
                 acc[c] = sacc;
             }
+        }
         }
     };
     for (int round = 0; round < a.rounds; ++round) {
@@ -1468,7 +1506,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             if (lane == 0) task = atomicAdd(s_task, 1);
             task = __builtin_amdgcn_readfirstlane(task);
             if (task >= ntask) break;
-            if (MULTI && !EXT && round > 0) {
+            if (MULTI && round > 0) {
                 // the previous round's fits may still be running beside this search (below): its records must have left the
                 // buffer before this round's are written — every fit wavefront counts itself in s_qn[5] once it holds its 64
                 // records in registers, microseconds before the first task of this round gets here (bounded: never a hang)
@@ -1594,9 +1632,8 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             if (tid == 0) *s_qcnt = 0;   // (this parity serves the round after next)
         }
         if (round + 1 < a.rounds) {   // (not the last round: its fits are part of the loop; the last round's follow the loop)
-            if constexpr (EXT || !MULTI) {
-                // (with estimate_extrinsics a fit wavefront's 64 rows of 14 doubles are 7 KB: more than its own 6 KB of candidate
-                // stage — the fourth one's rows reach into wavefront 4's stage — so there the fits finish before the search goes on)
+            if constexpr (!MULTI) {
+                // (not instantiated for multi-round scans any more: kept as the A/B form, LV_FUSED_MULTI=0 limits it to three rounds)
                 if (fitter) do_fits(false, false);
                 __syncthreads();
             } else if (fitter) {
@@ -1712,10 +1749,11 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
     const bool closing = pl.rounds == 0;
     if (pl.mp.estimate_extrinsics) {
         if (closing) hipLaunchKernelGGL((pass_kernel<true, true>), grid, block, 0, stream, a, b);
+        else if (pl.rounds > 1 && pl.multi_overlap) hipLaunchKernelGGL((pass_kernel<true, false, true>), grid, block, 0, stream, a, b);
         else hipLaunchKernelGGL((pass_kernel<true, false>), grid, block, 0, stream, a, b);
     } else {
         if (closing) hipLaunchKernelGGL((pass_kernel<false, true>), grid, block, 0, stream, a, b);
-        else if (pl.rounds > 1) hipLaunchKernelGGL((pass_kernel<false, false, true>), grid, block, 0, stream, a, b);
+        else if (pl.rounds > 1 && pl.multi_overlap) hipLaunchKernelGGL((pass_kernel<false, false, true>), grid, block, 0, stream, a, b);
         else hipLaunchKernelGGL((pass_kernel<false, false>), grid, block, 0, stream, a, b);
     }
     LV_HIP(hipGetLastError());

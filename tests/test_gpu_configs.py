@@ -123,6 +123,39 @@ def test_extrinsics_update_against_the_oracle(capi, oracle, lv, m, n, route):
         _pin_records(capi, oracle, sc, tree, dict(estimate_extrinsics=1), prm_o, states, orc, fused_ext=True)
 
 
+def test_shipped_non_default_configs_keep_one_launch_per_pass(capi, oracle, lv):
+    """the reference's shipped non-default configurations on the tuned path.  config/xaloc.yaml:13
+    (estimate_extrinsics: true) beyond 196 608 points — 262 144 points, four rounds per workgroup, through
+    pass_kernel<true, false, MULTI> (rows staged in two halves) — against the oracle; and degeneracy mode 1
+    (print_degeneracy_values, config/params.yaml:53: an eigenvalue REPORT) on one launch per pass with the eigenvalues derived
+    from the logged sums."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(1_048_576, 262_144, extrinsics="xaloc")
+    tree = oracle.KdTree(sc["map_xyz"])
+    prm_o = oracle.default_params(estimate_extrinsics=1)
+    ref = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=prm_o, tree=tree, nthreads=16)
+    with capi.Context(capi.default_params(estimate_extrinsics=1)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        res = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+    _check_update(res, ref, tol_state=TOL_STATE_EXT, tol_P=1e-6)
+    assert [s["n_valid"] for s in res[4]] == [s["n_valid"] for s in ref[4]]
+    assert np.abs(res[4][0]["HTH"] - ref[4][0]["HTH"]).max() <= TOL_SUMS_REL * np.abs(ref[4][0]["HTH"]).max()
+    sc = synth.make_scene(1_048_576, 65_536)
+    with capi.Context(capi.default_params(degeneracy_mode=1)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, p, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+        eig = ctx.degeneracy_values()
+    assert eig.shape == (p, 6)
+    for i in range(p):
+        want = np.linalg.eigvalsh(sums[i]["HTH"][:6, :6])
+        assert np.allclose(np.sort(eig[i]), want, rtol=1e-9, atol=1e-9 * want.max()), i
+
+
 def test_extrinsics_single_pass_per_point(capi, oracle, lv):
     """Per-point parity (kNN, plane, 12-column rows) of a captured pass at the headline size with xaloc's extrinsics."""
     from limo_velo_amd import synth

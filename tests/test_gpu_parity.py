@@ -480,8 +480,17 @@ def test_degeneracy_hook(capi, oracle, lv):
     with capi.Context(capi.default_params(degeneracy_mode=1)) as ctx:
         ctx.map_build(sc["map_xyz"])
         ctx.scan_set(ground)
+        # mode 1 only REPORTS: the update keeps the one-launch-per-pass form (round 5), the eigenvalues are derived on demand
+        # from the sums each pass logged; the three-kernel pass computes them on the device — same values
+        xf, Pf, pf, trf, sf = ctx.update(sc["x_init"], sc["P0"])
+        assert ctx.last_update_fused()
+        eig_f = ctx.degeneracy_values()
+        ctx.set_fused_pass(False)
         x1, P1, p1, tr1, s1 = ctx.update(sc["x_init"], sc["P0"])
+        assert not ctx.last_update_fused()
         eig = ctx.degeneracy_values()
+    assert pf == p1 and np.abs(xf - x1).max() < 1e-12
+    assert eig_f.shape == eig.shape and np.allclose(eig_f, eig, rtol=1e-9, atol=1e-9 * np.abs(eig).max())
     assert p1 == p0 and np.array_equal(x1, x0) and np.array_equal(P1, P0)
     assert eig.shape == (p1, 6)
     for i in range(p1):

@@ -78,13 +78,19 @@ def test_multi_round_scans_keep_the_one_launch_pass(capi, lv):
         ctx.scan_set(sc["scan_xyz"][:200_000])
         ctx.update(sc["x_init"], sc["P0"])
         assert not ctx.last_update_fused()
+    # estimate_extrinsics (config/xaloc.yaml:13): round 5 gave it the overlapped multi-round form too — a fit wavefront's 64 rows
+    # of 14 doubles staged in two halves inside its own 6 KB of candidate stage — so it keeps one launch per pass beyond three
+    # rounds; its sums must equal, BITWISE, those of round 3's barrier form (same rows, same contraction order)
+    scx = synth.make_scene(300_000, 330_000, extrinsics="xaloc")
     with capi.Context(capi.default_params(estimate_extrinsics=True)) as ctx:
-        ctx.map_build(sc["map_xyz"])
-        ctx.scan_set(sc["scan_xyz"][:190_000])
-        ctx.update(sc["x_init"], sc["P0"])
-        assert ctx.last_update_fused()
-        ctx.scan_set(sc["scan_xyz"][:200_000])
-        ctx.update(sc["x_init"], sc["P0"])
+        ctx.map_build(scx["map_xyz"])
+        for n in (131_072, 190_000, 200_000, 330_000):
+            a, b = _both(ctx, scx, scx["x_init"], scx["P0"], scx["scan_xyz"][:n])
+            assert a[5], n
+            _agree(a, b, tol_x=1e-9, tol_p_rel=1e-6)
+        ctx.set_option("fused_multi_round", 0)   # round 3's rule
+        ctx.scan_set(scx["scan_xyz"][:200_000])
+        ctx.update(scx["x_init"], scx["P0"])
         assert not ctx.last_update_fused()
 
 
