@@ -273,6 +273,7 @@ def main() -> None:
     ap.add_argument("--no-phases", action="store_true", help="skip the in-kernel phase stamps leg (N=1, one launch per pass)")
     ap.add_argument("--force-comm", action="store_true", help="diagnostic: take the multi-GPU route (library RCCL) even at N=1")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (GPU results of this run vs the CPU oracle)")
+    ap.add_argument("--no-ext", action="store_true", help="skip the estimate_extrinsics leg (config/xaloc.yaml's setting at the headline sizes)")
     ap.add_argument("--no-large", action="store_true", help="skip the large-N leg (262 144-point scan vs 5 M-point map on one GPU)")
     ap.add_argument("--no-cycle", action="store_true", help="skip the whole-cycle leg (message in -> de-skew -> correct -> map insert)")
     ap.add_argument("--resident-only", action="store_true", help="profiling aid (scripts/gpu_profile.sh): only the timed resident steps — no "
@@ -690,6 +691,44 @@ def main() -> None:
             del scl
         except Exception as e:  # noqa: BLE001
             large = {"error": str(e)}
+    # ---- the shipped non-default configuration (config/xaloc.yaml:13 estimate_extrinsics: true; 12 live Jacobian columns, 92 sums,
+    # 12 x 12 gain blocks) at the headline sizes, same synchronised step, a context of its own: it/s + roofline fraction
+    ext_rec = None
+    if world == 1 and not args.no_ext and not args.resident_only and not args.extrinsics:
+        try:
+            sce = synth.make_scene(M_POINTS, N_POINTS, extrinsics="xaloc")
+            with capi.Context(capi.default_params(estimate_extrinsics=1), device=local_rank) as c4:
+                c4.map_build(sce["map_xyz"])
+                c4.scan_set(sce["scan_xyz"])
+                xe = np.ascontiguousarray(sce["x_init"], np.float64); Pe = np.ascontiguousarray(sce["P0"], np.float64)
+                xep, Pep = xe.ctypes.data_as(C.c_void_p), Pe.ctypes.data_as(C.c_void_p)
+                for _ in range(10):
+                    c4.filter_set(xe, Pe); c4.correct(want_passes=False); c4.filter_get()
+                rates = []
+                for _ in range(3):
+                    c4.synchronize(); t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        if c4.lib.lv_filter_set(c4.h, xep, Pep) or c4.lib.lv_correct(c4.h, None) or c4.lib.lv_filter_get(c4.h, xgp, Pgp):
+                            raise RuntimeError(c4.lib.lv_last_error().decode())
+                    c4.synchronize()
+                    rates.append((time.perf_counter() - t0) / args.steps)
+                pe = c4.last_passes()
+                c4.set_profiling(True)
+                k_ms, cnt = 0.0, 0
+                for _ in range(min(args.steps, 50)):
+                    _, _, p_, _, _ = c4.update(xe, Pe, want_trace=False)
+                    k_ms += c4.timing()["last_reduce_ms"] * p_
+                    cnt += p_
+                c4.set_profiling(False)
+                us = sorted(rates)[1] * 1e6
+                k_us = k_ms / max(cnt, 1) * 1e3
+                ext_rec = {"workload": "estimate_extrinsics = true (config/xaloc.yaml), 65536-pt scan vs 1048576-pt map, xaloc extrinsics",
+                           "passes_per_update": int(pe), "us_per_update": us, "iters_per_s": pe / (us * 1e-6), "avg_kernel_us": k_us,
+                           "frac": (b_alg(M_POINTS) * N_POINTS / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if k_us > 0 else None,
+                           "one_launch_per_pass": bool(c4.last_update_fused())}
+            del sce
+        except Exception as e:  # noqa: BLE001
+            ext_rec = {"error": str(e)}
     # ---- parity gate, GPU side (every rank: with a communicator the update is a collective): one capturing pass over this
     # rank's shard at the initial state + the timed build once more with its per-pass log; rank 0 then checks against the oracle
     gate = None
@@ -832,6 +871,8 @@ def main() -> None:
             out["cycle_ms_64k"] = cycle
         if large is not None:
             out["large_n"] = large
+        if ext_rec is not None:
+            out["ext"] = ext_rec
         if gate is not None:
             if "error" in gate:
                 out["parity"] = {"ok": False, "error": gate["error"]}
