@@ -120,6 +120,7 @@ struct lv_ctx {
 
     int pass_index = -1;           // index of the pass being enqueued by lv_update's three-kernel loop (events of its collective)
     bool coll_timed = false;       // the last profiled update recorded events around its collectives
+    bool fast_fit = false;       // lv_set_option "fast_fit": the opt-in approximate plane fit of pass_kernel (v_rcp / v_sqrt + Newton; NOT bit-exact)
     bool multi_overlap = true;   // multi-round scans: plane fits beside the next round's search (LV_MULTI_OVERLAP=0: round 3's barrier form)
     bool in_update = false;
     bool want_log = false;         // download trace / per-pass sums at lv_update_end
@@ -496,6 +497,7 @@ int update_fused(lv_ctx* c) {
     pl.mp.max_dist_plane_sq = c->prm.MAX_DIST_PLANE * c->prm.MAX_DIST_PLANE;
     pl.mp.planes_threshold = c->prm.PLANES_THRESHOLD;
     pl.mp.estimate_extrinsics = c->prm.estimate_extrinsics;
+    pl.mp.fast_fit = c->fast_fit && !c->prm.estimate_extrinsics;
     pl.sp.R = c->prm.LiDAR_noise;
     pl.sp.R_inv = 1.0 / c->prm.LiDAR_noise;
     for (int i = 0; i < NS; ++i) pl.sp.limits[i] = c->prm.LIMITS[i];
@@ -1246,6 +1248,8 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     const bool on = value != 0;
     if (!std::strcmp(name, "fused_pass")) c->fused_pass = on;
     else if (!std::strcmp(name, "fused_ext")) c->fused_ext = on;
+    else if (!std::strcmp(name, "fast_fit")) c->fast_fit = on;
+    else if (!std::strcmp(name, "multi_overlap")) c->multi_overlap = on;
     else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on ? 1 : 0;
     else if (!std::strcmp(name, "keeper_by_cost")) c->keeper_by_cost = on;
     else if (!std::strcmp(name, "tile_lpt")) c->tile_lpt = on;

@@ -171,6 +171,7 @@ struct MatchParams {
     double max_dist_plane_sq;  // MAX_DIST_PLANE * MAX_DIST_PLANE (f64, Plane.cpp:42)
     float planes_threshold;
     int estimate_extrinsics;
+    int fast_fit;               // opt-in (lv_set_option "fast_fit"): approximate division / square root in the plane fit (pass_kernel, 6 columns)
 };
 
 struct DebugOut {  // all optional (nullptr = skip); indexed by ORIGINAL scan index

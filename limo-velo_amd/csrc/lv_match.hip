@@ -166,7 +166,28 @@ __device__ __forceinline__ float calc_dist(float qx, float qy, float qz, float4 
 // Column-pivoted Householder QR least squares for the K x 3 system A n = -1 (K = NUM_MATCH_POINTS: 5 on the tuned paths), f32.  Same operation
 // sequence as the oracle's restatement of R3Math::estimate_plane's
 // `A.colPivHouseholderQr().solve(b)` (reference src/Utils/Utils.cpp:47).
-template <int K>
+// fast_fit (opt-in, lv_set_option "fast_fit"; OFF by default): the plane fit's divisions and square roots by the hardware's
+// approximations — v_rcp_f32 + one Newton step on the quotient (2 fused multiply-adds), v_sqrt_f32 (1 ulp) — instead of the
+// correctly rounded expansions the bit-exact default needs (26 divisions ~10 instructions each, 13 square roots ~12 each: a third
+// of fit_row).  Results are within a few f32 ulps of the exact path: north_star's "residuals / state within a stated fp32
+// tolerance", NOT the bit-exactness every parity test of the default path holds; a plane on the edge of PLANES_THRESHOLD may
+// flip (tests/test_gpu_fast_fit.py counts the flips and bounds the band they come from).
+template <bool FAST>
+__device__ __forceinline__ float fit_div(float a, float b) {
+    if constexpr (FAST) {
+        const float r = __builtin_amdgcn_rcpf(b);
+        const float q = a * r;
+        return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    } else {
+        return a / b;
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ float fit_sqrt(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_sqrtf(x);
+    else return sqrtf(x);
+}
+template <int K, bool FAST = false>
 __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
     constexpr int rows = K, cols = 3, size = 3;
     const float eps = 1.1920928955078125e-07f;
@@ -178,7 +199,7 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < rows; ++i) s += A[i][k] * A[i][k];
-        nD[k] = nU[k] = sqrtf(s);
+        nD[k] = nU[k] = fit_sqrt<FAST>(s);
     }
     float maxn = fmaxf(nU[0], fmaxf(nU[1], nU[2]));
     float th = maxn * eps / (float)rows;
@@ -218,15 +239,15 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
 #if LV_QR_SELECT
         {   // both sides computed, selected (same operations on the side that counts => same bits; the discarded side may divide by zero)
             const bool tiny = tailSq <= 1.17549435e-38f;
-            float b = sqrtf(c0 * c0 + tailSq);
+            float b = fit_sqrt<FAST>(c0 * c0 + tailSq);
             if (c0 >= 0.f) b = -b;
             const float den = c0 - b;
 #pragma unroll
             for (int i = k + 1; i < rows; ++i) {
-                const float q = A[i][k] / den;
+                const float q = fit_div<FAST>(A[i][k], den);
                 A[i][k] = tiny ? 0.f : q;
             }
-            const float t = (b - c0) / b;
+            const float t = fit_div<FAST>(b - c0, b);
             tau = tiny ? 0.f : t;
             beta = tiny ? c0 : b;
         }
@@ -237,12 +258,12 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
 #pragma unroll
             for (int i = k + 1; i < rows; ++i) A[i][k] = 0.f;
         } else {
-            beta = sqrtf(c0 * c0 + tailSq);
+            beta = fit_sqrt<FAST>(c0 * c0 + tailSq);
             if (c0 >= 0.f) beta = -beta;
             float den = c0 - beta;
 #pragma unroll
-            for (int i = k + 1; i < rows; ++i) A[i][k] = A[i][k] / den;
-            tau = (beta - c0) / beta;
+            for (int i = k + 1; i < rows; ++i) A[i][k] = fit_div<FAST>(A[i][k], den);
+            tau = fit_div<FAST>(beta - c0, beta);
         }
 #endif
         A[k][k] = beta;
@@ -263,34 +284,34 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
         for (int j = k + 1; j < cols; ++j) {
 #if LV_QR_SELECT
             const bool nz = nU[j] != 0.f;
-            float temp = fabsf(A[k][j]) / nU[j];
+            float temp = fit_div<FAST>(fabsf(A[k][j]), nU[j]);
             temp = (1.f + temp) * (1.f - temp);
             temp = temp < 0.f ? 0.f : temp;
-            const float r = nU[j] / nD[j];
+            const float r = fit_div<FAST>(nU[j], nD[j]);
             const float temp2 = temp * (r * r);
             const bool redo = temp2 <= norm_downdate_threshold;
             float s = 0.f;
 #pragma unroll
             for (int i = k + 1; i < rows; ++i) s += A[i][j] * A[i][j];
-            const float nd_new = sqrtf(s);
-            const float nu_scaled = nU[j] * sqrtf(temp);
+            const float nd_new = fit_sqrt<FAST>(s);
+            const float nu_scaled = nU[j] * fit_sqrt<FAST>(temp);
             nD[j] = (nz && redo) ? nd_new : nD[j];
             nU[j] = nz ? (redo ? nd_new : nu_scaled) : nU[j];
 #else
             if (nU[j] != 0.f) {
-                float temp = fabsf(A[k][j]) / nU[j];
+                float temp = fit_div<FAST>(fabsf(A[k][j]), nU[j]);
                 temp = (1.f + temp) * (1.f - temp);
                 temp = temp < 0.f ? 0.f : temp;
-                float r = nU[j] / nD[j];
+                float r = fit_div<FAST>(nU[j], nD[j]);
                 float temp2 = temp * (r * r);
                 if (temp2 <= norm_downdate_threshold) {
                     float s = 0.f;
 #pragma unroll
                     for (int i = k + 1; i < rows; ++i) s += A[i][j] * A[i][j];
-                    nD[j] = sqrtf(s);
+                    nD[j] = fit_sqrt<FAST>(s);
                     nU[j] = nD[j];
                 } else {
-                    nU[j] *= sqrtf(temp);
+                    nU[j] *= fit_sqrt<FAST>(temp);
                 }
             }
 #endif
@@ -326,7 +347,7 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
             const float sj = sv - A[i][j] * c[j];
             sv = (j < nonzero_pivots) ? sj : sv;
         }
-        const float q = sv / A[i][i];
+        const float q = fit_div<FAST>(sv, A[i][i]);
         c[i] = (i < nonzero_pivots) ? q : c[i];
     }
 #else
@@ -352,7 +373,7 @@ __device__ inline void plane_qr_solve(float (&A)[K][3], float (&x)[3]) {
 #pragma unroll
             for (int j = i + 1; j < size; ++j)
                 if (j < nonzero_pivots) s -= A[i][j] * c[j];
-            c[i] = s / A[i][i];
+            c[i] = fit_div<FAST>(s, A[i][i]);
         }
     }
 #endif
@@ -776,7 +797,7 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
 // order; found < 0 marks a padding lane.  The row {J[0..W), h, valid} goes to srow (LDS).
 // KEEP: the row stays in the caller's registers (keep[0 .. W + 2)) instead of going to LDS — the multi-round
 // estimate_extrinsics pass stages a wavefront's 64 rows of 14 doubles in two halves (pass_kernel).
-template <int W, bool EXT, bool DBG, int K, bool KEEP = false>
+template <int W, bool EXT, bool DBG, int K, bool KEEP = false, bool FAST = false>
 __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams& prm, const DebugOut& dbg, int found,
                                         const float (&P)[K][3], const uint32_t (&nidx)[K], const uint32_t (&dbits)[K],
                                         float qx, float qy, float qz, uint32_t oq, double* srow, double* keep = nullptr) {
@@ -799,10 +820,10 @@ __device__ __forceinline__ void fit_row(const PoseConsts& pc, const MatchParams&
 #pragma unroll
             for (int j = 0; j < K; ++j) { A[j][0] = P[j][0]; A[j][1] = P[j][1]; A[j][2] = P[j][2]; }
             float nv[3];
-            plane_qr_solve(A, nv);                                        // Utils.cpp:47
-            const float nrm = sqrtf(dot3f(nv[0], nv[0], nv[1], nv[1], nv[2], nv[2]));  // Utils.cpp:50
-            const float e0 = nv[0] / nrm, e1 = nv[1] / nrm, e2 = nv[2] / nrm;
-            const float e3 = (float)(1.0 / (double)nrm);                  // Utils.cpp:54
+            plane_qr_solve<K, FAST>(A, nv);                               // Utils.cpp:47
+            const float nrm = fit_sqrt<FAST>(dot3f(nv[0], nv[0], nv[1], nv[1], nv[2], nv[2]));  // Utils.cpp:50
+            const float e0 = fit_div<FAST>(nv[0], nrm), e1 = fit_div<FAST>(nv[1], nrm), e2 = fit_div<FAST>(nv[2], nrm);
+            const float e3 = FAST ? fit_div<true>(1.0f, nrm) : (float)(1.0 / (double)nrm);   // Utils.cpp:54 (exact path: f64 divide)
             bool ok = true;                                               // Utils.cpp:59-66
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -1316,7 +1337,7 @@ constexpr int PK_BOOKW = PK_THREADS / 64 - PK_FITW;   // wavefronts of a workgro
 // MULTI: the instantiation for scans of more than one round per workgroup (round 4): a round's plane fits run BESIDE the next
 // round's search instead of between two barriers.  Scans of one round — the headline — keep the instantiation without it: the same
 // source compiled with the overlap logic in place fitted planes 0.4 us slower per launch (register allocation / loop peeling).
-template <bool EXT, bool CLOSING, bool MULTI = false>
+template <bool EXT, bool CLOSING, bool MULTI = false, bool FAST = false>
 __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
     constexpr int S = 8;
     constexpr int W = EXT ? 12 : 6;
@@ -1476,7 +1497,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
             }
         } else {
         double* srow = &rows_w[lane][0];
-        fit_row<W, EXT, false>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
+        fit_row<W, EXT, false, KNN, false, FAST>(s_pose, a.mp, nodbg, found, P, nidx, dbits, r[5].x, r[5].y, r[5].z, __float_as_uint(r[5].w), srow);
         wave_lds_fence();   // this wavefront's 64 rows are staged
         if (stamp) PK_STAMP(7, tid == 0);
 #pragma unroll
@@ -1753,8 +1774,14 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
         else hipLaunchKernelGGL((pass_kernel<true, false>), grid, block, 0, stream, a, b);
     } else {
         if (closing) hipLaunchKernelGGL((pass_kernel<false, true>), grid, block, 0, stream, a, b);
-        else if (pl.rounds > 1 && pl.multi_overlap) hipLaunchKernelGGL((pass_kernel<false, false, true>), grid, block, 0, stream, a, b);
-        else hipLaunchKernelGGL((pass_kernel<false, false>), grid, block, 0, stream, a, b);
+        else if (pl.rounds > 1 && pl.multi_overlap) {
+            if (pl.mp.fast_fit) hipLaunchKernelGGL((pass_kernel<false, false, true, true>), grid, block, 0, stream, a, b);
+            else hipLaunchKernelGGL((pass_kernel<false, false, true>), grid, block, 0, stream, a, b);
+        } else {
+            // (fast_fit: the opt-in approximate plane fit exists for the default 6-column configuration only)
+            if (pl.mp.fast_fit) hipLaunchKernelGGL((pass_kernel<false, false, false, true>), grid, block, 0, stream, a, b);
+            else hipLaunchKernelGGL((pass_kernel<false, false>), grid, block, 0, stream, a, b);
+        }
     }
     LV_HIP(hipGetLastError());
     return LV_OK;
