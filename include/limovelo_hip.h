@@ -147,6 +147,18 @@ int    lv_map_evict_box(lv_ctx* ctx, const float lo[3], const float hi[3], int k
 int    lv_map_evict_oldest(lv_ctx* ctx, size_t n_oldest, size_t* n_evicted);
 /* Force the periodic re-linearisation now (compaction of the ids + rebuild of every bucket). */
 int    lv_map_relinearise(lv_ctx* ctx);
+/* The same compaction + rebuild WITHOUT stopping the world (round 5).  ikd-Tree rebuilds unbalanced sub-trees on a second thread
+ * while searches go on (the tree the reference constructs with delete / balance criteria 0.3 / 0.6, src/Modules/Mapper.cpp:65);
+ * here a compacted copy of the living points is rebuilt by a worker thread on a stream of its own while searches and inserts
+ * keep using the active structure, the inserts / evictions of the meantime are replayed on the copy, and the two are swapped
+ * at the first map call after the worker has caught up (a cycle boundary of src/main.cpp:75-103).  Point set, id order and
+ * every search result are those of lv_map_relinearise.  lv_map_add / lv_map_add_scan start one by themselves when a third of
+ * the id space is dead and the map holds >= 200 000 points (lv_set_option "async_relinearise" 0: always the stop-the-world
+ * form; "async_relinearise_min": the size threshold).  Returns at once. */
+int    lv_map_relinearise_async(lv_ctx* ctx);
+/* out = {state (0 idle, 1 rebuilding, 2 rebuilt and waiting to be adopted, 3 failed), rebuilds started, rebuilds adopted,
+ * journaled operations not yet replayed}; wait != 0: block until a rebuild in flight has been adopted. */
+int    lv_map_rebuild_status(lv_ctx* ctx, int wait, uint64_t out[4]);
 /* KD_TREE<Point>::size()                          — src/Modules/Mapper.cpp:33,79 */
 size_t lv_map_size(lv_ctx* ctx);
 /* Copy the current map points (xyz packed, map order = the index space of lv_fetch_knn). */

@@ -9,6 +9,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
 
 namespace lv {
 
@@ -35,6 +39,36 @@ struct lv_ctx {
     hipStream_t stream = nullptr;
 
     MapStore map;
+    // ---- background re-linearisation of the map (row f-1; ikd-Tree rebuilds beside its searches too: the tree is constructed with
+    // delete / balance criteria 0.3 / 0.6, src/Modules/Mapper.cpp:65, and rebuilds sub-trees on a second thread).  When the
+    // active map wants a compaction (MapStore::wants_relinearise: a third of its id space is dead) and holds at least
+    // relin_async_min points, a compacted copy of its living points is taken (one launch chain on the context's stream) and its
+    // search structure is rebuilt by a WORKER THREAD on a stream of its own, while searches and inserts go on against the active
+    // map; every mutation of the active map in the meantime is journaled (a device copy of the staged batch) and replayed on the
+    // copy by the worker; the stores are swapped at the next map call after the worker has caught up.  The map's point set, id
+    // order and hence every search result are the same as with the stop-the-world rebuild (tests/test_gpu_map_async.py).
+    struct RelinEntry {
+        int kind = 0;                     // 0 add (Add_Points rule), 1 add, building if empty (Mapper::add), 2 evict box, 3 evict oldest
+        float4* d_pts = nullptr;          // device copy of the staged batch (owned)
+        uint32_t n = 0;
+        int downsample = 0;
+        float box = 0.2f;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        int keep_inside = 0;
+        uint32_t n_oldest = 0;
+        hipEvent_t ready = nullptr;       // the copy has landed (recorded on the stream that made it)
+    };
+    MapStore relin_shadow;
+    std::thread relin_worker;
+    std::mutex relin_mu;
+    std::deque<RelinEntry> relin_journal;
+    int relin_state = 0;                  // 0 idle, 1 running, 2 ready (worker caught up; guarded by relin_mu), 3 failed
+    std::string relin_error;
+    hipStream_t relin_stream = nullptr;
+    hipEvent_t relin_snapshot = nullptr;
+    bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
+    size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
+    uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
 
     ScanStore scan;
     CloudStore cloud;   // row f-4: device-resident LiDAR buffer
@@ -633,6 +667,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("LV_ASYNC_RELINEARISE")) c->relin_async = atoi(e) != 0;
     if (const char* e = getenv("LV_MULTI_OVERLAP")) c->multi_overlap = atoi(e) != 0;   // A/B: 0 = every round's fits between two barriers
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
@@ -693,13 +728,19 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     return LV_OK;
 }
 
+namespace { void relin_cancel(lv_ctx* c); }   // (background re-linearisation: defined with the map entry points below)
+
 void lv_destroy(lv_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     c->cloud.release();
     if (c->comm) { hipStreamSynchronize(c->stream); comm_destroy(c->comm); c->comm = nullptr; }
+    relin_cancel(c);
     hipDeviceSynchronize();
     c->map.release();
+    c->relin_shadow.release();
+    if (c->relin_stream) hipStreamDestroy(c->relin_stream);
+    if (c->relin_snapshot) hipEventDestroy(c->relin_snapshot);
     c->scan.release();
     free_capture(c);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -782,8 +823,155 @@ static hipStream_t insert_stream(lv_ctx* c) {
     return c->side_stream;
 }
 
+// ---- background re-linearisation (see lv_ctx::relin_*) -------------------------------------------------------------------------
+namespace {
+void relin_free_entry(lv_ctx::RelinEntry& e) {
+    if (e.d_pts) hipFree(e.d_pts);
+    if (e.ready) hipEventDestroy(e.ready);
+    e.d_pts = nullptr;
+    e.ready = nullptr;
+}
+
+// the worker: rebuild the copy's search structure, then replay what the active map went through since the copy was taken, until
+// the journal is empty at a moment the lock is held — from then on the two stores hold the same point set
+void relin_worker_main(lv_ctx* c) {
+    auto fail = [&](const char* what) {
+        std::lock_guard<std::mutex> g(c->relin_mu);
+        c->relin_error = std::string(what) + ": " + lv_last_error();
+        c->relin_state = 3;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) { fail("hipSetDevice"); return; }
+    MapStore& S = c->relin_shadow;
+    hipStream_t st = c->relin_stream;
+    if (hipStreamWaitEvent(st, c->relin_snapshot, 0) != hipSuccess) { fail("wait for the snapshot"); return; }
+    if (S.rebuild(st) != LV_OK) { fail("rebuild"); return; }
+    for (;;) {
+        lv_ctx::RelinEntry e;
+        {
+            std::lock_guard<std::mutex> g(c->relin_mu);
+            if (c->relin_journal.empty()) { c->relin_state = 2; return; }
+            e = c->relin_journal.front();
+            c->relin_journal.pop_front();
+        }
+        int rc = LV_OK;
+        if (e.kind <= 1) {
+            if (hipStreamWaitEvent(st, e.ready, 0) != hipSuccess) rc = LV_EHIP;
+            if (!rc) rc = S.reserve_batch(e.n);
+            if (!rc && hipMemcpyAsync(S.d_new, e.d_pts, (size_t)e.n * sizeof(float4), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = LV_EHIP;
+            if (!rc) rc = S.add_staged(st, e.n, e.downsample, e.box, e.kind == 1);
+            if (!rc) rc = S.settle(st);
+        } else if (e.kind == 2) {
+            rc = S.evict_box(st, e.lo, e.hi, e.keep_inside, nullptr);
+        } else {
+            rc = S.evict_oldest(st, e.n_oldest, nullptr);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = rc ? rc : LV_EHIP;
+        relin_free_entry(e);
+        if (rc) { fail("replay of a journaled map operation"); return; }
+        ++c->relin_replayed;
+    }
+}
+
+// join the worker and throw its work away (lv_map_build / lv_map_relinearise / lv_destroy while a rebuild is in flight)
+void relin_cancel(lv_ctx* c) {
+    if (c->relin_worker.joinable()) c->relin_worker.join();
+    for (auto& e : c->relin_journal) relin_free_entry(e);
+    c->relin_journal.clear();
+    c->relin_state = 0;
+    c->map.defer_relinearise = false;
+}
+
+// Called at the start of every map call: a finished rebuild is adopted here (the caller's thread, between two map operations =
+// the cycle boundary the reference's loop gives us, src/main.cpp:102), a failed one is dropped (the stop-the-world path remains).
+int relin_poll(lv_ctx* c) {
+    if (c->relin_state == 0) return LV_OK;
+    int st;
+    { std::lock_guard<std::mutex> g(c->relin_mu); st = c->relin_state; }
+    if (st == 1) return LV_OK;
+    if (c->relin_worker.joinable()) c->relin_worker.join();
+    if (st == 3) {
+        fprintf(stderr, "[limovelo_hip] background map rebuild failed (%s); the map stays as it is\n", c->relin_error.c_str());
+        relin_cancel(c);
+        return LV_OK;
+    }
+    // ready: the worker's stream is drained (it synchronised after its last operation).  Nothing the caller enqueued against
+    // the old store is disturbed — its buffers stay allocated (it becomes the next rebuild's target, written by launches that
+    // are ordered behind everything enqueued on the context's stream so far) — so the swap needs no wait at all.
+    std::swap(c->map, c->relin_shadow);           // (relin_shadow is the OLD active store from here on: it carries the history)
+    c->map.defer_relinearise = false;
+    c->relin_shadow.defer_relinearise = false;
+    c->map.relinearisations = c->relin_shadow.relinearisations + 1;
+    c->map.incremental_adds = c->relin_shadow.incremental_adds;
+    c->map.dropped_total = c->relin_shadow.dropped_total;
+    c->map.refresh_view();
+    c->relin_state = 0;
+    ++c->relin_swapped;
+    return LV_OK;
+}
+
+// take the compacted copy and start the worker (the active map must be settled)
+int relin_start(lv_ctx* c) {
+    if (c->relin_state != 0) return LV_OK;
+    if (!c->relin_stream) LV_HIP(hipStreamCreateWithFlags(&c->relin_stream, hipStreamNonBlocking));
+    if (!c->relin_snapshot) LV_HIP(hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming));
+    int rc = c->map.snapshot_into(c->relin_shadow, c->stream);
+    if (rc) return rc;
+    LV_HIP(hipEventRecord(c->relin_snapshot, c->stream));
+    c->map.defer_relinearise = true;
+    c->relin_error.clear();
+    c->relin_state = 1;
+    ++c->relin_started;
+    c->relin_worker = std::thread(relin_worker_main, c);
+    return LV_OK;
+}
+
+// an insert of n points is about to go to the active map: start a background rebuild if the map wants one
+int relin_maybe_start(lv_ctx* c, size_t incoming) {
+    if (c->relin_state != 0 || !c->relin_async || !c->map.built || c->map.m < c->relin_async_min) return LV_OK;
+    if ((uint64_t)c->map.n_ids + incoming > 0xFFFFFFF0ull) return LV_OK;     // id space exhausted: only the stop-the-world path helps
+    if (!c->map.wants_relinearise(incoming)) return LV_OK;
+    return relin_start(c);
+}
+
+// journal a batch staged in c->map.d_new (copied on the context's stream, which staged it) for the worker to replay
+int relin_journal_add(lv_ctx* c, uint32_t n, int downsample, float box, bool build_if_empty) {
+    if (c->relin_state == 0 || n == 0) return LV_OK;
+    lv_ctx::RelinEntry e;
+    e.kind = build_if_empty ? 1 : 0;
+    e.n = n;
+    e.downsample = downsample;
+    e.box = box;
+    LV_HIP(hipMalloc(&e.d_pts, (size_t)n * sizeof(float4)));
+    LV_HIP(hipMemcpyAsync(e.d_pts, c->map.d_new, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    LV_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+    LV_HIP(hipEventRecord(e.ready, c->stream));
+    std::lock_guard<std::mutex> g(c->relin_mu);
+    if (c->relin_state == 1) c->relin_journal.push_back(e);
+    else relin_free_entry(e);     // (cannot happen: relin_poll ran at the start of this call; a failed worker needs no journal)
+    return LV_OK;
+}
+int relin_journal_evict(lv_ctx* c, int kind, const float* lo, const float* hi, int keep_inside, uint32_t n_oldest) {
+    if (c->relin_state == 0) return LV_OK;
+    lv_ctx::RelinEntry e;
+    e.kind = kind;
+    if (lo) for (int a = 0; a < 3; ++a) { e.lo[a] = lo[a]; e.hi[a] = hi[a]; }
+    e.keep_inside = keep_inside;
+    e.n_oldest = n_oldest;
+    std::lock_guard<std::mutex> g(c->relin_mu);
+    if (c->relin_state == 1) c->relin_journal.push_back(e);
+    return LV_OK;
+}
+}  // namespace
+
+#define LV_RELIN_POLL(c)            \
+    do {                            \
+        int _rp = relin_poll(c);    \
+        if (_rp) return _rp;        \
+    } while (0)
+
 int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
     LV_CHECK_CTX(c);
+    relin_cancel(c);
     LV_SETTLE_MAP(c);
     int rc = check_map_points(points, stride, n);   // bad input leaves the previous map untouched
     if (rc) return rc;
@@ -805,13 +993,18 @@ int lv_map_build(lv_ctx* c, const void* points, size_t stride, size_t n) {
 int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downsample) {
     LV_CHECK_CTX(c);
     LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
     if (n == 0) return LV_OK;
     int rc = check_map_points(points, stride, n);
     if (rc) return rc;
     if ((uint64_t)c->map.n_ids + n > 0xFFFFFFF0ull) { set_error("map too large"); return LV_EINVAL; }
+    rc = relin_maybe_start(c, n);
+    if (rc) return rc;
     rc = c->map.reserve_batch(n);
     if (rc) return rc;
     rc = stage_map_points(c, points, stride, n, c->map.d_new);
+    if (rc) return rc;
+    rc = relin_journal_add(c, (uint32_t)n, downsample, 0.2f, false);
     if (rc) return rc;
     return c->map.add_staged(insert_stream(c), (uint32_t)n, downsample, 0.2f, false);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
 }
@@ -836,10 +1029,13 @@ __global__ void scan_to_world_kernel(const double* __restrict__ x, const float4*
 int lv_map_add_scan(lv_ctx* c, int downsample) {
     LV_CHECK_CTX(c);
     LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
     const uint32_t n = c->scan.n;
     if (n == 0) return LV_OK;   // Mapper::add returns on an empty cloud (Mapper.cpp:20)
     LV_FLUSH_PREDICTS(c);
-    int rc = c->map.reserve_batch(n);
+    int rc = relin_maybe_start(c, n);
+    if (rc) return rc;
+    rc = c->map.reserve_batch(n);
     if (rc) return rc;
     // the state of whichever path ran last (main.cpp:92,102: Xt2 = the state the update just produced — or, before the first
     // map exists, the propagated state the caller handed to lv_update)
@@ -853,6 +1049,8 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     // of ~150 us occupies a handful of CUs).  Everything that touches the map settles the insert first (LV_SETTLE_MAP: the
     // host waits for the note the chain's last kernel posts), so no other ordering is needed.  Only with the context's own
     // stream: a caller-provided stream keeps everything on that stream.
+    rc = relin_journal_add(c, n, downsample, 0.2f, true);
+    if (rc) return rc;
     return c->map.add_staged(insert_stream(c), n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
 }
 
@@ -860,6 +1058,9 @@ int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_i
     LV_CHECK_CTX(c);
     if (!lo || !hi) { set_error("null argument"); return LV_EINVAL; }
     uint32_t ne = 0;
+    LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
+    relin_journal_evict(c, 2, lo, hi, keep_inside, 0);
     int rc = c->map.evict_box(c->stream, lo, hi, keep_inside, &ne);
     if (n_evicted) *n_evicted = ne;
     return rc;
@@ -868,6 +1069,9 @@ int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_i
 int lv_map_evict_oldest(lv_ctx* c, size_t n_oldest, size_t* n_evicted) {
     LV_CHECK_CTX(c);
     uint32_t ne = 0;
+    LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
+    relin_journal_evict(c, 3, nullptr, nullptr, 0, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest));
     int rc = c->map.evict_oldest(c->stream, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest), &ne);
     if (n_evicted) *n_evicted = ne;
     return rc;
@@ -875,14 +1079,41 @@ int lv_map_evict_oldest(lv_ctx* c, size_t n_oldest, size_t* n_evicted) {
 
 int lv_map_relinearise(lv_ctx* c) {
     LV_CHECK_CTX(c);
+    relin_cancel(c);     // (a background rebuild in flight is superseded by this synchronous one)
     LV_SETTLE_MAP(c);
     if (!c->map.built) return LV_OK;
     return c->map.relinearise(c->stream);
 }
 
+int lv_map_relinearise_async(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
+    if (!c->map.built || c->map.m == 0) return LV_OK;
+    return relin_start(c);
+}
+
+int lv_map_rebuild_status(lv_ctx* c, int wait, uint64_t out[4]) {
+    LV_CHECK_CTX(c);
+    if (wait && c->relin_state != 0) {
+        if (c->relin_worker.joinable()) c->relin_worker.join();
+        LV_SETTLE_MAP(c);
+        LV_RELIN_POLL(c);
+    }
+    if (out) {
+        int st;
+        { std::lock_guard<std::mutex> g(c->relin_mu); st = c->relin_state; out[3] = (uint64_t)c->relin_journal.size(); }
+        out[0] = (uint64_t)st;
+        out[1] = c->relin_started;
+        out[2] = c->relin_swapped;
+    }
+    return LV_OK;
+}
+
 int lv_map_get_stats(lv_ctx* c, lv_map_stats* out) {
     LV_CHECK_CTX(c);
     LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
     if (!out) { set_error("null argument"); return LV_EINVAL; }
     static_assert(sizeof(lv_map_stats) == sizeof(MapStats), "lv_map_stats layout");
     MapStats st;
@@ -898,6 +1129,7 @@ int lv_map_get_stats(lv_ctx* c, lv_map_stats* out) {
 size_t lv_map_size(lv_ctx* c) {
     if (!c) return 0;
     c->map.settle(c->stream);
+    relin_poll(c);
     return c->map.m;
 }
 
@@ -1249,6 +1481,8 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_pass")) c->fused_pass = on;
     else if (!std::strcmp(name, "fused_ext")) c->fused_ext = on;
     else if (!std::strcmp(name, "fast_fit")) c->fast_fit = on;
+    else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
+    else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
     else if (!std::strcmp(name, "multi_overlap")) c->multi_overlap = on;
     else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on ? 1 : 0;
     else if (!std::strcmp(name, "keeper_by_cost")) c->keeper_by_cost = on;

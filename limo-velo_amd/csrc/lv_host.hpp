@@ -158,6 +158,13 @@ struct MapStore {
     int ensure_boxes(hipStream_t stream, float box_length);
     int ensure_alive_scratch();
     bool needs_relinearise(size_t incoming) const;
+    // background re-linearisation (lv_api.hip, round 5): while a compacted copy of this map is being rebuilt on another stream /
+    // thread, the stop-the-world relinearise is deferred (only id-space exhaustion still forces it)
+    bool defer_relinearise = false;
+    bool wants_relinearise(size_t incoming) const;   // the trigger, whatever defer_relinearise says
+    // the living points of this map, compacted in id order, into dst.d_orig (dst: an idle store whose search structure is not
+    // built yet): enqueued on `stream`, no host wait; m must be settled
+    int snapshot_into(MapStore& dst, hipStream_t stream);
     MapRW rw() const;
     void refresh_view();
     void stats(MapStats* out) const;

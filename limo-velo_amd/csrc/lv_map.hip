@@ -859,12 +859,43 @@ int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     return LV_OK;
 }
 
-bool MapStore::needs_relinearise(size_t incoming) const {
+bool MapStore::wants_relinearise(size_t incoming) const {
     if (!built) return false;
     if ((uint64_t)n_ids + incoming > 0xFFFFFFF0ull) return true;
     const uint64_t dead = (uint64_t)n_ids - m;
     if (dead > 65536 && dead > (uint64_t)n_ids / 3) return true;                      // a third of the id space is dead
     return false;
+}
+bool MapStore::needs_relinearise(size_t incoming) const {
+    if (!built) return false;
+    if ((uint64_t)n_ids + incoming > 0xFFFFFFF0ull) return true;
+    return defer_relinearise ? false : wants_relinearise(incoming);
+}
+
+int MapStore::snapshot_into(MapStore& dst, hipStream_t stream) {
+    int rc = ensure_alive_scratch();
+    if (rc) return rc;
+    dst.n_ids = 0;
+    dst.m = 0;
+    dst.built = false;
+    dst.have_boxes = false;
+    dst.counters_pending = false;
+    rc = dst.reserve((size_t)m + 1);
+    if (rc) return rc;
+    dst.cell = cell;
+    dst.origin_set = origin_set;          // the same voxel lattice
+    for (int a = 0; a < 3; ++a) dst.origin[a] = origin[a];
+    dst.sweep_evict = sweep_evict; dst.merged_back = merged_back; dst.surv_list = surv_list; dst.small_front = small_front;
+    if (n_ids) {
+        const uint32_t grid = (n_ids + 255) / 256;
+        hipLaunchKernelGGL(inc_alive_flags_kernel, dim3(grid), dim3(256), 0, stream, d_orig, n_ids, d_alive);
+        size_t tmp = ascan_tmp_bytes;
+        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_ascan_tmp, tmp, d_alive, d_apos, (int)n_ids, stream));
+        hipLaunchKernelGGL(inc_compact_kernel, dim3(grid), dim3(256), 0, stream, d_orig, d_alive, d_apos, n_ids, dst.d_orig);
+        LV_HIP(hipGetLastError());
+    }
+    dst.n_ids = m;   // (the living count is host-known once the last insert has been settled)
+    return LV_OK;
 }
 
 int MapStore::relinearise(hipStream_t stream) {

@@ -78,6 +78,12 @@ int main(int argc, char** argv) {
                 lv_reserve_stream(HipRuntime::ctx(), on_device ? win : 0, 8192);
             }
         }
+        // LV_DEMO_FORCE_REBUILD=K[:sync] — re-linearise the map after the K-th update (in the background; ":sync": stop-the-world)
+        std::vector<double> cycle_s;
+        int force_after = 0;
+        bool force_sync = false;
+        double forced_call_s = 0.0;
+        if (const char* e = getenv("LV_DEMO_FORCE_REBUILD")) { force_after = atoi(e); force_sync = std::string(e).find(":sync") != std::string::npos; }
         loop_times().on = getenv("LV_DEMO_TIMING") != nullptr;
         double t_ingest = 0.0, t_imu = 0.0;
         constexpr size_t STEADY_AFTER = 30;   // the first three sweeps' worth of updates: first-touch allocations, buffers growing to size
@@ -115,7 +121,19 @@ int main(int argc, char** argv) {
             for (int guard = 0; guard < 64; ++guard) {
                 State Xt2;
                 size_t np = 0;
+                const auto cyc0 = std::chrono::steady_clock::now();
                 if (!run_cycle(accum, comp, loc, map, clk, on_device, &Xt2, &np)) break;
+                cycle_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - cyc0).count());
+                if (force_after > 0 && out_t.size() + 1 == (size_t)force_after) {
+                    // a forced re-linearisation of the (10 M-point) map in the middle of the stream: stop-the-world
+                    // (lv_map_relinearise: the caller waits for compaction + rebuild) or in the background
+                    // (lv_map_relinearise_async: a worker thread rebuilds a copy, the cycles go on)
+                    const auto r0 = std::chrono::steady_clock::now();
+                    const int rcr = force_sync ? lv_map_relinearise(HipRuntime::ctx()) : lv_map_relinearise_async(HipRuntime::ctx());
+                    if (rcr) throw std::runtime_error(std::string("forced rebuild: ") + lv_last_error());
+                    forced_call_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+                    cycle_s.back() += forced_call_s;   // (the call is part of the cycle that made it)
+                }
                 if (getenv("LV_DEMO_VERBOSE") && out_t.size() < 6)
                     fprintf(stderr, "update %zu: t1 %.4f t2 %.4f points %zu pos %.4f %.4f %.4f vel %.3f %.3f passes %d states %d\n", out_t.size(),
                             clk.t1, clk.t2, np, loc.get_x().pos[0], loc.get_x().pos[1], loc.get_x().pos[2], loc.get_x().vel[0], loc.get_x().vel[1],
@@ -148,8 +166,22 @@ int main(int argc, char** argv) {
         double mean_pts = 0;
         for (uint32_t v : out_n) mean_pts += v;
         const double steady = n > STEADY_AFTER ? (double)(n - STEADY_AFTER) / steady_s : 0.0;
+        // cycle times (one run_cycle that produced an update) after the warm-up: median / p99 / max — what a forced rebuild does to them
+        double c_med = 0, c_p99 = 0, c_max = 0, c_max_after = 0;
+        uint64_t rb[4] = {0, 0, 0, 0};
+        if (cycle_s.size() > STEADY_AFTER + 2) {
+            std::vector<double> v(cycle_s.begin() + STEADY_AFTER, cycle_s.end());
+            std::sort(v.begin(), v.end());
+            c_med = v[v.size() / 2]; c_p99 = v[(size_t)((v.size() - 1) * 0.99)]; c_max = v.back();
+            if (force_after > 0 && (size_t)force_after <= cycle_s.size())
+                c_max_after = *std::max_element(cycle_s.begin() + (force_after - 1), cycle_s.end());
+        }
+        if (force_after > 0) lv_map_rebuild_status(HipRuntime::ctx(), 1, rb);
         printf("{\"updates\": %u, \"wall_s\": %.6f, \"updates_per_s\": %.1f, \"updates_per_s_after_30\": %.1f, \"on_device\": %d, \"scan_points_mean\": %.1f, "
-               "\"map_points\": %zu}\n", n, wall_s, n / wall_s, steady, (int)on_device, n ? mean_pts / n : 0.0, (size_t)map.size());
+               "\"map_points\": %zu, \"cycle_ms\": {\"median\": %.4f, \"p99\": %.4f, \"max\": %.4f}, \"forced_rebuild\": {\"after_update\": %d, \"sync\": %d, "
+               "\"call_ms\": %.3f, \"max_cycle_ms_from_there\": %.4f, \"rebuilds_started\": %llu, \"rebuilds_adopted\": %llu}}\n",
+               n, wall_s, n / wall_s, steady, (int)on_device, n ? mean_pts / n : 0.0, (size_t)map.size(), 1e3 * c_med, 1e3 * c_p99, 1e3 * c_max,
+               force_after, (int)force_sync, 1e3 * forced_call_s, 1e3 * c_max_after, (unsigned long long)rb[1], (unsigned long long)rb[2]);
         HipRuntime::shutdown();
         return 0;
     } catch (const std::exception& e) {

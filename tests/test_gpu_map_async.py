@@ -1,0 +1,127 @@
+"""Background re-linearisation of the map (row f-1; include/limovelo_hip.h lv_map_relinearise_async): a compacted copy of the
+living points is rebuilt by a worker thread on its own stream while inserts, evictions and searches keep using the active
+structure; what the active map went through in the meantime is replayed on the copy; the stores are swapped at the next map
+call after the worker caught up.  The bar is the one of the stop-the-world rebuild: the map — point for point, in id order — and
+every exact 5-NN result equal the oracle's (sequential ikd-Tree rule + brute force) before, DURING and after the swap."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi(lv):
+    from limo_velo_amd import capi as c
+
+    return c
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _knn_ok(ctx, oracle, ref, state, scan):
+    ctx.scan_set(scan)
+    ctx.iterate(state)
+    idx, d2 = ctx.fetch_knn()
+    oi, od, _, _ = oracle.knn_brute(ref, oracle.transform_scan(state, scan))
+    assert np.array_equal(idx, oi), f"kNN index mismatches at {(idx != oi).any(axis=1).sum()} points"
+    assert np.array_equal(_bits(d2), _bits(od))
+
+
+def test_forced_background_rebuild_with_inserts_and_evictions_in_flight(capi, oracle, lv):
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(400_000, 3000)
+    rng = np.random.default_rng(21)
+    ref = sc["map_xyz"]
+    L = float(sc["L"])
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        # make a third of the map dead first (the state a rolling window leaves behind)
+        lo, hi = np.array([-0.55 * L, -2 * L, -5.0], np.float32), np.array([2 * L, 2 * L, 50.0], np.float32)
+        inside = np.all((ref >= lo) & (ref <= hi), axis=1)
+        assert ctx.map_evict_box(lo, hi, keep_inside=True) == int((~inside).sum())
+        ref = ref[inside]
+        st0 = ctx.map_rebuild_status()
+        ctx.map_relinearise_async()
+        st1 = ctx.map_rebuild_status()
+        assert st1["started"] == st0["started"] + 1 and st1["state"] in (1, 2)
+        adopted_at = None
+        for step in range(40):
+            c = np.array([0.1 * L + 0.01 * L * step, 0.2 * L - 0.01 * L * step, 0.0], np.float32)
+            near = ref[np.linalg.norm(ref - c, axis=1) < 20.0]
+            pick = near[rng.integers(0, len(near), 1200)] + rng.normal(0, 0.03, (1200, 3)).astype(np.float32)
+            fresh = (rng.uniform(-1, 1, (200, 3)) * [5, 5, 0.02] + [L + 3.0 + 0.1 * step, c[1], 0.5]).astype(np.float32)
+            batch = np.concatenate([pick, fresh]).astype(np.float32)
+            ctx.map_add(batch, downsample=True)
+            ref = oracle.map_add(ref, batch, downsample=True)
+            if step == 5:      # evictions are journaled too
+                k = 5000
+                assert ctx.map_evict_oldest(k) == k
+                ref = ref[k:]
+            if step == 9:
+                hole_lo, hole_hi = np.array([c[0] - 2, c[1] - 2, -1], np.float32), np.array([c[0] + 2, c[1] + 2, 3], np.float32)
+                hole = np.all((ref >= hole_lo) & (ref <= hole_hi), axis=1)
+                assert ctx.map_evict_box(hole_lo, hole_hi, keep_inside=False) == int(hole.sum())
+                ref = ref[~hole]
+            assert ctx.map_size() == len(ref), step
+            if step % 4 == 0:
+                _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:600])
+            s = ctx.map_rebuild_status()
+            if adopted_at is None and s["adopted"] == st0["adopted"] + 1:
+                adopted_at = step
+                assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref)), "map differs right after the swap"
+                _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:1500])
+        s = ctx.map_rebuild_status(wait=True)
+        assert s["state"] == 0 and s["adopted"] == st0["adopted"] + 1 and s["journal"] == 0
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:1500])
+        st = ctx.map_stats()
+        assert st["living"] == len(ref)
+        # the whole timed update on the adopted structure
+        ctx.scan_set(sc["scan_xyz"])
+        x, P, passes, _, sums = ctx.update(sc["x_init"], sc["P0"])
+        xo, Po, po, _, so = oracle.update(sc["x_init"], sc["P0"], ref, sc["scan_xyz"])
+        assert passes == po and [v["n_valid"] for v in sums] == [v["n_valid"] for v in so] and np.abs(x - xo).max() < 1e-9
+        print(f"background rebuild adopted at insert {adopted_at} of 40")
+
+
+def test_automatic_trigger_does_not_stop_the_world(capi, oracle, lv):
+    """lv_map_add starts the background rebuild by itself when a third of the id space is dead (and the map is large enough);
+    with the option off the same insert pays the stop-the-world rebuild.  Timing is reported, the contract is the contents."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(1_500_000, 2000)
+    ref0 = sc["map_xyz"]
+    L = float(sc["L"])
+    batch = (ref0[:3000] + np.float32(0.013)).astype(np.float32)
+    out = {}
+    for mode in ("async", "sync"):
+        ref = ref0
+        with capi.Context() as ctx:
+            ctx.set_option("async_relinearise", int(mode == "async"))
+            ctx.map_build(ref)
+            lo, hi = np.array([-0.2 * L, -2 * L, -5.0], np.float32), np.array([2 * L, 2 * L, 50.0], np.float32)
+            inside = np.all((ref >= lo) & (ref <= hi), axis=1)
+            ctx.map_evict_box(lo, hi, keep_inside=True)
+            ref = ref[inside]
+            assert (~inside).sum() > len(ref0) / 3
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.map_add(batch, downsample=True)       # this insert finds a third of the ids dead
+            n1 = ctx.map_size()
+            out[mode] = time.perf_counter() - t0
+            ref = oracle.map_add(ref, batch, downsample=True)
+            assert n1 == len(ref)
+            s = ctx.map_rebuild_status()
+            assert s["started"] == (1 if mode == "async" else 0)
+            _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:500])        # searches while the worker rebuilds
+            s = ctx.map_rebuild_status(wait=True)
+            assert s["adopted"] == (1 if mode == "async" else 0)
+            assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+            _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:500])
+            assert ctx.map_stats()["relinearisations"] >= 1
+    print(f"insert that triggers the rebuild: background {out['async'] * 1e3:.2f} ms, stop-the-world {out['sync'] * 1e3:.2f} ms")
