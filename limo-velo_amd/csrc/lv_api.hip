@@ -69,6 +69,7 @@ struct lv_ctx {
     bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
+    int relin_test_delay_ms = 0;          // lv_set_option "async_relinearise_test_delay_ms": the worker pauses between rebuild and replay (tests)
 
     ScanStore scan;
     CloudStore cloud;   // row f-4: device-resident LiDAR buffer
@@ -845,6 +846,7 @@ void relin_worker_main(lv_ctx* c) {
     hipStream_t st = c->relin_stream;
     if (hipStreamWaitEvent(st, c->relin_snapshot, 0) != hipSuccess) { fail("wait for the snapshot"); return; }
     if (S.rebuild(st) != LV_OK) { fail("rebuild"); return; }
+    if (c->relin_test_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(c->relin_test_delay_ms));   // (test hook: lets the journal fill)
     for (;;) {
         lv_ctx::RelinEntry e;
         {
@@ -1483,6 +1485,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "fast_fit")) c->fast_fit = on;
     else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
     else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
+    else if (!std::strcmp(name, "async_relinearise_test_delay_ms")) c->relin_test_delay_ms = value;
     else if (!std::strcmp(name, "multi_overlap")) c->multi_overlap = on;
     else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on ? 1 : 0;
     else if (!std::strcmp(name, "keeper_by_cost")) c->keeper_by_cost = on;

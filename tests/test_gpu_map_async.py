@@ -46,10 +46,11 @@ def test_forced_background_rebuild_with_inserts_and_evictions_in_flight(capi, or
         assert ctx.map_evict_box(lo, hi, keep_inside=True) == int((~inside).sum())
         ref = ref[inside]
         st0 = ctx.map_rebuild_status()
+        ctx.set_option("async_relinearise_test_delay_ms", 400)   # the worker pauses after its rebuild: the operations below pile up in the journal
         ctx.map_relinearise_async()
         st1 = ctx.map_rebuild_status()
         assert st1["started"] == st0["started"] + 1 and st1["state"] in (1, 2)
-        adopted_at = None
+        adopted_at, max_journal = None, 0
         for step in range(40):
             c = np.array([0.1 * L + 0.01 * L * step, 0.2 * L - 0.01 * L * step, 0.0], np.float32)
             near = ref[np.linalg.norm(ref - c, axis=1) < 20.0]
@@ -71,6 +72,7 @@ def test_forced_background_rebuild_with_inserts_and_evictions_in_flight(capi, or
             if step % 4 == 0:
                 _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:600])
             s = ctx.map_rebuild_status()
+            max_journal = max(max_journal, s["journal"])
             if adopted_at is None and s["adopted"] == st0["adopted"] + 1:
                 adopted_at = step
                 assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref)), "map differs right after the swap"
@@ -86,7 +88,8 @@ def test_forced_background_rebuild_with_inserts_and_evictions_in_flight(capi, or
         x, P, passes, _, sums = ctx.update(sc["x_init"], sc["P0"])
         xo, Po, po, _, so = oracle.update(sc["x_init"], sc["P0"], ref, sc["scan_xyz"])
         assert passes == po and [v["n_valid"] for v in sums] == [v["n_valid"] for v in so] and np.abs(x - xo).max() < 1e-9
-        print(f"background rebuild adopted at insert {adopted_at} of 40")
+        assert max_journal >= 5, max_journal          # inserts AND both evictions went through the journal
+        print(f"background rebuild adopted at insert {adopted_at} of 40; up to {max_journal} journaled operations waiting")
 
 
 def test_automatic_trigger_does_not_stop_the_world(capi, oracle, lv):
