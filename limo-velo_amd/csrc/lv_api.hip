@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -57,12 +58,19 @@ struct lv_ctx {
         int keep_inside = 0;
         uint32_t n_oldest = 0;
         hipEvent_t ready = nullptr;       // the copy has landed (recorded on the stream that made it)
+        bool from_arena = false;
     };
+    std::condition_variable relin_cv;
+    bool relin_cancelled = false;
+    size_t relin_want = 0;                // id slots the copy is allocated for (living points + slack)
+    void* relin_arena = nullptr;          // device memory the journal's batch copies are carved from (allocated once, by the worker)
+    size_t relin_arena_bytes = 64u << 20, relin_arena_used = 0;
     MapStore relin_shadow;
     std::thread relin_worker;
     std::mutex relin_mu;
     std::deque<RelinEntry> relin_journal;
-    int relin_state = 0;                  // 0 idle, 1 running, 2 ready (worker caught up; guarded by relin_mu), 3 failed
+    int relin_state = 0;                  // 0 idle, 4 worker allocating, 5 allocated (waiting for the snapshot), 1 rebuilding / replaying, 2 ready
+                                          // (worker caught up), 3 failed — written under relin_mu
     std::string relin_error;
     hipStream_t relin_stream = nullptr;
     hipEvent_t relin_snapshot = nullptr;
@@ -740,6 +748,7 @@ void lv_destroy(lv_ctx* c) {
     hipDeviceSynchronize();
     c->map.release();
     c->relin_shadow.release();
+    if (c->relin_arena) hipFree(c->relin_arena);
     if (c->relin_stream) hipStreamDestroy(c->relin_stream);
     if (c->relin_snapshot) hipEventDestroy(c->relin_snapshot);
     c->scan.release();
@@ -827,14 +836,17 @@ static hipStream_t insert_stream(lv_ctx* c) {
 // ---- background re-linearisation (see lv_ctx::relin_*) -------------------------------------------------------------------------
 namespace {
 void relin_free_entry(lv_ctx::RelinEntry& e) {
-    if (e.d_pts) hipFree(e.d_pts);
+    if (e.d_pts && !e.from_arena) hipFree(e.d_pts);
     if (e.ready) hipEventDestroy(e.ready);
     e.d_pts = nullptr;
     e.ready = nullptr;
 }
 
-// the worker: rebuild the copy's search structure, then replay what the active map went through since the copy was taken, until
-// the journal is empty at a moment the lock is held — from then on the two stores hold the same point set
+// the worker.  Phase 1 (state 4): every allocation the copy needs — the id-indexed buffers for `relin_want` points, the journal
+// arena — happens HERE, not on the caller's thread (hipMalloc of ~1 GB takes ~20 ms for a 10 M-point map); then it reports
+// "allocated" (state 5) and sleeps until the caller has enqueued the snapshot (state 1).  Phase 2: rebuild the copy's search
+// structure, then replay what the active map went through since the snapshot, until the journal is empty at a moment the lock is
+// held — from then on the two stores hold the same point set (state 2).
 void relin_worker_main(lv_ctx* c) {
     auto fail = [&](const char* what) {
         std::lock_guard<std::mutex> g(c->relin_mu);
@@ -843,6 +855,19 @@ void relin_worker_main(lv_ctx* c) {
     };
     if (hipSetDevice(c->device) != hipSuccess) { fail("hipSetDevice"); return; }
     MapStore& S = c->relin_shadow;
+    S.n_ids = 0;
+    S.m = 0;
+    S.built = false;
+    if (S.reserve(c->relin_want) != LV_OK) { fail("reserve"); return; }
+    if (!c->relin_arena) {
+        if (hipMalloc(&c->relin_arena, c->relin_arena_bytes) != hipSuccess) { c->relin_arena = nullptr; (void)hipGetLastError(); }
+    }
+    {
+        std::unique_lock<std::mutex> g(c->relin_mu);
+        c->relin_state = 5;
+        c->relin_cv.wait(g, [&] { return c->relin_state != 5; });
+        if (c->relin_state != 1) return;   // cancelled
+    }
     hipStream_t st = c->relin_stream;
     if (hipStreamWaitEvent(st, c->relin_snapshot, 0) != hipSuccess) { fail("wait for the snapshot"); return; }
     if (S.rebuild(st) != LV_OK) { fail("rebuild"); return; }
@@ -876,20 +901,50 @@ void relin_worker_main(lv_ctx* c) {
 
 // join the worker and throw its work away (lv_map_build / lv_map_relinearise / lv_destroy while a rebuild is in flight)
 void relin_cancel(lv_ctx* c) {
-    if (c->relin_worker.joinable()) c->relin_worker.join();
+    {
+        std::lock_guard<std::mutex> g(c->relin_mu);
+        if (c->relin_state == 4 || c->relin_state == 5) c->relin_cancelled = true;
+    }
+    if (c->relin_worker.joinable()) {
+        for (;;) {   // a worker that is still allocating reaches its wait first
+            {
+                std::lock_guard<std::mutex> g(c->relin_mu);
+                if (c->relin_state == 5) { c->relin_state = 0; c->relin_cv.notify_all(); }
+                if (c->relin_state != 4) break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        c->relin_worker.join();
+    }
     for (auto& e : c->relin_journal) relin_free_entry(e);
     c->relin_journal.clear();
     c->relin_state = 0;
+    c->relin_cancelled = false;
+    c->relin_arena_used = 0;
     c->map.defer_relinearise = false;
 }
 
-// Called at the start of every map call: a finished rebuild is adopted here (the caller's thread, between two map operations =
-// the cycle boundary the reference's loop gives us, src/main.cpp:102), a failed one is dropped (the stop-the-world path remains).
+// Called at the start of every map call (the map is settled): the cycle boundary the reference's loop gives us
+// (src/main.cpp:102).  An allocated copy gets its snapshot here (a launch chain on the context's stream: no allocation, no wait);
+// a finished rebuild is adopted here; a failed one is dropped (the stop-the-world path remains).
 int relin_poll(lv_ctx* c) {
     if (c->relin_state == 0) return LV_OK;
     int st;
     { std::lock_guard<std::mutex> g(c->relin_mu); st = c->relin_state; }
-    if (st == 1) return LV_OK;
+    if (st == 1 || st == 4) return LV_OK;
+    if (st == 5) {
+        if ((size_t)c->map.m + 1 > c->relin_shadow.capacity) {   // (the map outgrew the slack while the worker was allocating: rare)
+            int rr = c->relin_shadow.reserve((size_t)c->map.m + 1);
+            if (rr) return rr;
+        }
+        int rc = c->map.snapshot_into(c->relin_shadow, c->stream);
+        if (rc) return rc;
+        LV_HIP(hipEventRecord(c->relin_snapshot, c->stream));
+        std::lock_guard<std::mutex> g(c->relin_mu);
+        c->relin_state = 1;
+        c->relin_cv.notify_all();
+        return LV_OK;
+    }
     if (c->relin_worker.joinable()) c->relin_worker.join();
     if (st == 3) {
         fprintf(stderr, "[limovelo_hip] background map rebuild failed (%s); the map stays as it is\n", c->relin_error.c_str());
@@ -907,21 +962,29 @@ int relin_poll(lv_ctx* c) {
     c->map.dropped_total = c->relin_shadow.dropped_total;
     c->map.refresh_view();
     c->relin_state = 0;
+    c->relin_arena_used = 0;
     ++c->relin_swapped;
     return LV_OK;
 }
 
-// take the compacted copy and start the worker (the active map must be settled)
+// start the worker (its first phase allocates; the snapshot follows at the next map call: relin_poll)
 int relin_start(lv_ctx* c) {
     if (c->relin_state != 0) return LV_OK;
-    if (!c->relin_stream) LV_HIP(hipStreamCreateWithFlags(&c->relin_stream, hipStreamNonBlocking));
+    if (!c->relin_stream) {
+        // LOWEST priority: the rebuild's kernels sort and scatter millions of points; the cycle's small launches on the context's
+        // streams must get the compute units as they free up, not queue behind them
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            LV_HIP(hipStreamCreateWithFlags(&c->relin_stream, hipStreamNonBlocking));
+        }
+    }
     if (!c->relin_snapshot) LV_HIP(hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming));
-    int rc = c->map.snapshot_into(c->relin_shadow, c->stream);
-    if (rc) return rc;
-    LV_HIP(hipEventRecord(c->relin_snapshot, c->stream));
+    c->relin_want = (size_t)c->map.m + (size_t)c->map.m / 8 + 262144;
     c->map.defer_relinearise = true;
     c->relin_error.clear();
-    c->relin_state = 1;
+    c->relin_state = 4;
     ++c->relin_started;
     c->relin_worker = std::thread(relin_worker_main, c);
     return LV_OK;
@@ -937,23 +1000,30 @@ int relin_maybe_start(lv_ctx* c, size_t incoming) {
 
 // journal a batch staged in c->map.d_new (copied on the context's stream, which staged it) for the worker to replay
 int relin_journal_add(lv_ctx* c, uint32_t n, int downsample, float box, bool build_if_empty) {
-    if (c->relin_state == 0 || n == 0) return LV_OK;
+    if (c->relin_state != 1 || n == 0) return LV_OK;    // (states 4 / 5: the snapshot is still to come and will contain this batch)
     lv_ctx::RelinEntry e;
     e.kind = build_if_empty ? 1 : 0;
     e.n = n;
     e.downsample = downsample;
     e.box = box;
-    LV_HIP(hipMalloc(&e.d_pts, (size_t)n * sizeof(float4)));
+    const size_t bytes = (((size_t)n * sizeof(float4)) + 255) & ~(size_t)255;
+    if (c->relin_arena && c->relin_arena_used + bytes <= c->relin_arena_bytes) {   // a bump arena: no hipMalloc on the caller's thread
+        e.d_pts = reinterpret_cast<float4*>(static_cast<char*>(c->relin_arena) + c->relin_arena_used);
+        e.from_arena = true;
+        c->relin_arena_used += bytes;
+    } else {
+        LV_HIP(hipMalloc(&e.d_pts, (size_t)n * sizeof(float4)));
+    }
     LV_HIP(hipMemcpyAsync(e.d_pts, c->map.d_new, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     LV_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
     LV_HIP(hipEventRecord(e.ready, c->stream));
     std::lock_guard<std::mutex> g(c->relin_mu);
     if (c->relin_state == 1) c->relin_journal.push_back(e);
-    else relin_free_entry(e);     // (cannot happen: relin_poll ran at the start of this call; a failed worker needs no journal)
+    else relin_free_entry(e);     // (the worker failed meanwhile: it needs no journal)
     return LV_OK;
 }
 int relin_journal_evict(lv_ctx* c, int kind, const float* lo, const float* hi, int keep_inside, uint32_t n_oldest) {
-    if (c->relin_state == 0) return LV_OK;
+    if (c->relin_state != 1) return LV_OK;
     lv_ctx::RelinEntry e;
     e.kind = kind;
     if (lo) for (int a = 0; a < 3; ++a) { e.lo[a] = lo[a]; e.hi[a] = hi[a]; }
@@ -1098,9 +1168,14 @@ int lv_map_relinearise_async(lv_ctx* c) {
 int lv_map_rebuild_status(lv_ctx* c, int wait, uint64_t out[4]) {
     LV_CHECK_CTX(c);
     if (wait && c->relin_state != 0) {
-        if (c->relin_worker.joinable()) c->relin_worker.join();
         LV_SETTLE_MAP(c);
-        LV_RELIN_POLL(c);
+        for (;;) {   // allocating -> (snapshot) -> rebuilding -> ready -> adopted
+            LV_RELIN_POLL(c);
+            int st;
+            { std::lock_guard<std::mutex> g(c->relin_mu); st = c->relin_state; }
+            if (st == 0) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
     }
     if (out) {
         int st;
