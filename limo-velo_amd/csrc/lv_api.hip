@@ -700,6 +700,12 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     LV_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     LV_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    {   // the background map rebuild's stream (lowest priority) and snapshot event: created here, creating a stream costs ~15 ms
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
+        if (hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming) != hipSuccess) { c->relin_snapshot = nullptr; (void)hipGetLastError(); }
+    }
     LV_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     if (const char* e = getenv("LV_OVERLAP_INSERT")) c->overlap_insert = atoi(e) != 0;
     if (const char* e = getenv("LV_BATCH_PREDICT")) c->batch_predict = atoi(e) != 0;
@@ -737,7 +743,24 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     return LV_OK;
 }
 
-namespace { void relin_cancel(lv_ctx* c); }   // (background re-linearisation: defined with the map entry points below)
+namespace {
+void relin_cancel(lv_ctx* c);   // (background re-linearisation: defined with the map entry points below)
+// the worker's stream and the snapshot event, created when the context is (creating a stream costs ~15 ms: not inside a cycle)
+int relin_streams(lv_ctx* c) {
+    if (!c->relin_stream) {
+        // LOWEST priority: the rebuild's kernels sort and scatter millions of points; the cycle's small launches on the context's
+        // streams must get the compute units as they free up, not queue behind them
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            LV_HIP(hipStreamCreateWithFlags(&c->relin_stream, hipStreamNonBlocking));
+        }
+    }
+    if (!c->relin_snapshot) LV_HIP(hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming));
+    return LV_OK;
+}
+}  // namespace
 
 void lv_destroy(lv_ctx* c) {
     if (!c) return;
@@ -970,17 +993,7 @@ int relin_poll(lv_ctx* c) {
 // start the worker (its first phase allocates; the snapshot follows at the next map call: relin_poll)
 int relin_start(lv_ctx* c) {
     if (c->relin_state != 0) return LV_OK;
-    if (!c->relin_stream) {
-        // LOWEST priority: the rebuild's kernels sort and scatter millions of points; the cycle's small launches on the context's
-        // streams must get the compute units as they free up, not queue behind them
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
-        if (hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) {
-            (void)hipGetLastError();
-            LV_HIP(hipStreamCreateWithFlags(&c->relin_stream, hipStreamNonBlocking));
-        }
-    }
-    if (!c->relin_snapshot) LV_HIP(hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming));
+    { int rs = relin_streams(c); if (rs) return rs; }
     c->relin_want = (size_t)c->map.m + (size_t)c->map.m / 8 + 262144;
     c->map.defer_relinearise = true;
     c->relin_error.clear();

@@ -84,6 +84,8 @@ int main(int argc, char** argv) {
         bool force_sync = false;
         double forced_call_s = 0.0;
         if (const char* e = getenv("LV_DEMO_FORCE_REBUILD")) { force_after = atoi(e); force_sync = std::string(e).find(":sync") != std::string::npos; }
+        int force_after2 = 0;   // LV_DEMO_FORCE_REBUILD2=K2: adopt the first rebuild (blocking, untimed), then force another one after update K2
+        if (const char* e = getenv("LV_DEMO_FORCE_REBUILD2")) force_after2 = atoi(e);
         loop_times().on = getenv("LV_DEMO_TIMING") != nullptr;
         double t_ingest = 0.0, t_imu = 0.0;
         constexpr size_t STEADY_AFTER = 30;   // the first three sweeps' worth of updates: first-touch allocations, buffers growing to size
@@ -124,6 +126,15 @@ int main(int argc, char** argv) {
                 const auto cyc0 = std::chrono::steady_clock::now();
                 if (!run_cycle(accum, comp, loc, map, clk, on_device, &Xt2, &np)) break;
                 cycle_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - cyc0).count());
+                if (force_after2 > 0 && out_t.size() + 1 == (size_t)force_after2) {
+                    // a SECOND forced background rebuild: the first one is adopted first (a blocking wait, outside the cycle
+                    // timing) so that this one runs into a store whose buffers are all allocated — the steady state of a node
+                    uint64_t rbw[4];
+                    lv_map_rebuild_status(HipRuntime::ctx(), 1, rbw);
+                    const auto r0 = std::chrono::steady_clock::now();
+                    if (lv_map_relinearise_async(HipRuntime::ctx())) throw std::runtime_error(std::string("forced rebuild 2: ") + lv_last_error());
+                    cycle_s.back() += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+                }
                 if (force_after > 0 && out_t.size() + 1 == (size_t)force_after) {
                     // a forced re-linearisation of the (10 M-point) map in the middle of the stream: stop-the-world
                     // (lv_map_relinearise: the caller waits for compaction + rebuild) or in the background
@@ -167,21 +178,32 @@ int main(int argc, char** argv) {
         for (uint32_t v : out_n) mean_pts += v;
         const double steady = n > STEADY_AFTER ? (double)(n - STEADY_AFTER) / steady_s : 0.0;
         // cycle times (one run_cycle that produced an update) after the warm-up: median / p99 / max — what a forced rebuild does to them
-        double c_med = 0, c_p99 = 0, c_max = 0, c_max_after = 0;
+        double c_med = 0, c_p99 = 0, c_max = 0, c_max_after = 0, c_max_after2 = 0, c_p99_after2 = 0, c_med_after2 = 0;
         uint64_t rb[4] = {0, 0, 0, 0};
         if (cycle_s.size() > STEADY_AFTER + 2) {
             std::vector<double> v(cycle_s.begin() + STEADY_AFTER, cycle_s.end());
             std::sort(v.begin(), v.end());
             c_med = v[v.size() / 2]; c_p99 = v[(size_t)((v.size() - 1) * 0.99)]; c_max = v.back();
-            if (force_after > 0 && (size_t)force_after <= cycle_s.size())
-                c_max_after = *std::max_element(cycle_s.begin() + (force_after - 1), cycle_s.end());
+            if (force_after > 0 && (size_t)force_after <= cycle_s.size()) {
+                const size_t end1 = (force_after2 > force_after && (size_t)force_after2 <= cycle_s.size()) ? (size_t)(force_after2 - 1) : cycle_s.size();
+                c_max_after = *std::max_element(cycle_s.begin() + (force_after - 1), cycle_s.begin() + end1);
+                if (end1 < cycle_s.size()) {
+                    std::vector<double> w(cycle_s.begin() + end1, cycle_s.end());
+                    std::sort(w.begin(), w.end());
+                    c_max_after2 = w.back();
+                    c_p99_after2 = w[(size_t)((w.size() - 1) * 0.99)];
+                    c_med_after2 = w[w.size() / 2];
+                }
+            }
         }
         if (force_after > 0) lv_map_rebuild_status(HipRuntime::ctx(), 1, rb);
         printf("{\"updates\": %u, \"wall_s\": %.6f, \"updates_per_s\": %.1f, \"updates_per_s_after_30\": %.1f, \"on_device\": %d, \"scan_points_mean\": %.1f, "
                "\"map_points\": %zu, \"cycle_ms\": {\"median\": %.4f, \"p99\": %.4f, \"max\": %.4f}, \"forced_rebuild\": {\"after_update\": %d, \"sync\": %d, "
-               "\"call_ms\": %.3f, \"max_cycle_ms_from_there\": %.4f, \"rebuilds_started\": %llu, \"rebuilds_adopted\": %llu}}\n",
+               "\"call_ms\": %.3f, \"max_cycle_ms_from_there\": %.4f, \"second_after_update\": %d, \"second_cycle_ms\": {\"median\": %.4f, \"p99\": %.4f, \"max\": %.4f}, "
+               "\"rebuilds_started\": %llu, \"rebuilds_adopted\": %llu}}\n",
                n, wall_s, n / wall_s, steady, (int)on_device, n ? mean_pts / n : 0.0, (size_t)map.size(), 1e3 * c_med, 1e3 * c_p99, 1e3 * c_max,
-               force_after, (int)force_sync, 1e3 * forced_call_s, 1e3 * c_max_after, (unsigned long long)rb[1], (unsigned long long)rb[2]);
+               force_after, (int)force_sync, 1e3 * forced_call_s, 1e3 * c_max_after, force_after2, 1e3 * c_med_after2, 1e3 * c_p99_after2, 1e3 * c_max_after2,
+               (unsigned long long)rb[1], (unsigned long long)rb[2]);
         HipRuntime::shutdown();
         return 0;
     } catch (const std::exception& e) {

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r05_stream
 mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_map_async.py -x -q -s 2>&1 | grep -v "^$" | tail -8
-LV_STREAM_AB="forced_async=LV_DEMO_FORCE_REBUILD=100;forced_sync=LV_DEMO_FORCE_REBUILD=100:sync" timeout 1500 python scripts/stream_bench_cpp.py 2>$O/stream_cpp.err | tail -1 > $O/stream_cpp_cfg4_r05.json
+LV_STREAM_AB="forced_async=LV_DEMO_FORCE_REBUILD=80,LV_DEMO_FORCE_REBUILD2=160;forced_sync=LV_DEMO_FORCE_REBUILD=100:sync" timeout 1500 python scripts/stream_bench_cpp.py 2>$O/stream_cpp.err | tail -1 > $O/stream_cpp_cfg4_r05.json
 python - <<PY
 import json
 d = json.load(open("$O/stream_cpp_cfg4_r05.json"))
