@@ -181,7 +181,22 @@ struct lv_ctx {
 
 namespace {
 
+// LV_SLOW_CALL_MS=<ms> in the environment: every entry point that lasted longer than that reports itself on stderr (a
+// diagnostic for latency hiccups: which call of a cycle stalled, profiles/experiments_r05/async_rebuild.txt)
+struct SlowCall {
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    static double limit_ms() { static const double v = [] { const char* e = getenv("LV_SLOW_CALL_MS"); return e ? atof(e) : 0.0; }(); return v; }
+    explicit SlowCall(const char* n) : name(n) { if (limit_ms() > 0.0) t0 = std::chrono::steady_clock::now(); }
+    ~SlowCall() {
+        if (limit_ms() > 0.0) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > limit_ms()) fprintf(stderr, "[limovelo_hip] slow call: %s took %.3f ms\n", name, ms);
+        }
+    }
+};
 #define LV_CHECK_CTX(ctx)                        \
+    SlowCall _slow_call(__func__);               \
     do {                                         \
         if (!(ctx)) {                            \
             set_error("null context");           \

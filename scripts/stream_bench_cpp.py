@@ -40,7 +40,7 @@ out = {"workload": f"{M}-pt prior map, 64 rings x {N_AZ} azimuth steps per 0.1 s
                    "1 GPU, C++ host (stream_demo over the shim)", "stream_generation_s": gen_s}
 # LV_STREAM_AB="NAME=ENV1=v,ENV2=v;NAME2=..." : extra device-resident runs of the SAME stream with those environment
 # settings (A/B of library knobs in one box), e.g. LV_STREAM_AB="separate_launches=LV_SMALL_WINDOW=0,LV_SMALL_INSERT=0"
-variants = [("device_resident", 1, {}), ("by_value", 0, {})]
+variants = [] if os.environ.get("LV_STREAM_ONLY_AB") else [("device_resident", 1, {}), ("by_value", 0, {})]
 for item in filter(None, os.environ.get("LV_STREAM_AB", "").split(";")):
     name, _, envs = item.partition("=")
     variants.append((name, 1, dict(e.split("=", 1) for e in envs.split(",") if e)))
@@ -52,6 +52,8 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
             r = subprocess.run([exe, inp, res], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
             if r.returncode != 0:
                 raise SystemExit(r.stdout + r.stderr)
+            if "slow call" in r.stderr:   # (LV_SLOW_CALL_MS diagnostic of the library: pass it on)
+                sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if "slow call" in ln))
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             rec = json.loads(line)
             t, x, npts = S._read_stream_output(res)
