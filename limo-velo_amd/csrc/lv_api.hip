@@ -718,7 +718,22 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     {   // the background map rebuild's stream (lowest priority) and snapshot event: created here, creating a stream costs ~15 ms
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
-        if (hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
+        // ... and, by default, on a SUBSET of the compute units (LV_RELIN_CUS, default 64 of 256; 0 = no mask): the rebuild of a
+        // 10 M-point map keeps every CU busy for tens of milliseconds, and stream priority alone did not keep the cycle's small
+        // launches from waiting behind it (profiles/experiments_r05/async_rebuild.txt)
+        int ncu_mask = 64;
+        if (const char* e = getenv("LV_RELIN_CUS")) ncu_mask = atoi(e);
+        hipDeviceProp_t prop;
+        int ncu = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu_mask > 0 && ncu_mask < ncu) {
+            // spread over the whole bit range (the XCDs' CUs interleave in the mask): every (ncu / ncu_mask)-th unit
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            const int stride = ncu / ncu_mask;
+            for (int i = 0; i < ncu; i += stride) mask[(size_t)i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&c->relin_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
+        }
+        if (!c->relin_stream && hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
         if (hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming) != hipSuccess) { c->relin_snapshot = nullptr; (void)hipGetLastError(); }
     }
     LV_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
