@@ -49,7 +49,10 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         for name, on_device, env in variants:
             inp, res = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
             S._write_stream_input(inp, on_device, 0.01, stream, N_REVS, x0)
-            r = subprocess.run([exe, inp, res], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
+            cmd = [exe, inp, res]
+            if os.environ.get("LV_STREAM_ROCPROF") and name != "by_value":   # kernel trace of this variant (scripts/gpu_r05_trace.sh)
+                cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", os.path.join(os.environ["LV_STREAM_ROCPROF"], name), "-o", "t", "--"] + cmd
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
             if r.returncode != 0:
                 raise SystemExit(r.stdout + r.stderr)
             if "slow call" in r.stderr:   # (LV_SLOW_CALL_MS diagnostic of the library: pass it on)
