@@ -77,6 +77,7 @@ struct lv_ctx {
     bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
+    uint32_t relin_slice_wgs = 32768;     // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids)
     int relin_test_delay_ms = 0;          // lv_set_option "async_relinearise_test_delay_ms": the worker pauses between rebuild and replay (tests)
 
     ScanStore scan;
@@ -692,6 +693,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("LV_ASYNC_RELINEARISE")) c->relin_async = atoi(e) != 0;
+    if (const char* e = getenv("LV_RELIN_SLICE_WGS")) c->relin_slice_wgs = (uint32_t)atol(e);
     if (const char* e = getenv("LV_MULTI_OVERLAP")) c->multi_overlap = atoi(e) != 0;   // A/B: 0 = every round's fits between two barriers
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
@@ -718,22 +720,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     {   // the background map rebuild's stream (lowest priority) and snapshot event: created here, creating a stream costs ~15 ms
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
-        // ... and, by default, on a SUBSET of the compute units (LV_RELIN_CUS, default 64 of 256; 0 = no mask): the rebuild of a
-        // 10 M-point map keeps every CU busy for tens of milliseconds, and stream priority alone did not keep the cycle's small
-        // launches from waiting behind it (profiles/experiments_r05/async_rebuild.txt)
-        int ncu_mask = 64;
-        if (const char* e = getenv("LV_RELIN_CUS")) ncu_mask = atoi(e);
-        hipDeviceProp_t prop;
-        int ncu = 256;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu_mask > 0 && ncu_mask < ncu) {
-            // spread over the whole bit range (the XCDs' CUs interleave in the mask): every (ncu / ncu_mask)-th unit
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            const int stride = ncu / ncu_mask;
-            for (int i = 0; i < ncu; i += stride) mask[(size_t)i / 32] |= 1u << (i % 32);
-            if (hipExtStreamCreateWithCUMask(&c->relin_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
-        }
-        if (!c->relin_stream && hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&c->relin_stream, hipStreamNonBlocking, lo) != hipSuccess) { c->relin_stream = nullptr; (void)hipGetLastError(); }
         if (hipEventCreateWithFlags(&c->relin_snapshot, hipEventDisableTiming) != hipSuccess) { c->relin_snapshot = nullptr; (void)hipGetLastError(); }
     }
     LV_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
@@ -911,6 +898,7 @@ void relin_worker_main(lv_ctx* c) {
     S.n_ids = 0;
     S.m = 0;
     S.built = false;
+    S.slice_wgs = c->relin_slice_wgs;   // the worker's big kernels leave the compute units every ~0.1 ms (MapStore::launch_sliced)
     if (S.reserve(c->relin_want) != LV_OK) { fail("reserve"); return; }
     if (!c->relin_arena) {
         if (hipMalloc(&c->relin_arena, c->relin_arena_bytes) != hipSuccess) { c->relin_arena = nullptr; (void)hipGetLastError(); }
@@ -1008,6 +996,7 @@ int relin_poll(lv_ctx* c) {
     // the old store is disturbed — its buffers stay allocated (it becomes the next rebuild's target, written by launches that
     // are ordered behind everything enqueued on the context's stream so far) — so the swap needs no wait at all.
     std::swap(c->map, c->relin_shadow);           // (relin_shadow is the OLD active store from here on: it carries the history)
+    c->map.slice_wgs = 0;
     c->map.defer_relinearise = false;
     c->relin_shadow.defer_relinearise = false;
     c->map.relinearisations = c->relin_shadow.relinearisations + 1;

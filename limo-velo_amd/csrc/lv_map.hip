@@ -131,8 +131,8 @@ __device__ __forceinline__ bool probe_cell(const GridLevelW& g, uint64_t key, ui
 
 // pass 1: every occupied voxel registers its 27 neighbours (incl. itself) in the bucket table
 __global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridLevelW bt, uint32_t* __restrict__ cell_slots,
-                                       uint32_t cell_cap, uint32_t* __restrict__ flags) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+                                       uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t block_base) {
+    const uint32_t t = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
     const uint32_t slot = t / 27, nb = t % 27;
     if (slot >= occ_slots) return;
     const uint4 e = occ.table[slot];
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLeve
                                                         const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
                                                         const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
                                                         uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
-                                                        float4* __restrict__ bucket, uint32_t* __restrict__ backptr) {
-    const uint32_t cell = blockIdx.x;
+                                                        float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t block_base) {
+    const uint32_t cell = blockIdx.x + block_base;
     if (cell >= n_cells) return;
     const int lane = threadIdx.x;
     const uint32_t slot = cell_slots[cell];
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLeve
 // cross-lane shuffles, no LDS, no barriers
 __global__ __launch_bounds__(256) void bucket_sort_wave_kernel(const uint32_t* __restrict__ bcount,
                                                                const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                               float4* __restrict__ bucket) {
-    const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
+                                                               float4* __restrict__ bucket, uint32_t block_base) {
+    const uint32_t cell = (blockIdx.x + block_base) * 4u + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (cell >= n_cells) return;
     const uint32_t n = bcount[cell];
@@ -243,9 +243,9 @@ constexpr int BSORT_THREADS = 256;
 constexpr uint32_t BSORT_LDS = 2048;
 __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ bcount,
                                                                     const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                                    float4* __restrict__ bucket) {
+                                                                    float4* __restrict__ bucket, uint32_t block_base) {
     __shared__ float4 s_pts[BSORT_LDS];
-    const uint32_t cell = blockIdx.x;
+    const uint32_t cell = blockIdx.x + block_base;
     if (cell >= n_cells) return;
     const uint32_t n = bcount[cell];
     if (n <= 64) return;  // handled by bucket_sort_wave_kernel
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
 }
 
 // the sorted float4 buckets -> 12-byte points (what the search kernel streams) + a parallel id array
-__global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx, uint32_t block_base) {
+    const uint32_t i = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = in[i];
     xyz[(size_t)i * 3] = p.x;
@@ -393,6 +393,20 @@ static inline int log2u(uint32_t size) {
         ptr = nullptr;                                                     \
         LV_HIP(hipMalloc(&ptr, (size_t)(count) * sizeof(type)));           \
     } while (0)
+
+// A (re)build's large grids — millions of small workgroups, 2..10 ms per kernel at 10 M points — go out in SLICES when the store
+// is being rebuilt in the background (MapStore::slice_wgs != 0): a workgroup that needs a whole compute unit (pass_kernel: 1024
+// threads, 128 VGPRs, 156 KB of LDS) cannot be placed while another stream keeps every CU topped up with small workgroups — it
+// waits for that stream's kernel to run out of workgroups, however the streams' priorities are set, and a CU mask on the
+// other stream is not honoured here (scripts/ubench/cu_mask_starve.hip: 52 ms behind a 52 ms flood).  At the end of a slice the
+// CUs drain and the waiting workgroup gets its unit: the stall is bounded by one slice (~0.1 ms), not by one kernel.
+// Every sliced kernel takes the first block index of its slice as its LAST argument.
+template <typename K, typename... A>
+static void launch_sliced(uint32_t slice, K kernel, uint32_t grid, uint32_t block, hipStream_t stream, A... args) {
+    if (slice == 0 || grid <= slice) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args..., 0u); return; }
+    for (uint32_t b = 0; b < grid; b += slice)
+        hipLaunchKernelGGL(kernel, dim3(grid - b < slice ? grid - b : slice), dim3(block), 0, stream, args..., b);
+}
 
 int MapStore::reserve(size_t cap) {
     if (cap <= capacity) return LV_OK;
@@ -691,8 +705,8 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
         GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - log2u(size))};
         const uint64_t threads = (uint64_t)occ_slots * 27;
-        hipLaunchKernelGGL(bucket_register_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, occ, occ_slots, bt,
-                           d_cell_slots, (uint32_t)(size / 2), d_flags);
+        launch_sliced(slice_wgs, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
+                      d_cell_slots, (uint32_t)(size / 2), d_flags);
         uint32_t flags[2];
         LV_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipStreamSynchronize(stream));
@@ -702,8 +716,8 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         }
         const uint32_t nb = flags[0];
         n_bcells[level] = nb;
-        hipLaunchKernelGGL((map_bucket_kernel<false>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb, d_sorted,
-                           d_bcount, d_bcap, d_boff, (float4*)nullptr, (uint32_t*)nullptr);
+        launch_sliced(slice_wgs, map_bucket_kernel<false>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
+                      d_bcount, d_bcap, (const uint32_t*)d_boff, (float4*)nullptr, (uint32_t*)nullptr);
         size_t stmp = scan_tmp_bytes;
         LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)nb, stream));
         uint32_t last_off = 0, last_cap = 0;
@@ -728,13 +742,13 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
                 LV_REALLOC(d_bidx[level], uint32_t, want);
                 pool_cap[level] = (size_t)want;
             }
-            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb,
-                               d_sorted, d_bcount, d_bcap, d_boff, d_bucket_tmp, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
-            hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(BSORT_THREADS), 0, stream, d_bcount, d_boff, nb, d_bucket_tmp);
+            launch_sliced(slice_wgs, map_bucket_kernel<true>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
+                          (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket_tmp, (uint32_t*)nullptr);
+            launch_sliced(slice_wgs, bucket_sort_wave_kernel, (nb + 3) / 4, 256u, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
+            launch_sliced(slice_wgs, bucket_sort_kernel, nb, (uint32_t)BSORT_THREADS, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
             if (total > 0)
-                hipLaunchKernelGGL(bucket_pack_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_bucket_tmp,
-                                   (uint32_t)total, d_bxyz[level], d_bidx[level]);
+                launch_sliced(slice_wgs, bucket_pack_kernel, (uint32_t)((total + 255) / 256), 256u, stream, (const float4*)d_bucket_tmp,
+                              (uint32_t)total, d_bxyz[level], d_bidx[level]);
         } else {                       // level 2: unordered records, every point remembers where it sits (deletions)
             if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {
                 pool_cap[level] = 0;
@@ -746,8 +760,8 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
                 LV_REALLOC(d_cellpos, uint32_t, capacity);
                 backptr_cap = capacity;
             }
-            hipLaunchKernelGGL((map_bucket_kernel<true>), dim3(nb), dim3(64), 0, stream, occ, bt, d_baux[level], d_cell_slots, nb,
-                               d_sorted, d_bcount, d_bcap, d_boff, d_bucket4, d_backptr);
+            launch_sliced(slice_wgs, map_bucket_kernel<true>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
+                          (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket4, d_backptr);
         }
         LV_HIP(hipGetLastError());
         pool_base[level] = (uint32_t)total;
@@ -853,7 +867,7 @@ int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     LV_HIP(hipMemsetAsync(d_box, 0xFF, (size_t)box_size * sizeof(uint4), stream));
     LV_HIP(hipMemsetAsync(&d_cnt->box_slots_used, 0, sizeof(uint32_t), stream));
     BoxRW Bx{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
-    if (n_ids) hipLaunchKernelGGL(box_build_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, Bx, d_orig, n_ids, d_cnt);
+    if (n_ids) launch_sliced(slice_wgs, box_build_kernel, (n_ids + 255) / 256, 256u, stream, Bx, (const float4*)d_orig, n_ids, d_cnt);
     LV_HIP(hipGetLastError());
     have_boxes = true;
     return LV_OK;

@@ -203,8 +203,9 @@ __device__ __forceinline__ uint32_t box_find_or_create(const BoxRW& B, uint64_t 
 }
 
 // every living id -> its box chain (first down-sampling insert after a (re)build)
-__global__ void box_build_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+// (block_base: the launch may be one slice of the grid — MapStore::launch_sliced)
+__global__ void box_build_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt, uint32_t block_base = 0) {
+    const uint32_t id = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
     if (id >= n_ids) return;
     const float4 p = orig[id];
     if (!pt_alive(p)) { B.next[id] = ID_NONE; return; }

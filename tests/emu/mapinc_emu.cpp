@@ -254,7 +254,7 @@ struct Emu {
         box.assign(next_pow2((uint64_t)orig.size() * 4), uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
         box_next.assign(orig.size(), ID_NONE);
         cnt.box_slots_used = 0;
-        if (n_ids) launch(box_build_kernel, n_ids, bx(), (const float4*)orig.data(), n_ids, &cnt);
+        if (n_ids) launch(box_build_kernel, n_ids, bx(), (const float4*)orig.data(), n_ids, &cnt, 0u);
         have_boxes = true;
     }
 
