@@ -77,7 +77,7 @@ struct lv_ctx {
     bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
-    uint32_t relin_slice_wgs = 32768;     // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids)
+    uint32_t relin_slice_wgs = 4096;      // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids)
     int relin_test_delay_ms = 0;          // lv_set_option "async_relinearise_test_delay_ms": the worker pauses between rebuild and replay (tests)
 
     ScanStore scan;

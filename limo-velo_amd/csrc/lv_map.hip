@@ -399,7 +399,8 @@ static inline int log2u(uint32_t size) {
 // threads, 128 VGPRs, 156 KB of LDS) cannot be placed while another stream keeps every CU topped up with small workgroups — it
 // waits for that stream's kernel to run out of workgroups, however the streams' priorities are set, and a CU mask on the
 // other stream is not honoured here (scripts/ubench/cu_mask_starve.hip: 52 ms behind a 52 ms flood).  At the end of a slice the
-// CUs drain and the waiting workgroup gets its unit: the stall is bounded by one slice (~0.1 ms), not by one kernel.
+// CUs drain and the waiting workgroup gets its unit: the stall is bounded by one slice (~0.1 ms: slice_wgs workgroups of the heaviest kernel, map_bucket_kernel<true>; eight times as
+// many of the lighter ones), not by one kernel.
 // Every sliced kernel takes the first block index of its slice as its LAST argument.
 template <typename K, typename... A>
 static void launch_sliced(uint32_t slice, K kernel, uint32_t grid, uint32_t block, hipStream_t stream, A... args) {
@@ -705,7 +706,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
         GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - log2u(size))};
         const uint64_t threads = (uint64_t)occ_slots * 27;
-        launch_sliced(slice_wgs, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
+        launch_sliced(slice_wgs * 8, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
                       d_cell_slots, (uint32_t)(size / 2), d_flags);
         uint32_t flags[2];
         LV_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
@@ -716,7 +717,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         }
         const uint32_t nb = flags[0];
         n_bcells[level] = nb;
-        launch_sliced(slice_wgs, map_bucket_kernel<false>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
+        launch_sliced(slice_wgs * 8, map_bucket_kernel<false>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
                       d_bcount, d_bcap, (const uint32_t*)d_boff, (float4*)nullptr, (uint32_t*)nullptr);
         size_t stmp = scan_tmp_bytes;
         LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)nb, stream));
@@ -744,10 +745,10 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
             }
             launch_sliced(slice_wgs, map_bucket_kernel<true>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
                           (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket_tmp, (uint32_t*)nullptr);
-            launch_sliced(slice_wgs, bucket_sort_wave_kernel, (nb + 3) / 4, 256u, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
-            launch_sliced(slice_wgs, bucket_sort_kernel, nb, (uint32_t)BSORT_THREADS, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
+            launch_sliced(slice_wgs * 8, bucket_sort_wave_kernel, (nb + 3) / 4, 256u, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
+            launch_sliced(slice_wgs * 8, bucket_sort_kernel, nb, (uint32_t)BSORT_THREADS, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
             if (total > 0)
-                launch_sliced(slice_wgs, bucket_pack_kernel, (uint32_t)((total + 255) / 256), 256u, stream, (const float4*)d_bucket_tmp,
+                launch_sliced(slice_wgs * 8, bucket_pack_kernel, (uint32_t)((total + 255) / 256), 256u, stream, (const float4*)d_bucket_tmp,
                               (uint32_t)total, d_bxyz[level], d_bidx[level]);
         } else {                       // level 2: unordered records, every point remembers where it sits (deletions)
             if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {
@@ -867,7 +868,9 @@ int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     LV_HIP(hipMemsetAsync(d_box, 0xFF, (size_t)box_size * sizeof(uint4), stream));
     LV_HIP(hipMemsetAsync(&d_cnt->box_slots_used, 0, sizeof(uint32_t), stream));
     BoxRW Bx{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
-    if (n_ids) launch_sliced(slice_wgs, box_build_kernel, (n_ids + 255) / 256, 256u, stream, Bx, (const float4*)d_orig, n_ids, d_cnt);
+    // (ALWAYS sliced: the boxes are built by the first down-sampling insert after a (re)build, on the insert's side stream,
+    // beside the cycle's whole-CU launches — 4 ms in one piece at 10 M ids, ~0.1 ms per slice of 1024 workgroups)
+    if (n_ids) launch_sliced(1024u, box_build_kernel, (n_ids + 255) / 256, 256u, stream, Bx, (const float4*)d_orig, n_ids, d_cnt);
     LV_HIP(hipGetLastError());
     have_boxes = true;
     return LV_OK;
