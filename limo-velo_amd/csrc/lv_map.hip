@@ -55,11 +55,11 @@ __device__ __forceinline__ int head_levels(const uint64_t* keys, uint32_t i, int
 }
 
 __global__ void map_count_heads_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels,
-                                       uint32_t* __restrict__ counts) {
+                                       uint32_t* __restrict__ counts, uint32_t block_base) {
     __shared__ uint32_t s_cnt[MAX_LEVELS];
     if (threadIdx.x < MAX_LEVELS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
     if (i < m) {
         int nl = head_levels(keys, i, n_levels);
         for (int l = 0; l < nl; ++l) atomicAdd(&s_cnt[l], 1u);
@@ -80,8 +80,8 @@ struct TablePtrs {
     uint32_t shift[MAX_LEVELS];
 };
 
-__global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp, uint32_t block_base) {
+    uint32_t i = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
     if (i >= m) return;
     int nl = head_levels(keys, i, n_levels);
     uint64_t k0 = keys[i];
@@ -627,7 +627,7 @@ int MapStore::rebuild(hipStream_t stream) {
     hipLaunchKernelGGL(map_gather_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_idx_sorted, m, d_sorted);
     if (!d_counts) LV_HIP(hipMalloc(&d_counts, 16 * sizeof(uint32_t)));
     LV_HIP(hipMemsetAsync(d_counts, 0, 16 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(map_count_heads_kernel, dim3(grid), dim3(B), 0, stream, d_keys_sorted, m, n_levels, d_counts);
+    launch_sliced(slice_wgs * 2, map_count_heads_kernel, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, d_counts);
     uint32_t counts[16];
     LV_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
@@ -651,7 +651,7 @@ int MapStore::rebuild(hipStream_t stream) {
         tp.shift[l] = (uint32_t)(64 - log2u(size));
         n_cells[l] = counts[l];
     }
-    hipLaunchKernelGGL(map_insert_kernel, dim3(grid), dim3(B), 0, stream, d_keys_sorted, m, n_levels, tp);
+    launch_sliced(slice_wgs * 2, map_insert_kernel, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, tp);
     LV_HIP(hipGetLastError());
     for (int l = 0; l < REPL_LEVELS; ++l) {
         int rc = build_buckets(stream, l, counts[l]);
@@ -706,7 +706,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
         GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - log2u(size))};
         const uint64_t threads = (uint64_t)occ_slots * 27;
-        launch_sliced(slice_wgs * 8, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
+        launch_sliced(slice_wgs * 2, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
                       d_cell_slots, (uint32_t)(size / 2), d_flags);
         uint32_t flags[2];
         LV_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));

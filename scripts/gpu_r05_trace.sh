@@ -28,6 +28,16 @@ for qid, rs in byq.items():
 top = sorted(rows, key=lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), reverse=True)[:25]
 for r in top:
     print("%9.3f ms  start %10.3f ms  q %s  grid %s  %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, (int(r["Start_Timestamp"]) - t0) / 1e6, r["Queue_Id"], r.get("Grid_Size"), r["Kernel_Name"][:90]))
+# kernels of the OTHER queues (rebuild worker, insert side stream) longer than 0.25 ms, by name: count / max / total
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+mq = set(qid for qid, rs in byq.items() if any("pass_kernel" in r["Kernel_Name"] for r in rs))
+first_pass = min(int(r["Start_Timestamp"]) for r in rows if "pass_kernel" in r["Kernel_Name"])
+for r in rows:
+    if r["Queue_Id"] in mq or int(r["Start_Timestamp"]) < first_pass: continue
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    if d > 0.25:
+        a = agg[r["Kernel_Name"].split("(")[0][:70]]; a[0] += 1; a[1] = max(a[1], d); a[2] += d
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]): print("other-queue kernel > 0.25 ms: %-72s n %4d  max %7.3f ms  total %8.3f ms" % (k, v[0], v[1], v[2]))
 # the main queue = the one holding pass_kernel: list its gaps > 1 ms
 mainq = [qid for qid, rs in byq.items() if any("pass_kernel" in r["Kernel_Name"] for r in rs)]
 print("main queues", mainq)
