@@ -2,7 +2,7 @@
 # Round artefacts: bench line + rocprofv3 kernel stats + PMC traffic for the same command.
 set -u
 export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -31,7 +31,7 @@ for s, e, closing in rows:
 ups = [u for u in ups if len(u) == 5]
 # keep the steady part of the resident regions: updates whose first launch follows the previous closing launch within 4 us
 steady = [u for p, u in zip(ups, ups[1:]) if u[0][0] - p[-1][1] < 4000]
-with open("$OUT/r04_resident_sequence.txt", "w") as o:
+with open("$OUT/${R}_resident_sequence.txt", "w") as o:
     print(f"updates in the trace {len(ups)}, of them back to back (first launch < 4 us behind the previous closing launch) {len(steady)}", file=o)
     for i in range(5):
         d = [(u[i][1] - u[i][0]) / 1e3 for u in steady]
@@ -40,7 +40,7 @@ with open("$OUT/r04_resident_sequence.txt", "w") as o:
     per = [(b[0][0] - a[0][0]) / 1e3 for a, b in zip(steady, steady[1:]) if b[0][0] - a[-1][1] < 4000]
     gap0 = [(b[0][0] - a[-1][1]) / 1e3 for a, b in zip(steady, steady[1:]) if b[0][0] - a[-1][1] < 4000]
     print(f"period of an update (first launch to first launch) median {st.median(per):.2f} us; gap closing -> next first launch median {st.median(gap0):.2f} us", file=o)
-print(open("$OUT/r04_resident_sequence.txt").read())
+print(open("$OUT/${R}_resident_sequence.txt").read())
 PY
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.csv" | head -20

@@ -4,7 +4,7 @@
 set -u
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 OUT=gpurun_out/streams_$R
 mkdir -p $OUT
 LV_STREAM_LOCKSTEP=6 timeout 1500 python scripts/stream_bench.py 2>$OUT/stream_bench.err | tail -1 > $OUT/stream_bench_cfg4_$R.json
