@@ -24,7 +24,10 @@
 #endif
 #include "lvref.h"
 
-Params Config;   // (src/main.cpp:15 defines it in the reference's executable; main.cpp is not part of this library)
+#ifndef LVREF_WITH_MAIN
+Params Config;   // (src/main.cpp:15 defines it in the reference's executable; main.cpp is not part of the library build)
+#endif
+namespace lvref { uint32_t last_points2match = 0; }   // Localizator::points2match.size() of every update (replay output)
 
 // ---- use-ikfom.cpp stand-in ------------------------------------------------------------------------------------------------
 namespace IKFoM {
@@ -37,6 +40,7 @@ void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_
     Localizator& KF = Localizator::getInstance();
     Mapper& MAP = Mapper::getInstance();
     Matches matches = MAP.match(State(s, 0.), KF.points2match);
+    lvref::last_points2match = (uint32_t)KF.points2match.size();
     if (matches.empty()) { ekfom_data.valid = false; return; }
     KF.calculate_H(s, matches, ekfom_data.h_x, ekfom_data.h);
     ekfom_data.valid = true;

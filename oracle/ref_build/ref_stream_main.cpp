@@ -1,0 +1,144 @@
+// ref_stream_main.cpp — the REFERENCE'S OWN main loop on a recorded stream.  src/main.cpp is compiled in place (its `main` renamed
+// lvref_main by -Dmain=lvref_main) together with every other in-tree source; this driver stands where the ROS master stood: it
+// answers fill_config's parameter queries (the values limo-velo_amd/host/stream_demo.cpp sets for the same stream), delivers the
+// recorded IMU and PointCloud2 messages through the callbacks main() subscribed, one IMU sample (preceded by the LiDAR sweeps that
+// have arrived by then) per ros::spinOnce(), and collects the filter state after every update.  Input and output are the files of
+// stream_demo (tests/test_gpu_shim.py::_write_stream_input / _read_stream_output), so the trajectory of the reference's code
+// (kNN, filter algebra and voxel grid: the stand-ins of oracle/ref_build) and of the HIP path over the shim can be laid side by
+// side, update by update.  TEST INFRASTRUCTURE.
+#ifndef __OBJECTS_H__
+#define __OBJECTS_H__
+#include "Headers/Common.hpp"
+#include "Headers/Utils.hpp"
+#include "Headers/Objects.hpp"
+#include "Headers/Publishers.hpp"
+#include "Headers/PointClouds.hpp"
+#include "Headers/Accumulator.hpp"
+#include "Headers/Compensator.hpp"
+#include "Headers/Localizator.hpp"
+#include "Headers/Mapper.hpp"
+#endif
+#include <fstream>
+
+extern struct Params Config;
+int lvref_main(int argc, char** argv);
+namespace lvref { extern uint32_t last_points2match; }
+
+template <typename T>
+static T rd(std::ifstream& f) {
+    T v;
+    f.read(reinterpret_cast<char*>(&v), sizeof(T));
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) { std::cerr << "usage: ref_stream_demo in.bin out.bin\n"; return 2; }
+    std::ifstream f(argv[1], std::ios::binary);
+    if (!f || rd<uint32_t>(f) != 0x5453564Cu) { std::cerr << "bad input file\n"; return 1; }
+    rd<uint32_t>(f);   // on_device: meaningless here
+    const double delta = rd<double>(f);
+    const uint32_t n_map = rd<uint32_t>(f);
+    std::vector<float> mapv((size_t)n_map * 3);
+    f.read(reinterpret_cast<char*>(mapv.data()), (std::streamsize)(mapv.size() * 4));
+    struct ImuRec { double t; float a[3], w[3], q[4]; };
+    std::vector<ImuRec> imus(rd<uint32_t>(f));
+    for (auto& r : imus) { r.t = rd<double>(f); f.read(reinterpret_cast<char*>(r.a), 12); f.read(reinterpret_cast<char*>(r.w), 12); f.read(reinterpret_cast<char*>(r.q), 16); }
+    struct Msg { double arrival; uint64_t stamp; uint32_t n; std::vector<unsigned char> data; };
+    std::vector<Msg> msgs(rd<uint32_t>(f));
+    for (auto& m : msgs) {
+        m.arrival = rd<double>(f); m.stamp = rd<uint64_t>(f); m.n = rd<uint32_t>(f);
+        m.data.resize((size_t)m.n * 48);
+        f.read(reinterpret_cast<char*>(m.data.data()), (std::streamsize)m.data.size());
+    }
+    // ---- what the parameter server would answer: stream_demo.cpp's settings over the shim's defaults (= config/params.yaml)
+    lvref::Overrides& ov = lvref::overrides();
+    ov.num = {{"mapping_online", getenv("LV_DEMO_MAPPING_OFFLINE") ? 0 : 1}, {"real_time", 0}, {"estimate_extrinsics", 0}, {"downsample_rate", 4},
+              {"downsample_prec", 0.5}, {"MAX_NUM_ITERS", 3}, {"NUM_MATCH_POINTS", 5}, {"MAX_POINTS2MATCH", 10}, {"MAX_DIST_PLANE", 2.0},
+              {"PLANES_THRESHOLD", 0.05}, {"LiDAR_noise", 0.001}, {"min_dist", 4.0}, {"imu_rate", 100}, {"full_rotation_time", 0.1},
+              {"empty_lidar_time", 1.0}, {"real_time_delay", 0.1}, {"covariance_gyroscope", 1e-4}, {"covariance_acceleration", 1e-2},
+              {"covariance_bias_gyroscope", 1e-5}, {"covariance_bias_acceleration", 1e-4}, {"offset_beginning", 0}, {"stamp_beginning", 0}};
+    ov.str = {{"LiDAR_type", "hesai"}, {"points_topic", "/points"}, {"imus_topic", "/imu"}};
+    ov.vec = {{"/Initialization/deltas", {delta}}, {"initial_gravity", {0.0, 0.0, -9.809}}, {"I_Rotation_L", {1, 0, 0, 0, 1, 0, 0, 0, 1}},
+              {"I_Translation_L", {0, 0, 0}}};
+    // ---- a prior map (the reference starts empty; either is Mapper::add — stream_demo does the same)
+    {
+        Points map_pts;
+        for (uint32_t i = 0; i < n_map; ++i) map_pts.push_back(Point(Eigen::Matrix<float, 3, 1>(mapv[3 * i], mapv[3 * i + 1], mapv[3 * i + 2])));
+        // (Config is filled by main(): NUM_MATCH_POINTS etc. are not needed to build)
+        Mapper::getInstance().add(map_pts, 0.0, false);
+    }
+    typedef esekfom::esekf<state_ikfom, 12, input_ikfom> Kf;
+    // ---- the start pose: the stream does not start at the origin at rest, which is what Localizator::initialize assumes; the
+    // same placement as stream_demo.cpp, applied when the filter has just been initialised (Accumulator::ready -> initialize)
+    lvo_state x0;
+    bool have_x0 = false;
+    {
+        std::ifstream pf(std::string(argv[1]) + ".x0", std::ios::binary);
+        if (pf && pf.read(reinterpret_cast<char*>(&x0), sizeof(x0))) have_x0 = true;
+    }
+    Kf::on_change_P() = [&] {
+        Localizator& loc = Localizator::getInstance();
+        Accumulator& accum = Accumulator::getInstance();
+        if (have_x0) { state_ikfom s; lvref::from_oracle(x0, s); Kf::last()->change_x(s); }
+        loc.last_time_integrated = accum.initial_time;
+        loc.last_time_updated = accum.initial_time;
+        accum.add(loc.latest_state(), accum.initial_time);
+        Kf::on_change_P() = nullptr;    // once
+    };
+    // ---- the feed
+    size_t ii = 0, mi = 0;
+    int tail = 4;
+    std::vector<uint32_t> npts;
+    size_t seen_updates = 0;
+    lvref::Feed& feed = lvref::feed();
+    feed.ok = [&] { return ii < imus.size() || tail-- > 0; };
+    feed.spin = [&] {
+        if (Kf::last() && Kf::last()->update_log.size() > seen_updates) { seen_updates = Kf::last()->update_log.size(); npts.push_back(lvref::last_points2match); }
+        if (ii >= imus.size()) return;
+        const ImuRec& r = imus[ii++];
+        while (mi < msgs.size() && msgs[mi].arrival <= r.t) {
+            boost::shared_ptr<sensor_msgs::PointCloud2> pc(new sensor_msgs::PointCloud2());
+            pc->header.stamp.sec = (uint32_t)(msgs[mi].stamp / 1000000ull);
+            pc->header.stamp.nsec = (uint32_t)((msgs[mi].stamp % 1000000ull) * 1000ull);
+            pc->width = msgs[mi].n; pc->height = 1; pc->point_step = 48; pc->row_step = 48 * msgs[mi].n;
+            const char* names[] = {"x", "y", "z", "intensity", "timestamp", "ring"};
+            const uint32_t offs[] = {0, 4, 8, 16, 24, 32};
+            const uint8_t dts[] = {7, 7, 7, 2, 8, 4};
+            for (int k = 0; k < 6; ++k) { sensor_msgs::PointField pf; pf.name = names[k]; pf.offset = offs[k]; pf.datatype = dts[k]; pf.count = 1; pc->fields.push_back(pf); }
+            pc->data.assign(msgs[mi].data.begin(), msgs[mi].data.end());
+            boost::shared_ptr<const sensor_msgs::PointCloud2> cpc = pc;
+            feed.subscribers.at("/points")(&cpc);
+            ++mi;
+        }
+        boost::shared_ptr<sensor_msgs::Imu> im(new sensor_msgs::Imu());
+        im->header.stamp = ros::Time(r.t);
+        im->linear_acceleration.x = r.a[0]; im->linear_acceleration.y = r.a[1]; im->linear_acceleration.z = r.a[2];
+        im->angular_velocity.x = r.w[0]; im->angular_velocity.y = r.w[1]; im->angular_velocity.z = r.w[2];
+        im->orientation.x = r.q[0]; im->orientation.y = r.q[1]; im->orientation.z = r.q[2]; im->orientation.w = r.q[3];
+        boost::shared_ptr<const sensor_msgs::Imu> cim = im;
+        feed.subscribers.at("/imu")(&cim);
+    };
+    char* av[] = {argv[0], nullptr};
+    lvref_main(1, av);
+    // ---- output: { t2, x[26], n_points } per update; the times are those of the states main() pushed (accum.add(Xt2, t2))
+    Kf* kf = Kf::last();
+    if (kf->update_log.size() > seen_updates) npts.push_back(lvref::last_points2match);
+    std::vector<double> times;
+    {
+        auto& bx = Accumulator::getInstance().BUFFER_X.content;    // newest first; the oldest is the start state placed above
+        for (auto it = bx.rbegin(); it != bx.rend(); ++it) times.push_back(it->time);
+        if (!times.empty()) times.erase(times.begin());
+    }
+    const uint32_t n = (uint32_t)std::min(kf->update_log.size(), times.size());
+    std::ofstream o(argv[2], std::ios::binary);
+    o.write(reinterpret_cast<const char*>(&n), 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        o.write(reinterpret_cast<const char*>(&times[i]), 8);
+        o.write(reinterpret_cast<const char*>(&kf->update_log[i]), sizeof(lvo_state));
+        const uint32_t np = i < npts.size() ? npts[i] : 0u;
+        o.write(reinterpret_cast<const char*>(&np), 4);
+    }
+    std::cout << "ref_stream_demo: " << n << " updates (" << kf->update_log.size() << " filter updates, " << times.size() << " states), map "
+              << Mapper::getInstance().size() << " points\n";
+    return 0;
+}

@@ -99,7 +99,12 @@ public:
     const state& get_x() const { return x_; }
     void change_x(state& s) { x_ = s; }
     cov get_P() const { return P_; }
-    void change_P(cov& P) { P_ = P; }
+    void change_P(cov& P) {
+        P_ = P;
+        if (on_change_P()) { auto f = on_change_P(); on_change_P() = nullptr; f(); on_change_P() = f; }   // (replay hook: the filter has just been initialised)
+    }
+    static std::function<void()>& on_change_P() { static std::function<void()> f; return f; }
+    std::vector<lvo_state> update_log;    // the state after every update_iterated_dyn_share_modified (replay output)
 
     // esekf::predict(dt, Q, i_in) -> the oracle's restatement; row-major buffers across the C interface
     void predict(double& dt, Eigen::Matrix<double, process_noise_dof, process_noise_dof>& Q, const input& i_in) {
@@ -165,6 +170,7 @@ public:
             }
         }
         lvref::from_oracle(x, x_);
+        update_log.push_back(x);
     }
 
     int passes = 0;

@@ -108,3 +108,56 @@ def test_deskew_window_against_the_reference_compensator(capi, lr, oracle):
             assert np.array_equal(_bits(key(got[:, :3])), _bits(key(ref)))
         else:
             assert np.abs(key(got[:, :3]) - key(ref)).max() < 2e-4
+
+
+def test_reference_main_loop_trajectory_beside_the_hip_pipeline(lr, lv, tmp_path):
+    """The same recorded stream through (a) the reference's own main loop (oracle/_ref/ref_stream_demo: src/main.cpp and every
+    in-tree source compiled in place, stand-ins for kNN / esekf algebra / voxel grid) and (b) the reference's loop over the shim
+    and the HIP library (limo-velo_amd/host/stream_demo, both hand-over modes): the same localisation schedule (every t2), the
+    same number of points in every update, and trajectories that agree the way the two HIP modes agree with each other — the
+    first twenty updates to 1e-5 (the reference's de-skew takes libm's sinf / cosf, the device a polynomial one ulp away in 2 %
+    of the arguments: a last-bit difference of a few scan points per window), later ones within what an update sitting on the
+    LIMITS threshold may move the weakly observable states."""
+    import os
+    import subprocess
+    import sys
+
+    from limo_velo_amd import synth
+
+    ref_exe = os.path.join(os.path.dirname(lr._LIB_PATH), "ref_stream_demo")
+    if not os.path.exists(ref_exe):
+        pytest.skip("oracle/_ref/ref_stream_demo did not travel with this snapshot")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "limo-velo_amd", "host")
+    exe = os.path.join(host, "stream_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", host])
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_shim as S
+
+    n_revs, delta = 9, 0.01
+    stream = synth.make_stream(1_048_576, n_revs, n_az=512, map_radius=62.0)
+    pos0, _, vel0, _, q0 = synth.stream_truth(0.30 - 0.1)
+    x0 = synth.make_state(pos0 + [0.02, -0.015, 0.01], synth.quat_mul(q0, synth.quat_from_rotvec([0.002, -0.001, 0.003])), vel=vel0,
+                          grav=(0, 0, synth.STREAM_G))
+    inp = tmp_path / "in.bin"
+    S._write_stream_input(inp, 0, delta, stream, n_revs, x0)
+    out_ref = tmp_path / "out_ref.bin"
+    r = subprocess.run([ref_exe, str(inp), str(out_ref)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tr, xr, nr = S._read_stream_output(out_ref)
+    worst = {}
+    for on_device in (0, 1):
+        inp_d, out_d = tmp_path / f"in{on_device}.bin", tmp_path / f"out{on_device}.bin"
+        S._write_stream_input(inp_d, on_device, delta, stream, n_revs, x0)
+        r = subprocess.run([exe, str(inp_d), str(out_d)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        t, x, n = S._read_stream_output(out_d)
+        k = min(len(t), len(tr))
+        assert k >= 50 and abs(len(t) - len(tr)) <= 1
+        assert np.allclose(t[:k], tr[:k], atol=1e-12)                      # the same localisation schedule
+        assert np.array_equal(n[:k], nr[:k])                               # the same scan sizes after window + voxel grid
+        d = np.abs(x[:k] - xr[:k])
+        worst[on_device] = (float(d[:20].max()), float(d[:, :3].max()), float(d.max()))
+        assert d[:20].max() < 1e-5 and d[:, :3].max() < 1e-3 and d.max() < 3e-3, worst
+    print("HIP pipeline vs the reference's main loop: max |dx| first 20 updates / positions overall / all states", worst)

@@ -327,3 +327,39 @@ def test_map_growth_through_mapper_add(lr, oracle):
     lr.map_add(np.zeros((0, 3), np.float32), 3.0, True)   # empty: returns before touching anything
     assert lr.map_size() == len(want)
     lr.reset()
+
+
+def test_reference_main_loop_replay_tracks_the_truth(lr, lv, tmp_path):
+    """The reference's OWN main loop — src/main.cpp compiled in place (its `main` renamed), its Accumulator / Compensator /
+    Localizator / Mapper / PointCloudProcessor as they are — fed a recorded 100 Hz stream by oracle/ref_build/ref_stream_main.cpp
+    (which stands where the ROS master stood: fill_config's parameters, the two subscribed callbacks, one IMU sample per
+    ros::spinOnce()).  71 localisations, one per 10 ms field of view, tracking the ground truth: the time management of
+    main.cpp:58-73, the window / de-skew / voxel-grid / correct / map.add sequence and the buffer clean-up all run as written.
+    (tests/test_gpu_ref.py lays the HIP path's trajectory over the shim beside this one, update by update.)"""
+    import os
+    import subprocess
+    import sys
+
+    from limo_velo_amd import synth
+
+    exe = os.path.join(os.path.dirname(lr._LIB_PATH), "ref_stream_demo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_stream_demo is not built")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_shim as S
+
+    n_revs, delta = 9, 0.01
+    stream = synth.make_stream(1_048_576, n_revs, n_az=512, map_radius=62.0)
+    pos0, _, vel0, _, q0 = synth.stream_truth(0.30 - 0.1)
+    x0 = synth.make_state(pos0 + [0.02, -0.015, 0.01], synth.quat_mul(q0, synth.quat_from_rotvec([0.002, -0.001, 0.003])), vel=vel0,
+                          grav=(0, 0, synth.STREAM_G))
+    inp, out = tmp_path / "in.bin", tmp_path / "out.bin"
+    S._write_stream_input(inp, 0, delta, stream, n_revs, x0)
+    r = subprocess.run([exe, str(inp), str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t, x, npts = S._read_stream_output(out)
+    assert len(t) >= 50 and np.allclose(np.diff(t), delta, atol=1e-9) and abs(t[0] - 0.21) < 1e-9
+    assert (npts >= 10).all()                                              # MAX_POINTS2MATCH (main.cpp:81)
+    truth = np.array([synth.stream_truth(tt)[0] for tt in t])
+    err = np.linalg.norm(x[:, :3] - truth, axis=1)
+    assert np.sqrt(np.mean(err ** 2)) < 0.03, err
