@@ -10,6 +10,9 @@
 #pragma once
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 
 #include "limovelo_shim.hpp"
 
@@ -47,6 +50,13 @@ inline bool run_cycle(Accumulator& accum, Compensator& comp, Localizator& loc, M
         Points compensated = comp.compensate(clk.t1, clk.t2);
         Points ds_compensated = comp.downsample(compensated);
         if ((int)ds_compensated.size() < Config.MAX_POINTS2MATCH) return false;
+        if (const char* pre = getenv("LV_DEMO_DUMP_PREFIX")) {   // (diagnostic: the scans of the first updates, tests/test_gpu_ref.py)
+            static int k = 0;
+            if (k < 6) {
+                FILE* fd = fopen((std::string(pre) + "_" + std::to_string(k++) + ".bin").c_str(), "wb");
+                if (fd) { for (const Point& q : ds_compensated) { const float v[3] = {q.x, q.y, q.z}; fwrite(v, 4, 3, fd); } fclose(fd); }
+            }
+        }
         loc.correct(ds_compensated, clk.t2);
         Xt2 = loc.latest_state();
         accum.add(Xt2, clk.t2);

@@ -41,6 +41,18 @@ void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_
     Mapper& MAP = Mapper::getInstance();
     Matches matches = MAP.match(State(s, 0.), KF.points2match);
     lvref::last_points2match = (uint32_t)KF.points2match.size();
+    if (const char* pre = getenv("LV_DEMO_DUMP_PREFIX")) {   // (diagnostic: the scans of the first updates, first pass of each)
+        static int k = 0;
+        static const void* last_scan = nullptr;
+        static double last_t = -1;
+        const double tnow = KF.points2match.empty() ? -2.0 : (double)KF.points2match.front().x * 1e3 + (double)KF.points2match.back().y + (double)KF.points2match.size();
+        if (k < 6 && tnow != last_t) {
+            last_t = tnow;
+            FILE* fd = fopen((std::string(pre) + "_" + std::to_string(k++) + ".bin").c_str(), "wb");
+            if (fd) { for (const Point& q : KF.points2match) { const float v[3] = {q.x, q.y, q.z}; fwrite(v, 4, 3, fd); } fclose(fd); }
+        }
+        (void)last_scan;
+    }
     if (matches.empty()) { ekfom_data.valid = false; return; }
     KF.calculate_H(s, matches, ekfom_data.h_x, ekfom_data.h);
     ekfom_data.valid = true;

@@ -114,10 +114,12 @@ def test_reference_main_loop_trajectory_beside_the_hip_pipeline(lr, lv, tmp_path
     """The same recorded stream through (a) the reference's own main loop (oracle/_ref/ref_stream_demo: src/main.cpp and every
     in-tree source compiled in place, stand-ins for kNN / esekf algebra / voxel grid) and (b) the reference's loop over the shim
     and the HIP library (limo-velo_amd/host/stream_demo, both hand-over modes): the same localisation schedule (every t2), the
-    same number of points in every update, and trajectories that agree the way the two HIP modes agree with each other — the
-    first twenty updates to 1e-5 (the reference's de-skew takes libm's sinf / cosf, the device a polynomial one ulp away in 2 %
-    of the arguments: a last-bit difference of a few scan points per window), later ones within what an update sitting on the
-    LIMITS threshold may move the weakly observable states."""
+    same number of points in every update, scans handed to correct() that differ by f32 rounding only (first update 4.8e-7 m max —
+    the reference's de-skew takes libm's sinf / cosf, the device a polynomial one ulp away in 2 % of the arguments — later ones
+    1e-6 m in the mean as the states they are de-skewed with differ at that level), and trajectories that agree by block: position
+    <= 2e-5 m, attitude <= 2e-6, velocity <= 5e-4 m/s (observed through consecutive positions: 1 / delta = 100 times the position
+    noise) over the first twenty updates; later ones within what an update sitting on the LIMITS threshold may move the weakly
+    observable states (the bound the two HIP hand-over modes are held to against each other)."""
     import os
     import subprocess
     import sys
@@ -151,21 +153,39 @@ def test_reference_main_loop_trajectory_beside_the_hip_pipeline(lr, lv, tmp_path
     inp = tmp_path / "in.bin"
     S._write_stream_input(inp, 0, delta, stream, n_revs, x0)
     out_ref = tmp_path / "out_ref.bin"
-    r = subprocess.run([ref_exe, str(inp), str(out_ref)], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([ref_exe, str(inp), str(out_ref)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, LV_DEMO_DUMP_PREFIX=str(tmp_path / "scan_ref")))
     assert r.returncode == 0, r.stdout + r.stderr
     tr, xr, nr = S._read_stream_output(out_ref)
     worst = {}
     for on_device in (0, 1):
         inp_d, out_d = tmp_path / f"in{on_device}.bin", tmp_path / f"out{on_device}.bin"
         S._write_stream_input(inp_d, on_device, delta, stream, n_revs, x0)
-        r = subprocess.run([exe, str(inp_d), str(out_d)], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([exe, str(inp_d), str(out_d)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, LV_DEMO_DUMP_PREFIX=str(tmp_path / f"scan_hip{on_device}")))
         assert r.returncode == 0, r.stdout + r.stderr
         t, x, n = S._read_stream_output(out_d)
+        if on_device == 0:   # the scans the two loops hand to correct(), update by update (the voxel grid orders them alike)
+            for j in range(6):
+                a = np.fromfile(str(tmp_path / f"scan_ref_{j}.bin"), np.float32).reshape(-1, 3)
+                b = np.fromfile(str(tmp_path / f"scan_hip0_{j}.bin"), np.float32).reshape(-1, 3)
+                same = a.shape == b.shape
+                dd = np.abs(a - b).max() if same else float("nan")
+                print(f"scan of update {j}: {a.shape[0]} vs {b.shape[0]} points, max |d| {dd:.3e}, mean |d| {np.abs(a - b).mean() if same else float('nan'):.3e}")
         k = min(len(t), len(tr))
         assert k >= 50 and abs(len(t) - len(tr)) <= 1
         assert np.allclose(t[:k], tr[:k], atol=1e-12)                      # the same localisation schedule
         assert np.array_equal(n[:k], nr[:k])                               # the same scan sizes after window + voxel grid
         d = np.abs(x[:k] - xr[:k])
         worst[on_device] = (float(d[:20].max()), float(d[:, :3].max()), float(d.max()))
-        assert d[:20].max() < 1e-5 and d[:, :3].max() < 1e-3 and d.max() < 3e-3, worst
+        names = ["pos"] * 3 + ["rot"] * 4 + ["offR"] * 4 + ["offT"] * 3 + ["vel"] * 3 + ["bg"] * 3 + ["ba"] * 3 + ["grav"] * 3
+        by_comp = {}
+        for j, nm in enumerate(names):
+            by_comp[nm] = max(by_comp.get(nm, 0.0), float(d[:20, j].max()))
+        print(f"on_device={on_device}: max |dx| over the first 20 updates by block {by_comp}; per update (max over state) {[float('%.2e' % v) for v in d[:24].max(axis=1)]}")
+        # by block over the first 20 updates: positions / attitude to the f32 noise of the de-skewed points (1e-6 m per point, mean),
+        # velocity 1 / delta = 100 times looser (it is observed through consecutive positions only), biases and gravity between
+        tol = {"pos": 2e-5, "rot": 2e-6, "offR": 1e-12, "offT": 1e-12, "vel": 5e-4, "bg": 2e-5, "ba": 2e-5, "grav": 1e-5}
+        assert all(by_comp[nm] <= tol[nm] for nm in tol), by_comp
+        assert d[:, :3].max() < 1e-3 and d.max() < 3e-3, worst
     print("HIP pipeline vs the reference's main loop: max |dx| first 20 updates / positions overall / all states", worst)
