@@ -8,7 +8,8 @@ bits of oracle/lv_oracle.cpp (the checker of every GPU parity test):
   estimate_plane's call structure, normalisation and the f64 `1.0 / n` · a-5 is_plane · a-6 Match / dist_to_plane / the chosen
   set · a-7 calculate_H rows (both extrinsics settings) · Localizator's x0 / P0 / Q / propagate_to schedule · f-2 State::
   propagate_f + Compensator::compensate (with this platform's sinf / cosf on both sides) · f-3 Accumulator windows · f-4 the
-  per-sensor time rules, temporal down-sampling and time sort of PointCloudProcessor.
+  per-sensor time rules, temporal down-sampling and time sort of PointCloudProcessor · the whole main loop (src/main.cpp compiled in
+  place) replayed on a recorded stream.
   NOT pinned (stand-ins on the reference side, [UPSTREAM-RECALL] on both): Eigen's QR internals and reduction order, ikd-Tree's
   search / insert rule, esekf's update algebra, pcl::VoxelGrid.
 
