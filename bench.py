@@ -228,16 +228,48 @@ def cpu_baseline(sc, passes_expected: int, budget_s: float = 20.0) -> dict:
     sweep = {t: rate(t, budget_s * 0.08)[0] for t in cand}
     best_t = max(sweep, key=sweep.get)
     best, reps, passes = rate(best_t, budget_s * 0.4)
+    ref_build = reference_build_baseline(sc)
     return {
         "value": best,
         "unit": "KF-update iters/s",
         "cores": best_t,
         "kind": "port",
+        # the reference's OWN Localizator::correct (src/Modules/{Localizator,Mapper}.cpp, src/Objects/*.cpp, src/Utils/Utils.cpp
+        # compiled in place: oracle/_ref) on one core, where the prebuilt library travelled with the snapshot; `value` stays the
+        # faster multi-threaded port (the conservative comparison)
+        "reference_build": ref_build,
         "sample": f"{reps} full updates ({passes} passes) of the same 64k-vs-1M workload on the oracle (pointer kd-tree, "
                   f"OpenMP {best_t} threads = fastest of {sorted(sweep)} on a {ncpu}-cpu host); reference configuration "
                   f"MP_PROC_NUM=3 threads: {ref3:.1f} iters/s",
         "reference_config_3_threads": ref3,
     }
+
+
+def reference_build_baseline(sc, max_updates: int = 2):
+    """The reference's own code on the CPU: oracle/_ref/liblvref.so = /root/reference/src compiled in place against stand-in headers
+    (oracle/ref_build; kNN = the oracle's pointer kd-tree behind ikd-Tree's interface, the filter algebra = the oracle's behind
+    esekf's; Mapper::match's loop runs on ONE thread: its OpenMP form races on push_back).  A bounded sample of the same
+    64k-vs-1M update.  None when the library did not travel (it is built only where the reference is mounted)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import lvref
+
+        if not os.path.exists(lvref._LIB_PATH):
+            return None
+        lvref.set_config()
+        lvref.reset()
+        lvref.map_add(sc["map_xyz"])
+        t0, passes, reps = time.perf_counter(), 0, 0
+        while reps < max_updates and time.perf_counter() - t0 < 12.0:
+            passes += lvref.update(sc["x_init"], sc["P0"], sc["scan_xyz"])[2]
+            reps += 1
+        dt = time.perf_counter() - t0
+        lvref.reset()
+        return {"value": passes / dt, "unit": "KF-update iters/s", "cores": 1, "kind": "reference",
+                "sample": f"{reps} updates ({passes} passes) of the same workload through Localizator::correct of the reference's compiled "
+                          "sources (first one includes the stand-in tree's build); stand-ins: kNN, esekf algebra"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
 
 
 def self_launch(n: int) -> int:
