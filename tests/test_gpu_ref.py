@@ -65,6 +65,33 @@ def test_per_point_outputs_equal_the_reference_code(capi, lr, extrinsics, est):
     lr.set_config()
 
 
+@pytest.mark.parametrize("name,mdp,pth", [("kitti", 2.23, 0.1), ("ouster", 2.0, 0.1)])
+def test_shipped_yaml_keys_on_ring_scans_equal_the_reference_code(capi, lr, name, mdp, pth):
+    """config/kitti.yaml / ouster.yaml hot keys (MAX_DIST_PLANE, PLANES_THRESHOLD) on a spinning-LiDAR scan (16 rings x 1024 azimuth
+    steps against a 300 k-point map: grazing incidence, sparse far rings — many points fail a gate): chosen set, planes, residuals
+    and rows of the HIP path equal Mapper::match + Localizator::calculate_H of the reference's compiled sources."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_ring_scene(300_000, 16, 1024)
+    lr.set_config(max_dist_plane=mdp, planes_threshold=pth)
+    lr.reset()
+    lr.map_add(sc["map_xyz"])
+    with capi.Context(capi.default_params(MAX_DIST_PLANE=mdp, PLANES_THRESHOLD=pth)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        m = lr.match(sc["x_init"], sc["scan_xyz"])
+        ctx.iterate(sc["x_init"])
+        valid, pw, abcd, dist = ctx.fetch_matches()
+        H, h = ctx.fetch_rows()
+        v = valid.astype(bool)
+        assert 0.2 * len(v) < v.sum() < len(v)
+        assert np.array_equal(np.nonzero(v)[0], m["src"])
+        assert np.array_equal(_bits(abcd[v]), _bits(m["abcd"])) and np.array_equal(_bits(dist[v]), _bits(m["dist"]))
+        Hr, hr, _ = lr.calculate_H(sc["x_init"], m["p_world"], m["abcd"])
+        assert np.array_equal(_bits(H[v]), _bits(Hr)) and np.array_equal(_bits(h[v]), _bits(hr))
+    lr.set_config()
+
+
 def test_iterated_update_lands_on_the_reference_glue_posterior(capi, lr):
     from limo_velo_amd import synth
 
