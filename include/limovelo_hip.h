@@ -402,15 +402,20 @@ int lv_last_passes(lv_ctx* ctx);
 /* Geometry of the one-launch-per-pass kernel for an n_scan-point scan on a part with n_cus compute units (pure host
  * logic, no GPU needed): out = {searching workgroups, search steps per round (1 or 2), rounds per workgroup,
  * 1 if one more workgroup only keeps the books (a CU is left over) else 0}.  A workgroup searches 4 tiles of 32 points
- * per step; lv_update takes this route up to 16 rounds (1 M points on a 256-CU part; 3 rounds with estimate_extrinsics). */
+ * per step; lv_update takes this route up to 16 rounds (1 M points on a 256-CU part), with and without estimate_extrinsics
+ * (round 5: its multi-round form stages a fit wavefront's rows in two halves). */
 int lv_pass_geometry(size_t n_scan, int n_cus, int out[4]);
 /* A/B knob: 0 = always the three-kernel pass (environment LV_FUSED_PASS sets the default at lv_create). */
 int lv_set_fused_pass(lv_ctx* ctx, int enabled);
 /* Tuning / test knobs by name (the environment variables LV_<NAME> set the defaults at lv_create): "fused_pass",
  * "fused_ext" (one launch per pass also with estimate_extrinsics), "fused_multi_round" (1: ... whatever the rounds per workgroup, 0: up to three — the rule of
  * round 3; default: up to 16), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused", "small_window" / "small_insert" (windows /
- * insert batches of up to 2048 points take their one-launch forms).  None of them changes a result beyond
- * the summation order of the workgroup partials.  LV_EINVAL for an unknown name. */
+ * insert batches of up to 2048 points take their one-launch forms), "multi_overlap" (0: multi-round scans fit every round
+ * between two barriers), "async_relinearise" / "async_relinearise_min" (the background map rebuild, lv_map_relinearise_async).
+ * None of those changes a result beyond the summation order of the workgroup partials.  ONE option does: "fast_fit" (default
+ * 0) switches pass_kernel's plane fit to hardware reciprocal / square root + one Newton step — within a few f32 ulps of the
+ * exact path, NOT bit-exact against the reference (tests/test_gpu_fast_fit.py states the flips and the state difference);
+ * it exists for the default 6-column configuration only and is ignored elsewhere.  LV_EINVAL for an unknown name. */
 int lv_set_option(lv_ctx* ctx, const char* name, int value);
 /* instrumentation (contexts created with LV_PASS_CLK=1 in the environment): for every launch of the last update
  * (MAX_NUM_ITERS + 2 of them) and every workgroup slot (capacity_wg >= CUs + 1 of them per launch; slot *n_wg is the
