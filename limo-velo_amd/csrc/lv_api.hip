@@ -164,7 +164,6 @@ struct lv_ctx {
 
     int pass_index = -1;           // index of the pass being enqueued by lv_update's three-kernel loop (events of its collective)
     bool coll_timed = false;       // the last profiled update recorded events around its collectives
-    bool fused_tail = false;     // lv_set_option "fused_tail" / LV_FUSED_TAIL=1 (A/B): the last searching launch also closes the update
     bool fast_fit = false;       // lv_set_option "fast_fit": the opt-in approximate plane fit of pass_kernel (v_rcp / v_sqrt + Newton; NOT bit-exact)
     bool multi_overlap = true;   // multi-round scans: plane fits beside the next round's search (LV_MULTI_OVERLAP=0: round 3's barrier form)
     bool in_update = false;
@@ -576,12 +575,8 @@ int update_fused(lv_ctx* c) {
     pl.qstride = c->qstride;
     c->qrec_valid = c->record_dump;
     c->last_update_fused = true;
-    // (A/B, lv_set_option "fused_tail"): the last searching launch closes the update itself — no closing launch
-    const bool tail = c->fused_tail && !gathered && !c->prm.estimate_extrinsics && rounds == 1 && npass >= 2 && !c->fast_fit && !c->d_pclk;
     for (int i = 0; i <= npass; ++i) {
         const bool closing = i == npass;
-        if (closing && tail) break;
-        pl.tail = tail && i == npass - 1;
         pl.mode = i == 0 ? (c->begin_pending ? 0 : 2) : 1;
         pl.recs_in = gathered ? c->d_gather[(i + 1) & 1] : c->d_cpart[(i + 1) & 1];
         pl.part_out = gathered ? c->d_gather[i & 1] + (size_t)c->comm_rank * slot : c->d_cpart[i & 1];
@@ -697,7 +692,6 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_PASS")) c->fused_pass = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_EXT")) c->fused_ext = atoi(e) != 0;
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("LV_FUSED_TAIL")) c->fused_tail = atoi(e) != 0;
     if (const char* e = getenv("LV_ASYNC_RELINEARISE")) c->relin_async = atoi(e) != 0;
     if (const char* e = getenv("LV_RELIN_SLICE_WGS")) c->relin_slice_wgs = (uint32_t)atol(e);
     if (const char* e = getenv("LV_MULTI_OVERLAP")) c->multi_overlap = atoi(e) != 0;   // A/B: 0 = every round's fits between two barriers
@@ -1596,7 +1590,6 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_pass")) c->fused_pass = on;
     else if (!std::strcmp(name, "fused_ext")) c->fused_ext = on;
     else if (!std::strcmp(name, "fast_fit")) c->fast_fit = on;
-    else if (!std::strcmp(name, "fused_tail")) c->fused_tail = on;
     else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
     else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
     else if (!std::strcmp(name, "async_relinearise_test_delay_ms")) c->relin_test_delay_ms = value;

@@ -261,7 +261,6 @@ struct PassLaunch {
                                   // launch = index of the launch in the update
     const uint32_t* cost_in;      // per searching workgroup: time of its search + fits in the previous launch (nullptr: none) ...
     uint32_t* cost_out;           // ... and where this launch leaves its own
-    bool tail = false;            // this searching launch also closes the update (pass_kernel<.., TAIL>; single round, default configuration only)
     bool multi_overlap = true;    // rounds > 1: a round's plane fits beside the next round's search (pass_kernel<.., MULTI>); false: round 3's barrier form
     int steps, dedicated;         // search steps per round (1 or 2); dedicated != 0: one more workgroup only keeps the books
                                   // (otherwise the last searching workgroup does, after its own fits)

@@ -1325,7 +1325,6 @@ __device__ __forceinline__ void keeper_books(const PassArgs& a, const BeginArg& 
         ps_out->t = 0;
         ps_out->iter = -1;
         ps_out->passes = 0;
-        kf->pad_[0] = 0;   // the arrival counter of a TAIL launch (pass_kernel): a kernel boundary lies between this store and its use
     }
     bar();   // K.x / K.xp are read by other wavefronts next
     prepare_next<W, T>(Bk, ps_out, K.x, K.xp, a.sp.R_inv, tid, bar, clk);
@@ -1338,11 +1337,7 @@ constexpr int PK_BOOKW = PK_THREADS / 64 - PK_FITW;   // wavefronts of a workgro
 // MULTI: the instantiation for scans of more than one round per workgroup (round 4): a round's plane fits run BESIDE the next
 // round's search instead of between two barriers.  Scans of one round — the headline — keep the instantiation without it: the same
 // source compiled with the overlap logic in place fitted planes 0.4 us slower per launch (register allocation / loop peeling).
-// TAIL (round 5, an A/B — lv_set_option "fused_tail", off by default): the LAST searching launch of an update also does the
-// closing launch's work, in the workgroup that arrives last at a device-scope counter (every workgroup: its partial and, the
-// bookkeeper, its books, then fence + atomic; the last one: fence, fold + solve of the last pass, terminal books, mailbox) —
-// one kernel boundary and one launch ramp less per update (profiles/experiments_r05/tail_closing_ab.txt).
-template <bool EXT, bool CLOSING, bool MULTI = false, bool FAST = false, bool TAIL = false>
+template <bool EXT, bool CLOSING, bool MULTI = false, bool FAST = false>
 __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
     constexpr int S = 8;
     constexpr int W = EXT ? 12 : 6;
@@ -1399,7 +1394,6 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
 
     // ---- 1. prologue ------------------------------------------------------------------------------------
     const bool searching = !CLOSING && a.rounds > 0 && bid < nwg;
-    bool tail_only = false;   // (TAIL) nothing left to do in this workgroup but to arrive
     if (a.mode == 1) {
         if (CLOSING) {   // the terminal pass: what it needs besides the solve, fetched while the prologue's own loads are in flight
             for (int e = tid; e < NS * NS; e += PK_THREADS) Bk.P[e / NS][e % NS] = ps_in->prep_P[e];
@@ -1421,16 +1415,14 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
         const int ended = L.last;
         __syncthreads();
         if (ended || !searching) {   // that solve ended the update (or this is the closing launch): nothing to search
-            if (keeper) {
-                // the books by the whole workgroup
-                WgBar bar;
-                const bool closing = a.rounds == 0;
-                bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, closing ? kf->P_prop : K.Pprop,
-                                           closing ? kf->x_prop : K.xp, closing, tid, bar, clk, CLOSING);
-                PK_STAMP(10, tid == 0);
-            }
-            if (!TAIL || ended) return;   // (TAIL: a dedicated bookkeeping workgroup of an update that goes on arrives like the others)
-            tail_only = true;
+            if (!keeper) return;
+            // the books by the whole workgroup
+            WgBar bar;
+            const bool closing = a.rounds == 0;
+            bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_in, ps_out, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, closing ? kf->P_prop : K.Pprop,
+                                       closing ? kf->x_prop : K.xp, closing, tid, bar, clk, CLOSING);
+            PK_STAMP(10, tid == 0);
+            return;
         }
     } else {
         if (a.mode == 2 && kf->done) return;
@@ -1443,7 +1435,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     PK_STAMP(3, tid == 0);
 
     if constexpr (!CLOSING) {
-    if (searching && !tail_only) {
+    if (searching) {
     // ---- 2. / 3. search and fit rounds ------------------------------------------------------------------
     const int gq = tid / S, gl = tid % S;           // lane group (0..127) = position of its point among the 128 of a step; lane in group
     // fit wavefronts: wavefront f < PK_FITW takes the 64 points [fbase, fbase + 64) of step fstep (wavefronts 0..3 of a
@@ -1713,42 +1705,15 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     if (a.cost_out && tid == 0 && bid < nwg) a.cost_out[bid] = (uint32_t)(wall_clock64() - t_begin);
     }   // !CLOSING
     PK_STAMP(9, tid == 0);
-    if (!TAIL && (!keeper || books_done)) return;
+    if (!keeper || books_done) return;
     // ---- 5. the books (one workgroup, after its own search and fits; its scratch lies above the staged rows) ---------
     // (Running them on the twelve wavefronts that do not fit planes, beside the fits, over an LDS-counter barrier was tried:
     // inlined into the round loop the books' register appetite spilled the search, the whole kernel ran 60 % longer.)
-    if (keeper && !books_done && !tail_only) {
+    {
         WgBar bar;
         keeper_books<W, PK_THREADS>(a, begin, K, Bk, kf, ps_in, ps_out, &s_pose, tid, bar, clk);
-        PK_STAMP(10, tid == 0);
     }
-    if constexpr (TAIL && !CLOSING) {
-        // ---- 6. (TAIL) arrive; the last workgroup closes the update.  Release: every thread's stores (partial, books) are made
-        // visible at device scope before the workgroup's arrival is counted; acquire: the last arriver invalidates its caches
-        // before it reads the others' partials and the bookkeeper's hand-over (agent-scope fences: cross-XCD L2 write-back /
-        // invalidate).  The fold order is by workgroup index, so WHICH workgroup arrives last changes nothing in the result.
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned prev = atomicAdd(reinterpret_cast<unsigned*>(&kf->pad_[0]), 1u);
-            s_qn[7] = prev == gridDim.x - 1u ? 1 : 0;
-            __threadfence();
-        }
-        __syncthreads();
-        if (!s_qn[7]) return;
-        __threadfence();
-        const KfDev::PassState* ps_c = ps_out;      // what this launch's bookkeeper left for the solve of THIS pass
-        KfDev::PassState* ps_n = &kf->ps[a.launch & 1];
-        for (int e = tid; e < NS * NS; e += PK_THREADS) Bk.P[e / NS][e % NS] = ps_c->prep_P[e];
-        if (tid < NX) Bk.xp[tid] = kf->x_prop[tid];
-        set_identity<PK_THREADS>(Bk.J, tid);
-        if (!solve_core<W, false>(L, kf, ps_c, a.part_out, a.nrec, a.sp, &s_pose, tid, nullptr, nullptr, 0, &Bk)) return;
-        keep_solve(K, L, tid);
-        __syncthreads();
-        WgBar bar;
-        bookkeeping<W, PK_THREADS>(K, Bk, kf, ps_c, ps_n, a.io, a.sums_out, a.sp.R_inv, a.sp.seq, &s_pose, kf->P_prop, kf->x_prop, true, tid, bar,
-                                   nullptr, true);
-    }
+    PK_STAMP(10, tid == 0);
 #undef PK_STAMP
 }
 
@@ -1814,8 +1779,7 @@ int launch_pass(hipStream_t stream, const PassLaunch& pl, const BeginArg* begin)
             else hipLaunchKernelGGL((pass_kernel<false, false, true>), grid, block, 0, stream, a, b);
         } else {
             // (fast_fit: the opt-in approximate plane fit exists for the default 6-column configuration only)
-            if (pl.tail) hipLaunchKernelGGL((pass_kernel<false, false, false, false, true>), grid, block, 0, stream, a, b);
-            else if (pl.mp.fast_fit) hipLaunchKernelGGL((pass_kernel<false, false, false, true>), grid, block, 0, stream, a, b);
+            if (pl.mp.fast_fit) hipLaunchKernelGGL((pass_kernel<false, false, false, true>), grid, block, 0, stream, a, b);
             else hipLaunchKernelGGL((pass_kernel<false, false>), grid, block, 0, stream, a, b);
         }
     }

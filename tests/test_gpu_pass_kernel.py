@@ -281,41 +281,3 @@ def test_filter_get_from_the_mailbox_equals_the_copy(capi, scene_small, case):
         assert not np.array_equal(xa, res[1][0][0])
     for a in res[1]:
         assert np.array_equal(a[0], res[0][0][0]) and np.array_equal(a[1], res[0][0][1]) and a[2] == res[0][0][2]
-
-
-def test_tail_closing_option_is_bitwise_the_closing_launch(capi, lv):
-    """lv_set_option "fused_tail" (an A/B of round 5, off by default): the last searching launch of an update closes it in the
-    workgroup that arrives last at a device-scope counter, instead of a closing launch of its own.  Same functions on the same
-    inputs, a fold by workgroup index whoever arrives last: the posterior must equal the closing launch's BIT FOR BIT — over 150
-    repetitions at the headline geometry (256 searching workgroups, every CU), with a dedicated bookkeeping workgroup, for updates
-    that converge early (no tail work) and through the resident filter."""
-    from limo_velo_amd import synth
-
-    sc = synth.make_scene(1_048_576, 65_536)
-    with capi.Context() as ctx:
-        ctx.map_build(sc["map_xyz"])
-        for n, reps in ((65_536, 150), (40_000, 40), (2_000, 40)):
-            ctx.scan_set(sc["scan_xyz"][:n])
-            ctx.set_option("fused_tail", 0)
-            x0, P0, p0, tr0, s0 = ctx.update(sc["x_init"], sc["P0"])
-            assert ctx.last_update_fused()
-            ctx.set_option("fused_tail", 1)
-            for r in range(reps):
-                x, P, p, tr, sm = ctx.update(sc["x_init"], sc["P0"])
-                assert ctx.last_update_fused()
-                assert p == p0 and np.array_equal(x, x0) and np.array_equal(P, P0), (n, r, np.abs(x - x0).max())
-                assert np.array_equal(np.asarray(tr), np.asarray(tr0))
-            ctx.filter_set(sc["x_init"], sc["P0"])
-            assert ctx.correct() == p0
-            xr, Pr = ctx.filter_get()
-            assert np.array_equal(xr, x0) and np.array_equal(Pr, P0)
-            # an update that converges at once (the true state, tight limits off): ends in a prologue, no tail work
-            xe0 = None
-            for opt in (0, 1):
-                ctx.set_option("fused_tail", opt)
-                xe, Pe, pe, _, _ = ctx.update(sc["x_true"], sc["P0"])
-                if xe0 is None:
-                    xe0, Pe0, pe0 = xe, Pe, pe
-                else:
-                    assert pe == pe0 and np.array_equal(xe, xe0) and np.array_equal(Pe, Pe0)
-        ctx.set_option("fused_tail", 0)
