@@ -24,9 +24,9 @@ struct SO3 : public Eigen::Quaterniond {
 // MTK::S2<double, 98090, 10000, 1>: a vector of fixed length 9.809 [UPSTREAM-RECALL S2.hpp: normalise, scale by den / num]
 struct S2 {
     Eigen::Vector3d vec;
-    static constexpr double length = 98090.0 / 10000.0;
-    S2() : vec(length * 1.0, 0.0, 0.0) {}
-    S2(const Eigen::Vector3d& v) : vec(v) { vec.normalize(); vec = vec * length; }
+    static double length() { return 98090.0 / 10000.0; }
+    S2() : vec(length() * 1.0, 0.0, 0.0) {}
+    S2(const Eigen::Vector3d& v) : vec(v) { vec.normalize(); const double l = length(); vec = vec * l; }
 };
 
 struct state_ikfom {   // field order: State.cpp:53-61, Localizator.cpp:137-150
