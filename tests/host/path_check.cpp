@@ -1,0 +1,55 @@
+// Host-only: the shim's Compensator::path (Accumulator::get_states / get_prev_state / get_imus / get_next_imu + the up-sampling
+// loop, limo-velo_amd/host/limovelo_shim.cpp) on cases written by tests/test_shim_host.py; the test lays its output beside
+// Compensator::path of the REFERENCE's compiled sources (oracle/_ref, lvr_path).  No GPU call is made: the state buffer is never
+// empty.  Input (little endian): u32 n_cases, per case { f64 t1, t2; u32 n_states; lv_motion_state[n_states];
+// u32 n_imu; { f64 t; f32 a[3], w[3] }[n_imu] }.  Output: per case u32 n, { lv_motion_state }[n].
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "limovelo_shim.hpp"
+
+template <typename T>
+static T rd(std::ifstream& f) {
+    T v;
+    f.read(reinterpret_cast<char*>(&v), sizeof(T));
+    return v;
+}
+static State from_motion(const lv_motion_state& m) {
+    State S;
+    std::memcpy(S.R, m.R, sizeof(S.R)); std::memcpy(S.pos, m.pos, sizeof(S.pos)); std::memcpy(S.vel, m.vel, sizeof(S.vel));
+    std::memcpy(S.bw, m.bw, sizeof(S.bw)); std::memcpy(S.ba, m.ba, sizeof(S.ba)); std::memcpy(S.g, m.g, sizeof(S.g));
+    std::memcpy(S.RLI, m.RLI, sizeof(S.RLI)); std::memcpy(S.tLI, m.tLI, sizeof(S.tLI));
+    std::memcpy(S.a, m.a, sizeof(S.a)); std::memcpy(S.w, m.w, sizeof(S.w));
+    S.time = m.time;
+    return S;
+}
+int main(int argc, char** argv) {
+    if (argc != 3) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    std::ofstream o(argv[2], std::ios::binary);
+    const uint32_t n_cases = rd<uint32_t>(f);
+    Accumulator& accum = Accumulator::getInstance();
+    Compensator comp;
+    for (uint32_t c = 0; c < n_cases; ++c) {
+        const double t1 = rd<double>(f), t2 = rd<double>(f);
+        accum.BUFFER_X.content.clear();
+        accum.BUFFER_I.content.clear();
+        const uint32_t ns = rd<uint32_t>(f);
+        for (uint32_t i = 0; i < ns; ++i) accum.add(from_motion(rd<lv_motion_state>(f)));
+        const uint32_t ni = rd<uint32_t>(f);
+        for (uint32_t i = 0; i < ni; ++i) {
+            const double t = rd<double>(f);
+            float a[3], w[3];
+            f.read(reinterpret_cast<char*>(a), 12); f.read(reinterpret_cast<char*>(w), 12);
+            accum.add(IMU(a, w, t));
+        }
+        const States p = comp.path(t1, t2);
+        const uint32_t n = (uint32_t)p.size();
+        o.write(reinterpret_cast<const char*>(&n), 4);
+        for (const State& s : p) { const lv_motion_state m = s.motion(); o.write(reinterpret_cast<const char*>(&m), sizeof(m)); }
+    }
+    std::printf("%u cases\n", n_cases);
+    return 0;
+}
