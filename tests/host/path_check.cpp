@@ -50,6 +50,15 @@ int main(int argc, char** argv) {
         o.write(reinterpret_cast<const char*>(&n), 4);
         for (const State& s : p) { const lv_motion_state m = s.motion(); o.write(reinterpret_cast<const char*>(&m), sizeof(m)); }
     }
-    std::printf("%u cases\n", n_cases);
+    // then: u32 n_x, { f64 x[26] }[n_x] -> { f32 R[9], pos[3], RLI[9], tLI[3] }[n_x]: State(const state_ikfom&, double) (State.cpp:51-62)
+    const uint32_t n_x = rd<uint32_t>(f);
+    for (uint32_t i = 0; i < n_x && f; ++i) {
+        state_ikfom x;
+        f.read(reinterpret_cast<char*>(&x), sizeof(x));
+        const State S(x, 0.0);
+        o.write(reinterpret_cast<const char*>(S.R), 36); o.write(reinterpret_cast<const char*>(S.pos), 12);
+        o.write(reinterpret_cast<const char*>(S.RLI), 36); o.write(reinterpret_cast<const char*>(S.tLI), 12);
+    }
+    std::printf("%u cases, %u states\n", n_cases, n_x);
     return 0;
 }

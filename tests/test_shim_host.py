@@ -80,6 +80,16 @@ def test_compensator_path_equals_the_reference_code(lv, oracle, tmp_path):
             f.write(struct.pack("<I", len(imu_t)))
             for t, a, w in zip(imu_t, imu_a, imu_w):
                 f.write(struct.pack("<d", float(t)) + a.tobytes() + w.tobytes())
+    xs = []
+    for k in range(200):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        qo = rng.normal(size=4); qo /= np.linalg.norm(qo)
+        x = np.zeros(26); x[0:3] = rng.uniform(-300, 300, 3); x[3:7] = q; x[7:11] = qo; x[11:14] = rng.uniform(-1, 1, 3); x[23:26] = [0, 0, -9.809]
+        xs.append(x)
+    with open(tmp_path / "cases.bin", "ab") as f:
+        f.write(struct.pack("<I", len(xs)))
+        for x in xs:
+            f.write(x.tobytes())
     r = subprocess.run([str(exe), str(tmp_path / "cases.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = np.fromfile(tmp_path / "out.bin", np.uint8)
@@ -101,4 +111,10 @@ def test_compensator_path_equals_the_reference_code(lv, oracle, tmp_path):
         else:
             assert np.abs(got["R"] - want["R"]).max() < 5e-6
             near += 1
-    assert off == len(raw) and exact >= 90 and near >= 190
+    assert exact >= 90 and near >= 190
+    # State(const state_ikfom&, double): the f32 mirror the shim's State builds on the host against the reference's (lvr_state_to_pose)
+    poses = raw[off:off + 96 * len(xs)].view(np.float32).reshape(len(xs), 24)
+    off += 96 * len(xs)
+    for x, got in zip(xs, poses):
+        assert np.array_equal(got.view(np.uint32), lvref.state_to_pose(x).view(np.uint32))
+    assert off == len(raw)
