@@ -606,8 +606,9 @@ def main() -> None:
 
         main_name = "allgather_one_launch" if fused_main else "allreduce_three_kernel"
         forms = {main_name: describe((None, None), (kern_ms, solve_ms, kern_cnt, coll_us))}   # (its rate = the headline value, filled in below)
-        if os.environ.get("LV_BENCH_PEER", "1") != "0" and dist is not None:
-            # (on by default with N > 1 — LV_BENCH_PEER=0 skips it — so that ONE run on a node yields all three forms; it has not run
+        if os.environ.get("LV_BENCH_PEER", "0") != "0" and dist is not None:
+            # (OPT-IN since round 5, LV_BENCH_PEER=1: this leg has never run across GPUs, and a fault in it — a bad peer mapping is a
+            # GPU page fault, not an exception — would take the whole line with it, the two RCCL forms included; it has not run
             # across GPUs yet: a failure stays inside this try and inside the second context, a lost rank ends a wait after
             # LV_PEER_TIMEOUT_MS) the same one-launch form with the partials pulled out of peer-mapped buffers
             # (lv_comm_peer_export / _init) by a second context per rank
