@@ -69,7 +69,7 @@ struct lv_ctx {
     std::thread relin_worker;
     std::mutex relin_mu;
     std::deque<RelinEntry> relin_journal;
-    int relin_state = 0;                  // 0 idle, 4 worker allocating, 5 allocated (waiting for the snapshot), 1 rebuilding / replaying, 2 ready
+    std::atomic<int> relin_state{0};      // 0 idle, 4 worker allocating, 5 allocated (waiting for the snapshot), 1 rebuilding / replaying, 2 ready
                                           // (worker caught up), 3 failed — written under relin_mu
     std::string relin_error;
     hipStream_t relin_stream = nullptr;
@@ -78,6 +78,7 @@ struct lv_ctx {
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
     uint32_t relin_slice_wgs = 4096;      // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids)
+    bool relin_test_race = false;         // lv_set_option "async_relinearise_test_race": see relin_journal_add
     int relin_test_delay_ms = 0;          // lv_set_option "async_relinearise_test_delay_ms": the worker pauses between rebuild and replay (tests)
 
     ScanStore scan;
@@ -1032,37 +1033,64 @@ int relin_maybe_start(lv_ctx* c, size_t incoming) {
 
 // journal a batch staged in c->map.d_new (copied on the context's stream, which staged it) for the worker to replay
 int relin_journal_add(lv_ctx* c, uint32_t n, int downsample, float box, bool build_if_empty) {
-    if (c->relin_state != 1 || n == 0) return LV_OK;    // (states 4 / 5: the snapshot is still to come and will contain this batch)
-    lv_ctx::RelinEntry e;
-    e.kind = build_if_empty ? 1 : 0;
-    e.n = n;
-    e.downsample = downsample;
-    e.box = box;
-    const size_t bytes = (((size_t)n * sizeof(float4)) + 255) & ~(size_t)255;
-    if (c->relin_arena && c->relin_arena_used + bytes <= c->relin_arena_bytes) {   // a bump arena: no hipMalloc on the caller's thread
-        e.d_pts = reinterpret_cast<float4*>(static_cast<char*>(c->relin_arena) + c->relin_arena_used);
-        e.from_arena = true;
-        c->relin_arena_used += bytes;
-    } else {
-        LV_HIP(hipMalloc(&e.d_pts, (size_t)n * sizeof(float4)));
+    if (n == 0) return LV_OK;
+    if (c->relin_test_race && c->relin_state == 1) {   // (test hook: let the worker report "ready" right here, between this call's poll and its journal entry)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c->relin_state == 1 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
-    LV_HIP(hipMemcpyAsync(e.d_pts, c->map.d_new, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-    LV_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
-    LV_HIP(hipEventRecord(e.ready, c->stream));
-    std::lock_guard<std::mutex> g(c->relin_mu);
-    if (c->relin_state == 1) c->relin_journal.push_back(e);
-    else relin_free_entry(e);     // (the worker failed meanwhile: it needs no journal)
-    return LV_OK;
+    int st = c->relin_state;
+    if (st != 1 && st != 2) return LV_OK;    // (0 idle; 4 / 5: the snapshot is still to come and will contain this batch; 3 failed)
+    lv_ctx::RelinEntry e;
+    if (st == 1) {
+        e.kind = build_if_empty ? 1 : 0;
+        e.n = n;
+        e.downsample = downsample;
+        e.box = box;
+        const size_t bytes = (((size_t)n * sizeof(float4)) + 255) & ~(size_t)255;
+        if (c->relin_arena && c->relin_arena_used + bytes <= c->relin_arena_bytes) {   // a bump arena: no hipMalloc on the caller's thread
+            e.d_pts = reinterpret_cast<float4*>(static_cast<char*>(c->relin_arena) + c->relin_arena_used);
+            e.from_arena = true;
+            c->relin_arena_used += bytes;
+        } else {
+            LV_HIP(hipMalloc(&e.d_pts, (size_t)n * sizeof(float4)));
+        }
+        LV_HIP(hipMemcpyAsync(e.d_pts, c->map.d_new, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        LV_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+        LV_HIP(hipEventRecord(e.ready, c->stream));
+        {
+            std::lock_guard<std::mutex> g(c->relin_mu);
+            st = c->relin_state;
+            if (st == 1) { c->relin_journal.push_back(e); return LV_OK; }
+        }
+        relin_free_entry(e);
+    }
+    if (st == 2) {
+        // The worker caught up and reported "ready" after this call's relin_poll: the copy no longer takes journal entries, so
+        // this batch must go to the copy AS THE ACTIVE MAP — adopt it now and move the staged batch over (it sits in the old
+        // store's staging buffer); the caller's add_staged then acts on the adopted store.
+        float4* staged_old = c->map.d_new;
+        int rc = relin_poll(c);
+        if (rc) return rc;
+        rc = c->map.reserve_batch(n);
+        if (rc) return rc;
+        LV_HIP(hipMemcpyAsync(c->map.d_new, staged_old, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return LV_OK;   // (3: the worker failed meanwhile — the active map simply stays)
 }
 int relin_journal_evict(lv_ctx* c, int kind, const float* lo, const float* hi, int keep_inside, uint32_t n_oldest) {
-    if (c->relin_state != 1) return LV_OK;
+    if (c->relin_state != 1 && c->relin_state != 2) return LV_OK;
     lv_ctx::RelinEntry e;
     e.kind = kind;
     if (lo) for (int a = 0; a < 3; ++a) { e.lo[a] = lo[a]; e.hi[a] = hi[a]; }
     e.keep_inside = keep_inside;
     e.n_oldest = n_oldest;
-    std::lock_guard<std::mutex> g(c->relin_mu);
-    if (c->relin_state == 1) c->relin_journal.push_back(e);
+    int st;
+    {
+        std::lock_guard<std::mutex> g(c->relin_mu);
+        st = c->relin_state;
+        if (st == 1) { c->relin_journal.push_back(e); return LV_OK; }
+    }
+    if (st == 2) return relin_poll(c);   // (ready since this call's poll: adopt the copy first, the caller's eviction then acts on it)
     return LV_OK;
 }
 }  // namespace
@@ -1593,6 +1621,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
     else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
     else if (!std::strcmp(name, "async_relinearise_test_delay_ms")) c->relin_test_delay_ms = value;
+    else if (!std::strcmp(name, "async_relinearise_test_race")) c->relin_test_race = on;
     else if (!std::strcmp(name, "multi_overlap")) c->multi_overlap = on;
     else if (!std::strcmp(name, "fused_multi_round")) c->fused_multi_round = on ? 1 : 0;
     else if (!std::strcmp(name, "keeper_by_cost")) c->keeper_by_cost = on;

@@ -128,3 +128,39 @@ def test_automatic_trigger_does_not_stop_the_world(capi, oracle, lv):
             _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:500])
             assert ctx.map_stats()["relinearisations"] >= 1
     print(f"insert that triggers the rebuild: background {out['async'] * 1e3:.2f} ms, stop-the-world {out['sync'] * 1e3:.2f} ms")
+
+
+def test_insert_that_meets_a_copy_that_has_just_caught_up(capi, oracle, lv):
+    """The window between an insert's poll ("still rebuilding") and its journal entry: if the worker reports "ready" right there,
+    the copy takes no more journal entries — the insert must adopt the copy first and go to IT (the staged batch moved over), or
+    the adopted map would lack the batch.  A test hook makes the insert wait inside that window until the worker is ready."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(300_000, 2000)
+    rng = np.random.default_rng(33)
+    ref = sc["map_xyz"]
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        ctx.map_relinearise_async()
+        ctx.map_size()                                  # a map call: the snapshot is taken, the worker rebuilds
+        ctx.set_option("async_relinearise_test_race", 1)
+        for step in range(3):
+            batch = (ref[rng.integers(0, len(ref), 1500)] + rng.normal(0, 0.03, (1500, 3))).astype(np.float32)
+            ctx.map_add(batch, downsample=True)         # (first one: waits in the window, adopts, inserts into the adopted store)
+            ref = oracle.map_add(ref, batch, downsample=True)
+            assert ctx.map_size() == len(ref), step
+        ctx.set_option("async_relinearise_test_race", 0)
+        s = ctx.map_rebuild_status(wait=True)
+        assert s["adopted"] == 1 and s["state"] == 0
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:800])
+        lo, hi = np.array([-5, -5, -2], np.float32), np.array([5, 5, 5], np.float32)
+        ctx.map_relinearise_async(); ctx.map_size()
+        ctx.set_option("async_relinearise_test_race", 1)
+        hole = np.all((ref >= lo) & (ref <= hi), axis=1)
+        # (evictions take the same window: state 2 at their journal entry -> adopt first)
+        time.sleep(0.3)
+        assert ctx.map_evict_box(lo, hi, keep_inside=False) == int(hole.sum())
+        ref = ref[~hole]
+        s = ctx.map_rebuild_status(wait=True)
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
