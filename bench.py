@@ -839,7 +839,10 @@ def main() -> None:
                 "lanes_per_query": prm.lanes_per_query,
                 "voxel_size": prm.voxel_size,
             },
+            # SURVEY 8(d) metric 2, "kNN Mpts/s": by the whole searching launch (solve of the previous pass + search + plane fits) and
+            # by the search phase alone (in-kernel stamps of a converged launch, instrumented context)
             "knn_mpts_per_s": n_local * world / avg_kernel_s / 1e6 if avg_kernel_s > 0 else None,
+            "knn_mpts_per_s_search_phase": (n_local / (phases["per_launch_us"]["search"][-1] * 1e-6) / 1e6) if phases else None,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "lv::pass_kernel (one launch per pass: solve of the previous pass + search + plane fits)" if fused else "lv::search_kernel",
