@@ -68,3 +68,33 @@ def test_next_rows_against_golden(lv):
         merged = ctx.map_fetch()
         assert len(merged) == int(g["map_add_n"]) and digest(merged) == str(g["map_add_sha256"])
         assert np.array_equal(merged[-32:], g["map_add_tail"])
+
+
+@pytest.mark.parametrize("tag,extrinsics,est", [("id", "identity", 0), ("ext", "xaloc", 1)])
+def test_hip_path_against_the_reference_generated_fixture(lv, tag, extrinsics, est):
+    """The HIP path against tests/golden/ref_cfg0.npz — arrays written by the reference's own compiled sources
+    (tests/golden/make_golden_ref.py) — with neither the oracle nor the reference present: world points of every scan point,
+    the chosen set, plane coefficients, residuals and Jacobian rows bit for bit; the iterated update to 1e-9."""
+    from limo_velo_amd import capi, synth
+
+    g = np.load("tests/golden/ref_cfg0.npz")
+    sc = synth.make_scene(50_000, 2_000, extrinsics=extrinsics)
+    assert float(g[tag + "_map_checksum"]) == float(sc["map_xyz"].astype(np.float64).sum())
+    b = lambda a: np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+    with capi.Context(capi.default_params(estimate_extrinsics=est)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        for st, x in (("init", sc["x_init"]), ("true", sc["x_true"])):
+            k = f"{tag}_{st}_"
+            ctx.iterate(x)
+            valid, pw, abcd, dist = ctx.fetch_matches()
+            H, h = ctx.fetch_rows()
+            v = valid.astype(bool)
+            assert np.array_equal(b(pw), b(g[k + "p_world_all"]))
+            assert np.array_equal(np.nonzero(v)[0], g[k + "src"])
+            assert np.array_equal(b(abcd[v]), b(g[k + "abcd"])) and np.array_equal(b(dist[v]), b(g[k + "dist"]))
+            assert np.array_equal(b(H[v]), b(g[k + "H"])) and np.array_equal(b(h[v]), b(g[k + "h"]))
+        x, P, passes, tr, sums = ctx.update(sc["x_init"], sc["P0"])
+        assert passes == int(g[tag + "_update_passes"]) and [q["n_valid"] for q in sums] == list(g[tag + "_update_n_valid"])
+        tol = 1e-9 if not est else 2e-6
+        assert np.abs(x - g[tag + "_update_x"]).max() < tol

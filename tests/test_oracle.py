@@ -432,3 +432,33 @@ def test_gain_branches_and_cholesky_pass_through(oracle, lv):
     K6 = np.linalg.inv(Hf6.T @ Hf6 + np.linalg.inv(P / R)) @ Hf6.T
     for got_h, got_x in ((qh1, qx1), (qh2, qx2)):
         assert np.abs(got_h - K6 @ o6["h"][s6]).max() < 1e-8 and np.abs(got_x - K6 @ Hf6).max() < 1e-8
+
+
+@pytest.mark.parametrize("tag,extrinsics,est", [("id", "identity", 0), ("ext", "xaloc", 1)])
+def test_oracle_against_the_reference_generated_fixture(oracle, lv, tag, extrinsics, est):
+    """tests/golden/ref_cfg0.npz was written by the REFERENCE'S OWN CODE (oracle/_ref = /root/reference/src compiled in place;
+    tests/golden/make_golden_ref.py) on BASELINE configs[0]: the oracle must reproduce it bit for bit — State mirror, world points,
+    chosen set, planes, residuals, Jacobian rows — and the iterated update to 1e-12, on any box, with or without the reference."""
+    import os
+
+    from limo_velo_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cfg0.npz"))
+    sc = synth.make_scene(50_000, 2_000, extrinsics=extrinsics)
+    assert float(g[tag + "_map_checksum"]) == float(sc["map_xyz"].astype(np.float64).sum())
+    prm = oracle.default_params(estimate_extrinsics=est)
+    tree = oracle.KdTree(sc["map_xyz"])
+    b = lambda a: np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+    for st, x in (("init", sc["x_init"]), ("true", sc["x_true"])):
+        k = f"{tag}_{st}_"
+        assert np.array_equal(b(oracle.state_to_pose(x)), b(g[k + "pose"]))
+        assert np.array_equal(b(oracle.transform_scan(x, sc["scan_xyz"])), b(g[k + "p_world_all"]))
+        o = oracle.iterate(x, sc["map_xyz"], sc["scan_xyz"], params=prm, tree=tree)
+        v = o["valid"].astype(bool)
+        assert np.array_equal(np.nonzero(v)[0], g[k + "src"])
+        assert np.array_equal(b(o["abcd"][v]), b(g[k + "abcd"])) and np.array_equal(b(o["dist"][v]), b(g[k + "dist"]))
+        assert np.array_equal(b(o["Hrows"][v]), b(g[k + "H"])) and np.array_equal(b(o["h"][v]), b(g[k + "h"]))
+    xo, Po, po, tro, so = oracle.update(sc["x_init"], sc["P0"], sc["map_xyz"], sc["scan_xyz"], params=prm, tree=tree)
+    assert po == int(g[tag + "_update_passes"]) and [s["n_valid"] for s in so] == list(g[tag + "_update_n_valid"])
+    tol = 1e-12 if not est else 1e-9
+    assert np.abs(xo - g[tag + "_update_x"]).max() < tol and np.abs(Po - g[tag + "_update_P"]).max() < tol * max(1.0, np.abs(Po).max())
