@@ -1254,11 +1254,11 @@ struct PassArgs {
 constexpr int PK_UNITS = PK_THREADS / 256;        // 256-thread units: one 32-point tile each per step
 constexpr int PK_GROUPS = PK_THREADS / 8;         // lane groups (= scan points in flight) per workgroup: 128
 constexpr int PK_STAGE = 64;                      // candidates of a lane group's first level-0 chunk kept in LDS
-constexpr int PK_STEPS = 2;                       // search steps per round
+constexpr int PK_STEPS = 2048 / PK_THREADS;       // search steps per round: 2 (256 scan points per workgroup and round either way)
 constexpr int PK_FITW = PK_STEPS * PK_GROUPS / 64;   // fit wavefronts: one per 64 points of a round (4)
 constexpr int PK_RPTS_MAX = PK_STEPS * PK_GROUPS;    // scan points per workgroup and round (256)
 constexpr int PK_CLK = 32;                        // stamp words per workgroup
-constexpr size_t PK_REGION0 = sizeof(Xyz) * PK_GROUPS * PK_STAGE;                     // 98304: stage | solve scratch | rows
+constexpr size_t PK_REGION0 = sizeof(Xyz) * PK_GROUPS * PK_STAGE < 65536 ? 65536 : sizeof(Xyz) * PK_GROUPS * PK_STAGE;   // 98304: stage | solve scratch | rows
 constexpr size_t PK_OFF_REC = PK_REGION0;                                             // float4 [steps][8 slots][128]
 constexpr size_t PK_OFF_PREF = PK_OFF_REC + sizeof(float4) * PK_STEPS * QREC_SLOTS * PK_GROUPS;
 constexpr size_t PK_OFF_POSE = PK_OFF_PREF + sizeof(uint32_t) * 2 * (PK_THREADS / 64) * 64;
@@ -1338,7 +1338,7 @@ constexpr int PK_BOOKW = PK_THREADS / 64 - PK_FITW;   // wavefronts of a workgro
 // round's search instead of between two barriers.  Scans of one round — the headline — keep the instantiation without it: the same
 // source compiled with the overlap logic in place fitted planes 0.4 us slower per launch (register allocation / loop peeling).
 template <bool EXT, bool CLOSING, bool MULTI = false, bool FAST = false>
-__global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginArg begin) {
+__global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(PassArgs a, BeginArg begin) {
     constexpr int S = 8;
     constexpr int W = EXT ? 12 : 6;
     constexpr int ROW_W = W + 2;
@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pass_kernel(PassArgs a, BeginAr
     // staged rows, nothing in the books depends on this launch's search.  Out here, after the round loop, the books' register
     // appetite competes with nothing that is live (inlined INTO the loop it spilled the search: round 2, 60 % slower).
     {
-        const bool beside = a.mode == 1 && keeper;
+        const bool beside = a.mode == 1 && keeper && 64 * PK_BOOKW >= NS * W;   // (the books' widest step takes NS * W threads)
         if (fitter) {
             do_fits(true, false);
         } else if (beside && wave >= PK_FITW) {

@@ -59,7 +59,11 @@ template <int NW> struct PassDims {
     static constexpr int OW = NW == 6 ? 32 : 96;              // record stride in doubles
 };
 
-constexpr int PK_THREADS = 1024;   // one workgroup per CU: 16 wavefronts
+#ifndef LV_PK_THREADS
+#define LV_PK_THREADS 1024
+#endif
+constexpr int PK_THREADS = LV_PK_THREADS;   // one workgroup per CU: 16 wavefronts (-DLV_PK_THREADS=512: the eight-wavefront / 256-VGPR experiment, profiles/experiments_r05/)
+static_assert(PK_THREADS == 1024 || PK_THREADS == 512, "pass_kernel is written for 16 or 8 wavefronts");
 
 // LDS of the prologue solve (every workgroup)
 struct SolveLds {
@@ -141,9 +145,9 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     // the previous launch's workgroup times: loaded with everything else (one round trip for up to 512 workgroups; more are
     // simply never chosen), reduced by the last wavefront AFTER the fold's barrier, beside the solve chain
     uint32_t cv[8];
-    if (tid >= 960) {
+    if (tid >= PK_THREADS - 64) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cv[u] = (tid - 960 + 64 * u < ncost) ? cost_in[tid - 960 + 64 * u] : 0xFFFFFFFFu;
+        for (int u = 0; u < 8; ++u) cv[u] = (tid - (PK_THREADS - 64) + 64 * u < ncost) ? cost_in[tid - (PK_THREADS - 64) + 64 * u] : 0xFFFFFFFFu;
     }
     // ---- fold, fixed order: thread (fo, fpart) sums records fpart, fpart + PARTS, ... (four interleaved running sums),
     // the PARTS part sums are then added left to right
@@ -159,8 +163,8 @@ __device__ inline bool solve_core(SolveLds& L, const KfDev* __restrict__ kf, con
     __syncthreads();
     if (L.done) return false;   // (the loads above were issued before this word was known: one round trip, not two)
     if (clk && tid == 0) { clk[1] = clock64(); clk[17] = wall_clock64(); }
-    if (tid >= 960) {   // argmin of the workgroup times (key = time << 16 | 65535 - index: ties go to the highest index)
-        const int ln = tid - 960;
+    if (tid >= PK_THREADS - 64) {   // argmin of the workgroup times (key = time << 16 | 65535 - index: ties go to the highest index)
+        const int ln = tid - (PK_THREADS - 64);
         unsigned long long best = ~0ull;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
