@@ -161,6 +161,7 @@ struct MapStore {
     // background re-linearisation (lv_api.hip, round 5): while a compacted copy of this map is being rebuilt on another stream /
     // thread, the stop-the-world relinearise is deferred (only id-space exhaustion still forces it)
     bool defer_relinearise = false;
+    uint32_t paced_wgs = 0;   // != 0 (with slice_wgs != 0): those grids as at most this many 1024-thread workgroups looping over the slice (launch_paced, lv_map.hip)
     uint32_t slice_wgs = 0;   // != 0: the large grids of a (re)build go out in slices of that many workgroups (a store rebuilt in the background)
     bool wants_relinearise(size_t incoming) const;   // the trigger, whatever defer_relinearise says
     // the living points of this map, compacted in id order, into dst.d_orig (dst: an idle store whose search structure is not

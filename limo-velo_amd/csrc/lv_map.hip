@@ -68,6 +68,35 @@ __global__ void map_count_heads_kernel(const uint64_t* __restrict__ keys, uint32
     if (threadIdx.x < n_levels && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+// Paced form (background rebuild, see launch_sliced): at most `gridDim.x` workgroups of PACED_THREADS threads loop over the
+// virtual blocks [vb_begin, vb_end) of the plain form — the grid never occupies more than half of the compute units, so a
+// workgroup of another stream that needs a whole one (pass_kernel) always finds one (scripts/ubench/half_chip_flood.hip).
+constexpr int PACED_THREADS = 1024;
+#define LV_PACED_FOR(VB, vb)                                                                                          \
+    for (uint32_t vb = vb_begin + blockIdx.x * (uint32_t)(PACED_THREADS / (VB)) + threadIdx.x / (uint32_t)(VB); vb < vb_end; \
+         vb += gridDim.x * (uint32_t)(PACED_THREADS / (VB)))
+__global__ __launch_bounds__(PACED_THREADS) void map_count_heads_paced_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels,
+                                                                              uint32_t* __restrict__ counts, uint32_t vb_begin, uint32_t vb_end) {
+    uint32_t mine[MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < MAX_LEVELS; ++l) mine[l] = 0;
+    LV_PACED_FOR(256, vb) {
+        const uint32_t i = vb * 256u + threadIdx.x % 256u;
+        if (i < m) {
+            const int nl = head_levels(keys, i, n_levels);
+#pragma unroll
+            for (int l = 0; l < MAX_LEVELS; ++l) mine[l] += l < nl ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < MAX_LEVELS; ++l) {   // one atomic per wavefront and level
+        uint32_t v = mine[l];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63u) == 0 && v && l < n_levels) atomicAdd(&counts[l], v);
+    }
+}
+
 struct GridLevelW {
     uint4* table;
     uint32_t mask;
@@ -80,8 +109,7 @@ struct TablePtrs {
     uint32_t shift[MAX_LEVELS];
 };
 
-__global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp, uint32_t block_base) {
-    uint32_t i = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void map_insert_item(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, const TablePtrs& tp, uint32_t i) {
     if (i >= m) return;
     int nl = head_levels(keys, i, n_levels);
     uint64_t k0 = keys[i];
@@ -110,6 +138,13 @@ __global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m,
         }
     }
 }
+__global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp, uint32_t block_base) {
+    map_insert_item(keys, m, n_levels, tp, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(PACED_THREADS) void map_insert_paced_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp,
+                                                                         uint32_t vb_begin, uint32_t vb_end) {
+    LV_PACED_FOR(256, vb) map_insert_item(keys, m, n_levels, tp, vb * 256u + threadIdx.x % 256u);
+}
 
 
 // ---- neighbourhood buckets -----------------------------------------------------------------------
@@ -130,9 +165,8 @@ __device__ __forceinline__ bool probe_cell(const GridLevelW& g, uint64_t key, ui
 }
 
 // pass 1: every occupied voxel registers its 27 neighbours (incl. itself) in the bucket table
-__global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridLevelW bt, uint32_t* __restrict__ cell_slots,
-                                       uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t block_base) {
-    const uint32_t t = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bucket_register_item(const GridLevelW& occ, uint32_t occ_slots, const GridLevelW& bt, uint32_t* __restrict__ cell_slots,
+                                                     uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t t) {
     const uint32_t slot = t / 27, nb = t % 27;
     if (slot >= occ_slots) return;
     const uint4 e = occ.table[slot];
@@ -158,6 +192,15 @@ __global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridL
     }
     flags[1] = 1;
 }
+__global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridLevelW bt, uint32_t* __restrict__ cell_slots,
+                                       uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t block_base) {
+    bucket_register_item(occ, occ_slots, bt, cell_slots, cell_cap, flags, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(PACED_THREADS) void bucket_register_paced_kernel(GridLevelW occ, uint32_t occ_slots, GridLevelW bt, uint32_t* __restrict__ cell_slots,
+                                                                              uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t vb_begin, uint32_t vb_end) {
+    // (the plain form's thread index is 32 bits wide as well: occ_slots * 27 < 2^32)
+    LV_PACED_FOR(256, vb) bucket_register_item(occ, occ_slots, bt, cell_slots, cell_cap, flags, vb * 256u + threadIdx.x % 256u);
+}
 
 // room a run of `count` entries is given when it is laid out (slack for appends; lv_mapinc.hpp relocates a run
 // that outgrows it)
@@ -165,14 +208,12 @@ __host__ __device__ __forceinline__ uint32_t run_capacity(uint32_t count) { retu
 
 // pass 2 (count) / pass 3 (fill): one 64-lane workgroup per bucket voxel; lane c < 27 owns neighbour c
 template <bool FILL>
-__global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLevelW bt, SlotAux* __restrict__ aux,
-                                                        const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
-                                                        const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
-                                                        uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
-                                                        float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t block_base) {
-    const uint32_t cell = blockIdx.x + block_base;
+__device__ __forceinline__ void map_bucket_cell(const GridLevelW& occ, const GridLevelW& bt, SlotAux* __restrict__ aux,
+                                                const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
+                                                const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
+                                                uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
+                                                float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t cell, int lane) {
     if (cell >= n_cells) return;
-    const int lane = threadIdx.x;
     const uint32_t slot = cell_slots[cell];
     const uint4 e = bt.table[slot];
     const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
@@ -208,6 +249,22 @@ __global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLeve
         }
     }
 }
+template <bool FILL>
+__global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLevelW bt, SlotAux* __restrict__ aux,
+                                                        const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
+                                                        const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
+                                                        uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
+                                                        float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t block_base) {
+    map_bucket_cell<FILL>(occ, bt, aux, cell_slots, n_cells, sorted, bcount, bcap, boff, bucket, backptr, blockIdx.x + block_base, (int)threadIdx.x);
+}
+template <bool FILL>
+__global__ __launch_bounds__(PACED_THREADS) void map_bucket_paced_kernel(GridLevelW occ, GridLevelW bt, SlotAux* __restrict__ aux,
+                                                                         const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
+                                                                         const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
+                                                                         uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
+                                                                         float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t vb_begin, uint32_t vb_end) {
+    LV_PACED_FOR(64, vb) map_bucket_cell<FILL>(occ, bt, aux, cell_slots, n_cells, sorted, bcount, bcap, boff, bucket, backptr, vb, (int)(threadIdx.x & 63u));
+}
 
 // Sort every bucket by ORIGINAL index (ascending).  The match kernel orders candidates by
 // (distance, position-in-bucket); with this layout that equals the reference's (distance, index)
@@ -215,11 +272,8 @@ __global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLeve
 // partners beyond n skipped == padding with +inf), valid for any n.  One workgroup per bucket.
 // small buckets (<= 64 points, the bulk at level 0): one wavefront per bucket, bitonic network through
 // cross-lane shuffles, no LDS, no barriers
-__global__ __launch_bounds__(256) void bucket_sort_wave_kernel(const uint32_t* __restrict__ bcount,
-                                                               const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                               float4* __restrict__ bucket, uint32_t block_base) {
-    const uint32_t cell = (blockIdx.x + block_base) * 4u + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void bucket_sort_wave_cell(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff, uint32_t n_cells,
+                                                      float4* __restrict__ bucket, uint32_t cell, int lane) {
     if (cell >= n_cells) return;
     const uint32_t n = bcount[cell];
     if (n < 2 || n > 64) return;
@@ -238,15 +292,23 @@ __global__ __launch_bounds__(256) void bucket_sort_wave_kernel(const uint32_t* _
     }
     if ((uint32_t)lane < n) g[lane] = v;
 }
+__global__ __launch_bounds__(256) void bucket_sort_wave_kernel(const uint32_t* __restrict__ bcount,
+                                                               const uint32_t* __restrict__ boff, uint32_t n_cells,
+                                                               float4* __restrict__ bucket, uint32_t block_base) {
+    bucket_sort_wave_cell(bcount, boff, n_cells, bucket, (blockIdx.x + block_base) * 4u + (threadIdx.x >> 6), (int)(threadIdx.x & 63u));
+}
+__global__ __launch_bounds__(PACED_THREADS) void bucket_sort_wave_paced_kernel(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
+                                                                               uint32_t n_cells, float4* __restrict__ bucket, uint32_t vb_begin, uint32_t vb_end) {
+    // (virtual block = the plain form's 256-thread block: four buckets, one wavefront each)
+    LV_PACED_FOR(256, vb) bucket_sort_wave_cell(bcount, boff, n_cells, bucket, vb * 4u + ((threadIdx.x % 256u) >> 6), (int)(threadIdx.x & 63u));
+}
 
 constexpr int BSORT_THREADS = 256;
 constexpr uint32_t BSORT_LDS = 2048;
-__global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ bcount,
-                                                                    const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                                    float4* __restrict__ bucket, uint32_t block_base) {
-    __shared__ float4 s_pts[BSORT_LDS];
-    const uint32_t cell = blockIdx.x + block_base;
-    if (cell >= n_cells) return;
+// one bucket of more than 64 points by a whole workgroup of T threads (every barrier is reached by all of them)
+template <int T>
+__device__ __forceinline__ void bucket_sort_cell(float4* s_pts, uint32_t* s_idx, const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
+                                                 float4* __restrict__ bucket, uint32_t cell, uint32_t tid) {
     const uint32_t n = bcount[cell];
     if (n <= 64) return;  // handled by bucket_sort_wave_kernel
     float4* g = bucket + boff[cell];
@@ -254,14 +316,13 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
         // rank by counting: original indices are unique, so the rank of a point is the number of points with a
         // smaller index — n compares per point out of LDS (broadcast reads), no barriers between steps; for the
         // few-hundred-point buckets this beats the bitonic network (log^2 n barrier-separated stages) severalfold
-        __shared__ uint32_t s_idx[BSORT_LDS];
-        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+        for (uint32_t i = tid; i < n; i += T) {
             const float4 p = g[i];
             s_pts[i] = p;
             s_idx[i] = __float_as_uint(p.w);
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+        for (uint32_t i = tid; i < n; i += T) {
             const uint32_t mine = s_idx[i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < n; ++j) rank += s_idx[j] < mine ? 1u : 0u;
@@ -273,7 +334,7 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
     for (uint32_t k = 2; (k >> 1) < n; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             const bool flip = (j == (k >> 1));
-            for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+            for (uint32_t i = tid; i < n; i += T) {
                 const uint32_t l = flip ? (i ^ (k - 1)) : (i ^ j);
                 if (l > i && l < n) {
                     const float4 x = a[i], y = a[l];
@@ -284,16 +345,53 @@ __global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32
         }
     }
 }
+__global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ bcount,
+                                                                    const uint32_t* __restrict__ boff, uint32_t n_cells,
+                                                                    float4* __restrict__ bucket, uint32_t block_base) {
+    __shared__ float4 s_pts[BSORT_LDS];
+    __shared__ uint32_t s_idx[BSORT_LDS];
+    const uint32_t cell = blockIdx.x + block_base;
+    if (cell >= n_cells) return;
+    bucket_sort_cell<BSORT_THREADS>(s_pts, s_idx, bcount, boff, bucket, cell, threadIdx.x);
+}
+// paced form: a workgroup looks at PACED_THREADS buckets at a time, lists the ones with more than 64 points and sorts those
+// one after the other (which workgroup sorts a bucket, and when, changes nothing: buckets are independent)
+__global__ __launch_bounds__(PACED_THREADS) void bucket_sort_paced_kernel(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
+                                                                          uint32_t n_cells, float4* __restrict__ bucket, uint32_t vb_begin, uint32_t vb_end) {
+    __shared__ float4 s_pts[BSORT_LDS];
+    __shared__ uint32_t s_idx[BSORT_LDS];
+    __shared__ uint32_t s_list[PACED_THREADS];
+    __shared__ uint32_t s_n;
+    const uint32_t end = vb_end < n_cells ? vb_end : n_cells;
+    for (uint32_t base = vb_begin + blockIdx.x * (uint32_t)PACED_THREADS; base < end; base += gridDim.x * (uint32_t)PACED_THREADS) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t cell = base + threadIdx.x;
+        if (cell < end && bcount[cell] > 64) s_list[atomicAdd(&s_n, 1u)] = cell;
+        __syncthreads();
+        const uint32_t nbig = s_n;
+        for (uint32_t k = 0; k < nbig; ++k) {
+            bucket_sort_cell<PACED_THREADS>(s_pts, s_idx, bcount, boff, bucket, s_list[k], threadIdx.x);
+            __syncthreads();   // (the next bucket reuses the scratch)
+        }
+    }
+}
 
 // the sorted float4 buckets -> 12-byte points (what the search kernel streams) + a parallel id array
-__global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx, uint32_t block_base) {
-    const uint32_t i = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bucket_pack_item(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx, uint32_t i) {
     if (i >= n) return;
     const float4 p = in[i];
     xyz[(size_t)i * 3] = p.x;
     xyz[(size_t)i * 3 + 1] = p.y;
     xyz[(size_t)i * 3 + 2] = p.z;
     idx[i] = __float_as_uint(p.w);
+}
+__global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx, uint32_t block_base) {
+    bucket_pack_item(in, n, xyz, idx, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(PACED_THREADS) void bucket_pack_paced_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx,
+                                                                          uint32_t vb_begin, uint32_t vb_end) {
+    LV_PACED_FOR(256, vb) bucket_pack_item(in, n, xyz, idx, vb * 256u + threadIdx.x % 256u);
 }
 
 // ---- level 2: voxel lists -----------------------------------------------------------------------------------
@@ -407,6 +505,23 @@ static void launch_sliced(uint32_t slice, K kernel, uint32_t grid, uint32_t bloc
     if (slice == 0 || grid <= slice) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args..., 0u); return; }
     for (uint32_t b = 0; b < grid; b += slice)
         hipLaunchKernelGGL(kernel, dim3(grid - b < slice ? grid - b : slice), dim3(block), 0, stream, args..., b);
+}
+// ... or PACED (MapStore::paced_wgs != 0, the background rebuild's default since the end of round 5): the kernel's paced twin — at
+// most paced_wgs workgroups of PACED_THREADS threads, each looping over the plain form's blocks ("virtual blocks" of `block`
+// threads, several side by side in a workgroup) — so that the grid never holds more than half of the chip's compute units: a
+// whole-CU workgroup of another stream then does not wait at all (scripts/ubench/half_chip_flood.hip: a 124-VGPR 1024-thread
+// probe beside 120-128 persistent workgroups of 1024 threads: p99 17.5 us, as on an idle GPU; beside 256 of them 9.8 ms), where
+// behind slices it waits for every slice it meets to drain — five whole-CU launches per cycle.  A launch covers `slice` virtual
+// blocks (bounds how long a 256-workgroup pass_kernel runs on half of the CUs).  per_wg: virtual blocks a workgroup takes side
+// by side (PACED_THREADS / block; bucket_sort_paced_kernel scans PACED_THREADS buckets at a time).
+template <typename K, typename KP, typename... A>
+static void launch_paced(uint32_t slice, uint32_t paced_wgs, K kernel, KP paced, uint32_t per_wg, uint32_t grid, uint32_t block, hipStream_t stream, A... args) {
+    if (paced_wgs == 0 || slice == 0) { launch_sliced(slice, kernel, grid, block, stream, args...); return; }
+    for (uint32_t b = 0; b < grid; b += slice) {
+        const uint32_t e = grid - b < slice ? grid : b + slice;
+        const uint32_t want = (e - b + per_wg - 1) / per_wg;
+        hipLaunchKernelGGL(paced, dim3(want < paced_wgs ? want : paced_wgs), dim3(PACED_THREADS), 0, stream, args..., b, e);
+    }
 }
 
 int MapStore::reserve(size_t cap) {
@@ -627,7 +742,7 @@ int MapStore::rebuild(hipStream_t stream) {
     hipLaunchKernelGGL(map_gather_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_idx_sorted, m, d_sorted);
     if (!d_counts) LV_HIP(hipMalloc(&d_counts, 16 * sizeof(uint32_t)));
     LV_HIP(hipMemsetAsync(d_counts, 0, 16 * sizeof(uint32_t), stream));
-    launch_sliced(slice_wgs * 2, map_count_heads_kernel, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, d_counts);
+    launch_paced(slice_wgs * 2, paced_wgs, map_count_heads_kernel, map_count_heads_paced_kernel, 4u, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, d_counts);
     uint32_t counts[16];
     LV_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
@@ -651,7 +766,7 @@ int MapStore::rebuild(hipStream_t stream) {
         tp.shift[l] = (uint32_t)(64 - log2u(size));
         n_cells[l] = counts[l];
     }
-    launch_sliced(slice_wgs * 2, map_insert_kernel, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, tp);
+    launch_paced(slice_wgs * 2, paced_wgs, map_insert_kernel, map_insert_paced_kernel, 4u, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, tp);
     LV_HIP(hipGetLastError());
     for (int l = 0; l < REPL_LEVELS; ++l) {
         int rc = build_buckets(stream, l, counts[l]);
@@ -706,7 +821,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
         GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - log2u(size))};
         const uint64_t threads = (uint64_t)occ_slots * 27;
-        launch_sliced(slice_wgs * 2, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
+        launch_paced(slice_wgs * 2, paced_wgs, bucket_register_kernel, bucket_register_paced_kernel, 4u, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
                       d_cell_slots, (uint32_t)(size / 2), d_flags);
         uint32_t flags[2];
         LV_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
@@ -717,7 +832,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         }
         const uint32_t nb = flags[0];
         n_bcells[level] = nb;
-        launch_sliced(slice_wgs * 8, map_bucket_kernel<false>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
+        launch_paced(slice_wgs * 8, paced_wgs, map_bucket_kernel<false>, map_bucket_paced_kernel<false>, 16u, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
                       d_bcount, d_bcap, (const uint32_t*)d_boff, (float4*)nullptr, (uint32_t*)nullptr);
         size_t stmp = scan_tmp_bytes;
         LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)nb, stream));
@@ -743,12 +858,12 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
                 LV_REALLOC(d_bidx[level], uint32_t, want);
                 pool_cap[level] = (size_t)want;
             }
-            launch_sliced(slice_wgs, map_bucket_kernel<true>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
+            launch_paced(slice_wgs, paced_wgs, map_bucket_kernel<true>, map_bucket_paced_kernel<true>, 16u, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
                           (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket_tmp, (uint32_t*)nullptr);
-            launch_sliced(slice_wgs * 8, bucket_sort_wave_kernel, (nb + 3) / 4, 256u, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
-            launch_sliced(slice_wgs * 8, bucket_sort_kernel, nb, (uint32_t)BSORT_THREADS, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
+            launch_paced(slice_wgs * 8, paced_wgs, bucket_sort_wave_kernel, bucket_sort_wave_paced_kernel, 4u, (nb + 3) / 4, 256u, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
+            launch_paced(slice_wgs * 8, paced_wgs, bucket_sort_kernel, bucket_sort_paced_kernel, (uint32_t)PACED_THREADS, nb, (uint32_t)BSORT_THREADS, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
             if (total > 0)
-                launch_sliced(slice_wgs * 8, bucket_pack_kernel, (uint32_t)((total + 255) / 256), 256u, stream, (const float4*)d_bucket_tmp,
+                launch_paced(slice_wgs * 8, paced_wgs, bucket_pack_kernel, bucket_pack_paced_kernel, 4u, (uint32_t)((total + 255) / 256), 256u, stream, (const float4*)d_bucket_tmp,
                               (uint32_t)total, d_bxyz[level], d_bidx[level]);
         } else {                       // level 2: unordered records, every point remembers where it sits (deletions)
             if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {
@@ -761,7 +876,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
                 LV_REALLOC(d_cellpos, uint32_t, capacity);
                 backptr_cap = capacity;
             }
-            launch_sliced(slice_wgs, map_bucket_kernel<true>, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
+            launch_paced(slice_wgs, paced_wgs, map_bucket_kernel<true>, map_bucket_paced_kernel<true>, 16u, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
                           (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket4, d_backptr);
         }
         LV_HIP(hipGetLastError());

@@ -87,6 +87,7 @@ int main(int argc, char** argv) {
         int force_after2 = 0;   // LV_DEMO_FORCE_REBUILD2=K2: adopt the first rebuild (blocking, untimed), then force another one after update K2
         if (const char* e = getenv("LV_DEMO_FORCE_REBUILD2")) force_after2 = atoi(e);
         loop_times().on = getenv("LV_DEMO_TIMING") != nullptr;
+        FILE* cycle_dump = getenv("LV_DEMO_CYCLE_DUMP") ? fopen(getenv("LV_DEMO_CYCLE_DUMP"), "w") : nullptr;   // "cycle ms rebuild-state adopted journal" per line
         double t_ingest = 0.0, t_imu = 0.0;
         constexpr size_t STEADY_AFTER = 30;   // the first three sweeps' worth of updates: first-touch allocations, buffers growing to size
         auto wall_steady0 = std::chrono::steady_clock::now();
@@ -126,6 +127,12 @@ int main(int argc, char** argv) {
                 const auto cyc0 = std::chrono::steady_clock::now();
                 if (!run_cycle(accum, comp, loc, map, clk, on_device, &Xt2, &np)) break;
                 cycle_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - cyc0).count());
+                if (cycle_dump) {   // (diagnostic: every cycle's time beside the background rebuild's state, read outside the timed part)
+                    uint64_t rs[4] = {0, 0, 0, 0};
+                    lv_map_rebuild_status(HipRuntime::ctx(), 0, rs);
+                    fprintf(cycle_dump, "%zu %.4f %llu %llu %llu\n", cycle_s.size(), 1e3 * cycle_s.back(), (unsigned long long)rs[0], (unsigned long long)rs[2],
+                            (unsigned long long)rs[3]);
+                }
                 if (force_after2 > 0 && out_t.size() + 1 == (size_t)force_after2) {
                     // a SECOND forced background rebuild: the first one is adopted first (a blocking wait, outside the cycle
                     // timing) so that this one runs into a store whose buffers are all allocated — the steady state of a node
@@ -204,6 +211,7 @@ int main(int argc, char** argv) {
                n, wall_s, n / wall_s, steady, (int)on_device, n ? mean_pts / n : 0.0, (size_t)map.size(), 1e3 * c_med, 1e3 * c_p99, 1e3 * c_max,
                force_after, (int)force_sync, 1e3 * forced_call_s, 1e3 * c_max_after, force_after2, 1e3 * c_med_after2, 1e3 * c_p99_after2, 1e3 * c_max_after2,
                (unsigned long long)rb[1], (unsigned long long)rb[2]);
+        if (cycle_dump) fclose(cycle_dump);
         HipRuntime::shutdown();
         return 0;
     } catch (const std::exception& e) {

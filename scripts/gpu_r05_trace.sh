@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r05_trace
 mkdir -p $O
 cd /tmp
-LV_STREAM_ROCPROF=$O/prof LV_STREAM_AB="forced_async=LV_DEMO_FORCE_REBUILD=80,LV_SLOW_CALL_MS=1.5" LV_STREAM_ONLY_AB=1 timeout 1500 python $GRAFT_REPO_ROOT/scripts/stream_bench_cpp.py 2>$O/err.txt | tail -1 > $O/stream.json
+LV_STREAM_ROCPROF=$O/prof LV_STREAM_AB="forced_async=LV_DEMO_FORCE_REBUILD=80,LV_SLOW_CALL_MS=${SLOW_MS:-1.5}${SLICE:+,LV_RELIN_SLICE_WGS=$SLICE}" LV_STREAM_ONLY_AB=1 timeout 1500 python $GRAFT_REPO_ROOT/scripts/stream_bench_cpp.py 2>$O/err.txt | tail -1 > $O/stream.json
 grep "slow call" $O/err.txt | head -40
 python - <<PY
 import csv, glob, collections
@@ -35,9 +35,9 @@ first_pass = min(int(r["Start_Timestamp"]) for r in rows if "pass_kernel" in r["
 for r in rows:
     if r["Queue_Id"] in mq or int(r["Start_Timestamp"]) < first_pass: continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    if d > 0.25:
+    if d > ${OTHER_MS:-0.25}:
         a = agg[r["Kernel_Name"].split("(")[0][:70]]; a[0] += 1; a[1] = max(a[1], d); a[2] += d
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]): print("other-queue kernel > 0.25 ms: %-72s n %4d  max %7.3f ms  total %8.3f ms" % (k, v[0], v[1], v[2]))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]): print("other-queue kernel > ${OTHER_MS:-0.25} ms: %-72s n %4d  max %7.3f ms  total %8.3f ms" % (k, v[0], v[1], v[2]))
 # the main queue = the one holding pass_kernel: list its gaps > 1 ms
 mainq = [qid for qid, rs in byq.items() if any("pass_kernel" in r["Kernel_Name"] for r in rs)]
 print("main queues", mainq)
@@ -48,7 +48,7 @@ for qid in mainq:
     for a, b in zip(rs, rs[1:]):
         gap = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e6
         dur = (int(b["End_Timestamp"]) - int(b["Start_Timestamp"])) / 1e6
-        if gap > 1.0 or dur > 1.0:
+        if gap > ${EVENT_MS:-1.0} or dur > ${EVENT_MS:-1.0}:
             out.append((round((int(b["Start_Timestamp"]) - t0) / 1e6, 3), round(gap, 3), round(dur, 3), b["Kernel_Name"][:70]))
 for o in out[:60]: print("main-queue event: at %.3f ms gap-before %.3f ms duration %.3f ms %s" % o)
 PY
