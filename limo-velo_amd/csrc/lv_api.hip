@@ -74,6 +74,7 @@ struct lv_ctx {
     std::string relin_error;
     hipStream_t relin_stream = nullptr;
     hipEvent_t relin_snapshot = nullptr;
+    bool relin_snap_side = false;         // the snapshot was enqueued on the side stream and the context's stream has not been ordered behind it yet (relin_order)
     bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
@@ -967,6 +968,10 @@ void relin_cancel(lv_ctx* c) {
         }
         c->relin_worker.join();
     }
+    if (c->relin_snap_side) {   // (a snapshot may still be reading the active store on the side stream: build / relinearise rewrite it)
+        if (c->side_stream) hipStreamSynchronize(c->side_stream);
+        c->relin_snap_side = false;
+    }
     for (auto& e : c->relin_journal) relin_free_entry(e);
     c->relin_journal.clear();
     c->relin_state = 0;
@@ -988,9 +993,19 @@ int relin_poll(lv_ctx* c) {
             int rr = c->relin_shadow.reserve((size_t)c->map.m + 1);
             if (rr) return rr;
         }
-        int rc = c->map.snapshot_into(c->relin_shadow, c->stream);
+        // The snapshot only READS the active store: with the context's own stream it goes to the side stream (behind everything
+        // the context's stream holds so far), where the inserts run as well — the cycle's next prediction / window / update do not
+        // queue up behind the compaction of every id (0.3-0.4 ms at 10 M points: it was the slowest cycle of a rebuild).  What
+        // MUTATES the map afterwards is ordered behind it: inserts by running on the side stream, anything on the context's
+        // stream by relin_order().
+        hipStream_t ss = c->stream;
+        if (c->overlap_insert && c->side_stream && c->stream == c->own_stream && hipEventRecord(c->ev_staged, c->stream) == hipSuccess &&
+            hipStreamWaitEvent(c->side_stream, c->ev_staged, 0) == hipSuccess)
+            ss = c->side_stream;
+        int rc = c->map.snapshot_into(c->relin_shadow, ss);
         if (rc) return rc;
-        LV_HIP(hipEventRecord(c->relin_snapshot, c->stream));
+        LV_HIP(hipEventRecord(c->relin_snapshot, ss));
+        c->relin_snap_side = ss != c->stream;
         std::lock_guard<std::mutex> g(c->relin_mu);
         c->relin_state = 1;
         c->relin_cv.notify_all();
@@ -1008,6 +1023,7 @@ int relin_poll(lv_ctx* c) {
     std::swap(c->map, c->relin_shadow);           // (relin_shadow is the OLD active store from here on: it carries the history)
     c->map.slice_wgs = 0;
     c->map.paced_wgs = 0;
+    c->relin_snap_side = false;   // (the snapshot was complete before the worker's first launch)
     c->map.defer_relinearise = false;
     c->relin_shadow.defer_relinearise = false;
     c->map.relinearisations = c->relin_shadow.relinearisations + 1;
@@ -1039,6 +1055,14 @@ int relin_maybe_start(lv_ctx* c, size_t incoming) {
     if ((uint64_t)c->map.n_ids + incoming > 0xFFFFFFF0ull) return LV_OK;     // id space exhausted: only the stop-the-world path helps
     if (!c->map.wants_relinearise(incoming)) return LV_OK;
     return relin_start(c);
+}
+
+// a mutation of the active map is about to be enqueued on `s`: it must not overtake a snapshot that is being taken on the side stream
+int relin_order(lv_ctx* c, hipStream_t s) {
+    if (!c->relin_snap_side || s == c->side_stream) return LV_OK;
+    LV_HIP(hipStreamWaitEvent(s, c->relin_snapshot, 0));
+    if (s == c->stream) c->relin_snap_side = false;   // (everything later on the context's stream is behind it as well)
+    return LV_OK;
 }
 
 // journal a batch staged in c->map.d_new (copied on the context's stream, which staged it) for the worker to replay
@@ -1148,7 +1172,10 @@ int lv_map_add(lv_ctx* c, const void* points, size_t stride, size_t n, int downs
     if (rc) return rc;
     rc = relin_journal_add(c, (uint32_t)n, downsample, 0.2f, false);
     if (rc) return rc;
-    return c->map.add_staged(insert_stream(c), (uint32_t)n, downsample, 0.2f, false);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
+    hipStream_t is = insert_stream(c);
+    rc = relin_order(c, is);
+    if (rc) return rc;
+    return c->map.add_staged(is, (uint32_t)n, downsample, 0.2f, false);  // box_length of KD_TREE(0.3, 0.6, 0.2), Mapper.cpp:65
 }
 
 namespace {
@@ -1193,7 +1220,10 @@ int lv_map_add_scan(lv_ctx* c, int downsample) {
     // stream: a caller-provided stream keeps everything on that stream.
     rc = relin_journal_add(c, n, downsample, 0.2f, true);
     if (rc) return rc;
-    return c->map.add_staged(insert_stream(c), n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
+    hipStream_t is = insert_stream(c);
+    rc = relin_order(c, is);
+    if (rc) return rc;
+    return c->map.add_staged(is, n, downsample, 0.2f, true);   // Mapper::add: an empty map is built from the cloud
 }
 
 int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_inside, size_t* n_evicted) {
@@ -1203,7 +1233,8 @@ int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_i
     LV_SETTLE_MAP(c);
     LV_RELIN_POLL(c);
     relin_journal_evict(c, 2, lo, hi, keep_inside, 0);
-    int rc = c->map.evict_box(c->stream, lo, hi, keep_inside, &ne);
+    int rc = relin_order(c, c->stream);
+    if (!rc) rc = c->map.evict_box(c->stream, lo, hi, keep_inside, &ne);
     if (n_evicted) *n_evicted = ne;
     return rc;
 }
@@ -1214,7 +1245,8 @@ int lv_map_evict_oldest(lv_ctx* c, size_t n_oldest, size_t* n_evicted) {
     LV_SETTLE_MAP(c);
     LV_RELIN_POLL(c);
     relin_journal_evict(c, 3, nullptr, nullptr, 0, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest));
-    int rc = c->map.evict_oldest(c->stream, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest), &ne);
+    int rc = relin_order(c, c->stream);
+    if (!rc) rc = c->map.evict_oldest(c->stream, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest), &ne);
     if (n_evicted) *n_evicted = ne;
     return rc;
 }

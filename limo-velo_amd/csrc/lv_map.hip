@@ -969,6 +969,13 @@ int MapStore::reserve_batch(size_t k) {
     return LV_OK;
 }
 
+// (paced twin of box_build_kernel, lv_mapinc.hpp: the worker's replay builds the copy's box table beside the running cycle — as
+// back-to-back slices of small workgroups it cost the cycle that met it 4.5 ms, the whole table: profiles/experiments_r05/async_rebuild.txt)
+__global__ __launch_bounds__(PACED_THREADS) void box_build_paced_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt,
+                                                                        uint32_t vb_begin, uint32_t vb_end) {
+    LV_PACED_FOR(256, vb) box_build_item(B, orig, n_ids, cnt, vb * 256u + threadIdx.x % 256u);
+}
+
 int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     if (have_boxes) return LV_OK;
     const uint32_t size = next_pow2((uint64_t)capacity * 4);
@@ -985,7 +992,8 @@ int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     BoxRW Bx{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
     // (ALWAYS sliced: the boxes are built by the first down-sampling insert after a (re)build, on the insert's side stream,
     // beside the cycle's whole-CU launches — 4 ms in one piece at 10 M ids, ~0.1 ms per slice of 1024 workgroups)
-    if (n_ids) launch_sliced(1024u, box_build_kernel, (n_ids + 255) / 256, 256u, stream, Bx, (const float4*)d_orig, n_ids, d_cnt);
+    if (n_ids) launch_paced(paced_wgs ? slice_wgs * 8 : 1024u, paced_wgs, box_build_kernel, box_build_paced_kernel, 4u, (n_ids + 255) / 256, 256u, stream, Bx,
+                            (const float4*)d_orig, n_ids, d_cnt);
     LV_HIP(hipGetLastError());
     have_boxes = true;
     return LV_OK;

@@ -204,14 +204,16 @@ __device__ __forceinline__ uint32_t box_find_or_create(const BoxRW& B, uint64_t 
 
 // every living id -> its box chain (first down-sampling insert after a (re)build)
 // (block_base: the launch may be one slice of the grid — MapStore::launch_sliced)
-__global__ void box_build_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt, uint32_t block_base = 0) {
-    const uint32_t id = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void box_build_item(const BoxRW& B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt, uint32_t id) {
     if (id >= n_ids) return;
     const float4 p = orig[id];
     if (!pt_alive(p)) { B.next[id] = ID_NONE; return; }
     const uint32_t slot = box_find_or_create(B, inc_box_key(p, B.len), cnt);
     if (slot == ID_NONE) return;
     B.next[id] = atomicExch(&B.table[slot].z, id);
+}
+__global__ void box_build_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt, uint32_t block_base = 0) {
+    box_build_item(B, orig, n_ids, cnt, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
 }
 
 // keys of the new points for the stable sort by box; points that cannot be inserted sort last
