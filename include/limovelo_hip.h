@@ -412,8 +412,9 @@ int lv_set_fused_pass(lv_ctx* ctx, int enabled);
  * round 3; default: up to 16), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused", "small_window" / "small_insert" (windows /
  * insert batches of up to 2048 points take their one-launch forms), "multi_overlap" (0: multi-round scans fit every round
  * between two barriers), "async_relinearise" / "async_relinearise_min" (the background map rebuild, lv_map_relinearise_async),
- * "async_relinearise_paced_wgs" (how many looping 1024-thread workgroups the worker's large grids run as; default 32, 0: the plain
- * kernels in slices of "async_relinearise_slice_wgs" workgroups, 0 there: whole grids), "async_relinearise_paced_slice".
+ * "async_relinearise_slice_wgs" (the worker's large grids go out in slices of that many workgroups; default 256, 0: whole grids),
+ * "async_relinearise_paced_wgs" (opt-in: those grids as that many looping 1024-thread workgroups instead; 32 is the measured
+ * choice, default 0) with "async_relinearise_paced_slice".
  * None of those changes a result beyond the summation order of the workgroup partials.  ONE option does: "fast_fit" (default
  * 0) switches pass_kernel's plane fit to hardware reciprocal / square root + one Newton step — within a few f32 ulps of the
  * exact path, NOT bit-exact against the reference (tests/test_gpu_fast_fit.py states the flips and the state difference);

@@ -79,9 +79,10 @@ struct lv_ctx {
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
     uint32_t relin_slice_wgs = 256;       // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids) when they are not paced
-    uint32_t relin_paced_wgs = 32;        // LV_RELIN_PACED_WGS: the worker's large grids as at most this many 1024-thread workgroups that loop (0: plain slices):
-                                          // an eighth of the CUs — a whole-CU workgroup of the cycle always finds a free one, and the rebuild's memory
-                                          // traffic stays a fraction of what the cycle's searches can use (profiles/experiments_r05/async_rebuild.txt)
+    uint32_t relin_paced_wgs = 0;         // LV_RELIN_PACED_WGS (opt-in; 32 is the measured choice): the worker's large grids as at most this many 1024-thread
+                                          // workgroups that loop — a whole-CU workgroup of the cycle always finds a free CU: p99 0.5 ms instead of 0.6, 22
+                                          // instead of 49 slow cycles of 281 — but in 5 of 17 replays the rebuild ran 10x longer and two cycles took 4.6 ms
+                                          // (never seen in 17 replays with plain slices; not understood: profiles/experiments_r05/async_rebuild.txt §10-11)
     uint32_t relin_paced_slice = 32768;   // LV_RELIN_PACED_SLICE: virtual blocks of the heaviest kernel per paced launch
     bool relin_test_race = false;         // lv_set_option "async_relinearise_test_race": see relin_journal_add
     int relin_test_delay_ms = 0;          // lv_set_option "async_relinearise_test_delay_ms": the worker pauses between rebuild and replay (tests)
