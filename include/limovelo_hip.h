@@ -165,8 +165,9 @@ size_t lv_map_size(lv_ctx* ctx);
 int    lv_map_fetch(lv_ctx* ctx, float* xyz_out, size_t capacity);
 typedef struct lv_map_stats {
     uint64_t living, ids, capacity;          /* points alive / ids handed out since the last re-linearisation / id slots allocated */
-    uint64_t pool_used[4], pool_cap[4];      /* entries of the level-0 / 1 / 2 bucket pools and of the voxel-list pool */
-    uint64_t slots_used[4], slots_cap[4];    /* occupied / total slots of the four hash tables */
+    uint64_t pool_used[4], pool_cap[4];      /* entries of [0] the level-0 bucket pool, [1] the voxel-list pool ([2], [3] unused since the
+                                                single-replicated-level map of round 6; rounds 1-5: three bucket pools + the lists) */
+    uint64_t slots_used[4], slots_cap[4];    /* occupied / total slots of [0] the bucket table, [1] the voxel-list table */
     uint64_t tombstones, dropped;            /* dead bucket entries since the last rebuild; points refused (non-finite / out of range) */
     uint64_t relinearisations, incremental_adds;
     uint64_t bytes;                          /* device memory held by the map */
@@ -412,9 +413,8 @@ int lv_set_fused_pass(lv_ctx* ctx, int enabled);
  * round 3; default: up to 16), "keeper_by_cost", "tile_lpt", "spin_wait", "comm_fused", "small_window" / "small_insert" (windows /
  * insert batches of up to 2048 points take their one-launch forms), "multi_overlap" (0: multi-round scans fit every round
  * between two barriers), "async_relinearise" / "async_relinearise_min" (the background map rebuild, lv_map_relinearise_async),
- * "async_relinearise_slice_wgs" (the worker's large grids go out in slices of that many workgroups; default 256, 0: whole grids),
- * "async_relinearise_paced_wgs" (opt-in: those grids as that many looping 1024-thread workgroups instead; 32 is the measured
- * choice, default 0) with "async_relinearise_paced_slice".
+ * "async_relinearise_slice_wgs" (the worker's large grids go out in slices of that many workgroups; default 256, 0: whole grids;
+ * round 5's opt-in "async_relinearise_paced_*" form was removed in round 6: LV_EINVAL like any unknown name).
  * None of those changes a result beyond the summation order of the workgroup partials.  ONE option does: "fast_fit" (default
  * 0) switches pass_kernel's plane fit to hardware reciprocal / square root + one Newton step — within a few f32 ulps of the
  * exact path, NOT bit-exact against the reference (tests/test_gpu_fast_fit.py states the flips and the state difference);

@@ -78,12 +78,9 @@ struct lv_ctx {
     bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
     uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
-    uint32_t relin_slice_wgs = 256;       // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids) when they are not paced
-    uint32_t relin_paced_wgs = 0;         // LV_RELIN_PACED_WGS (opt-in; 32 is the measured choice): the worker's large grids as at most this many 1024-thread
-                                          // workgroups that loop — a whole-CU workgroup of the cycle always finds a free CU: p99 0.5 ms instead of 0.6, 22
-                                          // instead of 49 slow cycles of 281 — but in 5 of 17 replays the rebuild ran 10x longer and two cycles took 4.6 ms
-                                          // (never seen in 17 replays with plain slices; not understood: profiles/experiments_r05/async_rebuild.txt §10-11)
-    uint32_t relin_paced_slice = 32768;   // LV_RELIN_PACED_SLICE: virtual blocks of the heaviest kernel per paced launch
+    uint32_t relin_slice_wgs = 256;       // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids).  (Round 5's opt-in PACED form — the
+                                          // grids as at most 32 looping 1024-thread workgroups — is gone: p99 0.5 instead of 0.6 ms, but two 4.6 ms cycles in 5 of
+                                          // 17 replays that plain slices never showed, cause not found: profiles/experiments_r05/async_rebuild.txt §10-11)
     bool relin_test_race = false;         // lv_set_option "async_relinearise_test_race": see relin_journal_add
     int relin_test_delay_ms = 0;          // lv_set_option "async_relinearise_test_delay_ms": the worker pauses between rebuild and replay (tests)
 
@@ -701,8 +698,6 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("LV_ASYNC_RELINEARISE")) c->relin_async = atoi(e) != 0;
     if (const char* e = getenv("LV_RELIN_SLICE_WGS")) c->relin_slice_wgs = (uint32_t)atol(e);
-    if (const char* e = getenv("LV_RELIN_PACED_WGS")) c->relin_paced_wgs = (uint32_t)atol(e);
-    if (const char* e = getenv("LV_RELIN_PACED_SLICE")) c->relin_paced_slice = (uint32_t)atol(e);
     if (const char* e = getenv("LV_MULTI_OVERLAP")) c->multi_overlap = atoi(e) != 0;   // A/B: 0 = every round's fits between two barriers
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
@@ -907,10 +902,8 @@ void relin_worker_main(lv_ctx* c) {
     S.n_ids = 0;
     S.m = 0;
     S.built = false;
-    // the worker's big kernels never hold more than half of the compute units (MapStore::launch_paced), or, unpaced, leave them
-    // every ~0.1 ms (launch_sliced)
-    S.paced_wgs = c->relin_slice_wgs ? c->relin_paced_wgs : 0;
-    S.slice_wgs = S.paced_wgs ? (c->relin_paced_slice ? c->relin_paced_slice : 32768u) : c->relin_slice_wgs;
+    // the worker's big kernels leave the compute units every ~0.1 ms (launch_sliced, lv_map.hip)
+    S.slice_wgs = c->relin_slice_wgs;
     if (S.reserve(c->relin_want) != LV_OK) { fail("reserve"); return; }
     if (!c->relin_arena) {
         if (hipMalloc(&c->relin_arena, c->relin_arena_bytes) != hipSuccess) { c->relin_arena = nullptr; (void)hipGetLastError(); }
@@ -1023,7 +1016,6 @@ int relin_poll(lv_ctx* c) {
     // are ordered behind everything enqueued on the context's stream so far) — so the swap needs no wait at all.
     std::swap(c->map, c->relin_shadow);           // (relin_shadow is the OLD active store from here on: it carries the history)
     c->map.slice_wgs = 0;
-    c->map.paced_wgs = 0;
     c->relin_snap_side = false;   // (the snapshot was complete before the worker's first launch)
     c->map.defer_relinearise = false;
     c->relin_shadow.defer_relinearise = false;
@@ -1663,8 +1655,6 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "fast_fit")) c->fast_fit = on;
     else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
     else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
-    else if (!std::strcmp(name, "async_relinearise_paced_wgs")) c->relin_paced_wgs = value > 0 ? (uint32_t)value : 0u;      // 0: plain slices
-    else if (!std::strcmp(name, "async_relinearise_paced_slice")) c->relin_paced_slice = value > 0 ? (uint32_t)value : 0u;
     else if (!std::strcmp(name, "async_relinearise_slice_wgs")) c->relin_slice_wgs = value > 0 ? (uint32_t)value : 0u;      // 0: whole grids
     else if (!std::strcmp(name, "async_relinearise_test_delay_ms")) c->relin_test_delay_ms = value;
     else if (!std::strcmp(name, "async_relinearise_test_race")) c->relin_test_race = on;

@@ -23,10 +23,18 @@ constexpr int PARTIAL_GROUP = 32;  // block partials folded per group record (st
 constexpr int N_OUT = 92;           // used entries of the record
 constexpr int CELL_OFFSET = 1 << 20;
 constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-force path
-constexpr int MAX_LEVELS = 3;             // voxel levels with tables: edge voxel_size * 2^l
-constexpr int REPL_LEVELS = 3;            // levels 0, 1, 2: 27-fold replicated neighbourhood buckets
-constexpr int SORTED_LEVELS = 2;          // levels 0, 1 (the common path): buckets in ascending id, 12-byte points
-constexpr int CELL_LEVEL = 2;             // level-2 voxels also keep one plain point list each (the level-3 block = 216 lists)
+constexpr int MAX_LEVELS = 3;             // voxel levels of the search: edge voxel_size * 2^l (the Morton key resolves three bits per level)
+// Round 6: ONE level of 27-fold replicated neighbourhood buckets (level 0).  The 27-voxel block of a LEVEL-1 voxel v — level-0 voxels
+// [2v - 2, 2v + 4) per axis — is tiled exactly by the EIGHT level-0 buckets centred on voxels 2v - 1 and 2v + 2 per axis (each covers
+// three voxels per axis, disjoint), so level 1 is searched in the level-0 structure (tiles_attempt, lv_match.hip) and stores nothing
+// of its own; levels 2 and 3 are searched as the 27 / 216 un-replicated level-2 voxel lists.  Rounds 1-5 replicated three levels:
+// 4.1 KB per map point, 81 runs touched per inserted point, 266 DRAM lines per deleted one.
+constexpr int REPL_LEVELS = 1;            // level 0: 27-fold replicated neighbourhood buckets
+constexpr int SORTED_LEVELS = 1;          // ... in ascending id, 12-byte points (== REPL_LEVELS: there is no unordered replicated level any more)
+constexpr int CELL_LEVEL = 2;             // level-2 voxels keep one plain point list each (level-2 block = 27 lists, level-3 block = 216)
+constexpr int N_OCC = 2;                  // occupancy tables of a (re)build: [0] level-0 voxels, [1] level-2 voxels (lives on as the voxel-list table)
+constexpr int OCC_CELL = 1;
+__host__ __device__ constexpr int occ_level(int t) { return t == 0 ? 0 : CELL_LEVEL; }
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr int MAX_PASSES = 16;
 
@@ -150,18 +158,16 @@ struct MapView {
     float origin[3];
     float cell;             // level-0 cell edge
     float inv_cell;
-    // levels 0, 1, 2: for every voxel whose 3x3x3 block holds at least one point, the points of that block in one
-    // contiguous run ("bucket") with slack behind it for appends.  bt[l].table entries are {key lo, key hi, bucket
-    // start, bucket count}.  Levels 0, 1: ascending id (deleted entries keep their place with x = +inf), 12-byte
-    // points (what the search streams) + a parallel id array (capturing launches / non-staged winners /
-    // deletions).  Level 2 (a handful of points per scan, ~1000 candidates each, searched by whole wavefronts with
-    // (distance, id) keys): unordered {x, y, z, id} records.
+    // level 0: for every voxel whose 3x3x3 block holds at least one point, the points of that block in one
+    // contiguous run ("bucket") with slack behind it for appends.  bt[0].table entries are {key lo, key hi, bucket
+    // start, bucket count}; ascending id (deleted entries keep their place with x = +inf), 12-byte points (what the
+    // search streams) + a parallel id array (capturing launches / deletions).  The level-1 block is eight of these
+    // buckets (see REPL_LEVELS).
     GridLevel bt[REPL_LEVELS];
     const float* bxyz[SORTED_LEVELS];
     const uint32_t* bidx[SORTED_LEVELS];
-    const float4* bucket4;
-    // one plain list of {x, y, z, id} records per level-2 voxel: the level-3 block (beyond the buckets) is searched as
-    // the 216 lists that tile it
+    // one plain list of {x, y, z, id} records per level-2 voxel: the level-2 block is searched as the 27 lists around the
+    // query's voxel, the level-3 block as the 216 lists that tile it (whole wavefronts, (distance, id) keys)
     GridLevel ct;
     const float4* cell4;
 };

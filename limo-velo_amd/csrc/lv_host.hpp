@@ -48,21 +48,21 @@ struct MapStore {
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t* d_counts = nullptr;
-    uint4* d_tables[MAX_LEVELS] = {};      // occupied voxels -> run in d_sorted; [2] lives on as the voxel-list table
-    uint32_t table_size[MAX_LEVELS] = {};
-    uint32_t n_cells[MAX_LEVELS] = {};
-    // ---- levels 0, 1: neighbourhood buckets with slack
+    uint4* d_tables[N_OCC] = {};           // occupied voxels -> run in d_sorted: [0] level 0, [OCC_CELL] level 2 (lives on as the voxel-list table)
+    uint32_t table_size[N_OCC] = {};
+    uint32_t n_cells[N_OCC] = {};
+    // ---- level 0: neighbourhood buckets with slack (built straight into their pool: no float4 staging copy since round 6)
     uint4* d_btable[REPL_LEVELS] = {};
     SlotAux* d_baux[REPL_LEVELS] = {};
     uint32_t btable_size[REPL_LEVELS] = {};
-    float4* d_bucket_tmp = nullptr;   // build scratch: one level's buckets as float4 {x,y,z,id} (fill + sort), then packed
-    size_t bucket_tmp_cap = 0;
-    float* d_bxyz[SORTED_LEVELS] = {};    // levels 0, 1: 12-byte points: what the search kernel streams
+    float* d_bxyz[SORTED_LEVELS] = {};    // 12-byte points: what the search kernel streams
     uint32_t* d_bidx[SORTED_LEVELS] = {}; // ids (ascending inside a bucket)
-    float4* d_bucket4 = nullptr;          // level 2: unordered {x, y, z, id} records
-    uint32_t* d_backptr = nullptr;        // [id * 27 + c]: position of a point in the level-2 bucket of its neighbour c
-    uint32_t* d_cellpos = nullptr;        // [id]: position of a point in its voxel's list (allocated with d_backptr)
-    size_t backptr_cap = 0;               // ids it is allocated for
+    uint16_t* d_backpos = nullptr;        // [id * 27 + c]: position of a point inside the bucket of its neighbour c (BACKPOS_FAR: beyond 16 bits,
+                                          // found by binary search): a deletion is 27 probes + 27 direct writes
+    uint32_t* d_cellpos = nullptr;        // [id]: position of a point in its voxel's list (allocated with d_backpos)
+    size_t backptr_cap = 0;               // ids they are allocated for
+    uint32_t* d_biglist = nullptr;        // build scratch: buckets of more than 64 points (a workgroup each)
+    size_t biglist_cap = 0;
     size_t pool_cap[INC_LEVELS] = {};     // entries per pool ([CELL_SLOT]: d_cell4)
     uint32_t pool_base[INC_LEVELS] = {};  // entries laid out by the last (re)build; the rest is split into arenas
     uint32_t n_bcells[REPL_LEVELS] = {};
@@ -101,7 +101,7 @@ struct MapStore {
     uint32_t* d_pslot = nullptr;
     uint32_t* d_gbase[REPL_LEVELS] = {};
     uint32_t* d_gslot[REPL_LEVELS] = {};
-    uint2* d_gdst[REPL_LEVELS] = {};
+    uint4* d_gdst[REPL_LEVELS] = {};
     uint32_t* d_gcnt = nullptr;        // [0] relocations of the batch
     uint4* d_reloc = nullptr;
     uint32_t reloc_cap = 0;
@@ -161,7 +161,6 @@ struct MapStore {
     // background re-linearisation (lv_api.hip, round 5): while a compacted copy of this map is being rebuilt on another stream /
     // thread, the stop-the-world relinearise is deferred (only id-space exhaustion still forces it)
     bool defer_relinearise = false;
-    uint32_t paced_wgs = 0;   // != 0 (with slice_wgs != 0): those grids as at most this many 1024-thread workgroups looping over the slice (launch_paced, lv_map.hip)
     uint32_t slice_wgs = 0;   // != 0: the large grids of a (re)build go out in slices of that many workgroups (a store rebuilt in the background)
     bool wants_relinearise(size_t incoming) const;   // the trigger, whatever defer_relinearise says
     // the living points of this map, compacted in id order, into dst.d_orig (dst: an idle store whose search structure is not

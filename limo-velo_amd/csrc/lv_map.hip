@@ -44,7 +44,7 @@ __global__ void map_gather_kernel(const float4* __restrict__ pts, const uint32_t
     sorted[i] = p;
 }
 
-// number of levels (from 0) at which element i starts a new voxel
+// number of Morton levels (from 0) at which element i starts a new voxel
 __device__ __forceinline__ int head_levels(const uint64_t* keys, uint32_t i, int n_levels) {
     if (i == 0) return n_levels;
     uint64_t x = keys[i] ^ keys[i - 1];
@@ -54,47 +54,20 @@ __device__ __forceinline__ int head_levels(const uint64_t* keys, uint32_t i, int
     return nl < n_levels ? nl : n_levels;
 }
 
-__global__ void map_count_heads_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels,
-                                       uint32_t* __restrict__ counts, uint32_t block_base) {
-    __shared__ uint32_t s_cnt[MAX_LEVELS];
-    if (threadIdx.x < MAX_LEVELS) s_cnt[threadIdx.x] = 0;
+// occupied voxels per occupancy table (level 0, level 2)
+__global__ void map_count_heads_kernel(const uint64_t* __restrict__ keys, uint32_t m, uint32_t* __restrict__ counts, uint32_t block_base) {
+    __shared__ uint32_t s_cnt[N_OCC];
+    if (threadIdx.x < N_OCC) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     uint32_t i = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
     if (i < m) {
-        int nl = head_levels(keys, i, n_levels);
-        for (int l = 0; l < nl; ++l) atomicAdd(&s_cnt[l], 1u);
+        const int nl = head_levels(keys, i, MAX_LEVELS);
+#pragma unroll
+        for (int t = 0; t < N_OCC; ++t)
+            if (nl > occ_level(t)) atomicAdd(&s_cnt[t], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < n_levels && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
-}
-
-// Paced form (background rebuild, see launch_sliced): at most `gridDim.x` workgroups of PACED_THREADS threads loop over the
-// virtual blocks [vb_begin, vb_end) of the plain form — the grid never occupies more than half of the compute units, so a
-// workgroup of another stream that needs a whole one (pass_kernel) always finds one (scripts/ubench/half_chip_flood.hip).
-constexpr int PACED_THREADS = 1024;
-#define LV_PACED_FOR(VB, vb)                                                                                          \
-    for (uint32_t vb = vb_begin + blockIdx.x * (uint32_t)(PACED_THREADS / (VB)) + threadIdx.x / (uint32_t)(VB); vb < vb_end; \
-         vb += gridDim.x * (uint32_t)(PACED_THREADS / (VB)))
-__global__ __launch_bounds__(PACED_THREADS) void map_count_heads_paced_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels,
-                                                                              uint32_t* __restrict__ counts, uint32_t vb_begin, uint32_t vb_end) {
-    uint32_t mine[MAX_LEVELS];
-#pragma unroll
-    for (int l = 0; l < MAX_LEVELS; ++l) mine[l] = 0;
-    LV_PACED_FOR(256, vb) {
-        const uint32_t i = vb * 256u + threadIdx.x % 256u;
-        if (i < m) {
-            const int nl = head_levels(keys, i, n_levels);
-#pragma unroll
-            for (int l = 0; l < MAX_LEVELS; ++l) mine[l] += l < nl ? 1u : 0u;
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < MAX_LEVELS; ++l) {   // one atomic per wavefront and level
-        uint32_t v = mine[l];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63u) == 0 && v && l < n_levels) atomicAdd(&counts[l], v);
-    }
+    if (threadIdx.x < N_OCC && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 struct GridLevelW {
@@ -104,16 +77,19 @@ struct GridLevelW {
 };
 
 struct TablePtrs {
-    uint4* table[MAX_LEVELS];
-    uint32_t mask[MAX_LEVELS];
-    uint32_t shift[MAX_LEVELS];
+    uint4* table[N_OCC];
+    uint32_t mask[N_OCC];
+    uint32_t shift[N_OCC];
 };
 
-__device__ __forceinline__ void map_insert_item(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, const TablePtrs& tp, uint32_t i) {
+__device__ __forceinline__ void map_insert_item(const uint64_t* __restrict__ keys, uint32_t m, const TablePtrs& tp, uint32_t i) {
     if (i >= m) return;
-    int nl = head_levels(keys, i, n_levels);
+    const int nl = head_levels(keys, i, MAX_LEVELS);
     uint64_t k0 = keys[i];
-    for (int l = 0; l < nl; ++l) {
+#pragma unroll
+    for (int t = 0; t < N_OCC; ++t) {
+        const int l = occ_level(t);
+        if (nl <= l) continue;
         uint64_t prefix = k0 >> (3 * l);
         // end = first j > i whose level-l prefix differs (keys are sorted)
         uint32_t lo = i + 1, hi = m;
@@ -124,8 +100,8 @@ __device__ __forceinline__ void map_insert_item(const uint64_t* __restrict__ key
         }
         uint32_t cx = compact21(k0) >> l, cy = compact21(k0 >> 1) >> l, cz = compact21(k0 >> 2) >> l;
         uint64_t key = pack_cell(cx, cy, cz);
-        uint32_t slot = hash_cell(key, tp.shift[l]) & tp.mask[l];
-        uint4* tbl = tp.table[l];
+        uint32_t slot = hash_cell(key, tp.shift[t]) & tp.mask[t];
+        uint4* tbl = tp.table[t];
         for (;;) {
             unsigned long long* kp = reinterpret_cast<unsigned long long*>(&tbl[slot]);
             unsigned long long old = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
@@ -134,25 +110,22 @@ __device__ __forceinline__ void map_insert_item(const uint64_t* __restrict__ key
                 tbl[slot].w = lo - i;
                 break;
             }
-            slot = (slot + 1) & tp.mask[l];
+            slot = (slot + 1) & tp.mask[t];
         }
     }
 }
-__global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp, uint32_t block_base) {
-    map_insert_item(keys, m, n_levels, tp, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
-}
-__global__ __launch_bounds__(PACED_THREADS) void map_insert_paced_kernel(const uint64_t* __restrict__ keys, uint32_t m, int n_levels, TablePtrs tp,
-                                                                         uint32_t vb_begin, uint32_t vb_end) {
-    LV_PACED_FOR(256, vb) map_insert_item(keys, m, n_levels, tp, vb * 256u + threadIdx.x % 256u);
+__global__ void map_insert_kernel(const uint64_t* __restrict__ keys, uint32_t m, TablePtrs tp, uint32_t block_base) {
+    map_insert_item(keys, m, tp, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
 }
 
 
 // ---- neighbourhood buckets -----------------------------------------------------------------------
-// For every level-l voxel c whose 3x3x3 block holds at least one point (the occupied voxels dilated by
+// For every level-0 voxel c whose 3x3x3 block holds at least one point (the occupied voxels dilated by
 // one), the points of that block are copied into one contiguous run ("bucket").  A query then needs ONE
-// hash probe and ONE coalesced stream per level instead of 27 probes + 27 short dependent gathers; the
+// hash probe and ONE coalesced stream instead of 27 probes + 27 short dependent gathers; the
 // search region, and therefore the exactness argument of lv_match.hip, is unchanged.  Every point lands
-// in 27 buckets per level: HBM capacity (288 GB) is traded for latency.
+// in 27 buckets: HBM capacity (288 GB) is traded for latency — on ONE level since round 6 (the level-1
+// block is eight of these buckets, lv_device.hpp REPL_LEVELS).
 __device__ __forceinline__ bool probe_cell(const GridLevelW& g, uint64_t key, uint32_t& start, uint32_t& count) {
     uint32_t slot = hash_cell(key, g.shift) & g.mask;
     for (;;) {
@@ -196,202 +169,176 @@ __global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridL
                                        uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t block_base) {
     bucket_register_item(occ, occ_slots, bt, cell_slots, cell_cap, flags, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
 }
-__global__ __launch_bounds__(PACED_THREADS) void bucket_register_paced_kernel(GridLevelW occ, uint32_t occ_slots, GridLevelW bt, uint32_t* __restrict__ cell_slots,
-                                                                              uint32_t cell_cap, uint32_t* __restrict__ flags, uint32_t vb_begin, uint32_t vb_end) {
-    // (the plain form's thread index is 32 bits wide as well: occ_slots * 27 < 2^32)
-    LV_PACED_FOR(256, vb) bucket_register_item(occ, occ_slots, bt, cell_slots, cell_cap, flags, vb * 256u + threadIdx.x % 256u);
-}
 
 // room a run of `count` entries is given when it is laid out (slack for appends; lv_mapinc.hpp relocates a run
-// that outgrows it)
-__host__ __device__ __forceinline__ uint32_t run_capacity(uint32_t count) { return count + (count / 2u > 8u ? count / 2u : 8u); }
+// that outgrows it, to 1.5 x its new size).  Round 6: a quarter of the count instead of half — with one replicated
+// level the slack IS the map's memory (27 x 16 bytes x slack per point).
+__host__ __device__ __forceinline__ uint32_t run_capacity(uint32_t count) { return count + (count / 4u > 8u ? count / 4u : 8u); }
 
-// pass 2 (count) / pass 3 (fill): one 64-lane workgroup per bucket voxel; lane c < 27 owns neighbour c
-template <bool FILL>
-__device__ __forceinline__ void map_bucket_cell(const GridLevelW& occ, const GridLevelW& bt, SlotAux* __restrict__ aux,
-                                                const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
-                                                const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
-                                                uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
-                                                float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t cell, int lane) {
-    if (cell >= n_cells) return;
-    const uint32_t slot = cell_slots[cell];
+// The 27 source runs (in `sorted`) of bucket voxel `cell`: lane c < 27 of a wavefront probes neighbour c of the bucket's voxel in the
+// occupancy table; returns this lane's (start, count) and the inclusive wave scan of the counts.
+__device__ __forceinline__ void bucket_sources(const GridLevelW& occ, const GridLevelW& bt, uint32_t slot, int lane, uint32_t& start, uint32_t& count,
+                                               uint32_t& incl, uint32_t& total) {
     const uint4 e = bt.table[slot];
     const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
     const uint32_t cx = (uint32_t)(key & 0x1fffff), cy = (uint32_t)((key >> 21) & 0x1fffff), cz = (uint32_t)((key >> 42) & 0x1fffff);
-    uint32_t start = 0, count = 0;
+    start = 0; count = 0;
     if (lane < 27) {
         const int dz = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dx = lane % 3 - 1;
         const uint32_t nx = cx + dx, ny = cy + dy, nz = cz + dz;
         if (nx < (1u << 21) && ny < (1u << 21) && nz < (1u << 21)) probe_cell(occ, pack_cell(nx, ny, nz), start, count);
     }
-    uint32_t incl = count;
+    incl = count;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         uint32_t v = __shfl_up(incl, off);
         if (lane >= off) incl += v;
     }
-    const uint32_t total = __shfl(incl, 63);
-    if (!FILL) {
-        if (lane == 0) { bcount[cell] = total; bcap[cell] = run_capacity(total); }
-    } else {
-        const uint32_t base = boff[cell] + (incl - count);
-        for (uint32_t j = 0; j < count; ++j) {
-            const float4 p = sorted[start + j];
-            bucket[(size_t)base + j] = p;
-            // seen from the point, this bucket's voxel is its neighbour 26 - lane (lane = offset of the point's voxel
-            // from the bucket's voxel)
-            if (backptr) backptr[(size_t)__float_as_uint(p.w) * 27 + (uint32_t)(26 - lane)] = (incl - count) + j;
-        }
-        if (lane == 0) {
-            bt.table[slot].z = boff[cell];
-            bt.table[slot].w = total;
-            aux[slot] = SlotAux{bcap[cell], 0u, 0u, 0u};
-        }
-    }
-}
-template <bool FILL>
-__global__ __launch_bounds__(64) void map_bucket_kernel(GridLevelW occ, GridLevelW bt, SlotAux* __restrict__ aux,
-                                                        const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
-                                                        const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
-                                                        uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
-                                                        float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t block_base) {
-    map_bucket_cell<FILL>(occ, bt, aux, cell_slots, n_cells, sorted, bcount, bcap, boff, bucket, backptr, blockIdx.x + block_base, (int)threadIdx.x);
-}
-template <bool FILL>
-__global__ __launch_bounds__(PACED_THREADS) void map_bucket_paced_kernel(GridLevelW occ, GridLevelW bt, SlotAux* __restrict__ aux,
-                                                                         const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
-                                                                         const float4* __restrict__ sorted, uint32_t* __restrict__ bcount,
-                                                                         uint32_t* __restrict__ bcap, const uint32_t* __restrict__ boff,
-                                                                         float4* __restrict__ bucket, uint32_t* __restrict__ backptr, uint32_t vb_begin, uint32_t vb_end) {
-    LV_PACED_FOR(64, vb) map_bucket_cell<FILL>(occ, bt, aux, cell_slots, n_cells, sorted, bcount, bcap, boff, bucket, backptr, vb, (int)(threadIdx.x & 63u));
+    total = __shfl(incl, 63);
 }
 
-// Sort every bucket by ORIGINAL index (ascending).  The match kernel orders candidates by
-// (distance, position-in-bucket); with this layout that equals the reference's (distance, index)
-// order, ties included.  Bitonic network in the "flip" form (always-ascending compare-exchange,
-// partners beyond n skipped == padding with +inf), valid for any n.  One workgroup per bucket.
-// small buckets (<= 64 points, the bulk at level 0): one wavefront per bucket, bitonic network through
-// cross-lane shuffles, no LDS, no barriers
-__device__ __forceinline__ void bucket_sort_wave_cell(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                      float4* __restrict__ bucket, uint32_t cell, int lane) {
+// pass 2 (count): one wavefront per bucket voxel; buckets of more than 64 points are listed for bucket_build_big_kernel
+__global__ __launch_bounds__(256) void bucket_count_kernel(GridLevelW occ, GridLevelW bt, const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
+                                                           uint32_t* __restrict__ bcount, uint32_t* __restrict__ bcap, uint32_t* __restrict__ biglist,
+                                                           uint32_t* __restrict__ flags, uint32_t block_base) {
+    const uint32_t cell = (blockIdx.x + block_base) * 4u + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
     if (cell >= n_cells) return;
-    const uint32_t n = bcount[cell];
-    if (n < 2 || n > 64) return;
-    float4* g = bucket + boff[cell];
-    float4 v = (uint32_t)lane < n ? g[lane] : make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+    uint32_t start, count, incl, total;
+    bucket_sources(occ, bt, cell_slots[cell], lane, start, count, incl, total);
+    if (lane == 0) {
+        bcount[cell] = total;
+        bcap[cell] = run_capacity(total);
+        if (total > 64u) biglist[atomicAdd(&flags[2], 1u)] = cell;
+    }
+}
+
+// where a point of the bucket around voxel (bx, by, bz) sits SEEN FROM THE POINT: the bucket's voxel is neighbour c of the point's
+// own voxel (what lv_mapinc.hpp calls target c) — the slot of the point's back-position
+__device__ __forceinline__ uint32_t backpos_slot(const float4& p, const float* origin, float inv_cell, uint32_t bx, uint32_t by, uint32_t bz) {
+    const int dx = (int)bx - cell_coord(p.x, origin[0], inv_cell), dy = (int)by - cell_coord(p.y, origin[1], inv_cell),
+              dz = (int)bz - cell_coord(p.z, origin[2], inv_cell);
+    return (uint32_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
+}
+struct BuildOut {
+    float* bxyz;
+    uint32_t* bidx;
+    uint16_t* backpos;
+    SlotAux* aux;
+    float origin[3];
+    float inv_cell;
+};
+__device__ __forceinline__ void bucket_emit(const BuildOut& o, size_t at, uint32_t pos, const float4& p, uint32_t bx, uint32_t by, uint32_t bz) {
+    o.bxyz[at * 3] = p.x;
+    o.bxyz[at * 3 + 1] = p.y;
+    o.bxyz[at * 3 + 2] = p.z;
+    const uint32_t id = __float_as_uint(p.w);
+    o.bidx[at] = id;
+    o.backpos[(size_t)id * 27 + backpos_slot(p, o.origin, o.inv_cell, bx, by, bz)] = (uint16_t)(pos < (uint32_t)BACKPOS_FAR ? pos : (uint32_t)BACKPOS_FAR);
+}
+
+// pass 3 (build), buckets of up to 64 points (the bulk): one wavefront per bucket gathers the block's points from `sorted`, orders
+// them by ORIGINAL index — the match kernel orders candidates by (distance, position-in-bucket); with this layout that equals
+// the reference's (distance, index) order, ties included — with a bitonic network through cross-lane shuffles (no LDS for the
+// keys, no barriers) and writes the 12-byte points, the ids and every point's back-position straight into the pool.  Rounds 1-5
+// went through a float4 staging copy of the whole level (fill -> sort -> pack: three passes, 730 bytes per map point of scratch).
+__global__ __launch_bounds__(256) void bucket_build_kernel(GridLevelW occ, GridLevelW bt, const uint32_t* __restrict__ cell_slots, uint32_t n_cells,
+                                                           const float4* __restrict__ sorted, const uint32_t* __restrict__ bcap,
+                                                           const uint32_t* __restrict__ boff, BuildOut o, uint32_t block_base) {
+    __shared__ uint32_t s_pref[4][32], s_start[4][32];
+    const uint32_t cell = (blockIdx.x + block_base) * 4u + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+    if (cell >= n_cells) return;   // (whole wavefronts leave: the LDS rows are per wavefront)
+    const uint32_t slot = cell_slots[cell];
+    uint32_t start, count, incl, total;
+    bucket_sources(occ, bt, slot, lane, start, count, incl, total);
+    const uint32_t off = boff[cell];
+    if (lane == 0) {
+        bt.table[slot].z = off;
+        bt.table[slot].w = total;
+        o.aux[slot] = SlotAux{bcap[cell], 0u, 0u, 0u};
+    }
+    if (total == 0u || total > 64u) return;   // (more than 64: bucket_build_big_kernel)
+    if (lane < 32) { s_pref[w][lane] = lane < 27 ? incl - count : total; s_start[w][lane] = start; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 v = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+    if ((uint32_t)lane < total) {
+        int L = 0;   // the last source run whose first position is <= lane (empty runs share their successor's)
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1)
+            if (s_pref[w][L + step] <= (uint32_t)lane) L += step;
+        v = sorted[s_start[w][L] + ((uint32_t)lane - s_pref[w][L])];
+    }
     for (int k = 2; k <= 64; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             const int partner = lane ^ j;
-            float4 o;
-            o.x = __shfl(v.x, partner); o.y = __shfl(v.y, partner); o.z = __shfl(v.z, partner); o.w = __shfl(v.w, partner);
+            float4 q;
+            q.x = __shfl(v.x, partner); q.y = __shfl(v.y, partner); q.z = __shfl(v.z, partner); q.w = __shfl(v.w, partner);
             const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
-            const uint32_t a = __float_as_uint(v.w), b = __float_as_uint(o.w);
+            const uint32_t a = __float_as_uint(v.w), b = __float_as_uint(q.w);
             const bool use_other = take_min ? (b < a) : (b > a);
-            if (use_other) v = o;
+            if (use_other) v = q;
         }
     }
-    if ((uint32_t)lane < n) g[lane] = v;
-}
-__global__ __launch_bounds__(256) void bucket_sort_wave_kernel(const uint32_t* __restrict__ bcount,
-                                                               const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                               float4* __restrict__ bucket, uint32_t block_base) {
-    bucket_sort_wave_cell(bcount, boff, n_cells, bucket, (blockIdx.x + block_base) * 4u + (threadIdx.x >> 6), (int)(threadIdx.x & 63u));
-}
-__global__ __launch_bounds__(PACED_THREADS) void bucket_sort_wave_paced_kernel(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
-                                                                               uint32_t n_cells, float4* __restrict__ bucket, uint32_t vb_begin, uint32_t vb_end) {
-    // (virtual block = the plain form's 256-thread block: four buckets, one wavefront each)
-    LV_PACED_FOR(256, vb) bucket_sort_wave_cell(bcount, boff, n_cells, bucket, vb * 4u + ((threadIdx.x % 256u) >> 6), (int)(threadIdx.x & 63u));
-}
-
-constexpr int BSORT_THREADS = 256;
-constexpr uint32_t BSORT_LDS = 2048;
-// one bucket of more than 64 points by a whole workgroup of T threads (every barrier is reached by all of them)
-template <int T>
-__device__ __forceinline__ void bucket_sort_cell(float4* s_pts, uint32_t* s_idx, const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
-                                                 float4* __restrict__ bucket, uint32_t cell, uint32_t tid) {
-    const uint32_t n = bcount[cell];
-    if (n <= 64) return;  // handled by bucket_sort_wave_kernel
-    float4* g = bucket + boff[cell];
-    if (n <= BSORT_LDS) {
-        // rank by counting: original indices are unique, so the rank of a point is the number of points with a
-        // smaller index — n compares per point out of LDS (broadcast reads), no barriers between steps; for the
-        // few-hundred-point buckets this beats the bitonic network (log^2 n barrier-separated stages) severalfold
-        for (uint32_t i = tid; i < n; i += T) {
-            const float4 p = g[i];
-            s_pts[i] = p;
-            s_idx[i] = __float_as_uint(p.w);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += T) {
-            const uint32_t mine = s_idx[i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; ++j) rank += s_idx[j] < mine ? 1u : 0u;
-            g[rank] = s_pts[i];
-        }
-        return;
-    }
-    float4* a = g;
-    for (uint32_t k = 2; (k >> 1) < n; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const bool flip = (j == (k >> 1));
-            for (uint32_t i = tid; i < n; i += T) {
-                const uint32_t l = flip ? (i ^ (k - 1)) : (i ^ j);
-                if (l > i && l < n) {
-                    const float4 x = a[i], y = a[l];
-                    if (__float_as_uint(x.w) > __float_as_uint(y.w)) { a[i] = y; a[l] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-__global__ __launch_bounds__(BSORT_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ bcount,
-                                                                    const uint32_t* __restrict__ boff, uint32_t n_cells,
-                                                                    float4* __restrict__ bucket, uint32_t block_base) {
-    __shared__ float4 s_pts[BSORT_LDS];
-    __shared__ uint32_t s_idx[BSORT_LDS];
-    const uint32_t cell = blockIdx.x + block_base;
-    if (cell >= n_cells) return;
-    bucket_sort_cell<BSORT_THREADS>(s_pts, s_idx, bcount, boff, bucket, cell, threadIdx.x);
-}
-// paced form: a workgroup looks at PACED_THREADS buckets at a time, lists the ones with more than 64 points and sorts those
-// one after the other (which workgroup sorts a bucket, and when, changes nothing: buckets are independent)
-__global__ __launch_bounds__(PACED_THREADS) void bucket_sort_paced_kernel(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ boff,
-                                                                          uint32_t n_cells, float4* __restrict__ bucket, uint32_t vb_begin, uint32_t vb_end) {
-    __shared__ float4 s_pts[BSORT_LDS];
-    __shared__ uint32_t s_idx[BSORT_LDS];
-    __shared__ uint32_t s_list[PACED_THREADS];
-    __shared__ uint32_t s_n;
-    const uint32_t end = vb_end < n_cells ? vb_end : n_cells;
-    for (uint32_t base = vb_begin + blockIdx.x * (uint32_t)PACED_THREADS; base < end; base += gridDim.x * (uint32_t)PACED_THREADS) {
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-        const uint32_t cell = base + threadIdx.x;
-        if (cell < end && bcount[cell] > 64) s_list[atomicAdd(&s_n, 1u)] = cell;
-        __syncthreads();
-        const uint32_t nbig = s_n;
-        for (uint32_t k = 0; k < nbig; ++k) {
-            bucket_sort_cell<PACED_THREADS>(s_pts, s_idx, bcount, boff, bucket, s_list[k], threadIdx.x);
-            __syncthreads();   // (the next bucket reuses the scratch)
-        }
+    if ((uint32_t)lane < total) {
+        const uint4 e = bt.table[slot];
+        bucket_emit(o, (size_t)off + (uint32_t)lane, (uint32_t)lane, v, e.x & 0x1fffffu, ((e.x >> 21) | (e.y << 11)) & 0x1fffffu, (e.y >> 10) & 0x1fffffu);
     }
 }
 
-// the sorted float4 buckets -> 12-byte points (what the search kernel streams) + a parallel id array
-__device__ __forceinline__ void bucket_pack_item(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx, uint32_t i) {
-    if (i >= n) return;
-    const float4 p = in[i];
-    xyz[(size_t)i * 3] = p.x;
-    xyz[(size_t)i * 3 + 1] = p.y;
-    xyz[(size_t)i * 3 + 2] = p.z;
-    idx[i] = __float_as_uint(p.w);
-}
-__global__ void bucket_pack_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx, uint32_t block_base) {
-    bucket_pack_item(in, n, xyz, idx, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
-}
-__global__ __launch_bounds__(PACED_THREADS) void bucket_pack_paced_kernel(const float4* __restrict__ in, uint32_t n, float* __restrict__ xyz, uint32_t* __restrict__ idx,
-                                                                          uint32_t vb_begin, uint32_t vb_end) {
-    LV_PACED_FOR(256, vb) bucket_pack_item(in, n, xyz, idx, vb * 256u + threadIdx.x % 256u);
+// ... and the buckets of more than 64 points, a workgroup each: rank by counting — original indices are unique, so the rank of
+// a point is the number of points of the bucket with a smaller index; up to BIG_LDS ids out of LDS (broadcast reads, no barriers
+// between steps), beyond that (a 1.5-voxel cube with thousands of points: a map far denser than its voxel size was chosen for) by
+// re-gathering them from memory: slow, exact.  The source is `sorted`, the destination the pool: nothing is permuted in place.
+constexpr int BIG_T = 256;
+constexpr uint32_t BIG_LDS = 4096;
+__global__ __launch_bounds__(BIG_T) void bucket_build_big_kernel(GridLevelW occ, GridLevelW bt, const uint32_t* __restrict__ cell_slots,
+                                                                 const uint32_t* __restrict__ biglist, uint32_t n_big,
+                                                                 const float4* __restrict__ sorted, const uint32_t* __restrict__ boff, BuildOut o,
+                                                                 uint32_t block_base) {
+    __shared__ uint32_t s_pref[32], s_start[32];
+    __shared__ uint32_t s_id[BIG_LDS];
+    const uint32_t b = blockIdx.x + block_base;
+    if (b >= n_big) return;
+    const uint32_t cell = biglist[b];
+    const uint32_t slot = cell_slots[cell];
+    const uint32_t tid = threadIdx.x;
+    uint32_t total = 0;
+    if (tid < 64u) {
+        uint32_t start, count, incl;
+        bucket_sources(occ, bt, slot, (int)tid, start, count, incl, total);
+        if (tid < 32u) { s_pref[tid] = tid < 27u ? incl - count : total; s_start[tid] = start; }
+    }
+    __syncthreads();
+    total = s_pref[31];
+    const uint4 e = bt.table[slot];
+    const uint32_t bx = e.x & 0x1fffffu, by = ((e.x >> 21) | (e.y << 11)) & 0x1fffffu, bz = (e.y >> 10) & 0x1fffffu;
+    const uint32_t off = boff[cell];
+    auto src_of = [&](uint32_t i) {
+        int L = 0;
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1)
+            if (s_pref[L + step] <= i) L += step;
+        return s_start[L] + (i - s_pref[L]);
+    };
+    const bool in_lds = total <= BIG_LDS;
+    if (in_lds) {
+        for (uint32_t i = tid; i < total; i += BIG_T) s_id[i] = __float_as_uint(sorted[src_of(i)].w);
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < total; i += BIG_T) {
+        const float4 p = sorted[src_of(i)];
+        const uint32_t mine = __float_as_uint(p.w);
+        uint32_t rank = 0;
+        if (in_lds) {
+            for (uint32_t j = 0; j < total; ++j) rank += s_id[j] < mine ? 1u : 0u;
+        } else {
+            for (uint32_t j = 0; j < total; ++j) rank += __float_as_uint(sorted[src_of(j)].w) < mine ? 1u : 0u;
+        }
+        bucket_emit(o, (size_t)off + rank, rank, p, bx, by, bz);
+    }
 }
 
 // ---- level 2: voxel lists -----------------------------------------------------------------------------------
@@ -497,31 +444,17 @@ static inline int log2u(uint32_t size) {
 // threads, 128 VGPRs, 156 KB of LDS) cannot be placed while another stream keeps every CU topped up with small workgroups — it
 // waits for that stream's kernel to run out of workgroups, however the streams' priorities are set, and a CU mask on the
 // other stream is not honoured here (scripts/ubench/cu_mask_starve.hip: 52 ms behind a 52 ms flood).  At the end of a slice the
-// CUs drain and the waiting workgroup gets its unit: the stall is bounded by one slice (~0.1 ms: slice_wgs workgroups of the heaviest kernel, map_bucket_kernel<true>; eight times as
-// many of the lighter ones), not by one kernel.
+// CUs drain and the waiting workgroup gets its unit: the stall is bounded by one slice (~0.1 ms: slice_wgs workgroups of the
+// heaviest kernel, bucket_build_kernel; more of the lighter ones), not by one kernel.
 // Every sliced kernel takes the first block index of its slice as its LAST argument.
+// (Round 5 also carried a PACED twin of every such kernel — at most 32 looping 1024-thread workgroups, so that half of the CUs
+// stay empty — which removed the waiting but showed two 4.6 ms cycles in 5 of 17 replays that plain slices never did; the cause
+// was not found and the form is gone: profiles/experiments_r05/async_rebuild.txt sections 7-11 keep its measurements.)
 template <typename K, typename... A>
 static void launch_sliced(uint32_t slice, K kernel, uint32_t grid, uint32_t block, hipStream_t stream, A... args) {
     if (slice == 0 || grid <= slice) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args..., 0u); return; }
     for (uint32_t b = 0; b < grid; b += slice)
         hipLaunchKernelGGL(kernel, dim3(grid - b < slice ? grid - b : slice), dim3(block), 0, stream, args..., b);
-}
-// ... or PACED (MapStore::paced_wgs != 0, the background rebuild's default since the end of round 5): the kernel's paced twin — at
-// most paced_wgs workgroups of PACED_THREADS threads, each looping over the plain form's blocks ("virtual blocks" of `block`
-// threads, several side by side in a workgroup) — so that the grid never holds more than half of the chip's compute units: a
-// whole-CU workgroup of another stream then does not wait at all (scripts/ubench/half_chip_flood.hip: a 124-VGPR 1024-thread
-// probe beside 120-128 persistent workgroups of 1024 threads: p99 17.5 us, as on an idle GPU; beside 256 of them 9.8 ms), where
-// behind slices it waits for every slice it meets to drain — five whole-CU launches per cycle.  A launch covers `slice` virtual
-// blocks (bounds how long a 256-workgroup pass_kernel runs on half of the CUs).  per_wg: virtual blocks a workgroup takes side
-// by side (PACED_THREADS / block; bucket_sort_paced_kernel scans PACED_THREADS buckets at a time).
-template <typename K, typename KP, typename... A>
-static void launch_paced(uint32_t slice, uint32_t paced_wgs, K kernel, KP paced, uint32_t per_wg, uint32_t grid, uint32_t block, hipStream_t stream, A... args) {
-    if (paced_wgs == 0 || slice == 0) { launch_sliced(slice, kernel, grid, block, stream, args...); return; }
-    for (uint32_t b = 0; b < grid; b += slice) {
-        const uint32_t e = grid - b < slice ? grid : b + slice;
-        const uint32_t want = (e - b + per_wg - 1) / per_wg;
-        hipLaunchKernelGGL(paced, dim3(want < paced_wgs ? want : paced_wgs), dim3(PACED_THREADS), 0, stream, args..., b, e);
-    }
 }
 
 int MapStore::reserve(size_t cap) {
@@ -556,12 +489,12 @@ int MapStore::reserve(size_t cap) {
         d_box_next = nn;
         box_next_cap = ncap;
     }
-    if (d_backptr) {   // positions inside the level-2 buckets are by id: keep them
-        uint32_t* nb = nullptr;
-        LV_HIP(hipMalloc(&nb, ncap * 27 * sizeof(uint32_t)));
-        if (n_ids) LV_HIP(hipMemcpy(nb, d_backptr, (size_t)n_ids * 27 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-        hipFree(d_backptr);
-        d_backptr = nb;
+    if (d_backpos) {   // positions inside the buckets are by id: keep them
+        uint16_t* nb = nullptr;
+        LV_HIP(hipMalloc(&nb, ncap * 27 * sizeof(uint16_t)));
+        if (n_ids) LV_HIP(hipMemcpy(nb, d_backpos, (size_t)n_ids * 27 * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+        hipFree(d_backpos);
+        d_backpos = nb;
         uint32_t* nc = nullptr;
         LV_HIP(hipMalloc(&nc, ncap * sizeof(uint32_t)));
         if (n_ids) LV_HIP(hipMemcpy(nc, d_cellpos, (size_t)n_ids * sizeof(uint32_t), hipMemcpyDeviceToDevice));
@@ -593,9 +526,9 @@ void MapStore::release() {
     hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_bcap); hipFree(d_boff); hipFree(d_scan_tmp);
     for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_baux[l]); }
     for (int l = 0; l < SORTED_LEVELS; ++l) { hipFree(d_bxyz[l]); hipFree(d_bidx[l]); }
-    hipFree(d_bucket4); hipFree(d_backptr); hipFree(d_cellpos);
-    hipFree(d_bucket_tmp); hipFree(d_caux); hipFree(d_cell4);
-    for (int l = 0; l < MAX_LEVELS; ++l) hipFree(d_tables[l]);
+    hipFree(d_backpos); hipFree(d_cellpos); hipFree(d_biglist);
+    hipFree(d_caux); hipFree(d_cell4);
+    for (int l = 0; l < N_OCC; ++l) hipFree(d_tables[l]);
     hipFree(d_cnt);
     if (h_cnt) hipHostFree(h_cnt);
     hipFree(d_new); hipFree(d_nkeys); hipFree(d_nkeys_sorted); hipFree(d_nidx); hipFree(d_nidx_sorted); hipFree(d_nalive);
@@ -623,10 +556,9 @@ void MapStore::refresh_view() {
         view.bxyz[l] = d_bxyz[l];
         view.bidx[l] = d_bidx[l];
     }
-    view.bucket4 = d_bucket4;
-    view.ct.table = d_tables[CELL_LEVEL];
-    view.ct.mask = table_size[CELL_LEVEL] ? table_size[CELL_LEVEL] - 1 : 0;
-    view.ct.shift = (uint32_t)(64 - log2u(table_size[CELL_LEVEL] ? table_size[CELL_LEVEL] : 1));
+    view.ct.table = d_tables[OCC_CELL];
+    view.ct.mask = table_size[OCC_CELL] ? table_size[OCC_CELL] - 1 : 0;
+    view.ct.shift = (uint32_t)(64 - log2u(table_size[OCC_CELL] ? table_size[OCC_CELL] : 1));
     view.cell4 = d_cell4;
 }
 
@@ -645,14 +577,13 @@ MapRW MapStore::rw() const {
         M.bxyz[l] = d_bxyz[l];
         M.bidx[l] = d_bidx[l];
     }
-    M.bucket4 = d_bucket4;
-    M.backptr = d_backptr;
+    M.backpos = d_backpos;
     M.cellpos = d_cellpos;
-    M.lv[CELL_SLOT].table = d_tables[CELL_LEVEL];
+    M.lv[CELL_SLOT].table = d_tables[OCC_CELL];
     M.lv[CELL_SLOT].aux = d_caux;
-    M.lv[CELL_SLOT].mask = table_size[CELL_LEVEL] - 1;
-    M.lv[CELL_SLOT].shift = (uint32_t)(64 - log2u(table_size[CELL_LEVEL]));
-    M.lv[CELL_SLOT].slot_limit = (uint32_t)((uint64_t)table_size[CELL_LEVEL] * 6 / 10);
+    M.lv[CELL_SLOT].mask = table_size[OCC_CELL] - 1;
+    M.lv[CELL_SLOT].shift = (uint32_t)(64 - log2u(table_size[OCC_CELL]));
+    M.lv[CELL_SLOT].slot_limit = (uint32_t)((uint64_t)table_size[OCC_CELL] * 6 / 10);
     M.lv[CELL_SLOT].pool_cap = (uint32_t)(pool_cap[CELL_SLOT] > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : pool_cap[CELL_SLOT]);
     M.cell4 = d_cell4;
     for (int a = 0; a < 3; ++a) M.origin[a] = origin[a];
@@ -681,14 +612,17 @@ void MapStore::stats(MapStats* out) const {
     }
     for (int l = 0; l < INC_LEVELS; ++l) out->pool_cap[l] = pool_cap[l];
     for (int l = 0; l < REPL_LEVELS; ++l) out->slots_cap[l] = btable_size[l];
-    out->slots_cap[CELL_SLOT] = table_size[CELL_LEVEL];
+    out->slots_cap[CELL_SLOT] = table_size[OCC_CELL];
     out->dropped = dropped_total;
     out->relinearisations = relinearisations;
     out->incremental_adds = incremental_adds;
-    uint64_t b = (uint64_t)capacity * (16 + 16 + 16 + 8 + 8 + 4 + 4 + 16);
-    for (int l = 0; l < REPL_LEVELS; ++l) b += (uint64_t)pool_cap[l] * 16 + (uint64_t)btable_size[l] * 32;
-    b += (uint64_t)pool_cap[CELL_SLOT] * 16 + (uint64_t)bucket_tmp_cap * 16 + (uint64_t)backptr_cap * 27 * 4;
-    for (int l = 0; l < MAX_LEVELS; ++l) b += (uint64_t)table_size[l] * 16;
+    // every device allocation that grows with the map (the per-batch scratch of an insert does not: reserve_batch)
+    uint64_t b = (uint64_t)capacity * (16 + 16 + 16 + 8 + 8 + 4 + 4 + 16);                                   // orig, orig2, sorted, keys x 2, idx x 2, dead
+    for (int l = 0; l < REPL_LEVELS; ++l) b += (uint64_t)pool_cap[l] * 16 + (uint64_t)btable_size[l] * 32;   // 12-byte points + ids; table + aux
+    b += (uint64_t)pool_cap[CELL_SLOT] * 16 + (uint64_t)caux_size * 16 + (uint64_t)backptr_cap * (27 * 2 + 4);   // lists, their aux; back-positions + cellpos
+    for (int l = 0; l < N_OCC; ++l) b += (uint64_t)table_size[l] * 16;
+    b += (uint64_t)cells_cap * 16 + (uint64_t)biglist_cap * 4;                                                // build scratch per bucket voxel
+    b += (uint64_t)alive_cap * 8;                                                                             // compaction / eviction flags + ranks
     b += (uint64_t)box_size * 16 + (uint64_t)box_next_cap * 4;
     out->bytes = b;
 }
@@ -732,7 +666,6 @@ int MapStore::rebuild(hipStream_t stream) {
             return LV_ERANGE;
         }
     }
-    const int n_levels = MAX_LEVELS;
     const float inv_cell = 1.0f / cell;
     hipLaunchKernelGGL(map_keys_kernel, dim3(grid), dim3(B), 0, stream, d_orig, m, origin[0], origin[1], origin[2], inv_cell, d_keys,
                        d_idx);
@@ -742,15 +675,15 @@ int MapStore::rebuild(hipStream_t stream) {
     hipLaunchKernelGGL(map_gather_kernel, dim3(grid), dim3(B), 0, stream, d_orig, d_idx_sorted, m, d_sorted);
     if (!d_counts) LV_HIP(hipMalloc(&d_counts, 16 * sizeof(uint32_t)));
     LV_HIP(hipMemsetAsync(d_counts, 0, 16 * sizeof(uint32_t), stream));
-    launch_paced(slice_wgs * 2, paced_wgs, map_count_heads_kernel, map_count_heads_paced_kernel, 4u, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, d_counts);
+    launch_sliced(slice_wgs * 2, map_count_heads_kernel, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, d_counts);
     uint32_t counts[16];
     LV_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, stream));
     LV_HIP(hipStreamSynchronize(stream));
 
     TablePtrs tp{};
-    for (int l = 0; l < n_levels; ++l) {
+    for (int l = 0; l < N_OCC; ++l) {
         // the level-2 table lives on as the voxel-list table of incremental inserts: give it room to grow
-        uint32_t size = next_pow2((uint64_t)counts[l] * (l == CELL_LEVEL ? 8 : 4));
+        uint32_t size = next_pow2((uint64_t)counts[l] * (l == OCC_CELL ? 8 : 4));
         // (re)builds also give memory BACK: a table 8x larger than this map wants — a rolling window that shrank from its
         // initial extent — is re-allocated (hysteresis: growth doubles, so 8x cannot oscillate)
         if (size > table_size[l] || ((uint64_t)size * 8 <= table_size[l] && table_size[l] > (1u << 20))) {
@@ -766,13 +699,13 @@ int MapStore::rebuild(hipStream_t stream) {
         tp.shift[l] = (uint32_t)(64 - log2u(size));
         n_cells[l] = counts[l];
     }
-    launch_paced(slice_wgs * 2, paced_wgs, map_insert_kernel, map_insert_paced_kernel, 4u, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, n_levels, tp);
+    launch_sliced(slice_wgs * 2, map_insert_kernel, grid, (uint32_t)B, stream, (const uint64_t*)d_keys_sorted, m, tp);
     LV_HIP(hipGetLastError());
     for (int l = 0; l < REPL_LEVELS; ++l) {
         int rc = build_buckets(stream, l, counts[l]);
         if (rc) return rc;
     }
-    int rc = build_cells(stream, counts[CELL_LEVEL]);
+    int rc = build_cells(stream, counts[OCC_CELL]);
     if (rc) return rc;
     for (int l = 0; l < INC_LEVELS; ++l) {   // the free part of every pool, split into arenas
         const uint64_t cap = pool_cap[l] > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : pool_cap[l];
@@ -783,7 +716,7 @@ int MapStore::rebuild(hipStream_t stream) {
         }
     }
     for (int l = 0; l < REPL_LEVELS; ++l) h_cnt->slots_used[l] = n_bcells[l];
-    h_cnt->slots_used[CELL_SLOT] = counts[CELL_LEVEL];
+    h_cnt->slots_used[CELL_SLOT] = counts[OCC_CELL];
     LV_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(MapCounters), hipMemcpyHostToDevice, stream));
     LV_HIP(hipStreamSynchronize(stream));
     built = true;
@@ -791,12 +724,18 @@ int MapStore::rebuild(hipStream_t stream) {
     return LV_OK;
 }
 
+// level 0 (the one replicated level; `level` stays a parameter of the pool / table arrays)
 int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) {
     GridLevelW occ{d_tables[level], table_size[level] - 1, (uint32_t)(64 - log2u(table_size[level]))};
     const uint32_t occ_slots = table_size[level];
     uint32_t size = next_pow2((uint64_t)n_occupied * 16);  // dilation factor <= 8 keeps the load <= 0.5
-    const bool give_back = (uint64_t)size * 8 <= btable_size[level] && btable_size[level] > (1u << 20);   // (see build_tables)
+    const bool give_back = (uint64_t)size * 8 <= btable_size[level] && btable_size[level] > (1u << 20);   // (see the occupancy tables)
     if (size < btable_size[level] && !give_back) size = btable_size[level];
+    if (backptr_cap < capacity) {   // back-positions and list positions are by id
+        LV_REALLOC(d_backpos, uint16_t, capacity * 27);
+        LV_REALLOC(d_cellpos, uint32_t, capacity);
+        backptr_cap = capacity;
+    }
     for (;;) {
         if (size != btable_size[level] || !d_btable[level]) {
             LV_REALLOC(d_btable[level], uint4, size);
@@ -816,12 +755,16 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
             LV_HIP(hipMalloc(&d_scan_tmp, scan_tmp_bytes));
             cells_cap = need_cells;
         }
+        if (need_cells > biglist_cap) {
+            LV_REALLOC(d_biglist, uint32_t, need_cells);
+            biglist_cap = need_cells;
+        }
         LV_HIP(hipMemsetAsync(d_btable[level], 0xFF, (size_t)size * sizeof(uint4), stream));
         LV_HIP(hipMemsetAsync(d_baux[level], 0, (size_t)size * sizeof(SlotAux), stream));
-        LV_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), stream));
+        LV_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(uint32_t), stream));
         GridLevelW bt{d_btable[level], size - 1, (uint32_t)(64 - log2u(size))};
         const uint64_t threads = (uint64_t)occ_slots * 27;
-        launch_paced(slice_wgs * 2, paced_wgs, bucket_register_kernel, bucket_register_paced_kernel, 4u, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
+        launch_sliced(slice_wgs * 2, bucket_register_kernel, (uint32_t)((threads + 255) / 256), 256u, stream, occ, occ_slots, bt,
                       d_cell_slots, (uint32_t)(size / 2), d_flags);
         uint32_t flags[2];
         LV_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
@@ -832,13 +775,14 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         }
         const uint32_t nb = flags[0];
         n_bcells[level] = nb;
-        launch_paced(slice_wgs * 8, paced_wgs, map_bucket_kernel<false>, map_bucket_paced_kernel<false>, 16u, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
-                      d_bcount, d_bcap, (const uint32_t*)d_boff, (float4*)nullptr, (uint32_t*)nullptr);
+        launch_sliced(slice_wgs * 2, bucket_count_kernel, (nb + 3) / 4, 256u, stream, occ, bt, (const uint32_t*)d_cell_slots, nb, d_bcount, d_bcap,
+                      d_biglist, d_flags);
         size_t stmp = scan_tmp_bytes;
         LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)nb, stream));
-        uint32_t last_off = 0, last_cap = 0;
+        uint32_t last_off = 0, last_cap = 0, n_big = 0;
         LV_HIP(hipMemcpyAsync(&last_off, d_boff + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipMemcpyAsync(&last_cap, d_bcap + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LV_HIP(hipMemcpyAsync(&n_big, d_flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         LV_HIP(hipStreamSynchronize(stream));
         const uint64_t total = (uint64_t)last_off + last_cap;   // entries laid out, slack included
         // the pool keeps room for runs that move and for the buckets of newly mapped space
@@ -847,38 +791,18 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         const uint64_t floor_entries = total < (1ull << 20) ? (1ull << 20) : (total > (8ull << 20) ? (8ull << 20) : total);
         const uint64_t want = total + total / 4 + floor_entries;
         if (want > 0xFFFFFFF0ull) { set_error("bucket pool exceeds 2^32 entries at level %d", level); return LV_ERANGE; }
-        if (level < SORTED_LEVELS) {   // ascending id, then packed to 12-byte points + id array
-            if (total > bucket_tmp_cap) {
-                LV_REALLOC(d_bucket_tmp, float4, total + total / 8);
-                bucket_tmp_cap = total + total / 8;
-            }
-            if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {   // (grow, or give back: see build_tables)
-                pool_cap[level] = 0;
-                LV_REALLOC(d_bxyz[level], float, want * 3 + 4);
-                LV_REALLOC(d_bidx[level], uint32_t, want);
-                pool_cap[level] = (size_t)want;
-            }
-            launch_paced(slice_wgs, paced_wgs, map_bucket_kernel<true>, map_bucket_paced_kernel<true>, 16u, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
-                          (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket_tmp, (uint32_t*)nullptr);
-            launch_paced(slice_wgs * 8, paced_wgs, bucket_sort_wave_kernel, bucket_sort_wave_paced_kernel, 4u, (nb + 3) / 4, 256u, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
-            launch_paced(slice_wgs * 8, paced_wgs, bucket_sort_kernel, bucket_sort_paced_kernel, (uint32_t)PACED_THREADS, nb, (uint32_t)BSORT_THREADS, stream, (const uint32_t*)d_bcount, (const uint32_t*)d_boff, nb, d_bucket_tmp);
-            if (total > 0)
-                launch_paced(slice_wgs * 8, paced_wgs, bucket_pack_kernel, bucket_pack_paced_kernel, 4u, (uint32_t)((total + 255) / 256), 256u, stream, (const float4*)d_bucket_tmp,
-                              (uint32_t)total, d_bxyz[level], d_bidx[level]);
-        } else {                       // level 2: unordered records, every point remembers where it sits (deletions)
-            if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {
-                pool_cap[level] = 0;
-                LV_REALLOC(d_bucket4, float4, want);
-                pool_cap[level] = (size_t)want;
-            }
-            if (backptr_cap < capacity) {
-                LV_REALLOC(d_backptr, uint32_t, capacity * 27);
-                LV_REALLOC(d_cellpos, uint32_t, capacity);
-                backptr_cap = capacity;
-            }
-            launch_paced(slice_wgs, paced_wgs, map_bucket_kernel<true>, map_bucket_paced_kernel<true>, 16u, nb, 64u, stream, occ, bt, d_baux[level], (const uint32_t*)d_cell_slots, nb,
-                          (const float4*)d_sorted, d_bcount, d_bcap, (const uint32_t*)d_boff, d_bucket4, d_backptr);
+        if (want > pool_cap[level] || (want * 3 <= pool_cap[level] && pool_cap[level] > (32u << 20))) {   // (grow, or give back: see the occupancy tables)
+            pool_cap[level] = 0;
+            LV_REALLOC(d_bxyz[level], float, want * 3 + 4);
+            LV_REALLOC(d_bidx[level], uint32_t, want);
+            pool_cap[level] = (size_t)want;
         }
+        BuildOut bo{d_bxyz[level], d_bidx[level], d_backpos, d_baux[level], {origin[0], origin[1], origin[2]}, 1.0f / cell};
+        launch_sliced(slice_wgs, bucket_build_kernel, (nb + 3) / 4, 256u, stream, occ, bt, (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
+                      (const uint32_t*)d_bcap, (const uint32_t*)d_boff, bo);
+        if (n_big)
+            launch_sliced(slice_wgs, bucket_build_big_kernel, n_big, (uint32_t)BIG_T, stream, occ, bt, (const uint32_t*)d_cell_slots,
+                          (const uint32_t*)d_biglist, n_big, (const float4*)d_sorted, (const uint32_t*)d_boff, bo);
         LV_HIP(hipGetLastError());
         pool_base[level] = (uint32_t)total;
         return LV_OK;
@@ -888,7 +812,7 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
 // level 2: the occupancy table of the level (runs of `sorted`) turns into the voxel-list table (runs of cell4)
 int MapStore::build_cells(hipStream_t stream, uint32_t n_occupied) {
     (void)n_occupied;
-    const uint32_t size = table_size[CELL_LEVEL];
+    const uint32_t size = table_size[OCC_CELL];
     if (size > caux_size) {
         LV_REALLOC(d_caux, SlotAux, size);
         caux_size = size;
@@ -906,7 +830,7 @@ int MapStore::build_cells(hipStream_t stream, uint32_t n_occupied) {
         cells_cap = size;
     }
     const int B = 256;
-    hipLaunchKernelGGL(cell_caps_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[CELL_LEVEL], size, d_bcap);
+    hipLaunchKernelGGL(cell_caps_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[OCC_CELL], size, d_bcap);
     size_t stmp = scan_tmp_bytes;
     LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)size, stream));
     uint32_t last_off = 0, last_cap = 0;
@@ -921,9 +845,9 @@ int MapStore::build_cells(hipStream_t stream, uint32_t n_occupied) {
         LV_REALLOC(d_cell4, float4, want);
         pool_cap[CELL_SLOT] = (size_t)want;
     }
-    GridLevelW t2{d_tables[CELL_LEVEL], size - 1, (uint32_t)(64 - log2u(size))};
+    GridLevelW t2{d_tables[OCC_CELL], size - 1, (uint32_t)(64 - log2u(size))};
     hipLaunchKernelGGL(cell_fill_kernel, dim3((m + B - 1) / B), dim3(B), 0, stream, d_keys_sorted, d_sorted, m, t2, d_boff, d_cell4, d_cellpos);
-    hipLaunchKernelGGL(cell_commit_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[CELL_LEVEL], size, d_bcap, d_boff, d_caux);
+    hipLaunchKernelGGL(cell_commit_kernel, dim3((size + B - 1) / B), dim3(B), 0, stream, d_tables[OCC_CELL], size, d_bcap, d_boff, d_caux);
     LV_HIP(hipGetLastError());
     pool_base[CELL_SLOT] = (uint32_t)total;
     return LV_OK;
@@ -950,7 +874,7 @@ int MapStore::reserve_batch(size_t k) {
         LV_REALLOC(d_gtab[l], uint4, gtab_size);
         LV_REALLOC(d_gbase[l], uint32_t, (size_t)gtab_size * GROUP_TARGETS);
         LV_REALLOC(d_gslot[l], uint32_t, (size_t)gtab_size * GROUP_TARGETS);
-        LV_REALLOC(d_gdst[l], uint2, (size_t)gtab_size * GROUP_TARGETS);
+        LV_REALLOC(d_gdst[l], uint4, (size_t)gtab_size * GROUP_TARGETS);
     }
     LV_REALLOC(d_prank, uint32_t, ncap * REPL_LEVELS);
     LV_REALLOC(d_pslot, uint32_t, ncap * REPL_LEVELS);
@@ -969,13 +893,6 @@ int MapStore::reserve_batch(size_t k) {
     return LV_OK;
 }
 
-// (paced twin of box_build_kernel, lv_mapinc.hpp: the worker's replay builds the copy's box table beside the running cycle — as
-// back-to-back slices of small workgroups it cost the cycle that met it 4.5 ms, the whole table: profiles/experiments_r05/async_rebuild.txt)
-__global__ __launch_bounds__(PACED_THREADS) void box_build_paced_kernel(BoxRW B, const float4* __restrict__ orig, uint32_t n_ids, MapCounters* cnt,
-                                                                        uint32_t vb_begin, uint32_t vb_end) {
-    LV_PACED_FOR(256, vb) box_build_item(B, orig, n_ids, cnt, vb * 256u + threadIdx.x % 256u);
-}
-
 int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     if (have_boxes) return LV_OK;
     const uint32_t size = next_pow2((uint64_t)capacity * 4);
@@ -992,8 +909,7 @@ int MapStore::ensure_boxes(hipStream_t stream, float box_length) {
     BoxRW Bx{d_box, d_box_next, box_size - 1, (uint32_t)(64 - log2u(box_size)), (uint32_t)((uint64_t)box_size * 6 / 10), box_length};
     // (ALWAYS sliced: the boxes are built by the first down-sampling insert after a (re)build, on the insert's side stream,
     // beside the cycle's whole-CU launches — 4 ms in one piece at 10 M ids, ~0.1 ms per slice of 1024 workgroups)
-    if (n_ids) launch_paced(paced_wgs ? slice_wgs * 8 : 1024u, paced_wgs, box_build_kernel, box_build_paced_kernel, 4u, (n_ids + 255) / 256, 256u, stream, Bx,
-                            (const float4*)d_orig, n_ids, d_cnt);
+    if (n_ids) launch_sliced(1024u, box_build_kernel, (n_ids + 255) / 256, 256u, stream, Bx, (const float4*)d_orig, n_ids, d_cnt);
     LV_HIP(hipGetLastError());
     have_boxes = true;
     return LV_OK;
@@ -1244,13 +1160,12 @@ __global__ __launch_bounds__(256) void inc_evict_sweep_kernel(MapRW M, int ti, f
                 const size_t at = (size_t)start + i;
                 float x, y, z;
                 if (ti < SORTED_LEVELS) { x = M.bxyz[ti][at * 3 + 0]; y = M.bxyz[ti][at * 3 + 1]; z = M.bxyz[ti][at * 3 + 2]; }
-                else { const float4 p = ti < REPL_LEVELS ? M.bucket4[at] : M.cell4[at]; x = p.x; y = p.y; z = p.z; }
+                else { const float4 p = M.cell4[at]; x = p.x; y = p.y; z = p.z; }
                 const bool inside = x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz;
                 const bool alive = x < pos_inf() && x > -pos_inf();
                 if (inside != (keep_inside != 0)) {   // (an entry that is dead already stays dead either way)
                     if (alive) {
                         if (ti < SORTED_LEVELS) M.bxyz[ti][at * 3 + 0] = pos_inf();
-                        else if (ti < REPL_LEVELS) M.bucket4[at].x = pos_inf();
                         else M.cell4[at].x = pos_inf();
                     }
                 } else {

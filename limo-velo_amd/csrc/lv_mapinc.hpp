@@ -6,12 +6,13 @@
 //
 //   points      ids are handed out in insertion order and never reused; a deleted point keeps its slot in `orig`
 //               with x = +inf.  Relative order of the living == the reference's map order.
-//   levels 0,1  neighbourhood buckets with slack: a new point is appended to the 27 buckets of its voxel's
+//   level 0     neighbourhood buckets with slack: a new point is appended to the 27 buckets of its voxel's
 //               neighbours (ids only grow, so "ascending id" survives an append once the batch's own tail is
-//               ordered); a bucket that runs out of room moves to fresh space at the end of its pool.  A deleted
-//               point is found by binary search over the bucket's ids and its x set to +inf (tombstone).
-//   level 2     the same buckets, unordered (searched with id keys): appends go anywhere in the tail; every point
-//               remembers its position in each of its 27 buckets (backptr), so a deletion is 27 direct writes.
+//               ordered); a bucket that runs out of room moves to fresh space at the end of its pool.  Every point
+//               remembers its position in each of its 27 buckets (backpos, 16 bits: positions are relative to the
+//               run's start, so a run that moves keeps them), so a deletion is 27 table probes + 27 direct writes
+//               (x set to +inf: tombstone); rounds 1-5 searched the bucket's ids (266 DRAM lines per deleted point
+//               over three replicated levels).  Level 1 has no storage (eight level-0 buckets tile its block).
 //   voxel lists one list per level-2 voxel, unordered: append / tombstone in the point's own voxel only.
 //   0.2 m boxes ikd-Tree's down-sampling rule needs "the points currently in this box": a hash table
 //               box -> chain of ids (box_next), built lazily by the first down-sampling insert.
@@ -33,8 +34,9 @@
 namespace lv {
 
 constexpr uint32_t ID_NONE = 0xFFFFFFFFu;
-constexpr int INC_SLOTS_PER_POINT = 27 * REPL_LEVELS + 1;   // 27 buckets on each of the levels 0, 1, 2 + its level-2 voxel's list
-constexpr int INC_LEVELS = REPL_LEVELS + 1;                 // tables: bt[0], bt[1], bt[2], voxel lists
+constexpr int INC_SLOTS_PER_POINT = 27 * REPL_LEVELS + 1;   // its 27 level-0 buckets + its level-2 voxel's list
+constexpr int INC_LEVELS = REPL_LEVELS + 1;                 // tables: bt[0], voxel lists
+constexpr uint16_t BACKPOS_FAR = 0xFFFFu;                   // back-position of an entry beyond 16 bits: found by binary search over the run's ids
 constexpr int CELL_SLOT = REPL_LEVELS;                      // index of the voxel-list table in the per-table arrays
 
 constexpr int N_ARENAS = 64;   // the free part of every pool is split into arenas with their own cursors: a run that
@@ -64,11 +66,10 @@ struct LevelRW {
 
 struct MapRW {
     float4* orig;
-    LevelRW lv[INC_LEVELS];          // [0], [1], [2]: bucket tables; [CELL_SLOT]: level-2 voxel-list table
+    LevelRW lv[INC_LEVELS];          // [0]: bucket table; [CELL_SLOT]: level-2 voxel-list table
     float* bxyz[SORTED_LEVELS];
     uint32_t* bidx[SORTED_LEVELS];
-    float4* bucket4;                 // level-2 buckets
-    uint32_t* backptr;               // [id * 27 + c]: position of point id inside the level-2 bucket of its neighbour c
+    uint16_t* backpos;               // [id * 27 + c]: position of point id inside the bucket of its neighbour c (BACKPOS_FAR: see above)
     uint32_t* cellpos;               // [id]: position of point id inside its voxel's list
     float4* cell4;
     float origin[3];
@@ -385,20 +386,19 @@ __device__ __forceinline__ void inc_kill_slot(const MapRW& M, const float4* __re
     if (slot == ID_NONE) return;
     const uint4 e = L.table[slot];
     if (level < SORTED_LEVELS) {
-        const uint32_t* ids = M.bidx[level] + e.z;
-        uint32_t lo = 0, hi = e.w;        // first position with ids[pos] >= id (ids ascend, tombstones keep theirs)
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (ids[mid] < id) lo = mid + 1; else hi = mid;
+        // the point knows where it sits (the 27 back-positions of an id are 54 contiguous bytes: one line per deleted point);
+        // only a position beyond 16 bits is searched for
+        uint32_t pos = M.backpos[(size_t)id * 27 + (uint32_t)(w % 27)];
+        if (pos == (uint32_t)BACKPOS_FAR) {
+            const uint32_t* ids = M.bidx[level] + e.z;
+            uint32_t lo = (uint32_t)BACKPOS_FAR < e.w ? (uint32_t)BACKPOS_FAR : e.w, hi = e.w;   // first position with ids[pos] >= id (ids ascend, tombstones keep theirs)
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (ids[mid] < id) lo = mid + 1; else hi = mid;
+            }
+            pos = (lo < e.w && ids[lo] == id) ? lo : e.w;
         }
-        if (lo < e.w && ids[lo] == id) {
-            M.bxyz[level][((size_t)e.z + lo) * 3] = pos_inf();
-        }
-    } else if (level < REPL_LEVELS) {
-        const uint32_t pos = M.backptr[(size_t)id * 27 + (uint32_t)(w % 27)];
-        if (pos < e.w && __float_as_uint(M.bucket4[(size_t)e.z + pos].w) == id) {
-            M.bucket4[(size_t)e.z + pos].x = pos_inf();
-        }
+        if (pos < e.w) M.bxyz[level][((size_t)e.z + pos) * 3] = pos_inf();
     } else {
         const uint32_t pos = M.cellpos[id];
         if (pos < e.w && __float_as_uint(M.cell4[(size_t)e.z + pos].w) == id) M.cell4[(size_t)e.z + pos].x = pos_inf();
@@ -418,9 +418,10 @@ struct GroupRW {
     uint32_t* pslot;               // [j * REPL_LEVELS + l]: scratch-table slot of that group
     uint32_t* gbase[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: offset of the group's points in the batch tail of target c
     uint32_t* gslot[REPL_LEVELS];  // [slot * GROUP_TARGETS + c]: table slot of target c (ID_NONE: outside the range)
-    uint2* gdst[REPL_LEVELS];      // [slot * GROUP_TARGETS + c]: {absolute pool index of target c's batch tail, entries the batch appends
-                                   // to it} (x = ID_NONE: no such target), written once per (group, target) after the room is made
-                                   // (inc_resolve): the per-point passes then need neither the table nor the aux record of the target
+    uint4* gdst[REPL_LEVELS];      // [slot * GROUP_TARGETS + c]: {absolute pool index of target c's batch tail, entries the batch appends
+                                   // to it, entries the target held before the batch, -} (x = ID_NONE: no such target), written once per
+                                   // (group, target) after the room is made (inc_resolve): the per-point passes then need neither the
+                                   // table nor the aux record of the target
     const uint32_t* surv;          // optional: the batch's survivors (indices into the batch) in the order the passes walk them —
                                    // the box sort's, i.e. Morton — and their number n_live (device word); nullptr: every point of
                                    // the batch is visited in input order and the dead leave at once
@@ -454,7 +455,7 @@ __global__ void inc_surv_list_kernel(const uint32_t* __restrict__ idx_sorted, co
                                      uint32_t k, uint32_t* __restrict__ surv) {
     inc_surv_list_item(idx_sorted, flag, fpos, k, surv, blockIdx.x * blockDim.x + threadIdx.x);
 }
-constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + (level 2 only) the voxel's own list
+constexpr int GROUP_TARGETS = 28;   // 27 neighbour buckets + the list of the level-2 voxel the group's voxel lies in
 // (No global work lists or group counters: an atomic whose result is needed costs ~10 ns when every thread of a
 // launch hits the same address — 400 000 list appends were 4 ms of a 6 ms insert.  The group that reserves the
 // FIRST share of a target's tail (offset 0) owns that target for the rest of the batch: it makes room and commits.)
@@ -550,9 +551,9 @@ __device__ __forceinline__ void inc_register_item(const MapRW& M, const GroupRW&
         tl = l;
         key = pack_cell(nx, ny, nz);
     } else {
-        if (l != CELL_LEVEL) return;
-        tl = CELL_SLOT;
-        key = vkey;
+        if (l != REPL_LEVELS - 1) return;
+        tl = CELL_SLOT;   // (several voxel groups may share a list: they take their shares of its tail like the groups of a bucket)
+        key = pack_cell(vx >> (CELL_LEVEL - l), vy >> (CELL_LEVEL - l), vz >> (CELL_LEVEL - l));
     }
     const LevelRW& L = M.lv[tl];
     const uint32_t slot = table_get_slot(L, key, &M.cnt->slots_used[tl], &M.cnt->overflow);
@@ -618,10 +619,10 @@ __device__ __forceinline__ void inc_resolve_item(const MapRW& M, const GroupRW& 
     if (!inc_group_leader(G, alive, k, t, l, c, gs)) return;
     const size_t r = (size_t)gs * GROUP_TARGETS + (size_t)c;
     const uint32_t slot = G.gslot[l][r];
-    if (slot == ID_NONE) { G.gdst[l][r] = uint2{ID_NONE, 0u}; return; }
+    if (slot == ID_NONE) { G.gdst[l][r] = uint4{ID_NONE, 0u, 0u, 0u}; return; }
     const LevelRW& L = M.lv[c < 27 ? l : CELL_SLOT];
     const SlotAux a = L.aux[slot];
-    G.gdst[l][r] = uint2{L.table[slot].z + a.tail0, a.pending};
+    G.gdst[l][r] = uint4{L.table[slot].z + a.tail0, a.pending, a.tail0, 0u};
 }
 __global__ void inc_resolve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
     inc_resolve_item(M, G, alive, k, inc_thread_id());
@@ -664,8 +665,7 @@ __device__ __forceinline__ void inc_relocate_item(const MapRW& M, const uint4* _
             inc_copy_run<LANES>(xs + (size_t)m.z * 3, xs + (size_t)m.y * 3, m.w * 3u, lane);   // (12-byte points as plain words: coalesced)
             inc_copy_run<LANES>(is + (size_t)m.z, is + (size_t)m.y, m.w, lane);
         } else {
-            float4* run = (int)m.x < REPL_LEVELS ? M.bucket4 : M.cell4;
-            inc_copy_run<LANES>(run + (size_t)m.z, run + (size_t)m.y, m.w, lane);
+            inc_copy_run<LANES>(M.cell4 + (size_t)m.z, M.cell4 + (size_t)m.y, m.w, lane);
         }
     }
 }
@@ -675,9 +675,9 @@ __global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, ui
 
 // where new point j goes in target w: the level's table index, the absolute pool index of the target's batch tail, the tail's
 // length and the point's offset inside it (arbitrary order: its group's share + its rank in the group); c = target of its level
-__device__ __forceinline__ bool inc_dst_of(const GroupRW& G, uint32_t j, int w, int& tl, int& l, int& c, size_t& r, uint2& dst, uint32_t& off) {
+__device__ __forceinline__ bool inc_dst_of(const GroupRW& G, uint32_t j, int w, int& tl, int& l, int& c, size_t& r, uint4& dst, uint32_t& off) {
     if (w < 27 * REPL_LEVELS) { l = w / 27; c = w % 27; tl = l; }
-    else { l = CELL_LEVEL; c = 27; tl = CELL_SLOT; }
+    else { l = REPL_LEVELS - 1; c = 27; tl = CELL_SLOT; }
     r = (size_t)G.pslot[(size_t)j * REPL_LEVELS + l] * GROUP_TARGETS + (size_t)c;
     dst = G.gdst[l][r];
     if (dst.x == ID_NONE) return false;
@@ -685,8 +685,8 @@ __device__ __forceinline__ bool inc_dst_of(const GroupRW& G, uint32_t j, int w, 
     return true;
 }
 
-// pass 4: ids into the tails of the sorted levels (arbitrary order inside a tail); the unordered runs (level-2 buckets,
-// voxel lists) take the whole record at once
+// pass 4: ids into the tails of the buckets (arbitrary order inside a tail); the unordered runs (voxel lists) take the whole
+// record at once
 __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, uint32_t t) {
     if (M.cnt->overflow) return;
@@ -695,7 +695,7 @@ __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, 
     if (!inc_item_point(G, alive, k, t / (uint32_t)INC_SLOTS_PER_POINT, j)) return;
     int tl, l, c;
     size_t r;
-    uint2 dst;
+    uint4 dst;
     uint32_t off;
     if (!inc_dst_of(G, j, w, tl, l, c, r, dst, off)) return;
     const uint32_t id = id_base + apos[j];
@@ -703,17 +703,10 @@ __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, 
     if (tl < SORTED_LEVELS) {
         M.bidx[tl][at] = id;
     } else {
-        // the unordered runs remember positions RELATIVE to the run's start (a run may move): that needs the count before
-        // the batch, i.e. the aux record after all (28 of a point's 82 targets)
+        // the lists remember positions RELATIVE to the run's start (a run may move): count before the batch + place in its tail
         const float4 p = newp[j];
-        const uint32_t pos = M.lv[tl].aux[G.gslot[l][r]].tail0 + off;
-        if (tl < REPL_LEVELS) {
-            M.bucket4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
-            M.backptr[(size_t)id * 27 + (uint32_t)c] = pos;
-        } else {
-            M.cell4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
-            M.cellpos[id] = pos;
-        }
+        M.cell4[at] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+        M.cellpos[id] = dst.z + off;
     }
 }
 __global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
@@ -730,7 +723,7 @@ __device__ __forceinline__ void inc_rank_item(const MapRW& M, const GroupRW& G, 
     if (!inc_item_point(G, alive, k, t / (uint32_t)(27 * SORTED_LEVELS), j)) return;
     int tl, l, c;
     size_t rr;
-    uint2 dst;
+    uint4 dst;
     uint32_t off;
     if (!inc_dst_of(G, j, w, tl, l, c, rr, dst, off)) return;
     const uint32_t* ids = M.bidx[tl] + (size_t)dst.x;
@@ -753,15 +746,18 @@ __device__ __forceinline__ void inc_place_item(const MapRW& M, const GroupRW& G,
     if (!inc_item_point(G, alive, k, t / (uint32_t)(27 * SORTED_LEVELS), j)) return;
     int tl, l, c;
     size_t rr;
-    uint2 dst;
+    uint4 dst;
     uint32_t off;
     if (!inc_dst_of(G, j, w, tl, l, c, rr, dst, off)) return;
     const float4 p = newp[j];
     const size_t at = (size_t)dst.x + rank[t];
+    const uint32_t id = id_base + apos[j];
     M.bxyz[tl][at * 3 + 0] = p.x;
     M.bxyz[tl][at * 3 + 1] = p.y;
     M.bxyz[tl][at * 3 + 2] = p.z;
-    M.bidx[tl][at] = id_base + apos[j];
+    M.bidx[tl][at] = id;
+    const uint32_t pos = dst.z + rank[t];   // relative to the run's start (the 27 threads of a point write 54 contiguous bytes)
+    M.backpos[(size_t)id * 27 + (uint32_t)c] = (uint16_t)(pos < (uint32_t)BACKPOS_FAR ? pos : (uint32_t)BACKPOS_FAR);
 }
 __global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                  const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {

@@ -539,48 +539,140 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     return false;
 }
 
-// The same for a level whose buckets are UNORDERED runs of {x, y, z, id} records (level 2): the key's low word is the
-// point id, so the reference's (distance, index) order needs no ordered bucket; the winners are read from map.orig.
+// ---- level 1 in the level-0 structure (round 6) -----------------------------------------------------------------------------
+// The 27-voxel block of the query's LEVEL-1 voxel v — level-0 voxels [2v - 2, 2v + 4) on every axis — is tiled EXACTLY by eight
+// level-0 neighbourhood buckets: the buckets of the voxels 2v - 1 and 2v + 2 cover three level-0 voxels each, side by side.  A
+// bucket exists for every voxel whose 27-block holds a point, so a tile that is not in the table is empty.  The candidate set is
+// the level-1 block's, the acceptance radius search_radius(.., 1) — what a replicated level-1 bucket gave (rounds 1-5) for 27 more
+// copies of every map point and a third of every insert / deletion.  A team of LANES lanes: lane tl probes tile tl (+ LANES ...),
+// then the team streams the eight runs one after the other, 8 loads per lane in flight.
+//
+// Order.  Inside ONE bucket position order is id order; across tiles it is not, so the key's low word (tile << 24 | position)
+// orders equal distances differently from the reference's (distance, index).  That can only change the result when two
+// candidates at bit-equal distance compete — among the five winners, or the fifth winner with a candidate that was dropped.
+// Both are detected (the smallest dropped distance is tracked through every selection: `drop`) and such a point is NOT decided
+// here: it goes on to the voxel lists, which carry ids in their keys.  Exact for every input; the detour is taken by points with
+// an exact f32 distance tie among their six nearest neighbours.
+constexpr int TILE_POS_BITS = 29;   // (a bucket of 2^29 entries cannot be built: MapStore::build_buckets / inc_reserve_item refuse it)
+template <int LANES>
+struct TileRuns {   // runs of the tiles this lane probed: tile r belongs to lane r % LANES, element r / LANES
+    static constexpr int PER = LANES >= 8 ? 1 : 8 / LANES;
+    uint32_t start[PER], count[PER];
+};
+template <int LANES>
+__device__ __forceinline__ void tile_run(const TileRuns<LANES>& T, int r, int team_base, uint32_t& start, uint32_t& count) {
+    uint32_t st = T.start[0], ct = T.count[0];
+#pragma unroll
+    for (int i = 1; i < TileRuns<LANES>::PER; ++i) { st = (r / LANES == i) ? T.start[i] : st; ct = (r / LANES == i) ? T.count[i] : ct; }
+    start = (uint32_t)__shfl((int)st, team_base + r % LANES);
+    count = (uint32_t)__shfl((int)ct, team_base + r % LANES);
+}
+// k, o sorted ascending -> k = the K smallest of the union (merge5), drop = min(drop, the distances that left)
+template <int K, typename T>
+__device__ __forceinline__ void merge5_drop(kkey (&k)[K], const T& o, uint32_t& drop) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const kkey lo = kmin(o[K - 1 - i], k[i]), hi = kmax(o[K - 1 - i], k[i]);
+        k[i] = lo;
+        drop = min(drop, key_hi(hi));   // (NONE's high word is above every distance: it never lowers the minimum)
+    }
+    order_selected<K>(k);
+}
+template <int CTRL, int K>
+__device__ __forceinline__ void merge_round_drop(kkey (&k)[K], uint32_t& drop) {
+    kkey o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) o[j] = dpp_key<CTRL>(k[j]);
+    const uint32_t od = (uint32_t)__builtin_amdgcn_update_dpp((int)drop, (int)drop, CTRL, 0xF, 0xF, true);
+    drop = min(drop, od);
+    merge5_drop(k, o, drop);
+}
 template <int LANES, int K>
-__device__ __forceinline__ bool bucket_attempt_by_id(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
-                                                     kkey (&k)[K]) {
-    const GridLevel g = map.bt[bl];
-    const uint64_t key = pack_cell((uint32_t)(geo.c0x >> bl), (uint32_t)(geo.c0y >> bl), (uint32_t)(geo.c0z >> bl));
-    uint32_t slot = hash_cell(key, g.shift) & g.mask;
-    uint32_t bstart = 0, bcount = 0;
-    for (;;) {
-        const uint4 e = g.table[slot];
-        asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));   // (one 16-byte load: see bucket_attempt)
-        const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-        if (ek == key) { bstart = e.z; bcount = e.w; break; }
-        if (ek == EMPTY_KEY) break;
-        slot = (slot + 1) & g.mask;
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) k[j] = none_key();
-    if (bcount < K) return false;
+__device__ __forceinline__ void merge_team_drop(kkey (&k)[K], uint32_t& drop) {   // (the DPP rounds of merge_group)
+    static_assert(LANES <= 16, "tiles_attempt serves lane groups of up to 16 lanes");
+    if (LANES >= 2) merge_round_drop<0xB1>(k, drop);
+    if (LANES >= 4) merge_round_drop<0x4E>(k, drop);
+    if (LANES >= 8) merge_round_drop<0x141>(k, drop);
+    if (LANES >= 16) merge_round_drop<0x140>(k, drop);
+}
+template <int LANES, int K>
+__device__ __forceinline__ bool tiles_attempt(const MapView& map, const QGeom& geo, float qx, float qy, float qz, int tl, kkey (&k)[K]) {
+    // (called by whole teams: every lane of the team is active, the other teams of the wavefront may not be)
+    TileRuns<LANES> T;
+    const GridLevel g = map.bt[0];
+    const int team_base = (int)(threadIdx.x & 63u) - tl;
+    auto probe = [&](const int i) {   // (spelled out per element: the optimizer does not unroll a loop around the probe's own loop)
+        const int r = tl + i * LANES;
+        T.start[i] = 0u;
+        T.count[i] = 0u;
+        if (r < 8) {
+            const uint32_t cx = (uint32_t)(((geo.c0x >> 1) << 1) - 1 + 3 * (r & 1)), cy = (uint32_t)(((geo.c0y >> 1) << 1) - 1 + 3 * ((r >> 1) & 1)),
+                           cz = (uint32_t)(((geo.c0z >> 1) << 1) - 1 + 3 * ((r >> 2) & 1));
+            const uint64_t key = pack_cell(cx, cy, cz);
+            uint32_t slot = hash_cell(key, g.shift) & g.mask;
+            for (;;) {
+                const uint4 e = g.table[slot];
+                asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));   // (one 16-byte load: see bucket_attempt)
+                const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                if (ek == key) { T.start[i] = e.z; T.count[i] = e.w; break; }
+                if (ek == EMPTY_KEY) break;
+                slot = (slot + 1) & g.mask;
+            }
+        }
+    };
+    probe(0);
+    if constexpr (TileRuns<LANES>::PER >= 2) probe(1);
+    if constexpr (TileRuns<LANES>::PER >= 4) { probe(2); probe(3); }
+    if constexpr (TileRuns<LANES>::PER >= 8) { probe(4); probe(5); probe(6); probe(7); }
+    uint32_t drop = 0x7FEFFFFFu;
     constexpr int U = 8;
-    const float4* __restrict__ bp = map.bucket4 + bstart;
-    for (uint32_t base = 0; base < bcount; base += LANES * U) {
-        float4 mpt[U];
+    const Xyz* __restrict__ pool = reinterpret_cast<const Xyz*>(map.bxyz[0]);
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        uint32_t rstart, rcount;
+        tile_run<LANES>(T, r, team_base, rstart, rcount);
+        const Xyz* __restrict__ bp = pool + rstart;
+        // (the teams of a wavefront serve different points: the loop runs while ANY of them has candidates left in its tile r)
+        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < rcount) != 0ull; base += LANES * U) {
+            Xyz mpt[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = base + (uint32_t)(u * LANES + tl);
-            mpt[u] = bp[j < bcount ? j : 0];
-        }
-        kkey ck[U];
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                mpt[u] = bp[j < rcount ? j : 0];
+            }
+            asm volatile("" :: "v"(mpt[0].x), "v"(mpt[1].x), "v"(mpt[2].x), "v"(mpt[3].x), "v"(mpt[4].x), "v"(mpt[5].x), "v"(mpt[6].x), "v"(mpt[7].x));   // (see bucket_attempt)
+            kkey ck[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = base + (uint32_t)(u * LANES + tl);
-            ck[u] = j < bcount ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();   // (selects + pinned loads: no difference here)
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + (uint32_t)(u * LANES + tl);
+                ck[u] = make_key_if(j < rcount, calc_dist(qx, qy, qz, mpt[u]), ((uint32_t)r << TILE_POS_BITS) | j);
+            }
+            sort8(ck);
+            if constexpr (K < U) drop = min(drop, key_hi(ck[K]));
+            merge5_drop(k, ck, drop);
         }
-        sort8(ck);
-        merge5(k, ck);
     }
-    merge_team<LANES>(k);
-    const float r = search_radius(map, geo, bl);
-    const float d5 = __uint_as_float(key_hi(k[K - 1]));
-    if (!is_none(k[K - 1]) && r > 0.f && d5 < r * r) return true;
+    merge_team_drop<LANES>(k, drop);
+    // (the query's voxel geometry is derived AGAIN here, from a copy of the coordinates the compiler cannot see through: kept live
+    // across the stream above, its seven registers are what tips the one-launch pass over its 128-register budget into scratch)
+    float gx = qx, gy = qy, gz = qz;
+    asm volatile("" : "+v"(gx), "+v"(gy), "+v"(gz));
+    const QGeom geo2 = make_geom(map, gx, gy, gz);
+    const float rr = search_radius(map, geo2, 1);
+    const uint32_t d5b = key_hi(k[K - 1]);
+    bool ok = !is_none(k[K - 1]) && rr > 0.f && __uint_as_float(d5b) < rr * rr && drop != d5b;
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) ok = ok && key_hi(k[j]) != key_hi(k[j + 1]);
+    // the winners' low words become ABSOLUTE pool positions (every lane of the team holds the same keys, so the lane that owns a
+    // winner's tile resolves the same tile index)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t lo = key_lo(k[j]);
+        uint32_t rstart, rcount;
+        tile_run<LANES>(T, (int)((lo >> TILE_POS_BITS) & 7u), team_base, rstart, rcount);
+        k[j] = __hiloint2double((int)key_hi(k[j]), (int)(rstart + (lo & ((1u << TILE_POS_BITS) - 1u))));
+    }
+    if (ok) return true;
 #pragma unroll
     for (int j = 0; j < K; ++j) k[j] = none_key();
     return false;
@@ -711,7 +803,7 @@ __device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict_
     int wbin = 5;
     bool done = false;
     if (w_in_range) {
-        done = bucket_attempt_by_id<64>(map, 2, wgeo, wx, wy, wz, lane, kw);
+        done = cells_attempt<CELL_LEVEL>(map, wgeo, wx, wy, wz, lane, kw, s_pref, s_start);
         if (done) wbin = 2;
         // not accepted: d5 >= r^2 (f32).  The reference's gate is (double)d5 < MAX_DIST_PLANE^2 (Plane.cpp:42)
         float r = search_radius(map, wgeo, 2);
@@ -761,14 +853,15 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     bool decided = !live || !finite;
     int hist_bin = -1;   // what decided (instrumentation): 0, 1 bucket level; 2, 3 voxel lists; 4 every id; 5 bounded stop
     if (live && in_range) {
-#pragma unroll
-        for (int bl = 0; bl < SORTED_LEVELS; ++bl) {
-            if (!decided) {
-                decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
-                                            bl == 0 ? stage0 : nullptr);
-                if (decided) { src = bl; hist_bin = bl; }
-            }
-        }
+        decided = bucket_attempt<S>(map, 0, geo, qx, qy, qz, gl, k, bstart, DBG ? clk : nullptr, stage0);
+        if (decided) { src = 0; hist_bin = 0; }
+    }
+    // level 1 = the eight level-0 buckets that tile its block (tiles_attempt; the key's low words come back as absolute pool
+    // positions: src = 1, bstart = 0).  Per team, like level 0: every exchange inside stays within the team (DPP rows, permutes
+    // whose source lane belongs to the team), so the teams whose point is decided sit it out.
+    if (live && in_range && !decided) {   // (k is all-NONE here)
+        decided = tiles_attempt<S>(map, geo, qx, qy, qz, gl, k);
+        if (decided) { src = 1; bstart = 0; hist_bin = 1; }
     }
     if (undecided) {   // the caller shares the coarse levels out among the wavefronts of its workgroup (pass_kernel)
         *undecided = !decided;
@@ -1002,8 +1095,8 @@ __global__ LV_SEARCH_BOUNDS void search_kernel(MapView map, const float4* __rest
                         const Xyz w = s_stage[gq][pos];
                         v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
                     } else if (src >= 0) {
-                        const Xyz w = reinterpret_cast<const Xyz*>(map.bxyz[src])[(size_t)bstart + pos];
-                        v = make_float4(w.x, w.y, w.z, __uint_as_float(map.bidx[src][(size_t)bstart + pos]));
+                        const Xyz w = reinterpret_cast<const Xyz*>(map.bxyz[0])[(size_t)bstart + pos];
+                        v = make_float4(w.x, w.y, w.z, __uint_as_float(map.bidx[0][(size_t)bstart + pos]));
                     } else {
                         v = map.orig[pos];
                         v.w = __uint_as_float(pos);
@@ -1591,7 +1684,7 @@ __global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(Pass
                             const Xyz w = s_stage[gq][pos];   // still in LDS (same wavefront wrote it)
                             v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
                         } else if (src >= 0) {
-                            const Xyz w = reinterpret_cast<const Xyz*>(a.map.bxyz[src])[(size_t)bstart + pos];
+                            const Xyz w = reinterpret_cast<const Xyz*>(a.map.bxyz[0])[(size_t)bstart + pos];
                             v = make_float4(w.x, w.y, w.z, __uint_as_float(0xFFFFFFFFu));
                         } else {
                             v = a.map.orig[pos];

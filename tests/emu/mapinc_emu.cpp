@@ -55,7 +55,7 @@ void launch(K kernel, uint64_t threads, A... args) {
 
 uint32_t next_pow2(uint64_t v) { uint32_t p = 64; while (p < v) p <<= 1; return p; }
 int log2u(uint32_t s) { int lg = 0; while ((1u << lg) < s) ++lg; return lg; }
-uint32_t run_capacity(uint32_t c) { return c + (c / 2u > 8u ? c / 2u : 8u); }
+uint32_t run_capacity(uint32_t c) { return c + (c / 4u > 8u ? c / 4u : 8u); }
 
 struct Emu {
     float cell = 0.5f, box_len = 0.2f;
@@ -66,11 +66,10 @@ struct Emu {
     std::vector<SlotAux> aux[INC_LEVELS];
     std::vector<float> bxyz[SORTED_LEVELS];
     std::vector<uint32_t> bidx[SORTED_LEVELS];
-    std::vector<float4> bucket4;        // level-2 buckets
-    std::vector<uint32_t> backptr;      // [id * 27 + c]
+    std::vector<uint16_t> backpos;      // [id * 27 + c]: position of id inside the bucket of its neighbour c
     std::vector<uint32_t> cellpos;      // [id]
     std::vector<float4> cell4;
-    uint32_t pool_cap[INC_LEVELS] = {0, 0, 0, 0};
+    uint32_t pool_cap[INC_LEVELS] = {};
     MapCounters cnt{};
     std::vector<uint4> box;
     std::vector<uint32_t> box_next;
@@ -111,8 +110,7 @@ struct Emu {
             M.lv[l].pool_cap = pool_cap[l];
         }
         for (int l = 0; l < SORTED_LEVELS; ++l) { M.bxyz[l] = bxyz[l].data(); M.bidx[l] = bidx[l].data(); }
-        M.bucket4 = bucket4.data();
-        M.backptr = backptr.data();
+        M.backpos = backpos.data();
         M.cellpos = cellpos.data();
         M.cell4 = cell4.data();
         for (int a = 0; a < 3; ++a) M.origin[a] = origin[a];
@@ -161,14 +159,10 @@ struct Emu {
             uint64_t total = 0;
             for (auto& kv : buckets) total += run_capacity((uint32_t)kv.second.size());
             pool_cap[l] = (uint32_t)(total + total / 4 + pool_reserve);
-            if (l < SORTED_LEVELS) {
-                bxyz[l].assign((size_t)pool_cap[l] * 3 + 4, 0.f);
-                bidx[l].assign(pool_cap[l], 0u);
-            } else {
-                bucket4.assign(pool_cap[l], float4{0, 0, 0, 0});
-                backptr.assign(orig.size() * 27, 0xFFFFFFFFu);
-                cellpos.assign(orig.size(), 0xFFFFFFFFu);
-            }
+            bxyz[l].assign((size_t)pool_cap[l] * 3 + 4, 0.f);
+            bidx[l].assign(pool_cap[l], 0u);
+            backpos.assign(orig.size() * 27, (uint16_t)0xFFFEu);
+            cellpos.assign(orig.size(), 0xFFFFFFFFu);
             uint32_t off = 0;
             for (auto& kv : buckets) {
                 uint32_t slot;
@@ -176,19 +170,14 @@ struct Emu {
                 aux[l][slot].cap = run_capacity((uint32_t)kv.second.size());
                 const int bcx = (int)(kv.first & 0x1fffff), bcy = (int)((kv.first >> 21) & 0x1fffff), bcz = (int)((kv.first >> 42) & 0x1fffff);
                 for (size_t i = 0; i < kv.second.size(); ++i) {
-                    // level 2 is unordered on the GPU (Morton order of the sources): use descending id here
-                    const uint32_t id = l < SORTED_LEVELS ? kv.second[i] : kv.second[kv.second.size() - 1 - i];
+                    const uint32_t id = kv.second[i];
                     const float4 p = orig[id];
-                    if (l < SORTED_LEVELS) {
-                        bxyz[l][(off + i) * 3 + 0] = p.x; bxyz[l][(off + i) * 3 + 1] = p.y; bxyz[l][(off + i) * 3 + 2] = p.z;
-                        bidx[l][off + i] = id;
-                    } else {
-                        bucket4[off + i] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
-                        int c[3];
-                        cell_of(p, c);
-                        const int dx = bcx - (c[0] >> l), dy = bcy - (c[1] >> l), dz = bcz - (c[2] >> l);   // bucket voxel seen from the point
-                        backptr[(size_t)id * 27 + (size_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1))] = (uint32_t)i;
-                    }
+                    bxyz[l][(off + i) * 3 + 0] = p.x; bxyz[l][(off + i) * 3 + 1] = p.y; bxyz[l][(off + i) * 3 + 2] = p.z;
+                    bidx[l][off + i] = id;
+                    int c[3];
+                    cell_of(p, c);
+                    const int dx = bcx - (c[0] >> l), dy = bcy - (c[1] >> l), dz = bcz - (c[2] >> l);   // bucket voxel seen from the point
+                    backpos[(size_t)id * 27 + (size_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1))] = (uint16_t)(i < 0xFFFFu ? i : 0xFFFFu);
                 }
                 off += aux[l][slot].cap;
             }
@@ -244,7 +233,7 @@ struct Emu {
         size_t n = orig.size() ? orig.size() : 1024;
         while (n < cap) n *= 2;
         orig.resize(n, float4{0, 0, 0, 0});
-        backptr.resize(n * 27, 0xFFFFFFFFu);
+        backpos.resize(n * 27, (uint16_t)0xFFFEu);
         cellpos.resize(n, 0xFFFFFFFFu);
         if (have_boxes) box_next.resize(n, ID_NONE);
     }
@@ -336,14 +325,14 @@ struct Emu {
         const uint32_t gsize = next_pow2((uint64_t)k * 4);
         std::vector<uint4> gtab[REPL_LEVELS];
         std::vector<uint32_t> gbase[REPL_LEVELS], gslot[REPL_LEVELS];
-        std::vector<uint2> gdst[REPL_LEVELS];
+        std::vector<uint4> gdst[REPL_LEVELS];
         std::vector<uint32_t> prank((size_t)k * REPL_LEVELS, 0u), pslot((size_t)k * REPL_LEVELS, 0u), gcnt(4, 0u);
         GroupRW G{};
         for (int l = 0; l < REPL_LEVELS; ++l) {
             gtab[l].assign(gsize, uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
             gbase[l].assign((size_t)gsize * GROUP_TARGETS, 0xDEADBEEFu);
             gslot[l].assign((size_t)gsize * GROUP_TARGETS, 0xDEADBEEFu);
-            gdst[l].assign((size_t)gsize * GROUP_TARGETS, uint2{0xDEADBEEFu, 0xDEADBEEFu});
+            gdst[l].assign((size_t)gsize * GROUP_TARGETS, uint4{0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu});
             G.table[l] = gtab[l].data(); G.gbase[l] = gbase[l].data(); G.gslot[l] = gslot[l].data(); G.gdst[l] = gdst[l].data();
         }
         G.mask = gsize - 1;
@@ -462,11 +451,11 @@ struct Emu {
                 std::vector<uint32_t> got;
                 uint32_t prev = 0;
                 for (uint32_t i = 0; i < e.w; ++i) {
-                    const uint32_t id = l < SORTED_LEVELS ? bidx[l][e.z + i] : __float_as_uint(bucket4[e.z + i].w);
-                    if (l < SORTED_LEVELS && i && id <= prev) return fail("level %d bucket %llx: ids not ascending at %u (%u after %u)", l, (unsigned long long)key, i, id, prev);
+                    const uint32_t id = bidx[l][e.z + i];
+                    if (i && id <= prev) return fail("level %d bucket %llx: ids not ascending at %u (%u after %u)", l, (unsigned long long)key, i, id, prev);
                     prev = id;
                     if (id >= n_ids) return fail("level %d bucket %llx: id %u out of range", l, (unsigned long long)key, id);
-                    const float* rec = l < SORTED_LEVELS ? &bxyz[l][(size_t)(e.z + i) * 3] : &bucket4[e.z + i].x;
+                    const float* rec = &bxyz[l][(size_t)(e.z + i) * 3];
                     if (std::isinf(rec[0])) {
                         if (pt_alive(orig[id])) return fail("level %d bucket %llx: tombstone for living id %u", l, (unsigned long long)key, id);
                         continue;
@@ -474,17 +463,16 @@ struct Emu {
                     if (!pt_alive(orig[id])) return fail("level %d bucket %llx: dead id %u still listed", l, (unsigned long long)key, id);
                     if (std::memcmp(rec, &orig[id], 12) != 0)
                         return fail("level %d bucket %llx: coordinates of id %u differ", l, (unsigned long long)key, id);
-                    if (l >= SORTED_LEVELS) {   // the point must know this position
+                    {   // the point must know this position (16 bits; beyond: the FAR mark)
                         int c[3];
                         cell_of(orig[id], c);
                         const int dx = (int)(key & 0x1fffff) - (c[0] >> l), dy = (int)((key >> 21) & 0x1fffff) - (c[1] >> l),
                                   dz = (int)((key >> 42) & 0x1fffff) - (c[2] >> l);
-                        if (backptr[(size_t)id * 27 + (size_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1))] != i)
-                            return fail("level %d bucket %llx: back-pointer of id %u is stale", l, (unsigned long long)key, id);
+                        if (backpos[(size_t)id * 27 + (size_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1))] != (uint16_t)(i < 0xFFFFu ? i : 0xFFFFu))
+                            return fail("level %d bucket %llx: back-position of id %u is stale", l, (unsigned long long)key, id);
                     }
                     got.push_back(id);
                 }
-                if (l >= SORTED_LEVELS) std::sort(got.begin(), got.end());
                 auto it = want.find(key);
                 const std::vector<uint32_t> none;
                 const std::vector<uint32_t>& w = it == want.end() ? none : it->second;

@@ -31,13 +31,12 @@ def _knn_ok(ctx, oracle, ref, state, scan):
     assert np.array_equal(_bits(d2), _bits(od))
 
 
-@pytest.mark.parametrize("form", ["paced", "paced_small_launches", "sliced", "whole_grids"])
+@pytest.mark.parametrize("form", ["sliced", "small_slices", "whole_grids"])
 def test_forced_background_rebuild_with_inserts_and_evictions_in_flight(capi, oracle, lv, form):
-    """form: how the worker's large grids are launched — "sliced": the default (the plain kernels, 256 workgroups at a time);
-    "paced": opt-in, at most 32 workgroups of 1024 threads looping over the grid (lv_map.hip launch_paced);
-    "paced_small_launches": 7 such workgroups and 500 blocks per launch (every grid-stride loop takes many turns, every grid
-    many launches); "whole_grids": the plain kernels as the foreground build launches them.  The result must be the same map,
-    bit for bit."""
+    """form: how the worker's large grids are launched — "sliced": the default (256 workgroups at a time, lv_map.hip
+    launch_sliced); "small_slices": 7 workgroups at a time (every grid takes many launches: the slice offsets get exercised);
+    "whole_grids": as the foreground build launches them.  The result must be the same map, bit for bit.  (Round 5's opt-in
+    paced form was removed in round 6.)"""
     from limo_velo_amd import synth
 
     sc = synth.make_scene(400_000, 3000)
@@ -45,9 +44,8 @@ def test_forced_background_rebuild_with_inserts_and_evictions_in_flight(capi, or
     ref = sc["map_xyz"]
     L = float(sc["L"])
     with capi.Context() as ctx:
-        for name, value in {"paced": [("async_relinearise_paced_wgs", 32)],
-                            "paced_small_launches": [("async_relinearise_paced_wgs", 7), ("async_relinearise_paced_slice", 500)],
-                            "sliced": [("async_relinearise_paced_wgs", 0), ("async_relinearise_slice_wgs", 256)],
+        for name, value in {"sliced": [("async_relinearise_slice_wgs", 256)],
+                            "small_slices": [("async_relinearise_slice_wgs", 7)],
                             "whole_grids": [("async_relinearise_slice_wgs", 0)]}[form]:
             ctx.set_option(name, value)
         ctx.map_build(ref)
