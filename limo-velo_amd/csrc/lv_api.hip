@@ -1007,8 +1007,14 @@ int relin_poll(lv_ctx* c) {
     }
     if (c->relin_worker.joinable()) c->relin_worker.join();
     if (st == 3) {
-        fprintf(stderr, "[limovelo_hip] background map rebuild failed (%s); the map stays as it is\n", c->relin_error.c_str());
+        //  a failed worker — out of memory for the second store is the likely, and persistent, cause — must not be
+        // started again by the very call that found it failed: relin_cancel lifts the deferral, and with the background form
+        // switched off for this context the insert that follows takes the stop-the-world path (MapStore::needs_relinearise),
+        // which rebuilds in place and needs no second store.  lv_set_option "async_relinearise" 1 turns it back on.
+        fprintf(stderr, "[limovelo_hip] background map rebuild failed (%s); the map stays as it is, re-linearisations of this context stop the world from here on\n",
+                c->relin_error.c_str());
         relin_cancel(c);
+        c->relin_async = false;
         return LV_OK;
     }
     // ready: the worker's stream is drained (it synchronised after its last operation).  Nothing the caller enqueued against

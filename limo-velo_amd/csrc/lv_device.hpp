@@ -26,9 +26,13 @@ constexpr int CELL_FAR = 1 << 19;   // |cell - offset| beyond this -> brute-forc
 constexpr int MAX_LEVELS = 3;             // voxel levels of the search: edge voxel_size * 2^l (the Morton key resolves three bits per level)
 // Round 6: ONE level of 27-fold replicated neighbourhood buckets (level 0).  The 27-voxel block of a LEVEL-1 voxel v — level-0 voxels
 // [2v - 2, 2v + 4) per axis — is tiled exactly by the EIGHT level-0 buckets centred on voxels 2v - 1 and 2v + 2 per axis (each covers
-// three voxels per axis, disjoint), so level 1 is searched in the level-0 structure (tiles_attempt, lv_match.hip) and stores nothing
-// of its own; levels 2 and 3 are searched as the 27 / 216 un-replicated level-2 voxel lists.  Rounds 1-5 replicated three levels:
-// 4.1 KB per map point, 81 runs touched per inserted point, 266 DRAM lines per deleted one.
+// three voxels per axis, disjoint), and every level-0 bucket belongs to exactly one such GROUP (an odd centre c is tile 0 of
+// v = (c + 1) / 2, an even one tile 1 of v = (c - 2) / 2, per axis).  A (re)build lays the eight runs of a group out side by side
+// (slack filled with +inf), so level 1 is ONE probe of the group table + ONE contiguous stream over level-0 storage (group_attempt,
+// lv_match.hip) and stores no points of its own; a group that an insert breaks up (a run moved, a tile appeared) is marked and its
+// points go on to the lists until the next re-linearisation.  Levels 2 and 3 are searched as the 27 / 216 un-replicated level-2
+// voxel lists.  Rounds 1-5 replicated three levels: 4.1 KB per map point, 81 runs touched per inserted point, 266 DRAM lines per
+// deleted one.
 constexpr int REPL_LEVELS = 1;            // level 0: 27-fold replicated neighbourhood buckets
 constexpr int SORTED_LEVELS = 1;          // ... in ascending id, 12-byte points (== REPL_LEVELS: there is no unordered replicated level any more)
 constexpr int CELL_LEVEL = 2;             // level-2 voxels keep one plain point list each (level-2 block = 27 lists, level-3 block = 216)
@@ -143,7 +147,7 @@ struct GridLevel {
 struct SlotAux {
     uint32_t cap;      // entries the run can hold before it has to move
     uint32_t pending;  // entries the current insert batch will append
-    uint32_t fill;     // append cursor of the batch
+    uint32_t dead;     // deleted entries (tombstones) among the run's entries: what an in-place compaction would give back (bucket runs)
     uint32_t tail0;    // count before the batch
 };
 
@@ -162,8 +166,10 @@ struct MapView {
     // contiguous run ("bucket") with slack behind it for appends.  bt[0].table entries are {key lo, key hi, bucket
     // start, bucket count}; ascending id (deleted entries keep their place with x = +inf), 12-byte points (what the
     // search streams) + a parallel id array (capturing launches / deletions).  The level-1 block is eight of these
-    // buckets (see REPL_LEVELS).
+    // buckets (see REPL_LEVELS): gt maps a level-1 voxel to the region {start, extent} its group's eight runs occupy in the
+    // pool (extent 0: the group is no longer in one piece).
     GridLevel bt[REPL_LEVELS];
+    GridLevel gt;
     const float* bxyz[SORTED_LEVELS];
     const uint32_t* bidx[SORTED_LEVELS];
     // one plain list of {x, y, z, id} records per level-2 voxel: the level-2 block is searched as the 27 lists around the
@@ -330,6 +336,14 @@ __device__ __forceinline__ int cell_coord(float p, float origin, float inv_cell)
 }
 __device__ __forceinline__ uint64_t pack_cell(uint32_t ix, uint32_t iy, uint32_t iz) {
     return (uint64_t)ix | ((uint64_t)iy << 21) | ((uint64_t)iz << 42);
+}
+// the tile group of the level-0 bucket around voxel (cx, cy, cz): the level-1 voxel whose block it tiles and its place (0..7) there
+__device__ __forceinline__ void tile_group_of(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t& vx, uint32_t& vy, uint32_t& vz, int& r) {
+    const uint32_t ax = (cx & 1u) ^ 1u, ay = (cy & 1u) ^ 1u, az = (cz & 1u) ^ 1u;   // odd centre: tile 0, even centre: tile 1
+    vx = ax ? (cx - 2u) >> 1 : (cx + 1u) >> 1;
+    vy = ay ? (cy - 2u) >> 1 : (cy + 1u) >> 1;
+    vz = az ? (cz - 2u) >> 1 : (cz + 1u) >> 1;
+    r = (int)(ax | (ay << 1) | (az << 2));
 }
 __device__ __forceinline__ uint32_t hash_cell(uint64_t key, uint32_t shift) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift);

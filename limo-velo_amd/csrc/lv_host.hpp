@@ -63,6 +63,20 @@ struct MapStore {
     size_t backptr_cap = 0;               // ids they are allocated for
     uint32_t* d_biglist = nullptr;        // build scratch: buckets of more than 64 points (a workgroup each)
     size_t biglist_cap = 0;
+    // tile groups (lv_device.hpp REPL_LEVELS): level-1 voxel -> {start, extent} of the region its eight level-0 runs were laid out in
+    uint4* d_gtable = nullptr;
+    uint32_t gtable_size = 0;
+    uint32_t* d_gext = nullptr;           // build scratch: a group's extent while its runs take their places, then the groups' offsets
+    uint32_t* d_goff = nullptr;
+    size_t gscratch_cap = 0;
+    uint32_t* d_broken = nullptr;         // groups an insert batch broke up (table slots) + their re-layout plans (lv_mapinc.hpp inc_regroup_*)
+    RegroupPlan* d_regroup = nullptr;
+    uint32_t broken_cap = 0;
+    uint32_t n_groups = 0;
+    uint4* d_comp = nullptr;              // runs an insert batch compacts in place (lv_mapinc.hpp inc_compact_*), their staging area
+    float4* d_cstage = nullptr;
+    uint32_t* d_cnew = nullptr;
+    uint32_t comp_cap = 0, cstage_cap = 0;
     size_t pool_cap[INC_LEVELS] = {};     // entries per pool ([CELL_SLOT]: d_cell4)
     uint32_t pool_base[INC_LEVELS] = {};  // entries laid out by the last (re)build; the rest is split into arenas
     uint32_t n_bcells[REPL_LEVELS] = {};
@@ -161,6 +175,7 @@ struct MapStore {
     // background re-linearisation (lv_api.hip, round 5): while a compacted copy of this map is being rebuilt on another stream /
     // thread, the stop-the-world relinearise is deferred (only id-space exhaustion still forces it)
     bool defer_relinearise = false;
+    bool pool_low = false;    // the last insert left less than a quarter of the bucket pool's free part (settle): a re-linearisation is wanted
     uint32_t slice_wgs = 0;   // != 0: the large grids of a (re)build go out in slices of that many workgroups (a store rebuilt in the background)
     bool wants_relinearise(size_t incoming) const;   // the trigger, whatever defer_relinearise says
     // the living points of this map, compacted in id order, into dst.d_orig (dst: an idle store whose search structure is not

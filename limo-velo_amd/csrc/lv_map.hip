@@ -170,10 +170,20 @@ __global__ void bucket_register_kernel(GridLevelW occ, uint32_t occ_slots, GridL
     bucket_register_item(occ, occ_slots, bt, cell_slots, cell_cap, flags, (blockIdx.x + block_base) * blockDim.x + threadIdx.x);
 }
 
-// room a run of `count` entries is given when it is laid out (slack for appends; lv_mapinc.hpp relocates a run
-// that outgrows it, to 1.5 x its new size).  Round 6: a quarter of the count instead of half — with one replicated
-// level the slack IS the map's memory (27 x 16 bytes x slack per point).
-__host__ __device__ __forceinline__ uint32_t run_capacity(uint32_t count) { return count + (count / 4u > 8u ? count / 4u : 8u); }
+// room a run of `count` entries is given when it is laid out: half its count, at least 8 entries (slack for appends; lv_mapinc.hpp
+// relocates a run that outgrows it, to 1.5 x its new size, and lays its tile group out again).  With one replicated level the
+// slack IS the map's memory (27 x 16 bytes x slack per point) and level 1 streams it with the runs (a group's region: runs +
+// slack), so less was tried (profiles/experiments_r06): a quarter / 8 saves 0.13 KB per point and 1 us of the headline update's
+// first launch — and makes every insert of new points pay for thousands of runs that outgrow their room at once, each taking its
+// whole group along (64k new points 0.9 ms instead of 0.55, the pool gone after five scans); an eighth / 4 re-linearises every
+// other scan.
+#ifndef LV_RUN_SLACK_DIV
+#define LV_RUN_SLACK_DIV 2u
+#endif
+#ifndef LV_RUN_SLACK_MIN
+#define LV_RUN_SLACK_MIN 8u
+#endif
+__host__ __device__ __forceinline__ uint32_t run_capacity(uint32_t count) { return count + (count / LV_RUN_SLACK_DIV > LV_RUN_SLACK_MIN ? count / LV_RUN_SLACK_DIV : LV_RUN_SLACK_MIN); }
 
 // The 27 source runs (in `sorted`) of bucket voxel `cell`: lane c < 27 of a wavefront probes neighbour c of the bucket's voxel in the
 // occupancy table; returns this lane's (start, count) and the inclusive wave scan of the counts.
@@ -213,13 +223,52 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(GridLevelW occ, GridL
     }
 }
 
-// where a point of the bucket around voxel (bx, by, bz) sits SEEN FROM THE POINT: the bucket's voxel is neighbour c of the point's
-// own voxel (what lv_mapinc.hpp calls target c) — the slot of the point's back-position
-__device__ __forceinline__ uint32_t backpos_slot(const float4& p, const float* origin, float inv_cell, uint32_t bx, uint32_t by, uint32_t bz) {
-    const int dx = (int)bx - cell_coord(p.x, origin[0], inv_cell), dy = (int)by - cell_coord(p.y, origin[1], inv_cell),
-              dz = (int)bz - cell_coord(p.z, origin[2], inv_cell);
-    return (uint32_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
+// ---- tile groups: the eight level-0 runs that tile a level-1 block side by side (lv_device.hpp REPL_LEVELS) ----------------------
+// pass 2b: every bucket joins its group (a slot of the group table) and takes its place in the group's region: the running sum
+// of the capacities of the runs that came before it (the order of the runs inside a region is of no consequence: level 1 streams
+// the region as ONE candidate array).  boff[cell] = the group's slot, bcount[cell] = the run's offset inside the region.
+__global__ void group_join_kernel(GridLevelW bt, const uint32_t* __restrict__ cell_slots, uint32_t n_cells, const uint32_t* __restrict__ bcap,
+                                  GridLevelW gt, uint32_t* __restrict__ gext, uint32_t* __restrict__ boff, uint32_t* __restrict__ bcount,
+                                  uint32_t* __restrict__ flags, uint32_t block_base) {
+    const uint32_t cell = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    const uint4 e = bt.table[cell_slots[cell]];
+    const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    uint32_t vx, vy, vz;
+    int r;
+    tile_group_of((uint32_t)(key & 0x1fffff), (uint32_t)((key >> 21) & 0x1fffff), (uint32_t)((key >> 42) & 0x1fffff), vx, vy, vz, r);
+    const uint64_t gkey = pack_cell(vx & 0x1fffffu, vy & 0x1fffffu, vz & 0x1fffffu);
+    uint32_t gs = hash_cell(gkey, gt.shift) & gt.mask;
+    for (uint32_t probes = 0; probes <= gt.mask; ++probes) {
+        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&gt.table[gs]);
+        const unsigned long long old = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)gkey);
+        if (old == (unsigned long long)EMPTY_KEY) atomicAdd(&flags[3], 1u);   // groups (the host checks the table's load)
+        if (old == (unsigned long long)EMPTY_KEY || old == (unsigned long long)gkey) {
+            boff[cell] = gs;
+            bcount[cell] = atomicAdd(&gext[gs], bcap[cell]);
+            return;
+        }
+        gs = (gs + 1) & gt.mask;
+    }
+    flags[1] = 1;
 }
+// pass 2c (after the exclusive scan of the extents): a run's place in the pool = its group's offset + its offset in the region;
+// the group table's entries become {key, region start, region extent}
+__global__ void group_place_kernel(uint32_t n_cells, const uint32_t* __restrict__ goff, uint32_t* __restrict__ boff, const uint32_t* __restrict__ bcount,
+                                   uint32_t block_base) {
+    const uint32_t cell = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    boff[cell] = goff[boff[cell]] + bcount[cell];
+}
+__global__ void group_commit_kernel(GridLevelW gt, const uint32_t* __restrict__ goff, const uint32_t* __restrict__ gext, uint32_t block_base) {
+    const uint32_t gs = (blockIdx.x + block_base) * blockDim.x + threadIdx.x;
+    if (gs > gt.mask) return;
+    const uint4 e = gt.table[gs];
+    if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == EMPTY_KEY) return;
+    gt.table[gs].z = goff[gs];
+    gt.table[gs].w = gext[gs];
+}
+
 struct BuildOut {
     float* bxyz;
     uint32_t* bidx;
@@ -526,7 +575,8 @@ void MapStore::release() {
     hipFree(d_cell_slots); hipFree(d_flags); hipFree(d_bcount); hipFree(d_bcap); hipFree(d_boff); hipFree(d_scan_tmp);
     for (int l = 0; l < REPL_LEVELS; ++l) { hipFree(d_btable[l]); hipFree(d_baux[l]); }
     for (int l = 0; l < SORTED_LEVELS; ++l) { hipFree(d_bxyz[l]); hipFree(d_bidx[l]); }
-    hipFree(d_backpos); hipFree(d_cellpos); hipFree(d_biglist);
+    hipFree(d_backpos); hipFree(d_cellpos); hipFree(d_biglist); hipFree(d_gtable); hipFree(d_gext); hipFree(d_goff);
+    hipFree(d_broken); hipFree(d_regroup); hipFree(d_comp); hipFree(d_cstage); hipFree(d_cnew);
     hipFree(d_caux); hipFree(d_cell4);
     for (int l = 0; l < N_OCC; ++l) hipFree(d_tables[l]);
     hipFree(d_cnt);
@@ -556,6 +606,9 @@ void MapStore::refresh_view() {
         view.bxyz[l] = d_bxyz[l];
         view.bidx[l] = d_bidx[l];
     }
+    view.gt.table = d_gtable;
+    view.gt.mask = gtable_size ? gtable_size - 1 : 0;
+    view.gt.shift = (uint32_t)(64 - log2u(gtable_size ? gtable_size : 1));
     view.ct.table = d_tables[OCC_CELL];
     view.ct.mask = table_size[OCC_CELL] ? table_size[OCC_CELL] - 1 : 0;
     view.ct.shift = (uint32_t)(64 - log2u(table_size[OCC_CELL] ? table_size[OCC_CELL] : 1));
@@ -578,6 +631,19 @@ MapRW MapStore::rw() const {
         M.bidx[l] = d_bidx[l];
     }
     M.backpos = d_backpos;
+    M.gtable = d_gtable;
+    M.gmask = gtable_size ? gtable_size - 1 : 0;
+    M.gshift = (uint32_t)(64 - log2u(gtable_size ? gtable_size : 1));
+    M.gslot_limit = (uint32_t)((uint64_t)gtable_size * 7 / 10);
+    M.broken = nullptr;   // (add_staged hands the batch's lists over; sweeps break groups without listing them)
+    M.broken_cap = 0;
+    M.n_broken = nullptr;
+    M.comp = nullptr;
+    M.comp_cap = 0;
+    M.n_comp = nullptr;
+    M.cstage = nullptr;
+    M.cnew = nullptr;
+    M.cstage_cap = 0;
     M.cellpos = d_cellpos;
     M.lv[CELL_SLOT].table = d_tables[OCC_CELL];
     M.lv[CELL_SLOT].aux = d_caux;
@@ -622,6 +688,7 @@ void MapStore::stats(MapStats* out) const {
     b += (uint64_t)pool_cap[CELL_SLOT] * 16 + (uint64_t)caux_size * 16 + (uint64_t)backptr_cap * (27 * 2 + 4);   // lists, their aux; back-positions + cellpos
     for (int l = 0; l < N_OCC; ++l) b += (uint64_t)table_size[l] * 16;
     b += (uint64_t)cells_cap * 16 + (uint64_t)biglist_cap * 4;                                                // build scratch per bucket voxel
+    b += (uint64_t)gtable_size * 16 + (uint64_t)gscratch_cap * 8;                                             // tile groups: table + build scratch
     b += (uint64_t)alive_cap * 8;                                                                             // compaction / eviction flags + ranks
     b += (uint64_t)box_size * 16 + (uint64_t)box_next_cap * 4;
     out->bytes = b;
@@ -631,6 +698,7 @@ void MapStore::stats(MapStats* out) const {
 int MapStore::rebuild(hipStream_t stream) {
     built = false;
     have_boxes = false;
+    pool_low = false;
     tombstones = 0;
     view = MapView();
     refresh_view();
@@ -716,6 +784,7 @@ int MapStore::rebuild(hipStream_t stream) {
         }
     }
     for (int l = 0; l < REPL_LEVELS; ++l) h_cnt->slots_used[l] = n_bcells[l];
+    h_cnt->gslots_used = n_groups;
     h_cnt->slots_used[CELL_SLOT] = counts[OCC_CELL];
     LV_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(MapCounters), hipMemcpyHostToDevice, stream));
     LV_HIP(hipStreamSynchronize(stream));
@@ -777,14 +846,57 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
         n_bcells[level] = nb;
         launch_sliced(slice_wgs * 2, bucket_count_kernel, (nb + 3) / 4, 256u, stream, occ, bt, (const uint32_t*)d_cell_slots, nb, d_bcount, d_bcap,
                       d_biglist, d_flags);
-        size_t stmp = scan_tmp_bytes;
-        LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_bcap, d_boff, (int)nb, stream));
-        uint32_t last_off = 0, last_cap = 0, n_big = 0;
-        LV_HIP(hipMemcpyAsync(&last_off, d_boff + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LV_HIP(hipMemcpyAsync(&last_cap, d_bcap + (nb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LV_HIP(hipMemcpyAsync(&n_big, d_flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LV_HIP(hipStreamSynchronize(stream));
-        const uint64_t total = (uint64_t)last_off + last_cap;   // entries laid out, slack included
+        // the runs are laid out GROUP BY GROUP (the eight buckets that tile a level-1 block side by side): every bucket joins its
+        // group and takes its place in the group's region, the regions follow each other in table-slot order
+        uint32_t gsize = next_pow2(nb);   // (a group holds up to eight buckets; on surfaces ~4: load ~0.25; checked below)
+        uint64_t total = 0;
+        uint32_t n_big = 0;
+        for (;;) {
+            if (gsize > gtable_size || ((uint64_t)gsize * 8 <= gtable_size && gtable_size > (1u << 20))) {
+                LV_REALLOC(d_gtable, uint4, gsize);
+                gtable_size = gsize;
+            }
+            gsize = gtable_size;
+            if (gsize > gscratch_cap) {
+                LV_REALLOC(d_gext, uint32_t, gsize);
+                LV_REALLOC(d_goff, uint32_t, gsize);
+                gscratch_cap = gsize;
+            }
+            {   // (the scan's scratch was sized for the bucket voxels; a group table can be larger for tiny maps and after a retry)
+                size_t need = 0;
+                LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_gext, d_goff, (int)gsize, (hipStream_t)0));
+                if (need > scan_tmp_bytes) {
+                    if (d_scan_tmp) hipFree(d_scan_tmp);
+                    d_scan_tmp = nullptr;
+                    LV_HIP(hipMalloc(&d_scan_tmp, need));
+                    scan_tmp_bytes = need;
+                }
+            }
+            LV_HIP(hipMemsetAsync(d_gtable, 0xFF, (size_t)gsize * sizeof(uint4), stream));
+            LV_HIP(hipMemsetAsync(d_gext, 0, (size_t)gsize * sizeof(uint32_t), stream));
+            LV_HIP(hipMemsetAsync(d_flags + 3, 0, sizeof(uint32_t), stream));
+            GridLevelW gt{d_gtable, gsize - 1, (uint32_t)(64 - log2u(gsize))};
+            launch_sliced(slice_wgs * 8, group_join_kernel, (nb + 255) / 256, 256u, stream, bt, (const uint32_t*)d_cell_slots, nb, (const uint32_t*)d_bcap, gt,
+                          d_gext, d_boff, d_bcount, d_flags);
+            size_t stmp = scan_tmp_bytes;
+            LV_HIP((hipError_t)hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, stmp, d_gext, d_goff, (int)gsize, stream));
+            uint32_t last_off = 0, last_ext = 0, hf[4] = {0, 0, 0, 0};
+            LV_HIP(hipMemcpyAsync(&last_off, d_goff + (gsize - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            LV_HIP(hipMemcpyAsync(&last_ext, d_gext + (gsize - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            LV_HIP(hipMemcpyAsync(hf, d_flags, sizeof(hf), hipMemcpyDeviceToHost, stream));
+            LV_HIP(hipStreamSynchronize(stream));
+            if (hf[1] || (uint64_t)hf[3] * 10 > (uint64_t)gsize * 7) {   // too many groups for this table (isolated buckets): double and retry
+                gsize *= 2;
+                LV_HIP(hipMemsetAsync(d_flags + 1, 0, sizeof(uint32_t), stream));
+                continue;
+            }
+            total = (uint64_t)last_off + last_ext;   // entries laid out, slack included
+            n_big = hf[2];
+            n_groups = hf[3];
+            launch_sliced(slice_wgs * 8, group_place_kernel, (nb + 255) / 256, 256u, stream, nb, (const uint32_t*)d_goff, d_boff, (const uint32_t*)d_bcount);
+            launch_sliced(slice_wgs * 8, group_commit_kernel, (gsize + 255) / 256, 256u, stream, gt, (const uint32_t*)d_goff, (const uint32_t*)d_gext);
+            break;
+        }
         // the pool keeps room for runs that move and for the buckets of newly mapped space
         // (the floor follows the map: 1 Mi entries for the small maps of tests and multi-context processes, up to the 8 Mi a
         // streaming map wants for a few scans' worth of newly mapped space between two re-linearisations)
@@ -797,6 +909,9 @@ int MapStore::build_buckets(hipStream_t stream, int level, uint32_t n_occupied) 
             LV_REALLOC(d_bidx[level], uint32_t, want);
             pool_cap[level] = (size_t)want;
         }
+        // the slack behind every run reads as +inf (a candidate at distance +inf, like a deleted entry): level 1 streams a group's
+        // region runs AND slack
+        if (total) LV_HIP(hipMemsetD32Async((hipDeviceptr_t)d_bxyz[level], 0x7F800000, (size_t)total * 3, stream));
         BuildOut bo{d_bxyz[level], d_bidx[level], d_backpos, d_baux[level], {origin[0], origin[1], origin[2]}, 1.0f / cell};
         launch_sliced(slice_wgs, bucket_build_kernel, (nb + 3) / 4, 256u, stream, occ, bt, (const uint32_t*)d_cell_slots, nb, (const float4*)d_sorted,
                       (const uint32_t*)d_bcap, (const uint32_t*)d_boff, bo);
@@ -881,6 +996,18 @@ int MapStore::reserve_batch(size_t k) {
     if (!d_gcnt) LV_HIP(hipMalloc(&d_gcnt, 4 * sizeof(uint32_t)));
     reloc_cap = (uint32_t)(ncap * 27 > 0x0FFFFFF0ull ? 0x0FFFFFF0ull : ncap * 27);
     LV_REALLOC(d_reloc, uint4, reloc_cap);
+    // a batch of k points breaks up at most 27 k groups (one per target bucket), in practice a few per cent of k: more than this
+    // raises `overflow` and the map is re-linearised
+    broken_cap = (uint32_t)(ncap * 2 < 4096 ? 4096 : ncap * 2);
+    LV_REALLOC(d_broken, uint32_t, broken_cap);
+    LV_REALLOC(d_regroup, RegroupPlan, broken_cap);
+    // runs compacted in place: the list (one entry per run) and the staging area (one entry per bucket entry of a listed run; a
+    // run that finds it full moves instead)
+    comp_cap = reloc_cap;
+    cstage_cap = (uint32_t)(ncap * 32 < (1u << 20) ? (1u << 20) : ncap * 32);
+    LV_REALLOC(d_comp, uint4, comp_cap);
+    LV_REALLOC(d_cstage, float4, cstage_cap);
+    LV_REALLOC(d_cnew, uint32_t, cstage_cap);
     if (d_ntmp) hipFree(d_ntmp);
     d_ntmp = nullptr;
     size_t a = 0, b = 0;
@@ -920,6 +1047,7 @@ bool MapStore::wants_relinearise(size_t incoming) const {
     if ((uint64_t)n_ids + incoming > 0xFFFFFFF0ull) return true;
     const uint64_t dead = (uint64_t)n_ids - m;
     if (dead > 65536 && dead > (uint64_t)n_ids / 3) return true;                      // a third of the id space is dead
+    if (pool_low) return true;                                                         // the bucket pool is running out of room (settle)
     return false;
 }
 bool MapStore::needs_relinearise(size_t incoming) const {
@@ -1149,7 +1277,11 @@ __global__ __launch_bounds__(256) void inc_evict_sweep_kernel(MapRW M, int ti, f
             const bool none_goes = keep_inside ? all_in : disjoint, all_go = keep_inside ? disjoint : all_in;
             action = clamped ? 2 : (none_goes ? 0 : (all_go ? 1 : 2));
         }
-        if (action == 1) L.table[slot].w = 0u;
+        if (action == 1) {
+            L.table[slot].w = 0u;
+            L.aux[slot].dead = 0u;   // (an empty run carries no tombstones)
+            if (ti < REPL_LEVELS) inc_break_group(M, key);   // (the entries stay as they are: the group's region is no longer a valid candidate array)
+        }
         unsigned long long cut = __ballot(action == 2);
         while (cut) {
             const int src = __ffsll((long long)cut) - 1;
@@ -1165,7 +1297,7 @@ __global__ __launch_bounds__(256) void inc_evict_sweep_kernel(MapRW M, int ti, f
                 const bool alive = x < pos_inf() && x > -pos_inf();
                 if (inside != (keep_inside != 0)) {   // (an entry that is dead already stays dead either way)
                     if (alive) {
-                        if (ti < SORTED_LEVELS) M.bxyz[ti][at * 3 + 0] = pos_inf();
+                        if (ti < SORTED_LEVELS) { M.bxyz[ti][at * 3 + 0] = pos_inf(); atomicAdd(&L.aux[s0 + (uint32_t)src].dead, 1u); }
                         else M.cell4[at].x = pos_inf();
                     }
                 } else {
@@ -1174,7 +1306,7 @@ __global__ __launch_bounds__(256) void inc_evict_sweep_kernel(MapRW M, int ti, f
             }
             // a run without a living entry left is dropped like one that lies outside altogether: later sweeps (a rolling window
             // cuts the same neighbourhood again and again) and searches skip it, later inserts reuse its space
-            if (!__any(survivor) && lane == 0u) L.table[s0 + (uint32_t)src].w = 0u;
+            if (!__any(survivor) && lane == 0u) { L.table[s0 + (uint32_t)src].w = 0u; L.aux[s0 + (uint32_t)src].dead = 0u; }
         }
     }
 }
@@ -1186,6 +1318,13 @@ __global__ void inc_post_counters_kernel(const MapCounters* __restrict__ cnt, un
     note_post(note + 1, seq, cnt->n_dead);
     note_post(note + 2, seq, cnt->dropped);
     note_post(note + 3, seq, cnt->overflow);
+    // what is left of the bucket pool's free part (entries): the host starts a re-linearisation BEFORE a batch runs out of room
+    uint32_t left = 0;
+    for (int a = 0; a < N_ARENAS; ++a) {
+        const uint32_t cur = cnt->arena_cur[0][a], end = cnt->arena_end[0][a];
+        left += cur < end ? end - cur : 0u;
+    }
+    note_post(note + 4, seq, left);
 }
 
 // the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
@@ -1289,7 +1428,16 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         rc = reset_batch_counters(*this, stream);
         if (rc) return rc;
     }
-    const MapRW M = rw();
+    MapRW M = rw();
+    M.broken = d_broken;
+    M.broken_cap = broken_cap;
+    M.n_broken = d_gcnt + 1;   // (zeroed with the batch's other counters: inc_clear_groups_kernel)
+    M.comp = d_comp;
+    M.comp_cap = comp_cap;
+    M.n_comp = d_gcnt + 2;
+    M.cstage = d_cstage;
+    M.cnew = d_cnew;
+    M.cstage_cap = cstage_cap;
     BoxRW Bx{};
     if (downsample) {
         rc = ensure_boxes(stream, box_length);
@@ -1380,16 +1528,20 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     const uint64_t t_need = t_grp * RELOC_LANES < t_rel ? t_grp * RELOC_LANES : t_rel;
     const uint64_t g_need = (t_need + B - 1) / B;
     const uint32_t g_rel = (uint32_t)(g_need < 2048 ? g_need : 2048);
+    const uint32_t g_cmp = k <= (uint32_t)SMALL_BATCH ? 64u : 1024u;   // in-place compactions: how many is only known on the device (grid-stride)
     if (merged_back) {   // (see inc_kill_register_kernel)
         const uint32_t g_kill = counted_kill ? 256u : 0u;   // the occupants that lost: how many is only known on the device
         hipLaunchKernelGGL(inc_kill_register_kernel, dim3(g_kill + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_dead, (uint32_t)dead_cap, g_kill);
         hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+        // runs that only their deleted entries made too long are compacted where they lie: staged here, written back below
+        hipLaunchKernelGGL(inc_compact_gather_kernel, dim3(g_cmp), dim3(B), 0, stream, M);
         if (k <= (uint32_t)SMALL_BATCH)   // few runs move: a workgroup each
             hipLaunchKernelGGL(inc_relocate_resolve_kernel<RELOC_LANES_SMALL>, dim3(g_rel + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc,
                                (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
         else
             hipLaunchKernelGGL(inc_relocate_resolve_kernel<RELOC_LANES>, dim3(g_rel + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc,
                                (uint32_t)(t_rel / RELOC_LANES), d_gcnt, g_rel);
+        hipLaunchKernelGGL(inc_compact_scatter_kernel, dim3(g_cmp), dim3(B), 0, stream, M);
         hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
         hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
         hipLaunchKernelGGL(inc_place_commit_kernel, dim3(g_rep + g_grp), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank, g_rep);
@@ -1397,13 +1549,20 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     if (counted_kill) hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(256), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
     hipLaunchKernelGGL(inc_register_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
+    hipLaunchKernelGGL(inc_compact_gather_kernel, dim3(g_cmp), dim3(B), 0, stream, M);
     hipLaunchKernelGGL(inc_relocate_kernel, dim3(g_rel), dim3(B), 0, stream, M, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
     hipLaunchKernelGGL(inc_resolve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
+    hipLaunchKernelGGL(inc_compact_scatter_kernel, dim3(g_cmp), dim3(B), 0, stream, M);
     hipLaunchKernelGGL(inc_fill_kernel, dim3(g_all), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids);
     hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_place_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank);
     hipLaunchKernelGGL(inc_commit_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     }
+    // the tile groups this batch broke up (a run outgrew its room, a bucket appeared) are laid out again: level 1 streams a group's
+    // region as one candidate array (bucket_attempt, lv_match.hip); three small launches that find nothing to do in most batches
+    hipLaunchKernelGGL(inc_regroup_plan_kernel, dim3(64), dim3(B), 0, stream, M, d_regroup);
+    hipLaunchKernelGGL(inc_regroup_move_kernel, dim3(512), dim3(B), 0, stream, M, (const RegroupPlan*)d_regroup);
+    hipLaunchKernelGGL(inc_regroup_commit_kernel, dim3(64), dim3(B), 0, stream, M, (const RegroupPlan*)d_regroup);
     LV_HIP(hipGetLastError());
     // the insert's outcome (ids handed out, occupants that lost, overflow) is read back WITHOUT waiting for it: settle() picks
     // it up when the map's bookkeeping is needed next (the following search or insert), by which time it has long arrived
@@ -1424,8 +1583,12 @@ int MapStore::settle(hipStream_t stream) {
     // (the note is posted by the last kernel of the insert's chain, on the stream the chain ran on — the context's side stream
     // when the insert overlaps the next cycle's prediction and window: once it has arrived the whole insert has completed, so
     // whatever the caller enqueues next, on any stream, sees the finished map)
-    uint32_t v[4] = {0, 0, 0, 0};   // n_new, n_dead, dropped, overflow
-    if (!note_wait(notes, 0, 4, counters_seq, v, counters_stream)) { set_error("map insert: the counters never arrived"); return LV_EHIP; }
+    uint32_t v[5] = {0, 0, 0, 0, 0};   // n_new, n_dead, dropped, overflow, free entries left in the bucket pool
+    if (!note_wait(notes, 0, 5, counters_seq, v, counters_stream)) { set_error("map insert: the counters never arrived"); return LV_EHIP; }
+    // three quarters of the pool's free part are gone (runs that moved, groups laid out again, newly mapped space): ask for a
+    // re-linearisation now — in the background for a large map (lv_api.hip relin_maybe_start) — instead of meeting `overflow`
+    // in the middle of a later batch, which costs that batch's work and a stop-the-world rebuild
+    pool_low = (uint64_t)v[4] * 4 < (uint64_t)(pool_cap[0] > pool_base[0] ? pool_cap[0] - pool_base[0] : 0);
     uint32_t n_dead = pending_n_dead;
     if (pending_counted_kill) n_dead = v[1] < dead_cap ? v[1] : (uint32_t)dead_cap;
     n_ids += v[0];

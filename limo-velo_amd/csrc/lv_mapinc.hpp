@@ -52,7 +52,7 @@ struct MapCounters {
     uint32_t dropped;                  // new points that were not finite or outside the voxel range
     uint32_t box_slots_used;
     uint32_t tombstones;               // (unused on the device: the host counts INC_SLOTS_PER_POINT per deleted point)
-    uint32_t pad_;
+    uint32_t gslots_used;              // occupied slots of the tile-group table
 };
 
 struct LevelRW {
@@ -70,6 +70,19 @@ struct MapRW {
     float* bxyz[SORTED_LEVELS];
     uint32_t* bidx[SORTED_LEVELS];
     uint16_t* backpos;               // [id * 27 + c]: position of point id inside the bucket of its neighbour c (BACKPOS_FAR: see above)
+    uint4* gtable;                   // tile groups: level-1 voxel -> {start, extent} of its eight runs' region (extent 0: not in one piece)
+    uint32_t gmask, gshift, gslot_limit;
+    uint32_t* broken;                // optional: the groups broken up by the batch in flight (table slots), re-laid out by inc_regroup_*
+    uint32_t broken_cap;
+    uint32_t* n_broken;
+    // optional (an insert batch): runs that outgrew their room only because of the deleted entries they carry are compacted IN PLACE
+    // (inc_compact_*) instead of moving: {table slot, living entries, entries before, first staging entry} per run, the staging area
+    uint4* comp;
+    uint32_t comp_cap;
+    uint32_t* n_comp;                // [0]: runs listed, [1]: staging entries handed out
+    float4* cstage;                  // {x, y, z, id} of a listed run's entries as they were
+    uint32_t* cnew;                  // their new positions (ID_NONE: a deleted entry)
+    uint32_t cstage_cap;
     uint32_t* cellpos;               // [id]: position of point id inside its voxel's list
     float4* cell4;
     float origin[3];
@@ -84,6 +97,10 @@ struct BoxRW {
     uint32_t shift;
     uint32_t slot_limit;
     float len;           // box_length (0.2 m, Mapper.cpp:65)
+};
+
+struct RegroupPlan {   // per listed group: the table slot, old start, new start, count and capacity of its tiles (slot ID_NONE: no such bucket)
+    uint32_t slot[8], from[8], to[8], count[8], cap[8];
 };
 
 // The kernels below are compiled by ONE translation unit (lv_map.hip, or the host emulation in tests/emu): it
@@ -117,6 +134,49 @@ __device__ __forceinline__ uint32_t table_find(const uint4* table, uint32_t mask
     return ID_NONE;
 }
 
+// The tile group of the level-0 bucket `key` is no longer one contiguous region of up-to-date runs (one of its runs moved, a new
+// tile appeared outside the region, a run was dropped with its entries left as they were): level 1 stops streaming it
+// (bucket_attempt, lv_match.hip: extent 0 -> the point goes on to the lists).  An insert batch lists the groups it breaks
+// (M.broken) and lays them out again, in fresh space, behind its last pass (inc_regroup_*): a group stays broken only until
+// then — or, broken by an eviction sweep (no list), until an insert touches it or the map is re-linearised.
+// Entry states: extent > 0 intact; extent 0 broken; start == ID_NONE: broken and listed by the batch in flight.
+__device__ __forceinline__ void inc_break_group(const MapRW& M, uint64_t key) {
+    if (!M.gtable) return;
+    uint32_t vx, vy, vz;
+    int r;
+    tile_group_of((uint32_t)(key & 0x1fffff), (uint32_t)((key >> 21) & 0x1fffff), (uint32_t)((key >> 42) & 0x1fffff), vx, vy, vz, r);
+    if (vx >= (1u << 21) || vy >= (1u << 21) || vz >= (1u << 21)) return;
+    const uint64_t gkey = pack_cell(vx, vy, vz);
+    uint32_t slot = hash_cell(gkey, M.gshift) & M.gmask;
+    bool found = false, created = false;
+    for (uint32_t probes = 0; probes <= M.gmask && probes < 256u; ++probes) {
+        uint64_t ek = entry_key(M.gtable[slot]);
+        if (ek == EMPTY_KEY) {
+            if (!M.broken) return;   // (a sweep does not create groups)
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&M.gtable[slot]), (unsigned long long)EMPTY_KEY,
+                                                     (unsigned long long)gkey);
+            if (old == (unsigned long long)EMPTY_KEY) {   // a group of newly mapped space (start == ID_NONE from the table's 0xFF fill: "listed"
+                created = true;                            // — by this thread, below)
+                const uint32_t n = atomicAdd(&M.cnt->gslots_used, 1u);
+                if (n + 1u > M.gslot_limit) atomicExch(&M.cnt->overflow, 1u);
+                ek = gkey;
+            } else {
+                ek = (uint64_t)old;
+            }
+        }
+        if (ek == gkey) { found = true; break; }
+        slot = (slot + 1) & M.gmask;
+    }
+    if (!found) { if (M.broken) atomicExch(&M.cnt->overflow, 1u); return; }
+    M.gtable[slot].w = 0u;
+    if (!M.broken) return;
+    if (created || atomicExch(&M.gtable[slot].z, ID_NONE) != ID_NONE) {   // first breaker of this batch
+        const uint32_t i = atomicAdd(M.n_broken, 1u);
+        if (i < M.broken_cap) M.broken[i] = slot;
+        else atomicExch(&M.cnt->overflow, 1u);
+    }
+}
+
 // (level, neighbour) of work item w in [0, INC_SLOTS_PER_POINT): the key of the slot that must hold point p.
 // Returns false if the neighbour voxel is outside the coordinate range.
 __device__ __forceinline__ bool inc_slot_key(const MapRW& M, const float4& p, int w, int& level, uint64_t& key) {
@@ -142,6 +202,14 @@ __device__ __forceinline__ bool inc_point_ok(const MapRW& M, const float4& p) {
               cz = cell_coord(p.z, M.origin[2], M.inv_cell);
     const int amax = max(abs(cx - CELL_OFFSET), max(abs(cy - CELL_OFFSET), abs(cz - CELL_OFFSET)));
     return amax < CELL_FAR;
+}
+
+// where a point of the bucket around voxel (bx, by, bz) sits SEEN FROM THE POINT: the bucket's voxel is neighbour c of the point's
+// own voxel (target c of the insert passes) — the slot of the point's back-position
+__device__ __forceinline__ uint32_t backpos_slot(const float4& p, const float* origin, float inv_cell, uint32_t bx, uint32_t by, uint32_t bz) {
+    const int dx = (int)bx - cell_coord(p.x, origin[0], inv_cell), dy = (int)by - cell_coord(p.y, origin[1], inv_cell),
+              dz = (int)bz - cell_coord(p.z, origin[2], inv_cell);
+    return (uint32_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
 }
 
 // ---- ikd-Tree box rule --------------------------------------------------------------------------------------
@@ -398,7 +466,10 @@ __device__ __forceinline__ void inc_kill_slot(const MapRW& M, const float4* __re
             }
             pos = (lo < e.w && ids[lo] == id) ? lo : e.w;
         }
-        if (pos < e.w) M.bxyz[level][((size_t)e.z + pos) * 3] = pos_inf();
+        if (pos < e.w) {
+            M.bxyz[level][((size_t)e.z + pos) * 3] = pos_inf();
+            atomicAdd(&L.aux[slot].dead, 1u);   // (a point dies once: every tombstone is counted once)
+        }
     } else {
         const uint32_t pos = M.cellpos[id];
         if (pos < e.w && __float_as_uint(M.cell4[(size_t)e.z + pos].w) == id) M.cell4[(size_t)e.z + pos].x = pos_inf();
@@ -494,7 +565,7 @@ __global__ void inc_group_kernel(MapRW M, GroupRW G, const float4* __restrict__ 
 
 // slot of `key` in a bucket / list table, inserting it if absent (plain probe first: most slots exist)
 constexpr uint32_t MAX_PROBES = 256;   // a longer probe sequence means the table is too full: re-linearise
-__device__ __forceinline__ uint32_t table_get_slot(const LevelRW& L, uint64_t key, uint32_t* slots_used, uint32_t* overflow) {
+__device__ __forceinline__ uint32_t table_get_slot(const LevelRW& L, uint64_t key, uint32_t* slots_used, uint32_t* overflow, bool* created = nullptr) {
     uint32_t slot = hash_cell(key, L.shift) & L.mask;
     for (uint32_t probes = 0; probes <= L.mask && probes < MAX_PROBES; ++probes) {
         uint64_t ek = entry_key(L.table[slot]);
@@ -505,6 +576,7 @@ __device__ __forceinline__ uint32_t table_get_slot(const LevelRW& L, uint64_t ke
                 L.table[slot].z = 0u;
                 L.table[slot].w = 0u;
                 atomicAdd(slots_used, 1u);   // statistics only (result unused)
+                if (created) *created = true;
                 return slot;
             }
             ek = (uint64_t)old;
@@ -556,8 +628,10 @@ __device__ __forceinline__ void inc_register_item(const MapRW& M, const GroupRW&
         key = pack_cell(vx >> (CELL_LEVEL - l), vy >> (CELL_LEVEL - l), vz >> (CELL_LEVEL - l));
     }
     const LevelRW& L = M.lv[tl];
-    const uint32_t slot = table_get_slot(L, key, &M.cnt->slots_used[tl], &M.cnt->overflow);
+    bool created = false;
+    const uint32_t slot = table_get_slot(L, key, &M.cnt->slots_used[tl], &M.cnt->overflow, &created);
     if (slot == ID_NONE) return;
+    if (created && tl < REPL_LEVELS) inc_break_group(M, key);   // a new bucket lies outside its group's region
     G.gbase[l][r] = atomicAdd(&L.aux[slot].pending, n_v);
     G.gslot[l][r] = slot;
 }
@@ -581,7 +655,28 @@ __device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& 
     const uint4 e = L.table[slot];
     const SlotAux a = L.aux[slot];
     const uint32_t need = e.w + a.pending;
-    if (need > a.cap) {
+    uint32_t tail0 = e.w;
+    bool compacted = false;
+    if (need > a.cap && level < SORTED_LEVELS && M.comp && e.w >= 8u) {
+        // A bucket over re-observed ground grows by its DELETED entries: every scan's points compete with the occupants of their
+        // 0.2 m boxes, the loser stays behind as a tombstone.  If the living entries and the batch fit the run's room, the run is
+        // compacted where it lies (inc_compact_gather / _scatter: order kept, back-positions rewritten) instead of moving — a
+        // move takes the run's whole tile group along to fresh space (inc_regroup_*) and the pool with it: five 64k-point scans
+        // over the same ground used up the pool of a 1 M-point map, a re-linearisation every sixth scan.
+        const uint32_t living = e.w - (a.dead < e.w ? a.dead : e.w);   // (the run's tombstones are counted as they are written: inc_kill_slot, the eviction sweep)
+        if (living + a.pending <= a.cap && living + 4u <= e.w) {
+            const uint32_t base = atomicAdd(&M.n_comp[1], e.w);
+            if ((uint64_t)base + e.w <= (uint64_t)M.cstage_cap) {
+                const uint32_t ci = atomicAdd(&M.n_comp[0], 1u);
+                if (ci < M.comp_cap) {
+                    M.comp[ci] = uint4{slot, living, e.w, base};
+                    tail0 = living;
+                    compacted = true;
+                }
+            }
+        }
+    }
+    if (need > a.cap && !compacted) {
         const uint32_t extra = need / 2u > 8u ? need / 2u : 8u;
         const uint32_t ncap = need + extra;
         uint32_t ns = 0;
@@ -601,9 +696,10 @@ __device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& 
             }
             L.table[slot].z = ns;
             L.aux[slot].cap = ncap;
+            if (level < REPL_LEVELS) inc_break_group(M, entry_key(e));   // the run leaves its group's region
         }
     }
-    L.aux[slot].tail0 = e.w;
+    L.aux[slot].tail0 = tail0;
 }
 __global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
                                    uint32_t reloc_cap, uint32_t* __restrict__ n_reloc) {
@@ -773,12 +869,167 @@ __device__ __forceinline__ void inc_commit_item(const MapRW& M, const GroupRW& G
     const uint32_t slot = G.gslot[l][r];
     if (slot == ID_NONE || G.gbase[l][r] != 0u) return;
     const LevelRW& L = M.lv[c < 27 ? l : CELL_SLOT];
-    if (M.cnt->overflow == 0u) L.table[slot].w += L.aux[slot].pending;
+    if (M.cnt->overflow == 0u) L.table[slot].w = L.aux[slot].tail0 + L.aux[slot].pending;   // (tail0: the count before the batch — after an in-place compaction, the living entries)
     L.aux[slot].pending = 0u;
-    L.aux[slot].fill = 0u;
 }
 __global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
     inc_commit_item(M, G, alive, k, inc_thread_id());
+}
+
+// ---- runs compacted in place (see inc_reserve_item) -------------------------------------------------------------------------------
+// COMPACT_LANES threads per listed run.  gather (with the launch that moves runs, before the batch's entries arrive): every entry
+// is staged as it was, a living one with its new position = the number of living entries before it; scatter (with the launch that
+// writes the batch's ids into the tails [living, living + pending), which it does not touch): the living entries go to their new
+// positions — ascending id survives — with their back-positions, the positions behind the new tail read +inf.
+constexpr int COMPACT_LANES = 64;
+__device__ __forceinline__ void inc_compact_gather_item(const MapRW& M, uint32_t t, uint32_t n_threads) {
+    if (M.cnt->overflow) return;
+    const uint32_t n = M.n_comp[0] < M.comp_cap ? M.n_comp[0] : M.comp_cap;
+    const uint32_t lane = t % (uint32_t)COMPACT_LANES;
+    for (uint32_t r = t / (uint32_t)COMPACT_LANES; r < n; r += n_threads / (uint32_t)COMPACT_LANES) {
+        const uint4 c = M.comp[r];   // {slot, living, count before, staging base}
+        const uint4 e = M.lv[0].table[c.x];
+        const float* xs = M.bxyz[0] + (size_t)e.z * 3;
+        const uint32_t* is = M.bidx[0] + e.z;
+        for (uint32_t i = lane; i < c.z; i += (uint32_t)COMPACT_LANES) {
+            const float x = xs[(size_t)i * 3];
+            M.cstage[c.w + i] = make_float4(x, xs[(size_t)i * 3 + 1], xs[(size_t)i * 3 + 2], __uint_as_float(is[i]));
+            uint32_t np = ID_NONE;
+            if (x < pos_inf()) {
+                np = 0;
+                for (uint32_t j = 0; j < i; ++j) np += xs[(size_t)j * 3] < pos_inf() ? 1u : 0u;
+            }
+            M.cnew[c.w + i] = np;
+            if (i + 1u == c.z) {   // (the run's last entry checks the count the decision was taken with: a mismatch would misplace the batch's tail)
+                const uint32_t total = (np == ID_NONE ? 0u : np + 1u);
+                uint32_t before = 0;
+                if (np == ID_NONE) for (uint32_t j = 0; j < i; ++j) before += xs[(size_t)j * 3] < pos_inf() ? 1u : 0u;
+                if ((np == ID_NONE ? before : total) != c.y) atomicExch(&M.cnt->overflow, 1u);
+            }
+        }
+    }
+}
+__global__ void inc_compact_gather_kernel(MapRW M) { inc_compact_gather_item(M, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
+__device__ __forceinline__ void inc_compact_scatter_item(const MapRW& M, uint32_t t, uint32_t n_threads) {
+    if (M.cnt->overflow) return;
+    const uint32_t n = M.n_comp[0] < M.comp_cap ? M.n_comp[0] : M.comp_cap;
+    const uint32_t lane = t % (uint32_t)COMPACT_LANES;
+    for (uint32_t r = t / (uint32_t)COMPACT_LANES; r < n; r += n_threads / (uint32_t)COMPACT_LANES) {
+        const uint4 c = M.comp[r];
+        const uint4 e = M.lv[0].table[c.x];
+        const uint64_t key = entry_key(e);
+        const uint32_t bx = (uint32_t)(key & 0x1fffff), by = (uint32_t)((key >> 21) & 0x1fffff), bz = (uint32_t)((key >> 42) & 0x1fffff);
+        const uint32_t tail_end = c.y + M.lv[0].aux[c.x].pending;   // the batch's entries take [living, living + pending)
+        float* xs = M.bxyz[0] + (size_t)e.z * 3;
+        uint32_t* is = M.bidx[0] + e.z;
+        if (lane == 0u) M.lv[0].aux[c.x].dead = 0u;
+        for (uint32_t i = lane; i < c.z; i += (uint32_t)COMPACT_LANES) {
+            const uint32_t np = M.cnew[c.w + i];
+            if (np != ID_NONE) {
+                const float4 p = M.cstage[c.w + i];
+                xs[(size_t)np * 3] = p.x; xs[(size_t)np * 3 + 1] = p.y; xs[(size_t)np * 3 + 2] = p.z;
+                const uint32_t id = __float_as_uint(p.w);
+                is[np] = id;
+                M.backpos[(size_t)id * 27 + backpos_slot(p, M.origin, M.inv_cell, bx, by, bz)] = (uint16_t)(np < (uint32_t)BACKPOS_FAR ? np : (uint32_t)BACKPOS_FAR);
+            }
+            if (i >= tail_end) { xs[(size_t)i * 3] = pos_inf(); xs[(size_t)i * 3 + 1] = pos_inf(); xs[(size_t)i * 3 + 2] = pos_inf(); }
+        }
+    }
+}
+__global__ void inc_compact_scatter_kernel(MapRW M) { inc_compact_scatter_item(M, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
+
+// ---- tile groups broken up by the batch: laid out again ------------------------------------------------------------------------
+// (behind the batch's last pass: counts and capacities are final).  A group's region = its up to eight runs side by side, every
+// run with its capacity, the slack reading +inf; the old runs are abandoned where they lie (space comes back with the next
+// re-linearisation, like the old place of a run that moved).  Positions inside a run do not change: back-positions stay valid.
+// pass R1, one thread per listed group: find the group's buckets, take room for the region, publish the group's entry
+__device__ __forceinline__ void inc_regroup_plan_item(const MapRW& M, RegroupPlan* __restrict__ plan, uint32_t g) {
+    const uint32_t nb = *M.n_broken < M.broken_cap ? *M.n_broken : M.broken_cap;
+    if (g >= nb || M.cnt->overflow) return;
+    const uint32_t gs = M.broken[g];
+    const uint64_t gkey = entry_key(M.gtable[gs]);
+    const uint32_t vx = (uint32_t)(gkey & 0x1fffff), vy = (uint32_t)((gkey >> 21) & 0x1fffff), vz = (uint32_t)((gkey >> 42) & 0x1fffff);
+    const LevelRW& L = M.lv[0];
+    RegroupPlan& P = plan[g];
+    uint32_t extent = 0;
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t cx = 2u * vx - 1u + 3u * (uint32_t)(r & 1), cy = 2u * vy - 1u + 3u * (uint32_t)((r >> 1) & 1), cz = 2u * vz - 1u + 3u * (uint32_t)((r >> 2) & 1);
+        P.slot[r] = ID_NONE;
+        P.count[r] = P.cap[r] = P.from[r] = P.to[r] = 0u;
+        if (cx >= (1u << 21) || cy >= (1u << 21) || cz >= (1u << 21)) continue;
+        const uint32_t slot = table_find(L.table, L.mask, L.shift, pack_cell(cx, cy, cz));
+        if (slot == ID_NONE) continue;
+        const uint4 e = L.table[slot];
+        P.slot[r] = slot;
+        P.from[r] = e.z;
+        P.count[r] = e.w;
+        // every run of the group gets room again (half its count, like a run that moves): a group that is laid out afresh should
+        // not come back with the next batch because a sibling run was one entry short
+        const uint32_t fresh = e.w + (e.w / 2u > 8u ? e.w / 2u : 8u), have = L.aux[slot].cap;
+        P.cap[r] = have > fresh ? have : fresh;
+        P.to[r] = extent;        // (relative: the region's start is added below)
+        extent += P.cap[r];
+    }
+    uint32_t ns = 0;
+    bool got = extent == 0u;
+    for (int tr = 0; tr < 4 && !got; ++tr) {
+        const uint32_t ar = (gs + (uint32_t)tr * 17u) & (uint32_t)(N_ARENAS - 1);
+        ns = atomicAdd(&M.cnt->arena_cur[0][ar], extent);
+        got = (uint64_t)ns + extent <= (uint64_t)M.cnt->arena_end[0][ar];
+    }
+    if (!got) {
+        atomicExch(&M.cnt->overflow, 1u);
+        for (int r = 0; r < 8; ++r) P.slot[r] = ID_NONE;   // (nothing moves; the group stays broken until the re-linearisation that follows)
+        M.gtable[gs].z = 0u;
+        return;
+    }
+    for (int r = 0; r < 8; ++r) P.to[r] += ns;
+    M.gtable[gs].z = ns;
+    M.gtable[gs].w = extent;
+}
+__global__ void inc_regroup_plan_kernel(MapRW M, RegroupPlan* __restrict__ plan) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < M.broken_cap; g += gridDim.x * blockDim.x) inc_regroup_plan_item(M, plan, g);
+}
+// pass R2, REGROUP_LANES threads per listed group: the runs move (entries [0, count)), the slack behind them reads +inf
+constexpr int REGROUP_LANES = 64;
+__device__ __forceinline__ void inc_regroup_move_item(const MapRW& M, const RegroupPlan* __restrict__ plan, uint32_t t, uint32_t n_threads) {
+    const uint32_t nb = *M.n_broken < M.broken_cap ? *M.n_broken : M.broken_cap;
+    if (M.cnt->overflow) return;
+    const uint32_t lane = t % (uint32_t)REGROUP_LANES;
+    for (uint32_t g = t / (uint32_t)REGROUP_LANES; g < nb; g += n_threads / (uint32_t)REGROUP_LANES) {
+        const RegroupPlan& P = plan[g];
+        for (int r = 0; r < 8; ++r) {
+            if (P.slot[r] == ID_NONE) continue;
+            float* xs = M.bxyz[0];
+            uint32_t* is = M.bidx[0];
+            for (uint32_t i = lane; i < P.cap[r]; i += (uint32_t)REGROUP_LANES) {
+                const size_t d = (size_t)P.to[r] + i, sidx = (size_t)P.from[r] + i;
+                if (i < P.count[r]) {
+                    xs[d * 3] = xs[sidx * 3]; xs[d * 3 + 1] = xs[sidx * 3 + 1]; xs[d * 3 + 2] = xs[sidx * 3 + 2];
+                    is[d] = is[sidx];
+                } else {
+                    xs[d * 3] = pos_inf(); xs[d * 3 + 1] = pos_inf(); xs[d * 3 + 2] = pos_inf();
+                }
+            }
+        }
+    }
+}
+__global__ void inc_regroup_move_kernel(MapRW M, const RegroupPlan* __restrict__ plan) {
+    inc_regroup_move_item(M, plan, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+// pass R3, one thread per (listed group, tile): the buckets point at their new runs
+__device__ __forceinline__ void inc_regroup_commit_item(const MapRW& M, const RegroupPlan* __restrict__ plan, uint32_t t) {
+    const uint32_t nb = *M.n_broken < M.broken_cap ? *M.n_broken : M.broken_cap;
+    if (t / 8u >= nb || M.cnt->overflow) return;
+    const RegroupPlan& P = plan[t / 8u];
+    const int r = (int)(t % 8u);
+    if (P.slot[r] != ID_NONE) {
+        M.lv[0].table[P.slot[r]].z = P.to[r];
+        M.lv[0].aux[P.slot[r]].cap = P.cap[r];
+    }
+}
+__global__ void inc_regroup_commit_kernel(MapRW M, const RegroupPlan* __restrict__ plan) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < M.broken_cap * 8u; t += gridDim.x * blockDim.x) inc_regroup_commit_item(M, plan, t);
 }
 
 // ---- eviction --------------------------------------------------------------------------------------------------

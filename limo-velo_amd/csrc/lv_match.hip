@@ -444,19 +444,65 @@ __device__ __forceinline__ void merge_team(kkey (&k)[K]) {
 // entries / ids are not)
 __device__ __forceinline__ bool key_real(kkey k) { return key_hi(k) < 0x7F800000u; }
 
+// k, o sorted ascending -> k = the K smallest of the union (merge5), drop = min(drop, the distances that left)
+template <int K, typename T>
+__device__ __forceinline__ void merge5_drop(kkey (&k)[K], const T& o, uint32_t& drop) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const kkey lo = kmin(o[K - 1 - i], k[i]), hi = kmax(o[K - 1 - i], k[i]);
+        k[i] = lo;
+        drop = min(drop, key_hi(hi));   // (NONE's high word is above every distance: it never lowers the minimum)
+    }
+    order_selected<K>(k);
+}
+template <int CTRL, int K>
+__device__ __forceinline__ void merge_round_drop(kkey (&k)[K], uint32_t& drop) {
+    kkey o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) o[j] = dpp_key<CTRL>(k[j]);
+    const uint32_t od = (uint32_t)__builtin_amdgcn_update_dpp((int)drop, (int)drop, CTRL, 0xF, 0xF, true);
+    drop = min(drop, od);
+    merge5_drop(k, o, drop);
+}
+template <int LANES, int K>
+__device__ __forceinline__ void merge_team_drop(kkey (&k)[K], uint32_t& drop) {   // (the DPP rounds of merge_group)
+    static_assert(LANES <= 16, "lane groups of up to 16 lanes");
+    if (LANES >= 2) merge_round_drop<0xB1>(k, drop);
+    if (LANES >= 4) merge_round_drop<0x4E>(k, drop);
+    if (LANES >= 8) merge_round_drop<0x141>(k, drop);
+    if (LANES >= 16) merge_round_drop<0x140>(k, drop);
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One bucket-level attempt by a team of LANES lanes (tl = lane in team): ONE probe of the level's bucket table
 // and ONE coalesced stream over the neighbourhood bucket of the query's voxel (a miss means the whole
 // 27-voxel block is empty).  k is all-NONE on entry; returns true with the sorted result in k (low words =
 // positions inside the bucket starting at bstart) iff 5 candidates were found inside the guaranteed radius,
 // otherwise false with k reset to NONE.  Deleted entries stay in place with x = +inf: their distance is +inf,
 // which loses against every real candidate and fails the radius test.
+// bl == 1 (round 6): the level-1 block in level-0 storage.  Its 27 voxels are tiled exactly by the eight level-0 buckets of one tile
+// GROUP (lv_device.hpp REPL_LEVELS), which a (re)build lays out side by side: ONE probe of the group table and ONE stream over the
+// region {start, extent} — runs with their slack, the slack filled with +inf (distance +inf, like a deleted entry) — give the
+// candidate set a replicated level-1 bucket gave (rounds 1-5) for 27 more copies of every map point and two thirds of every
+// insert / deletion.  A group that an insert broke up has extent 0: the point is not decided here and goes on to the lists.
+// Order.  Inside ONE bucket position order is id order; across the eight runs it is not, so here the key's low word (position in
+// the region) orders equal distances differently from the reference's (distance, index).  That can only change the result when
+// two candidates at bit-equal distance compete — among the five winners, or the fifth winner with a candidate that was dropped.
+// Both are detected (the smallest dropped distance is tracked through every selection: `drop`) and such a point is NOT decided
+// here either: the lists carry ids in their keys.  Exact for every input; the detour is taken by points with an exact f32
+// distance tie among their six nearest neighbours.
 template <int LANES, int K>
 __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
                                                kkey (&k)[K], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
     // stage (LDS, LANES * 8 entries of this team, or nullptr): the first chunk's candidates are kept there by
     // position, so that the caller can pick the winners up without another trip to memory
-    const GridLevel g = map.bt[bl];
+    const GridLevel g = bl == 0 ? map.bt[0] : map.gt;
     const uint64_t key = pack_cell((uint32_t)(geo.c0x >> bl), (uint32_t)(geo.c0y >> bl), (uint32_t)(geo.c0z >> bl));
+    uint32_t drop = 0x7FEFFFFFu;   // (bl == 1) smallest distance that left a selection
     uint32_t slot = hash_cell(key, g.shift) & g.mask;
     uint32_t bcount = 0;
     for (;;) {
@@ -472,7 +518,7 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
     if (clk) { asm volatile("" :: "v"(bcount)); clk[2] = clock64(); }
     if (bcount < K) return false;
     constexpr int U = 8;
-    const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[bl]) + bstart;
+    const Xyz* __restrict__ bp = reinterpret_cast<const Xyz*>(map.bxyz[0]) + bstart;
     uint32_t base = 0;
     do {
         // (round 4) A bucket of the benchmark's map holds 62 candidates on average and more than the 64 of a chunk one time in four:
@@ -522,155 +568,29 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
             ck[u] = make_key_if(j < bcount, calc_dist(qx, qy, qz, mpt[u]), j);
         }
         sort8(ck);
+#ifndef LV_DIAG_NODROP
+#define LV_DIAG_NODROP 0   // (diagnostic build only: level 1 without the tie tracking — NOT exact)
+#endif
+        if (bl != 0 && K < U && !LV_DIAG_NODROP) drop = min(drop, key_hi(ck[K < U ? K : 0]));
         if (base == 0) {   // k is still all-NONE: the union's five smallest are the chunk's
 #pragma unroll
             for (int i = 0; i < K; ++i) k[i] = ck[i];
+        } else if (bl != 0 && !LV_DIAG_NODROP) {
+            merge5_drop(k, ck, drop);
         } else {
             merge5(k, ck);
         }
         base += LANES * U;
     } while ((LV_HALF_CHUNK && K == KNN && bl == 0) ? __builtin_amdgcn_ballot_w64(base < bcount) != 0ull : base < bcount);
-    merge_team<LANES>(k);
+    if (bl != 0 && !LV_DIAG_NODROP) merge_team_drop<LANES>(k, drop);
+    else merge_team<LANES>(k);
     const float r = search_radius(map, geo, bl);
     const float d5 = __uint_as_float(key_hi(k[K - 1]));
-    if (!is_none(k[K - 1]) && r > 0.f && d5 < r * r) return true;
+    bool ok = !is_none(k[K - 1]) && r > 0.f && d5 < r * r;
+    if (bl != 0) {   // (see "Order" above)
+        ok = ok && drop != key_hi(k[K - 1]);
 #pragma unroll
-    for (int j = 0; j < K; ++j) k[j] = none_key();
-    return false;
-}
-
-// ---- level 1 in the level-0 structure (round 6) -----------------------------------------------------------------------------
-// The 27-voxel block of the query's LEVEL-1 voxel v — level-0 voxels [2v - 2, 2v + 4) on every axis — is tiled EXACTLY by eight
-// level-0 neighbourhood buckets: the buckets of the voxels 2v - 1 and 2v + 2 cover three level-0 voxels each, side by side.  A
-// bucket exists for every voxel whose 27-block holds a point, so a tile that is not in the table is empty.  The candidate set is
-// the level-1 block's, the acceptance radius search_radius(.., 1) — what a replicated level-1 bucket gave (rounds 1-5) for 27 more
-// copies of every map point and a third of every insert / deletion.  A team of LANES lanes: lane tl probes tile tl (+ LANES ...),
-// then the team streams the eight runs one after the other, 8 loads per lane in flight.
-//
-// Order.  Inside ONE bucket position order is id order; across tiles it is not, so the key's low word (tile << 24 | position)
-// orders equal distances differently from the reference's (distance, index).  That can only change the result when two
-// candidates at bit-equal distance compete — among the five winners, or the fifth winner with a candidate that was dropped.
-// Both are detected (the smallest dropped distance is tracked through every selection: `drop`) and such a point is NOT decided
-// here: it goes on to the voxel lists, which carry ids in their keys.  Exact for every input; the detour is taken by points with
-// an exact f32 distance tie among their six nearest neighbours.
-constexpr int TILE_POS_BITS = 29;   // (a bucket of 2^29 entries cannot be built: MapStore::build_buckets / inc_reserve_item refuse it)
-template <int LANES>
-struct TileRuns {   // runs of the tiles this lane probed: tile r belongs to lane r % LANES, element r / LANES
-    static constexpr int PER = LANES >= 8 ? 1 : 8 / LANES;
-    uint32_t start[PER], count[PER];
-};
-template <int LANES>
-__device__ __forceinline__ void tile_run(const TileRuns<LANES>& T, int r, int team_base, uint32_t& start, uint32_t& count) {
-    uint32_t st = T.start[0], ct = T.count[0];
-#pragma unroll
-    for (int i = 1; i < TileRuns<LANES>::PER; ++i) { st = (r / LANES == i) ? T.start[i] : st; ct = (r / LANES == i) ? T.count[i] : ct; }
-    start = (uint32_t)__shfl((int)st, team_base + r % LANES);
-    count = (uint32_t)__shfl((int)ct, team_base + r % LANES);
-}
-// k, o sorted ascending -> k = the K smallest of the union (merge5), drop = min(drop, the distances that left)
-template <int K, typename T>
-__device__ __forceinline__ void merge5_drop(kkey (&k)[K], const T& o, uint32_t& drop) {
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const kkey lo = kmin(o[K - 1 - i], k[i]), hi = kmax(o[K - 1 - i], k[i]);
-        k[i] = lo;
-        drop = min(drop, key_hi(hi));   // (NONE's high word is above every distance: it never lowers the minimum)
-    }
-    order_selected<K>(k);
-}
-template <int CTRL, int K>
-__device__ __forceinline__ void merge_round_drop(kkey (&k)[K], uint32_t& drop) {
-    kkey o[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) o[j] = dpp_key<CTRL>(k[j]);
-    const uint32_t od = (uint32_t)__builtin_amdgcn_update_dpp((int)drop, (int)drop, CTRL, 0xF, 0xF, true);
-    drop = min(drop, od);
-    merge5_drop(k, o, drop);
-}
-template <int LANES, int K>
-__device__ __forceinline__ void merge_team_drop(kkey (&k)[K], uint32_t& drop) {   // (the DPP rounds of merge_group)
-    static_assert(LANES <= 16, "tiles_attempt serves lane groups of up to 16 lanes");
-    if (LANES >= 2) merge_round_drop<0xB1>(k, drop);
-    if (LANES >= 4) merge_round_drop<0x4E>(k, drop);
-    if (LANES >= 8) merge_round_drop<0x141>(k, drop);
-    if (LANES >= 16) merge_round_drop<0x140>(k, drop);
-}
-template <int LANES, int K>
-__device__ __forceinline__ bool tiles_attempt(const MapView& map, const QGeom& geo, float qx, float qy, float qz, int tl, kkey (&k)[K]) {
-    // (called by whole teams: every lane of the team is active, the other teams of the wavefront may not be)
-    TileRuns<LANES> T;
-    const GridLevel g = map.bt[0];
-    const int team_base = (int)(threadIdx.x & 63u) - tl;
-    auto probe = [&](const int i) {   // (spelled out per element: the optimizer does not unroll a loop around the probe's own loop)
-        const int r = tl + i * LANES;
-        T.start[i] = 0u;
-        T.count[i] = 0u;
-        if (r < 8) {
-            const uint32_t cx = (uint32_t)(((geo.c0x >> 1) << 1) - 1 + 3 * (r & 1)), cy = (uint32_t)(((geo.c0y >> 1) << 1) - 1 + 3 * ((r >> 1) & 1)),
-                           cz = (uint32_t)(((geo.c0z >> 1) << 1) - 1 + 3 * ((r >> 2) & 1));
-            const uint64_t key = pack_cell(cx, cy, cz);
-            uint32_t slot = hash_cell(key, g.shift) & g.mask;
-            for (;;) {
-                const uint4 e = g.table[slot];
-                asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));   // (one 16-byte load: see bucket_attempt)
-                const uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                if (ek == key) { T.start[i] = e.z; T.count[i] = e.w; break; }
-                if (ek == EMPTY_KEY) break;
-                slot = (slot + 1) & g.mask;
-            }
-        }
-    };
-    probe(0);
-    if constexpr (TileRuns<LANES>::PER >= 2) probe(1);
-    if constexpr (TileRuns<LANES>::PER >= 4) { probe(2); probe(3); }
-    if constexpr (TileRuns<LANES>::PER >= 8) { probe(4); probe(5); probe(6); probe(7); }
-    uint32_t drop = 0x7FEFFFFFu;
-    constexpr int U = 8;
-    const Xyz* __restrict__ pool = reinterpret_cast<const Xyz*>(map.bxyz[0]);
-#pragma unroll 1
-    for (int r = 0; r < 8; ++r) {
-        uint32_t rstart, rcount;
-        tile_run<LANES>(T, r, team_base, rstart, rcount);
-        const Xyz* __restrict__ bp = pool + rstart;
-        // (the teams of a wavefront serve different points: the loop runs while ANY of them has candidates left in its tile r)
-        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < rcount) != 0ull; base += LANES * U) {
-            Xyz mpt[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = base + (uint32_t)(u * LANES + tl);
-                mpt[u] = bp[j < rcount ? j : 0];
-            }
-            asm volatile("" :: "v"(mpt[0].x), "v"(mpt[1].x), "v"(mpt[2].x), "v"(mpt[3].x), "v"(mpt[4].x), "v"(mpt[5].x), "v"(mpt[6].x), "v"(mpt[7].x));   // (see bucket_attempt)
-            kkey ck[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = base + (uint32_t)(u * LANES + tl);
-                ck[u] = make_key_if(j < rcount, calc_dist(qx, qy, qz, mpt[u]), ((uint32_t)r << TILE_POS_BITS) | j);
-            }
-            sort8(ck);
-            if constexpr (K < U) drop = min(drop, key_hi(ck[K]));
-            merge5_drop(k, ck, drop);
-        }
-    }
-    merge_team_drop<LANES>(k, drop);
-    // (the query's voxel geometry is derived AGAIN here, from a copy of the coordinates the compiler cannot see through: kept live
-    // across the stream above, its seven registers are what tips the one-launch pass over its 128-register budget into scratch)
-    float gx = qx, gy = qy, gz = qz;
-    asm volatile("" : "+v"(gx), "+v"(gy), "+v"(gz));
-    const QGeom geo2 = make_geom(map, gx, gy, gz);
-    const float rr = search_radius(map, geo2, 1);
-    const uint32_t d5b = key_hi(k[K - 1]);
-    bool ok = !is_none(k[K - 1]) && rr > 0.f && __uint_as_float(d5b) < rr * rr && drop != d5b;
-#pragma unroll
-    for (int j = 0; j + 1 < K; ++j) ok = ok && key_hi(k[j]) != key_hi(k[j + 1]);
-    // the winners' low words become ABSOLUTE pool positions (every lane of the team holds the same keys, so the lane that owns a
-    // winner's tile resolves the same tile index)
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t lo = key_lo(k[j]);
-        uint32_t rstart, rcount;
-        tile_run<LANES>(T, (int)((lo >> TILE_POS_BITS) & 7u), team_base, rstart, rcount);
-        k[j] = __hiloint2double((int)key_hi(k[j]), (int)(rstart + (lo & ((1u << TILE_POS_BITS) - 1u))));
+        for (int j = 0; j + 1 < K; ++j) ok = ok && key_hi(k[j]) != key_hi(k[j + 1]);
     }
     if (ok) return true;
 #pragma unroll
@@ -678,28 +598,30 @@ __device__ __forceinline__ bool tiles_attempt(const MapView& map, const QGeom& g
     return false;
 }
 
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// A block of SIDE x SIDE x SIDE level-2 voxels (origin (bx, by, bz) in level-2 voxel coordinates) searched by a WHOLE wavefront over
+// the level-2 voxel lists: every lane probes one voxel (SIDE^3 <= 64: one round; the 6 x 6 x 6 = 216 lists of the level-3 block:
+// four), a wave scan turns the list lengths into one virtual candidate array, and the lanes stream it 8 loads per lane in flight
+// (each load finds its list by a 6-step binary search over the prefix sums in LDS).  Keys are (distance, id); r = the radius the
+// block guarantees for this query (block_radius); on success k holds the sorted result on every lane.  s_pref / s_start: 64 words
+// each, private to this wavefront.
+// Blocks in use: the 27 lists around the query's level-2 voxel (SIDE 3, the level-2 block); the 64 lists of the 4 x 4 x 4 block
+// that extends it, on every axis, on the side of the voxel wall the query is nearer to (SIDE 4: covers 3 m where the 3-block
+// covers between 2 and 3 — taken by the timed launches when the 3-block cannot certify MAX_DIST_PLANE); the 216 lists that tile
+// the level-3 block (SIDE 6, capturing launches).
+// guaranteed radius of a block of `side` level-`lvl` voxels per axis whose lower corner is voxel (bx, by, bz) (level-lvl voxel
+// coordinates) for THIS query: the distance to the nearest face, shrunk like search_radius
+__device__ __forceinline__ float block_radius(const MapView& map, const QGeom& g, int lvl, int bx, int by, int bz, int side) {
+    const float lox = (float)((bx << lvl) - CELL_OFFSET), loy = (float)((by << lvl) - CELL_OFFSET), loz = (float)((bz << lvl) - CELL_OFFSET);
+    const float ext = (float)(side << lvl);
+    const float mx = fminf(g.tx - lox, lox + ext - g.tx), my = fminf(g.ty - loy, loy + ext - g.ty), mz = fminf(g.tz - loz, loz + ext - g.tz);
+    const float m = fmaxf(fminf(mx, fminf(my, mz)), 0.f);
+    return map.cell * (m * 0.999f - 8.f * 1.1920928955078125e-07f * ((float)g.amax + 2.f * ext));
 }
-
-// The 27-voxel block of level LVL (2 or 3) searched by a WHOLE wavefront over the level-2 voxel lists (27 lists
-// at level 2, the 6 x 6 x 6 = 216 lists that tile the level-3 block at level 3): every lane probes one voxel,
-// a wave scan turns the list lengths into one virtual candidate array, and the lanes stream it 8 loads per lane in
-// flight (each load finds its list by a 6-step binary search over the prefix sums in LDS).  Keys are
-// (distance, id); on success k holds the sorted result on every lane.  s_pref / s_start: 64 words each, private
-// to this wavefront.
-template <int LVL, int K>
-__device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& geo, float qx, float qy, float qz, int lane,
+template <int K>
+__device__ __forceinline__ bool cells_attempt(const MapView& map, int bx, int by, int bz, int SIDE, float r, float qx, float qy, float qz, int lane,
                                               kkey (&k)[K], uint32_t* s_pref, uint32_t* s_start) {
-    static_assert(LVL == CELL_LEVEL || LVL == CELL_LEVEL + 1, "the level-2 block = 27 lists, the level-3 block = 216");
-    constexpr int SIDE = LVL == CELL_LEVEL ? 3 : 6;
-    constexpr int NC = SIDE * SIDE * SIDE;
+    const int NC = SIDE * SIDE * SIDE;
     constexpr int U = 8;
-    const int bx = LVL == CELL_LEVEL ? (geo.c0x >> 2) - 1 : ((geo.c0x >> 3) - 1) * 2;
-    const int by = LVL == CELL_LEVEL ? (geo.c0y >> 2) - 1 : ((geo.c0y >> 3) - 1) * 2;
-    const int bz = LVL == CELL_LEVEL ? (geo.c0z >> 2) - 1 : ((geo.c0z >> 3) - 1) * 2;
     const GridLevel g = map.ct;
 #pragma unroll
     for (int j = 0; j < K; ++j) k[j] = none_key();
@@ -707,7 +629,9 @@ __device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& g
         const int ci = r0 + lane;
         uint32_t start = 0, cnt = 0;
         if (ci < NC) {
-            const int dz = ci / (SIDE * SIDE), dy = (ci / SIDE) % SIDE, dx = ci % SIDE;
+            // (SIDE is 3, 4 or 6: divisions by constants, selected)
+            const int dz = SIDE == 3 ? ci / 9 : (SIDE == 4 ? ci >> 4 : ci / 36), dy = SIDE == 3 ? (ci / 3) % 3 : (SIDE == 4 ? (ci >> 2) & 3 : (ci / 6) % 6),
+                      dx = SIDE == 3 ? ci % 3 : (SIDE == 4 ? ci & 3 : ci % 6);
             const uint32_t nx = (uint32_t)(bx + dx), ny = (uint32_t)(by + dy), nz = (uint32_t)(bz + dz);
             if (nx < (1u << 19) && ny < (1u << 19) && nz < (1u << 19)) {
                 const uint64_t key = pack_cell(nx, ny, nz);
@@ -735,29 +659,44 @@ __device__ __forceinline__ bool cells_attempt(const MapView& map, const QGeom& g
         s_start[lane] = start;
         wave_lds_fence();
         for (uint32_t base = 0; base < total; base += 64 * U) {
+            // the chunk's positions FIRST — the eight look-ups advance together: eight independent LDS reads per step of the
+            // binary search (six steps), then the eight loads back to back.  One look-up after the other (round 2's form) was
+            // 48 dependent LDS round trips per chunk: what made "a list block cost a wavefront ~2x a bucket" (experiments_r03)
+            uint32_t at[U];
+            {
+                uint32_t vv[U];
+                int Lr[U];   // the last list whose first virtual index is <= vv (empty lists share their successor's)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t v = base + (uint32_t)(u * 64 + lane);
+                    vv[u] = v < total ? v : 0u;
+                    Lr[u] = 0;
+                }
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    uint32_t pv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) pv[u] = s_pref[Lr[u] + step];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) Lr[u] += pv[u] <= vv[u] ? step : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) at[u] = s_start[Lr[u]] + (vv[u] - s_pref[Lr[u]]);
+            }
             float4 mpt[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t v = base + (uint32_t)(u * 64 + lane);
-                const uint32_t vv = v < total ? v : 0u;
-                int L = 0;   // the last list whose first virtual index is <= vv (empty lists share their successor's)
+            for (int u = 0; u < U; ++u) mpt[u] = map.cell4[at[u]];
+            kkey ck[8];
 #pragma unroll
-                for (int step = 32; step >= 1; step >>= 1)
-                    if (s_pref[L + step] <= vv) L += step;
-                mpt[u] = map.cell4[(size_t)s_start[L] + (vv - s_pref[L])];
-            }
-            kkey ck[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const uint32_t v = base + (uint32_t)(u * 64 + lane);
-                ck[u] = v < total ? make_key(calc_dist(qx, qy, qz, mpt[u]), __float_as_uint(mpt[u].w)) : none_key();
+                ck[u] = (u < U && v < total) ? make_key(calc_dist(qx, qy, qz, mpt[u < U ? u : 0]), __float_as_uint(mpt[u < U ? u : 0].w)) : none_key();
             }
             sort8(ck);
             merge5(k, ck);
         }
     }
     merge_team<64>(k);
-    const float r = search_radius(map, geo, LVL);
     const float d5 = __uint_as_float(key_hi(k[K - 1]));
     if (!is_none(k[K - 1]) && r > 0.f && d5 < r * r) return true;
 #pragma unroll
@@ -793,9 +732,15 @@ __device__ __forceinline__ void brute_attempt(const MapView& map, float qx, floa
 // One scan point that the per-lane-group bucket levels left undecided, searched by a WHOLE wavefront: level-2 bucket, the
 // level-3 block as 216 voxel lists, finally every id (see knn_search).  On return every lane holds the sorted result in kw
 // (keys carry point ids); returns what decided (2, 3 voxel levels; 4 every id; 5 bounded stop: no neighbours reported).
+#ifndef LV_COARSE_INLINE
+#define LV_COARSE_INLINE __forceinline__
+#endif
 template <bool DBG, int K>
-__device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict__ kf, float wx, float wy, float wz, int lane, kkey (&kw)[K],
+__device__ LV_COARSE_INLINE int knn_coarse(const MapView& map, KfDev* __restrict__ kf, float wx, float wy, float wz, int lane, kkey (&kw)[K],
                                           double max_dist_sq, uint32_t* s_pref, uint32_t* s_start) {
+#ifdef LV_DIAG_NO_COARSE
+    return 5;
+#endif
     const QGeom wgeo = make_geom(map, wx, wy, wz);
     const bool w_in_range = wgeo.amax < CELL_FAR;
 #pragma unroll
@@ -803,17 +748,38 @@ __device__ __forceinline__ int knn_coarse(const MapView& map, KfDev* __restrict_
     int wbin = 5;
     bool done = false;
     if (w_in_range) {
-        done = cells_attempt<CELL_LEVEL>(map, wgeo, wx, wy, wz, lane, kw, s_pref, s_start);
-        if (done) wbin = 2;
-        // not accepted: d5 >= r^2 (f32).  The reference's gate is (double)d5 < MAX_DIST_PLANE^2 (Plane.cpp:42)
-        float r = search_radius(map, wgeo, 2);
-        bool stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
-        if (!done && !stop) {
-            if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
-            done = cells_attempt<CELL_LEVEL + 1>(map, wgeo, wx, wy, wz, lane, kw, s_pref, s_start);
-            if (done) wbin = 3;
-            r = search_radius(map, wgeo, CELL_LEVEL + 1);
-            stop = !DBG && r > 0.f && (double)(r * r) >= max_dist_sq;
+        bool stop = false;
+        const int c2x = wgeo.c0x >> 2, c2y = wgeo.c0y >> 2, c2z = wgeo.c0z >> 2;
+        if constexpr (DBG) {   // capturing launches: the level-2 block, then the level-3 block, to the exact answer
+            done = cells_attempt(map, c2x - 1, c2y - 1, c2z - 1, 3, search_radius(map, wgeo, 2), wx, wy, wz, lane, kw, s_pref, s_start);
+            if (done) wbin = 2;
+            if (!done) {
+                if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
+                done = cells_attempt(map, ((wgeo.c0x >> 3) - 1) * 2, ((wgeo.c0y >> 3) - 1) * 2, ((wgeo.c0z >> 3) - 1) * 2, 6, search_radius(map, wgeo, 3),
+                                     wx, wy, wz, lane, kw, s_pref, s_start);
+                if (done) wbin = 3;
+            }
+        } else {
+            // timed launches: ONE list block.  A block that is not accepted proves d5 >= r^2 (f32), and the reference's gate is
+            // (double)d5 < MAX_DIST_PLANE^2 (Plane.cpp:42): once r^2 reaches that, the point has no match whatever its
+            // neighbours are.  The level-2 block guarantees between 2 and 3 m (cell 0.5); when that is not enough for the gate
+            // (MAX_DIST_PLANE = 2 and the query within millimetres of a wall of its level-2 voxel; larger MAX_DIST_PLANE) the block
+            // grows to 4 x 4 x 4 voxels, extended on every axis towards the wall the query is nearer to: >= 3 m.  One call site
+            // with run-time geometry: a second inlined copy (the level-3 block, rounds 1-5) cost the one-launch pass 1.5 us per
+            // launch in register allocation alone (profiles/experiments_r06).
+            float r = search_radius(map, wgeo, 2);
+            int side = 3, bx = c2x - 1, by = c2y - 1, bz = c2z - 1;
+            if (!(r > 0.f && (double)(r * r) >= max_dist_sq)) {
+                side = 4;
+                bx = c2x - 1 - ((wgeo.tx - (float)((c2x << 2) - CELL_OFFSET)) < 2.f ? 1 : 0);
+                by = c2y - 1 - ((wgeo.ty - (float)((c2y << 2) - CELL_OFFSET)) < 2.f ? 1 : 0);
+                bz = c2z - 1 - ((wgeo.tz - (float)((c2z << 2) - CELL_OFFSET)) < 2.f ? 1 : 0);
+                r = block_radius(map, wgeo, 2, bx, by, bz, 4);
+                if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
+            }
+            done = cells_attempt(map, bx, by, bz, side, r, wx, wy, wz, lane, kw, s_pref, s_start);
+            if (done) wbin = side == 3 ? 2 : 3;
+            stop = r > 0.f && (double)(r * r) >= max_dist_sq;
         }
         if (!done && !stop) { brute_attempt(map, wx, wy, wz, lane, kw); wbin = 4; }
     } else {   // outside the voxel range (2^19 voxels from the map origin): no structure to lean on
@@ -853,15 +819,17 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     bool decided = !live || !finite;
     int hist_bin = -1;   // what decided (instrumentation): 0, 1 bucket level; 2, 3 voxel lists; 4 every id; 5 bounded stop
     if (live && in_range) {
-        decided = bucket_attempt<S>(map, 0, geo, qx, qy, qz, gl, k, bstart, DBG ? clk : nullptr, stage0);
-        if (decided) { src = 0; hist_bin = 0; }
-    }
-    // level 1 = the eight level-0 buckets that tile its block (tiles_attempt; the key's low words come back as absolute pool
-    // positions: src = 1, bstart = 0).  Per team, like level 0: every exchange inside stays within the team (DPP rows, permutes
-    // whose source lane belongs to the team), so the teams whose point is decided sit it out.
-    if (live && in_range && !decided) {   // (k is all-NONE here)
-        decided = tiles_attempt<S>(map, geo, qx, qy, qz, gl, k);
-        if (decided) { src = 1; bstart = 0; hist_bin = 1; }
+#pragma unroll
+#ifndef LV_DIAG_LEVELS
+#define LV_DIAG_LEVELS 2
+#endif
+        for (int bl = 0; bl < LV_DIAG_LEVELS; ++bl) {   // level 0: the query's bucket; level 1: the region of its tile group (bucket_attempt)
+            if (!decided) {
+                decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
+                                            bl == 0 ? stage0 : nullptr);
+                if (decided) { src = bl; hist_bin = bl; }
+            }
+        }
     }
     if (undecided) {   // the caller shares the coarse levels out among the wavefronts of its workgroup (pass_kernel)
         *undecided = !decided;
@@ -1709,7 +1677,16 @@ __global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(Pass
         if (tid == 0) *s_task = 0;   // (this parity serves the round after next: published by the next round's barrier)
         if (round == 0) PK_STAMP(6, tid == 0);
         const int nq = *s_qcnt;
-        if (nq > 0) {   // (uniform) the open points, one per wavefront at a time: level-2 bucket / level-3 lists / every id
+        // (`unlikely` is for the register allocator, not the branch: spill weights follow the estimated block frequencies, and without
+        // the hint this loop — a handful of points per launch — looked hotter than the plane fits behind it: the allocator kept the
+        // loop clean and put nine scratch reloads, each an exposed trip to memory, into the middle of the QR: fits 3.7 -> 4.45 us)
+#ifndef LV_COARSE_EXPECT
+#define LV_COARSE_EXPECT 0
+#endif
+#ifndef LV_COARSE_PROB
+#define LV_COARSE_PROB 0.0005
+#endif
+        if (__builtin_expect_with_probability(nq > 0, 1, LV_COARSE_PROB)) {   // (uniform) the open points, one per wavefront at a time: the level-2 / level-3 lists / every id
             for (int i = wave; i < nq; i += PK_THREADS / 64) {
                 const float4 e = s_queue[i];
                 const int p = __float_as_int(e.w);

@@ -55,7 +55,7 @@ void launch(K kernel, uint64_t threads, A... args) {
 
 uint32_t next_pow2(uint64_t v) { uint32_t p = 64; while (p < v) p <<= 1; return p; }
 int log2u(uint32_t s) { int lg = 0; while ((1u << lg) < s) ++lg; return lg; }
-uint32_t run_capacity(uint32_t c) { return c + (c / 4u > 8u ? c / 4u : 8u); }
+uint32_t run_capacity(uint32_t c) { return c + (c / 2u > 8u ? c / 2u : 8u); }
 
 struct Emu {
     float cell = 0.5f, box_len = 0.2f;
@@ -67,6 +67,15 @@ struct Emu {
     std::vector<float> bxyz[SORTED_LEVELS];
     std::vector<uint32_t> bidx[SORTED_LEVELS];
     std::vector<uint16_t> backpos;      // [id * 27 + c]: position of id inside the bucket of its neighbour c
+    std::vector<uint4> gtable;          // tile groups: level-1 voxel -> {start, extent} of its runs' region
+    std::vector<uint32_t> broken;       // groups the batch in flight broke up
+    std::vector<RegroupPlan> plans;
+    uint32_t n_broken = 0;
+    uint64_t regrouped = 0, compacted = 0;
+    std::vector<uint4> comp;            // runs compacted in place by the batch in flight + their staging area
+    std::vector<float4> cstage;
+    std::vector<uint32_t> cnew;
+    uint32_t n_comp[2] = {0, 0};
     std::vector<uint32_t> cellpos;      // [id]
     std::vector<float4> cell4;
     uint32_t pool_cap[INC_LEVELS] = {};
@@ -111,6 +120,10 @@ struct Emu {
         }
         for (int l = 0; l < SORTED_LEVELS; ++l) { M.bxyz[l] = bxyz[l].data(); M.bidx[l] = bidx[l].data(); }
         M.backpos = backpos.data();
+        M.gtable = gtable.data();
+        M.gmask = (uint32_t)gtable.size() - 1;
+        M.gshift = (uint32_t)(64 - log2u((uint32_t)gtable.size()));
+        M.gslot_limit = (uint32_t)(gtable.size() * 7 / 10);
         M.cellpos = cellpos.data();
         M.cell4 = cell4.data();
         for (int a = 0; a < 3; ++a) M.origin[a] = origin[a];
@@ -163,8 +176,22 @@ struct Emu {
             bidx[l].assign(pool_cap[l], 0u);
             backpos.assign(orig.size() * 27, (uint16_t)0xFFFEu);
             cellpos.assign(orig.size(), 0xFFFFFFFFu);
-            uint32_t off = 0;
+            // the runs are laid out group by group (the eight buckets that tile a level-1 block side by side), the slack reads +inf
+            std::map<uint64_t, std::vector<uint64_t>> groups;
             for (auto& kv : buckets) {
+                uint32_t vx, vy, vz; int r;
+                tile_group_of((uint32_t)(kv.first & 0x1fffff), (uint32_t)((kv.first >> 21) & 0x1fffff), (uint32_t)((kv.first >> 42) & 0x1fffff), vx, vy, vz, r);
+                groups[pack_cell(vx, vy, vz)].push_back(kv.first);
+            }
+            gtable.assign(next_pow2((uint64_t)buckets.size()), uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
+            cnt.gslots_used = (uint32_t)groups.size();
+            for (size_t i = 0; i < (size_t)pool_cap[l] * 3; ++i) bxyz[l][i] = INFINITY;
+            uint32_t off = 0;
+            for (auto& gk : groups) {
+              const uint32_t gstart = off;
+              for (uint64_t bkey : gk.second) {
+                auto kvit = buckets.find(bkey);
+                auto& kv = *kvit;
                 uint32_t slot;
                 table_put(table[l], kv.first, off, (uint32_t)kv.second.size(), slot);
                 aux[l][slot].cap = run_capacity((uint32_t)kv.second.size());
@@ -180,6 +207,9 @@ struct Emu {
                     backpos[(size_t)id * 27 + (size_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1))] = (uint16_t)(i < 0xFFFFu ? i : 0xFFFFu);
                 }
                 off += aux[l][slot].cap;
+              }
+              uint32_t gslot;
+              table_put(gtable, gk.first, gstart, off - gstart, gslot);
             }
             set_arenas(l, off);
             cnt.slots_used[l] = (uint32_t)buckets.size();
@@ -299,6 +329,22 @@ struct Emu {
         reset_batch();
         if (downsample) ensure_boxes();
         MapRW M = rw();
+        broken.assign((size_t)k * 27 + 64, 0xDEADBEEFu);
+        plans.assign(broken.size(), RegroupPlan{});
+        n_broken = 0;
+        M.broken = broken.data();
+        M.broken_cap = (uint32_t)broken.size();
+        M.n_broken = &n_broken;
+        comp.assign((size_t)k * 27 + 64, uint4{0, 0, 0, 0});
+        cstage.assign(1u << 18, float4{0, 0, 0, 0});
+        cnew.assign(1u << 18, 0xDEADBEEFu);
+        n_comp[0] = n_comp[1] = 0;
+        M.comp = comp.data();
+        M.comp_cap = (uint32_t)comp.size();
+        M.n_comp = n_comp;
+        M.cstage = cstage.data();
+        M.cnew = cnew.data();
+        M.cstage_cap = (uint32_t)cstage.size();
         BoxRW B = have_boxes ? bx() : BoxRW{};
         std::vector<uint64_t> keys(k), keys_sorted(k);
         std::vector<uint32_t> idx(k), idx_sorted(k), alive(k), apos(k);
@@ -362,13 +408,21 @@ struct Emu {
         launch(inc_reserve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k, reloc.data(), (uint32_t)reloc.size(), gcnt.data());
         // (the product launches a grid for the runs a batch can list, at most 2048 workgroups, and walks longer lists in strides:
         // 16 runs per sweep here, so that the stride loop is exercised)
+        launch(inc_compact_gather_kernel, (uint64_t)8 * COMPACT_LANES, M);   // (8 runs per sweep: the stride loop is exercised)
         launch(inc_relocate_kernel, (uint64_t)16 * RELOC_LANES, M, (const uint4*)reloc.data(), (uint32_t)reloc.size(), (const uint32_t*)gcnt.data());
         launch(inc_resolve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
+        launch(inc_compact_scatter_kernel, (uint64_t)8 * COMPACT_LANES, M);
+        compacted += n_comp[0];
         launch(inc_fill_kernel, t_all, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids);
         launch(inc_rank_kernel, t_rep, M, G, (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids, rank.data());
         launch(inc_place_kernel, t_rep, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
                (const uint32_t*)rank.data());
         launch(inc_commit_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
+        // the groups the batch broke up are laid out again (twin of the three launches at the end of MapStore::add_staged)
+        launch(inc_regroup_plan_kernel, 512, M, plans.data());
+        launch(inc_regroup_move_kernel, 1024, M, (const RegroupPlan*)plans.data());
+        launch(inc_regroup_commit_kernel, 512, M, (const RegroupPlan*)plans.data());
+        regrouped += n_broken;
         relocations += gcnt[0];
         n_ids += cnt.n_new;
         m += cnt.n_new;
@@ -445,7 +499,8 @@ struct Emu {
                 if (key == EMPTY_KEY) continue;
                 ++used_slots;
                 const SlotAux a = aux[l][s];
-                if (a.pending || a.fill) return fail("level %d slot %zu: batch counters not cleared", l, s);
+                if (a.pending) return fail("level %d slot %zu: batch counters not cleared", l, s);
+                uint32_t n_tomb = 0;
                 if (e.w > a.cap) return fail("level %d slot %zu: count %u > cap %u", l, s, e.w, a.cap);
                 if (a.cap) runs.push_back({e.z, a.cap});
                 std::vector<uint32_t> got;
@@ -458,6 +513,7 @@ struct Emu {
                     const float* rec = &bxyz[l][(size_t)(e.z + i) * 3];
                     if (std::isinf(rec[0])) {
                         if (pt_alive(orig[id])) return fail("level %d bucket %llx: tombstone for living id %u", l, (unsigned long long)key, id);
+                        ++n_tomb;
                         continue;
                     }
                     if (!pt_alive(orig[id])) return fail("level %d bucket %llx: dead id %u still listed", l, (unsigned long long)key, id);
@@ -477,6 +533,7 @@ struct Emu {
                 const std::vector<uint32_t> none;
                 const std::vector<uint32_t>& w = it == want.end() ? none : it->second;
                 if (got != w) return fail("level %d bucket %llx: %zu living entries, %zu expected", l, (unsigned long long)key, got.size(), w.size());
+                if (n_tomb != a.dead) return fail("level %d bucket %llx: %u tombstones, the run's count says %u", l, (unsigned long long)key, n_tomb, a.dead);
                 if (it != want.end()) want.erase(it);
             }
             if (!want.empty()) return fail("level %d: %zu voxels with living neighbours have no bucket", l, want.size());
@@ -487,6 +544,39 @@ struct Emu {
                 if (i && runs[i - 1].first + runs[i - 1].second > runs[i].first) return fail("level %d: runs overlap", l);
             }
         }
+        {   // tile groups: an intact group's region is exactly its buckets' runs side by side, everything outside the runs' entries
+            // reads +inf, and every bucket that belongs to the group lies inside; no group is left "listed"
+            std::map<uint64_t, std::vector<size_t>> members;
+            for (size_t s = 0; s < table[0].size(); ++s) {
+                const uint64_t key = entry_key(table[0][s]);
+                if (key == EMPTY_KEY) continue;
+                uint32_t vx, vy, vz; int r;
+                tile_group_of((uint32_t)(key & 0x1fffff), (uint32_t)((key >> 21) & 0x1fffff), (uint32_t)((key >> 42) & 0x1fffff), vx, vy, vz, r);
+                members[pack_cell(vx, vy, vz)].push_back(s);
+            }
+            uint32_t gused = 0;
+            for (size_t g = 0; g < gtable.size(); ++g) {
+                const uint4 ge = gtable[g];
+                const uint64_t gkey = entry_key(ge);
+                if (gkey == EMPTY_KEY) continue;
+                ++gused;
+                if (ge.w == 0u) { if (ge.z == ID_NONE) return fail("group %llx: still listed after the batch", (unsigned long long)gkey); continue; }   // broken (by a sweep): nothing is claimed
+                if ((uint64_t)ge.z + ge.w > pool_cap[0]) return fail("group %llx: region beyond the pool", (unsigned long long)gkey);
+                std::vector<uint8_t> covered(ge.w, 0);
+                auto it = members.find(gkey);
+                if (it == members.end()) return fail("group %llx: intact but without buckets", (unsigned long long)gkey);
+                for (size_t s : it->second) {
+                    const uint4 e = table[0][s];
+                    const uint32_t cap = aux[0][s].cap;
+                    if (e.z < ge.z || (uint64_t)e.z + cap > (uint64_t)ge.z + ge.w) return fail("group %llx: a bucket's run lies outside the region", (unsigned long long)gkey);
+                    for (uint32_t i = 0; i < e.w; ++i) covered[e.z - ge.z + i] = 1;
+                }
+                for (uint32_t i = 0; i < ge.w; ++i)
+                    if (!covered[i] && !std::isinf(bxyz[0][(size_t)(ge.z + i) * 3])) return fail("group %llx: slack entry %u does not read +inf", (unsigned long long)gkey, i);
+            }
+            if (gused != cnt.gslots_used) return fail("groups: gslots_used %u, table holds %u", cnt.gslots_used, gused);
+            // (a bucket whose group has no entry, or a broken one, is searched through the lists: allowed)
+        }
         {
             std::vector<uint8_t> seen(n_ids, 0);
             std::vector<std::pair<uint32_t, uint32_t>> runs;
@@ -495,7 +585,7 @@ struct Emu {
                 const uint64_t key = entry_key(e);
                 if (key == EMPTY_KEY) continue;
                 const SlotAux a = aux[CELL_SLOT][s];
-                if (a.pending || a.fill) return fail("voxel list %zu: batch counters not cleared", s);
+                if (a.pending) return fail("voxel list %zu: batch counters not cleared", s);
                 if (e.w > a.cap) return fail("voxel list %zu: count %u > cap %u", s, e.w, a.cap);
                 if (a.cap) runs.push_back({e.z, a.cap});
                 for (uint32_t i = 0; i < e.w; ++i) {
@@ -553,6 +643,8 @@ uint32_t emu_size(void* h) { return static_cast<Emu*>(h)->m; }
 uint32_t emu_ids(void* h) { return static_cast<Emu*>(h)->n_ids; }
 uint64_t emu_relinearisations(void* h) { return static_cast<Emu*>(h)->relinearisations; }
 uint64_t emu_relocations(void* h) { return static_cast<Emu*>(h)->relocations; }
+uint64_t emu_regrouped(void* h) { return static_cast<Emu*>(h)->regrouped; }
+uint64_t emu_compacted(void* h) { return static_cast<Emu*>(h)->compacted; }
 // the pure helpers of the insert's work order (lv_mapinc.hpp), exposed for tests/test_mapinc_emulation.py
 uint32_t emu_block_of(uint32_t b, uint32_t n) { return inc_block_of(b, n); }
 uint64_t emu_box_key(float x, float y, float z, float len) { return inc_box_key(float4{x, y, z, 0.f}, len); }

@@ -45,6 +45,10 @@ def emu():
     lib.emu_relinearisations.restype = C.c_uint64
     lib.emu_relocations.argtypes = [C.c_void_p]
     lib.emu_relocations.restype = C.c_uint64
+    lib.emu_regrouped.argtypes = [C.c_void_p]
+    lib.emu_regrouped.restype = C.c_uint64
+    lib.emu_compacted.argtypes = [C.c_void_p]
+    lib.emu_compacted.restype = C.c_uint64
     lib.emu_tombstones.argtypes = [C.c_void_p]
     lib.emu_tombstones.restype = C.c_uint32
     lib.emu_fetch.argtypes = [C.c_void_p, C.c_void_p]
@@ -137,6 +141,7 @@ def test_relocation_and_overflow_paths(emu, oracle):
         assert np.array_equal(mp.fetch().view(np.uint32), ref.view(np.uint32)), f"step {step}"
     assert emu.emu_relinearisations(mp.h) >= 1
     assert emu.emu_relocations(mp.h) >= 1
+    assert emu.emu_regrouped(mp.h) >= 1   # ... and the tile groups those moves broke up were laid out again (emu_check holds them to it)
     mp.close()
 
 
@@ -245,3 +250,26 @@ def test_work_order_helpers_of_the_insert(emu):
     off = 1 << 20
     assert np.array_equal(compact(keys, 0) - off, box[:, 0]) and np.array_equal(compact(keys, 1) - off, box[:, 1])
     assert np.array_equal(compact(keys, 2) - off, box[:, 2])
+
+
+@pytest.mark.parametrize("order", [0, 2])
+def test_reobserved_ground_compacts_runs_in_place(emu, oracle, order):
+    """The same surface scanned again and again (what a LiDAR at rest does, and bench.py's cycle): every scan's points compete with
+    the occupants of their 0.2 m boxes, the losers stay behind as tombstones, and a bucket outgrows its room by its DEAD entries.
+    Such a run is compacted where it lies (inc_compact_gather / _scatter) instead of moving with its whole tile group: ascending
+    ids, back-positions and the tile groups' regions are held by emu_check after every batch, the living points by the oracle."""
+    emu.emu_set_order(order, 4242)
+    rng = np.random.default_rng(11)
+    base = _surface_points(rng, 5000, -4.0, 4.0)
+    mp = Map(emu)
+    mp.add(base, False)
+    ref = base.copy()
+    scan = _surface_points(rng, 2500, -4.0, 4.0)
+    for step in range(14):
+        jit = (scan + rng.normal(0, 0.004, scan.shape)).astype(np.float32)   # the same ground, sensor noise
+        mp.add(jit, True)
+        ref = oracle.map_add(ref, jit, downsample=True)
+        mp.check()
+        assert np.array_equal(mp.fetch().view(np.uint32), ref.view(np.uint32)), f"step {step}"
+    assert emu.emu_compacted(mp.h) >= 1
+    mp.close()
