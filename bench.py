@@ -203,6 +203,37 @@ def cycle_64k(ctx, sc, capi, reps: int = 10) -> dict:
     return out
 
 
+def predicted_scaling(world: int, n_points: int, passes: int = 4, collective_us: float = 6.0) -> dict | None:
+    """The builder's PREDICTION for an N-rank run, so that the first execution across xGMI is read against it:
+    one rank's update on its shard from the newest committed single-GPU sweep (profiles/shard_size_sweep_r*.txt, by-value
+    one-launch form, log-interpolated between the measured sizes) + `passes` collectives of ~6 us each (4.6 us all-gather measured
+    with ONE rank + a launch boundary: a real ring over xGMI will cost more, so the ratio is an upper bound)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "shard_size_sweep_r*.txt")))
+    if not files:
+        return None
+    pts = []
+    for line in open(files[-1]):
+        mm = re.search(r"fused scan\s+(\d+) points:\s+([0-9.]+) us per update", line)
+        if mm:
+            pts.append((int(mm.group(1)), float(mm.group(2))))
+    if len(pts) < 2:
+        return None
+    pts.sort()
+    xs, ys = np.log(np.array([p[0] for p in pts], float)), np.array([p[1] for p in pts], float)
+
+    def us_of(n):
+        return float(np.interp(np.log(max(n, pts[0][0])), xs, ys))
+    one = us_of(n_points)
+    shard = -(-n_points // world)
+    pred = us_of(shard) + (passes * collective_us if world > 1 else 0.0)
+    return {"source": "profiles/" + os.path.basename(files[-1]), "shard_points": int(shard), "us_per_update_1gpu": round(one, 1),
+            "us_per_update_predicted": round(pred, 1), "ratio_vs_1gpu_predicted": round(one / pred, 3),
+            "collective_us_assumed": collective_us,
+            "note": "a prediction from single-GPU sweeps, NOT a measurement: nothing has crossed xGMI in rounds 1-6"}
+
+
 def cpu_baseline(sc, passes_expected: int, budget_s: float = 20.0) -> dict:
     """Times the CPU oracle (a port/restatement — the reference binary cannot be built here) on this
     host's cores, same scene, same update, bounded to ~budget_s seconds."""
@@ -307,6 +338,7 @@ def main() -> None:
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (GPU results of this run vs the CPU oracle)")
     ap.add_argument("--no-ext", action="store_true", help="skip the estimate_extrinsics leg (config/xaloc.yaml's setting at the headline sizes)")
     ap.add_argument("--no-large", action="store_true", help="skip the large-N leg (262 144-point scan vs 5 M-point map on one GPU)")
+    ap.add_argument("--no-cfgs", action="store_true", help="skip the BASELINE configs[1] / configs[2] legs (ring scans vs 500k / 2M-point maps)")
     ap.add_argument("--no-cycle", action="store_true", help="skip the whole-cycle leg (message in -> de-skew -> correct -> map insert)")
     ap.add_argument("--resident-only", action="store_true", help="profiling aid (scripts/gpu_profile.sh): only the timed resident steps — no "
                     "by-value legs, no event-instrumented repetition — so that a rocprofv3 run of this command sees the timed step alone")
@@ -724,6 +756,64 @@ def main() -> None:
             del scl
         except Exception as e:  # noqa: BLE001
             large = {"error": str(e)}
+    # ---- BASELINE configs[1] and configs[2], driver-timed, each in a context of its own with the parity counts
+    # of THAT leg against the oracle: cfg1 = a 16-ring VLP-16 scan (~30 k points, ray-cast) against a 500 k-point map, ONE
+    # measurement pass (MAX_NUM_ITERS = 0: "single iteration"); cfg2 = a 64-ring scan (~120 k points) against a 2 M-point map,
+    # 4 passes.  Same synchronised step as `value`; fraction = algorithmic bytes of all passes / wall time of a step / 8 TB/s.
+    cfg_legs = {}
+    if world == 1 and not args.no_cfgs and not args.resident_only:
+        for name, (mm, rings, n_az, fov, iters, what) in {
+                "cfg1": (500_000, 16, 1875, (-15.0, 15.0), 0, "BASELINE configs[1]: VLP-16 ring scan vs 500k-pt map, k=5, single iteration"),
+                "cfg2": (2_000_000, 64, 2048, (-25.0, 15.0), 3, "BASELINE configs[2]: 64-line ring scan vs 2M-pt map, 4 IKFoM passes")}.items():
+            try:
+                scc = synth.make_ring_scene(mm, rings, n_az, fov_deg=fov)
+                nn = len(scc["scan_xyz"])
+                with capi.Context(capi.default_params(MAX_NUM_ITERS=iters), device=local_rank) as c5:
+                    c5.map_build(scc["map_xyz"])
+                    c5.scan_set(scc["scan_xyz"])
+                    xc = np.ascontiguousarray(scc["x_init"], np.float64); Pc = np.ascontiguousarray(scc["P0"], np.float64)
+                    xcp, Pcp = xc.ctypes.data_as(C.c_void_p), Pc.ctypes.data_as(C.c_void_p)
+                    for _ in range(10):
+                        c5.filter_set(xc, Pc); c5.correct(want_passes=False); c5.filter_get()
+                    rates = []
+                    for _ in range(3):
+                        c5.synchronize(); t0 = time.perf_counter()
+                        for _ in range(args.steps):
+                            if c5.lib.lv_filter_set(c5.h, xcp, Pcp) or c5.lib.lv_correct(c5.h, None) or c5.lib.lv_filter_get(c5.h, xgp, Pgp):
+                                raise RuntimeError(c5.lib.lv_last_error().decode())
+                        c5.synchronize()
+                        rates.append((time.perf_counter() - t0) / args.steps)
+                    pc_ = c5.last_passes()
+                    us = sorted(rates)[1] * 1e6
+                    leg = {"workload": f"{what} ({nn}-pt scan)", "scan_points": int(nn), "map_points": int(mm), "passes_per_update": int(pc_),
+                           "us_per_update": us, "iters_per_s": pc_ / (us * 1e-6), "alg_bytes_per_point_pass": b_alg(mm),
+                           "frac": b_alg(mm) * nn * pc_ / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "one_launch_per_pass": bool(c5.last_update_fused())}
+                    if not args.no_parity:
+                        # the leg's own gate: one capturing pass + the timed build's update, against the oracle on the same inputs
+                        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                        import lvoracle as lo
+                        g0 = c5.iterate(scc["x_init"])
+                        gi, gd = c5.fetch_knn()
+                        xg_, Pg_, pg_, trg_, sumsg_ = c5.update(scc["x_init"], scc["P0"])
+                        tree = lo.KdTree(scc["map_xyz"])
+                        o = lo.iterate(scc["x_init"], scc["map_xyz"], scc["scan_xyz"], tree=tree, nthreads=16)
+                        xo_, Po_, po_, tro_, so_ = lo.update(scc["x_init"], scc["P0"], scc["map_xyz"], scc["scan_xyz"],
+                                                             params=lo.default_params(max_num_iters=iters), tree=tree, nthreads=16)
+                        par = {"knn_index_mismatches": int((gi != o["knn_idx"]).any(axis=1).sum()),
+                               "knn_distance_bit_mismatches": int((gd.view(np.uint32) != o["knn_d2"].view(np.uint32)).any(axis=1).sum()),
+                               "n_valid_gpu_oracle": [int(g0["n_valid"]), int(o["n_valid"])],
+                               "HTH_rel_diff": float(np.abs(g0["HTH"] - o["HTH"]).max() / max(np.abs(o["HTH"]).max(), 1e-300))}
+                        if xo_ is not None:
+                            par.update({"passes_gpu_oracle": [int(pg_), int(po_)], "state_max_abs_diff": float(np.abs(xg_ - xo_).max()),
+                                        "cov_max_abs_diff": float(np.abs(Pg_ - Po_).max())})
+                        par["ok"] = bool(par["knn_index_mismatches"] == 0 and par["knn_distance_bit_mismatches"] == 0
+                                         and par["n_valid_gpu_oracle"][0] == par["n_valid_gpu_oracle"][1] and par["HTH_rel_diff"] < 1e-9
+                                         and (xo_ is None or (par["passes_gpu_oracle"][0] == par["passes_gpu_oracle"][1] and par["state_max_abs_diff"] < 1e-7)))
+                        leg["parity"] = par
+                    cfg_legs[name] = leg
+                del scc
+            except Exception as e:  # noqa: BLE001
+                cfg_legs[name] = {"error": str(e)}
     # ---- the shipped non-default configuration (config/xaloc.yaml:13 estimate_extrinsics: true; 12 live Jacobian columns, 92 sums,
     # 12 x 12 gain blocks) at the headline sizes, same synchronised step, a context of its own: it/s + roofline fraction
     ext_rec = None
@@ -895,9 +985,10 @@ def main() -> None:
         if world > 1 or forms:
             out["multi_gpu"] = {"measured_on": f"{world} ranks" + (" on ONE GPU (--same-device)" if same_dev else ""),
                                 "ranks": rank_report,
-                                "note_scaling": "no scaling curve has been measured by the builder (one GPU per lease in rounds 1-5): the driver's "
+                                "note_scaling": "no scaling curve has been measured by the builder (one GPU per lease in rounds 1-6): the driver's "
                                                 "N = 1, 2, 4, 8 runs of this file are the first executions across xGMI",
-                                "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]], "forms": forms}
+                                "collective_us_per_pass": [round(float(v), 2) for v in coll_us[:4]], "forms": forms,
+                                "predicted": predicted_scaling(world, N_POINTS)}
             if same_dev:
                 out["multi_gpu"]["same_device"] = True
                 out["multi_gpu"]["note"] = ("FUNCTIONAL leg: the ranks share one GPU (and its L2) and time-slice it — value is NOT a "
@@ -907,6 +998,10 @@ def main() -> None:
             out["cycle_ms_64k"] = cycle
         if large is not None:
             out["large_n"] = large
+        for kname_, leg_ in cfg_legs.items():
+            out[kname_] = leg_
+            if isinstance(leg_, dict) and isinstance(leg_.get("parity"), dict) and not leg_["parity"].get("ok", True):
+                rc = 3   # (a leg whose results differ from the oracle's fails the run like the headline's gate)
         if ext_rec is not None:
             out["ext"] = ext_rec
         if gate is not None:

@@ -441,6 +441,7 @@ void kd_search(const KdNode* n, const float* q, TopK& best) {
 // ---------------------------------------------------------------------------------------------
 // Plane fit: R3Math::estimate_plane (Utils.cpp:32-57)
 // ---------------------------------------------------------------------------------------------
+static int g_qr_backsub_columns = 0;   // lvo_set_qr_backsub_columns: see the back substitution below
 // Column-pivoted Householder QR least squares, f32, for an n x 3 system (n <= 8), restating the
 // structure of Eigen 3.3 ColPivHouseholderQR::computeInPlace + _solve_impl [UPSTREAM-RECALL]:
 // pivot on the largest running column norm, LAPACK-WN176 norm downdate, rank cut by
@@ -538,6 +539,18 @@ void colpiv_qr_solve_f32(float A[][3], int rows, const float* b_in, float x[3]) 
             for (int i = k + 1; i < rows; ++i) c[i] -= tau * A[i][k] * tmp;
         }
     }
+    if (g_qr_backsub_columns) {
+        // Eigen 3.3's `triangularView<Upper>().solveInPlace(vector)` on a column-major matrix goes through
+        // triangular_solve_vector<.., OnTheLeft, Upper, false, ColMajor> [UPSTREAM-RECALL], which is COLUMN oriented: divide
+        // rhs[i], then rhs.head(i) -= rhs[i] * col(i).head(i) — for x0 that is ((c0 - x2 A02) - x1 A01) / A00 where the
+        // row-oriented form below computes ((c0 - A01 x1) - A02 x2) / A00: the same x1, x2, a different association for x0.
+        // NOT the default: VERDICT r05 asked what moves if the recall of the row form is wrong (tests/test_oracle_pins.py,
+        // DESIGN "if the recall is wrong here"); lvo_set_qr_backsub_columns(1) switches it on.
+        for (int i = nonzero_pivots - 1; i >= 0; --i) {
+            c[i] = c[i] / A[i][i];
+            for (int j = 0; j < i; ++j) c[j] -= c[i] * A[j][i];
+        }
+    } else
     for (int i = nonzero_pivots - 1; i >= 0; --i) {  // back substitution on the upper triangle
         float s = c[i];
         for (int j = i + 1; j < nonzero_pivots; ++j) s -= A[i][j] * c[j];
@@ -1364,6 +1377,9 @@ extern "C" void lvo_sincos_vs_libm(const float* x, size_t n, int64_t* n_sin_diff
 // the default (0) is the polynomial the device evaluates as well (lvo_sincos_vs_libm measures the distance between the two).
 static int g_sincos_libm = 0;
 extern "C" void lvo_set_sincos_libm(int on) { g_sincos_libm = on; }
+// lvo_set_qr_backsub_columns(1): the plane fit's back substitution in Eigen's column-oriented order (colpiv_qr_solve_f32): the
+// "what moves if the recall is wrong" experiment of tests/test_oracle_pins.py; NOT the default, never the reference of a parity test
+extern "C" void lvo_set_qr_backsub_columns(int on) { g_qr_backsub_columns = on; }
 
 // SO3Math::Exp<float,float>(ang_vel, dt) — include/Headers/Utils.hpp:30-53
 static void so3_exp_f32(const float w[3], float dt, float E[9]) {

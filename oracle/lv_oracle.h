@@ -167,6 +167,8 @@ void lvo_state_integrate(lvo_motion_state* s, const float a[3], const float w[3]
 /* on != 0: SO3Math::Exp inside lvo_state_integrate / lvo_deskew evaluates sin / cos with this platform's sinf / cosf (what the
  * reference calls) instead of the pinned polynomial below — used only to compare the oracle with oracle/_ref bit for bit. */
 void lvo_set_sincos_libm(int on);
+/* Experiment switch (NOT the default): the plane fit's back substitution in Eigen 3.3's column-oriented order (tests/test_oracle_pins.py, DESIGN "if the recall is wrong here"). */
+void lvo_set_qr_backsub_columns(int on);
 /* sin / cos of f32 arguments as rows f-2 / f-3 evaluate them (one fixed f64 polynomial, rounded to f32) */
 void lvo_sincos_f32(const float* x, size_t n, float* sn, float* cs);
 /* The pinned sin / cos polynomial of row f-2 against this platform's sinf / cosf (what the reference calls,

@@ -196,6 +196,12 @@ def iterate(state, map_xyz, scan_xyz, params=None, tree: KdTree | None = None, n
     return res
 
 
+def set_qr_backsub_columns(on: bool) -> None:
+    """Experiment switch (NOT the default, never used as the reference of a parity test): the plane fit's back substitution in
+    Eigen 3.3's column-oriented order instead of the row-oriented one the oracle, the stand-in Eigen and the device share."""
+    lib().lvo_set_qr_backsub_columns(1 if on else 0)
+
+
 def update(state, P, map_xyz, scan_xyz, params=None, tree: KdTree | None = None, nthreads=8):
     """Full iterated update.  Returns (x_post[26], P_post[23,23], passes, trace[passes,49], per-pass sums)."""
     prm = params or default_params()
