@@ -3,7 +3,10 @@
 #include "../csrc/lv_sincos.hpp"
 #include "limovelo_shim.hpp"
 
-struct Params Config;
+// (`Params Config` — the reference's global, src/main.cpp:14 — is NOT defined in this library: the program defines it, as the
+// reference's main.cpp does; programs that do not name it link liblimovelo_shim_config.a, which holds a default-constructed one
+// (limovelo_config.cpp).  A definition in here, however weak, would be constructed and destroyed a second time at the address
+// of the program's own.)
 
 namespace {
 lv_ctx* g_ctx = nullptr;

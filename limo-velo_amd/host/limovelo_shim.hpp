@@ -40,29 +40,36 @@ struct InitializationParams {  // reference Common.hpp:51-54
     std::vector<double> deltas = {0.1};
 };
 
-struct Params {  // hot-path keys of reference struct Params (Common.hpp:56-107), same names
+struct Params {  // reference struct Params (Common.hpp:56-107): every key src/main.cpp's fill_config reads, the reference's types
     bool estimate_extrinsics = false;
+    bool print_extrinsics = false;                           // (publishers only)
     double degeneracy_threshold = 5.0;
+    bool print_degeneracy_values = false;
     int MAX_NUM_ITERS = 3;
     int MAX_POINTS2MATCH = 10;
     std::vector<double> LIMITS = std::vector<double>(23, 0.001);
     int NUM_MATCH_POINTS = 5;
     double MAX_DIST_PLANE = 2.0;
     float PLANES_THRESHOLD = 5.e-2f;
+    float PLANES_CHOOSE_CONSTANT = 9.0f;                     // (read by fill_config, used nowhere in the reference either)
     double LiDAR_noise = 0.001;
     double cov_acc = 1.e-2, cov_gyro = 1.e-4, cov_bias_acc = 1.e-4, cov_bias_gyro = 1.e-5;  // config/params.yaml:39-42
+    double wx_MULTIPLIER = 1, wy_MULTIPLIER = 1, wz_MULTIPLIER = 1;   // (read by fill_config, used nowhere in the reference)
     double full_rotation_time = 0.1;
     bool stamp_beginning = false, offset_beginning = false;   // config/params.yaml:30-31
     int downsample_rate = 4;                                 // :35
-    float min_dist = 4.f;                                    // :34
+    double min_dist = 4.;                                    // :34
+    std::string LiDAR_type = "hesai";                        // (the wire format: lv_cloud_format_preset; the ROS side's switch)
     float downsample_prec = 0.5f;
+    bool high_quality_publish = false;                       // (publishers only)
     std::vector<float> initial_gravity = {0.f, 0.f, -9.807f};
     std::vector<float> I_Rotation_L = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     std::vector<float> I_Translation_L = {0, 0, 0};
     bool real_time = false, mapping_online = true;           // config/params.yaml:2-3
     double real_time_delay = 0.1;                            // :24
-    int imu_rate = 400;                                      // :33
+    double imu_rate = 400;                                   // :33
     double empty_lidar_time = 0.2;                           // :23
+    std::string points_topic = "/velodyne_points", imus_topic = "/vectornav/IMU";
     InitializationParams Initialization;                     // :59-66
 };
 extern struct Params Config;  // the reference's global (src/main.cpp:14)

@@ -215,4 +215,22 @@ def test_reference_main_loop_trajectory_beside_the_hip_pipeline(lr, lv, tmp_path
         tol = {"pos": 2e-5, "rot": 2e-6, "offR": 1e-12, "offT": 1e-12, "vel": 5e-4, "bg": 2e-5, "ba": 2e-5, "grav": 1e-5}
         assert all(by_comp[nm] <= tol[nm] for nm in tol), by_comp
         assert d[:, :3].max() < 1e-3 and d.max() < 3e-3, worst
+        if on_device == 0:
+            by_value = (t, x, n)
     print("HIP pipeline vs the reference's main loop: max |dx| first 20 updates / positions overall / all states", worst)
+    # (c) the THIRD program: the reference's own src/main.cpp compiled UNCHANGED against the shim (limo-velo_amd/host/Makefile
+    # `refmain`: ref_main/Headers/*.hpp put the shim's classes where the reference's headers were, ref_main/ros/ros.h stands where
+    # the ROS master stood) on the same stream.  stream_demo runs host/main_loop.hpp, a hand restatement of main.cpp:52-128 — so
+    # the two must agree BIT FOR BIT, update by update: the loop a maintainer keeps is the reference's file itself.
+    main_exe = os.path.join(os.path.dirname(lr._LIB_PATH), "ref_main_over_shim")
+    if not os.path.exists(main_exe):
+        pytest.skip("oracle/_ref/ref_main_over_shim did not travel with this snapshot")
+    out_m = tmp_path / "out_main.bin"
+    r = subprocess.run([main_exe, str(tmp_path / "in0.bin"), str(out_m)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tm, xm, nm_ = S._read_stream_output(out_m)
+    t0_, x0_, n0_ = by_value
+    assert len(tm) == len(t0_) and len(tm) >= 50, (len(tm), len(t0_))
+    assert np.array_equal(tm, t0_) and np.array_equal(nm_, n0_)
+    assert np.array_equal(xm.view(np.uint64), x0_.view(np.uint64)), f"max |dx| {np.abs(xm - x0_).max():.3e}"
+    print(f"the reference's src/main.cpp over the shim == stream_demo (main_loop.hpp): {len(tm)} updates, states bit-equal")

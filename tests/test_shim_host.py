@@ -14,7 +14,7 @@ def test_get_prev_state_follows_the_reference_index_arithmetic(lv, tmp_path):
     exe = tmp_path / "accum_check"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", HOST, "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "host", "accum_check.cpp"), "-o", str(exe),
-                           "-L", os.path.join(ROOT, "limo-velo_amd"), "-llimovelo_shim", "-llimovelo_hip",
+                           "-L", os.path.join(ROOT, "limo-velo_amd"), "-llimovelo_shim", "-llimovelo_shim_config", "-llimovelo_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "limo-velo_amd")])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -46,7 +46,7 @@ def test_compensator_path_equals_the_reference_code(lv, oracle, tmp_path):
     exe = tmp_path / "path_check"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", HOST, "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "host", "path_check.cpp"), "-o", str(exe),
-                           "-L", os.path.join(ROOT, "limo-velo_amd"), "-llimovelo_shim", "-llimovelo_hip",
+                           "-L", os.path.join(ROOT, "limo-velo_amd"), "-llimovelo_shim", "-llimovelo_shim_config", "-llimovelo_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "limo-velo_amd")])
     rng = np.random.default_rng(17)
     cases = []
