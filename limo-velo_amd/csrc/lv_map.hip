@@ -993,17 +993,17 @@ int MapStore::reserve_batch(size_t k) {
     }
     LV_REALLOC(d_prank, uint32_t, ncap * REPL_LEVELS);
     LV_REALLOC(d_pslot, uint32_t, ncap * REPL_LEVELS);
-    if (!d_gcnt) LV_HIP(hipMalloc(&d_gcnt, 4 * sizeof(uint32_t)));
+    if (!d_gcnt) LV_HIP(hipMalloc(&d_gcnt, 4 * LIST_SHARDS * sizeof(uint32_t)));
     reloc_cap = (uint32_t)(ncap * 27 > 0x0FFFFFF0ull ? 0x0FFFFFF0ull : ncap * 27);
     LV_REALLOC(d_reloc, uint4, reloc_cap);
     // a batch of k points breaks up at most 27 k groups (one per target bucket), in practice a few per cent of k: more than this
     // raises `overflow` and the map is re-linearised
-    broken_cap = (uint32_t)(ncap * 2 < 4096 ? 4096 : ncap * 2);
+    broken_cap = (uint32_t)(ncap * 2 < 16384 ? 16384 : ncap * 2);   // (sharded 64 ways by table slot: room for an uneven spread)
     LV_REALLOC(d_broken, uint32_t, broken_cap);
     LV_REALLOC(d_regroup, RegroupPlan, broken_cap);
     // runs compacted in place: the list (one entry per run) and the staging area (one entry per bucket entry of a listed run; a
     // run that finds it full moves instead)
-    comp_cap = reloc_cap;
+    comp_cap = reloc_cap < (1u << 18) ? reloc_cap : (1u << 18);
     cstage_cap = (uint32_t)(ncap * 32 < (1u << 20) ? (1u << 20) : ncap * 32);
     LV_REALLOC(d_comp, uint4, comp_cap);
     LV_REALLOC(d_cstage, float4, cstage_cap);
@@ -1330,7 +1330,7 @@ __global__ void inc_post_counters_kernel(const MapCounters* __restrict__ cnt, un
 // the scratch tables of a batch back to empty (0xFF) and its group counters to zero: one launch instead of four fills
 __global__ void inc_clear_groups_kernel(GroupRW G, uint32_t* __restrict__ gcnt, MapCounters* __restrict__ cnt) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 4u) gcnt[t] = 0u;
+    if (t < 4u * LIST_SHARDS) gcnt[t] = 0u;   // (the sharded cursors of the batch's work lists: runs that move, groups broken up, runs compacted, their staging area)
     if (t == 0u && cnt) { cnt->n_new = 0u; cnt->n_dead = 0u; cnt->overflow = 0u; cnt->dropped = 0u; }   // (reset_batch_counters)
     const uint32_t l = t / G.size, e = t % G.size;
     if (l < (uint32_t)REPL_LEVELS) G.table[l][e] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -1431,10 +1431,10 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     MapRW M = rw();
     M.broken = d_broken;
     M.broken_cap = broken_cap;
-    M.n_broken = d_gcnt + 1;   // (zeroed with the batch's other counters: inc_clear_groups_kernel)
+    M.n_broken = d_gcnt + LIST_SHARDS;   // (zeroed with the batch's other counters: inc_clear_groups_kernel)
     M.comp = d_comp;
     M.comp_cap = comp_cap;
-    M.n_comp = d_gcnt + 2;
+    M.n_comp = d_gcnt + 2 * LIST_SHARDS;   // (+ the staging cursors behind them)
     M.cstage = d_cstage;
     M.cnew = d_cnew;
     M.cstage_cap = cstage_cap;
@@ -1527,7 +1527,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     // at most one run per (group, target) of this batch can be listed; 2048 workgroups walk longer lists in strides
     const uint64_t t_need = t_grp * RELOC_LANES < t_rel ? t_grp * RELOC_LANES : t_rel;
     const uint64_t g_need = (t_need + B - 1) / B;
-    const uint32_t g_rel = (uint32_t)(g_need < 2048 ? g_need : 2048);
+    const uint32_t g_rel = ((uint32_t)(g_need < 2048 ? g_need : 2048) + 15u) & ~15u;   // (a multiple of 16 workgroups: 64 x n runs at a time, one per list shard)
     const uint32_t g_cmp = k <= (uint32_t)SMALL_BATCH ? 64u : 1024u;   // in-place compactions: how many is only known on the device (grid-stride)
     if (merged_back) {   // (see inc_kill_register_kernel)
         const uint32_t g_kill = counted_kill ? 256u : 0u;   // the occupants that lost: how many is only known on the device

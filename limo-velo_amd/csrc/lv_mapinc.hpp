@@ -42,6 +42,11 @@ constexpr int CELL_SLOT = REPL_LEVELS;                      // index of the voxe
 constexpr int N_ARENAS = 64;   // the free part of every pool is split into arenas with their own cursors: a run that
                                // needs room bumps the cursor of arena (slot mod 64) — one shared cursor costs ~10 ns per
                                // allocation (same-address atomics whose result is needed), 200 us when 20k buckets are new
+// Work lists of an insert batch (runs that move, runs compacted in place, tile groups broken up): 64 sub-lists with their own
+// cursors — shard s owns the indices [s * cap / 64, (s + 1) * cap / 64) — because an append needs the atomic's RESULT, and such
+// an atomic costs ~10 ns when a whole launch hits one address: 30 000 appends to one cursor were most of inc_reserve_kernel's
+// 120 us (round 6; the arenas above are the same cure for the pool cursors).
+constexpr uint32_t LIST_SHARDS = 64;
 struct MapCounters {
     uint32_t arena_cur[INC_LEVELS][N_ARENAS];   // next free entry of each arena
     uint32_t arena_end[INC_LEVELS][N_ARENAS];
@@ -79,7 +84,7 @@ struct MapRW {
     // (inc_compact_*) instead of moving: {table slot, living entries, entries before, first staging entry} per run, the staging area
     uint4* comp;
     uint32_t comp_cap;
-    uint32_t* n_comp;                // [0]: runs listed, [1]: staging entries handed out
+    uint32_t* n_comp;                // [0 .. 64): the list's cursors, [64 .. 128): staging entries handed out per shard
     float4* cstage;                  // {x, y, z, id} of a listed run's entries as they were
     uint32_t* cnew;                  // their new positions (ID_NONE: a deleted entry)
     uint32_t cstage_cap;
@@ -134,6 +139,34 @@ __device__ __forceinline__ uint32_t table_find(const uint4* table, uint32_t mask
     return ID_NONE;
 }
 
+// append to a sharded list: the entry's index, or ID_NONE if the shard is full
+__device__ __forceinline__ uint32_t list_push(uint32_t* cursors, uint32_t cap, uint32_t shard) {
+    const uint32_t seg = cap / LIST_SHARDS, s = shard & (LIST_SHARDS - 1u);
+    const uint32_t i = atomicAdd(&cursors[s], 1u);
+    return i < seg ? s * seg + i : ID_NONE;
+}
+// worker w of W visits every listed index once across the workers (W a multiple of 64: worker w serves shard w % 64; any other W —
+// the host emulation's small launches — walks every shard)
+template <class F>
+__device__ __forceinline__ void list_for_each(const uint32_t* cursors, uint32_t cap, uint32_t w, uint32_t W, F f) {
+    const uint32_t seg = cap / LIST_SHARDS;
+    if (W % LIST_SHARDS == 0u) {
+        const uint32_t s = w % LIST_SHARDS, n = cursors[s] < seg ? cursors[s] : seg;
+        for (uint32_t i = w / LIST_SHARDS; i < n; i += W / LIST_SHARDS) f(s * seg + i);
+    } else {
+        for (uint32_t s = 0; s < LIST_SHARDS; ++s) {
+            const uint32_t n = cursors[s] < seg ? cursors[s] : seg;
+            for (uint32_t i = w; i < n; i += W) f(s * seg + i);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t list_count(const uint32_t* cursors, uint32_t cap) {
+    const uint32_t seg = cap / LIST_SHARDS;
+    uint32_t n = 0;
+    for (uint32_t s = 0; s < LIST_SHARDS; ++s) n += cursors[s] < seg ? cursors[s] : seg;
+    return n;
+}
+
 // The tile group of the level-0 bucket `key` is no longer one contiguous region of up-to-date runs (one of its runs moved, a new
 // tile appeared outside the region, a run was dropped with its entries left as they were): level 1 stops streaming it
 // (bucket_attempt, lv_match.hip: extent 0 -> the point goes on to the lists).  An insert batch lists the groups it breaks
@@ -171,8 +204,8 @@ __device__ __forceinline__ void inc_break_group(const MapRW& M, uint64_t key) {
     M.gtable[slot].w = 0u;
     if (!M.broken) return;
     if (created || atomicExch(&M.gtable[slot].z, ID_NONE) != ID_NONE) {   // first breaker of this batch
-        const uint32_t i = atomicAdd(M.n_broken, 1u);
-        if (i < M.broken_cap) M.broken[i] = slot;
+        const uint32_t i = list_push(M.n_broken, M.broken_cap, slot);
+        if (i != ID_NONE) M.broken[i] = slot;
         else atomicExch(&M.cnt->overflow, 1u);
     }
 }
@@ -665,11 +698,12 @@ __device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& 
         // over the same ground used up the pool of a 1 M-point map, a re-linearisation every sixth scan.
         const uint32_t living = e.w - (a.dead < e.w ? a.dead : e.w);   // (the run's tombstones are counted as they are written: inc_kill_slot, the eviction sweep)
         if (living + a.pending <= a.cap && living + 4u <= e.w) {
-            const uint32_t base = atomicAdd(&M.n_comp[1], e.w);
-            if ((uint64_t)base + e.w <= (uint64_t)M.cstage_cap) {
-                const uint32_t ci = atomicAdd(&M.n_comp[0], 1u);
-                if (ci < M.comp_cap) {
-                    M.comp[ci] = uint4{slot, living, e.w, base};
+            const uint32_t sseg = M.cstage_cap / LIST_SHARDS, sh = slot & (LIST_SHARDS - 1u);
+            const uint32_t sb = atomicAdd(&M.n_comp[LIST_SHARDS + sh], e.w);   // (the staging area is sharded like the list)
+            if ((uint64_t)sb + e.w <= (uint64_t)sseg) {
+                const uint32_t ci = list_push(M.n_comp, M.comp_cap, slot);
+                if (ci != ID_NONE) {
+                    M.comp[ci] = uint4{slot, living, e.w, sh * sseg + sb};
                     tail0 = living;
                     compacted = true;
                 }
@@ -690,8 +724,8 @@ __device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& 
             atomicExch(&M.cnt->overflow, 1u);
         } else {
             if (e.w) {
-                const uint32_t ri = atomicAdd(n_reloc, 1u);
-                if (ri < reloc_cap) reloc[ri] = uint4{(uint32_t)level, e.z, ns, e.w};
+                const uint32_t ri = list_push(n_reloc, reloc_cap, slot);
+                if (ri != ID_NONE) reloc[ri] = uint4{(uint32_t)level, e.z, ns, e.w};
                 else atomicExch(&M.cnt->overflow, 1u);
             }
             L.table[slot].z = ns;
@@ -750,10 +784,9 @@ __device__ __forceinline__ void inc_relocate_item(const MapRW& M, const uint4* _
                                                   uint32_t t, uint32_t n_threads) {
     if (M.cnt->overflow) return;
     const uint32_t lane = t % (uint32_t)LANES;
-    const uint32_t n = *n_reloc < reloc_cap ? *n_reloc : reloc_cap;
     // (grid-stride over the listed runs: how many there are is only known here, and a launch sized for the list's capacity
     // spent 23 us of a small batch on workgroups that had nothing to move)
-    for (uint32_t r = t / (uint32_t)LANES; r < n; r += n_threads / (uint32_t)LANES) {
+    list_for_each(n_reloc, reloc_cap, t / (uint32_t)LANES, n_threads / (uint32_t)LANES, [&](uint32_t r) {
         const uint4 m = reloc[r];   // {level, old start, new start, count}
         if ((int)m.x < SORTED_LEVELS) {
             float* xs = M.bxyz[m.x];
@@ -763,7 +796,7 @@ __device__ __forceinline__ void inc_relocate_item(const MapRW& M, const uint4* _
         } else {
             inc_copy_run<LANES>(M.cell4 + (size_t)m.z, M.cell4 + (size_t)m.y, m.w, lane);
         }
-    }
+    });
 }
 __global__ void inc_relocate_kernel(MapRW M, const uint4* __restrict__ reloc, uint32_t reloc_cap, const uint32_t* __restrict__ n_reloc) {
     inc_relocate_item(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
@@ -884,13 +917,33 @@ __global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict
 constexpr int COMPACT_LANES = 64;
 __device__ __forceinline__ void inc_compact_gather_item(const MapRW& M, uint32_t t, uint32_t n_threads) {
     if (M.cnt->overflow) return;
-    const uint32_t n = M.n_comp[0] < M.comp_cap ? M.n_comp[0] : M.comp_cap;
     const uint32_t lane = t % (uint32_t)COMPACT_LANES;
-    for (uint32_t r = t / (uint32_t)COMPACT_LANES; r < n; r += n_threads / (uint32_t)COMPACT_LANES) {
+    list_for_each(M.n_comp, M.comp_cap, t / (uint32_t)COMPACT_LANES, n_threads / (uint32_t)COMPACT_LANES, [&](uint32_t r) {
         const uint4 c = M.comp[r];   // {slot, living, count before, staging base}
         const uint4 e = M.lv[0].table[c.x];
         const float* xs = M.bxyz[0] + (size_t)e.z * 3;
         const uint32_t* is = M.bidx[0] + e.z;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // on the device the COMPACT_LANES threads of a run ARE one wavefront (consecutive thread ids, workgroups of a multiple of
+        // 64 threads): the living entries before entry i = a ballot + a population count, 64 entries per step.  (The host
+        // emulation below counts them one by one — the same positions; the one exception to "no wave intrinsics in this header":
+        // the counting loop was 50 us of every batch.)
+        static_assert(COMPACT_LANES == 64, "one wavefront per run");
+        uint32_t before = 0;
+        for (uint32_t i0 = 0; i0 < c.z; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            const bool in = i < c.z;
+            const float x = in ? xs[(size_t)i * 3] : pos_inf();
+            const bool alive = in && x < pos_inf();
+            const unsigned long long mask = __ballot(alive);
+            if (in) {
+                M.cstage[c.w + i] = make_float4(x, xs[(size_t)i * 3 + 1], xs[(size_t)i * 3 + 2], __uint_as_float(is[i]));
+                M.cnew[c.w + i] = alive ? before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) : ID_NONE;
+            }
+            before += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0u && before != c.y) atomicExch(&M.cnt->overflow, 1u);   // (the count the decision was taken with: a mismatch would misplace the batch's tail)
+#else
         for (uint32_t i = lane; i < c.z; i += (uint32_t)COMPACT_LANES) {
             const float x = xs[(size_t)i * 3];
             M.cstage[c.w + i] = make_float4(x, xs[(size_t)i * 3 + 1], xs[(size_t)i * 3 + 2], __uint_as_float(is[i]));
@@ -907,14 +960,14 @@ __device__ __forceinline__ void inc_compact_gather_item(const MapRW& M, uint32_t
                 if ((np == ID_NONE ? before : total) != c.y) atomicExch(&M.cnt->overflow, 1u);
             }
         }
-    }
+#endif
+    });
 }
 __global__ void inc_compact_gather_kernel(MapRW M) { inc_compact_gather_item(M, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
 __device__ __forceinline__ void inc_compact_scatter_item(const MapRW& M, uint32_t t, uint32_t n_threads) {
     if (M.cnt->overflow) return;
-    const uint32_t n = M.n_comp[0] < M.comp_cap ? M.n_comp[0] : M.comp_cap;
     const uint32_t lane = t % (uint32_t)COMPACT_LANES;
-    for (uint32_t r = t / (uint32_t)COMPACT_LANES; r < n; r += n_threads / (uint32_t)COMPACT_LANES) {
+    list_for_each(M.n_comp, M.comp_cap, t / (uint32_t)COMPACT_LANES, n_threads / (uint32_t)COMPACT_LANES, [&](uint32_t r) {
         const uint4 c = M.comp[r];
         const uint4 e = M.lv[0].table[c.x];
         const uint64_t key = entry_key(e);
@@ -934,7 +987,7 @@ __device__ __forceinline__ void inc_compact_scatter_item(const MapRW& M, uint32_
             }
             if (i >= tail_end) { xs[(size_t)i * 3] = pos_inf(); xs[(size_t)i * 3 + 1] = pos_inf(); xs[(size_t)i * 3 + 2] = pos_inf(); }
         }
-    }
+    });
 }
 __global__ void inc_compact_scatter_kernel(MapRW M) { inc_compact_scatter_item(M, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
 
@@ -944,8 +997,7 @@ __global__ void inc_compact_scatter_kernel(MapRW M) { inc_compact_scatter_item(M
 // re-linearisation, like the old place of a run that moved).  Positions inside a run do not change: back-positions stay valid.
 // pass R1, one thread per listed group: find the group's buckets, take room for the region, publish the group's entry
 __device__ __forceinline__ void inc_regroup_plan_item(const MapRW& M, RegroupPlan* __restrict__ plan, uint32_t g) {
-    const uint32_t nb = *M.n_broken < M.broken_cap ? *M.n_broken : M.broken_cap;
-    if (g >= nb || M.cnt->overflow) return;
+    if (M.cnt->overflow) return;
     const uint32_t gs = M.broken[g];
     const uint64_t gkey = entry_key(M.gtable[gs]);
     const uint32_t vx = (uint32_t)(gkey & 0x1fffff), vy = (uint32_t)((gkey >> 21) & 0x1fffff), vz = (uint32_t)((gkey >> 42) & 0x1fffff);
@@ -988,15 +1040,14 @@ __device__ __forceinline__ void inc_regroup_plan_item(const MapRW& M, RegroupPla
     M.gtable[gs].w = extent;
 }
 __global__ void inc_regroup_plan_kernel(MapRW M, RegroupPlan* __restrict__ plan) {
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < M.broken_cap; g += gridDim.x * blockDim.x) inc_regroup_plan_item(M, plan, g);
+    list_for_each(M.n_broken, M.broken_cap, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, [&](uint32_t g) { inc_regroup_plan_item(M, plan, g); });
 }
 // pass R2, REGROUP_LANES threads per listed group: the runs move (entries [0, count)), the slack behind them reads +inf
 constexpr int REGROUP_LANES = 64;
 __device__ __forceinline__ void inc_regroup_move_item(const MapRW& M, const RegroupPlan* __restrict__ plan, uint32_t t, uint32_t n_threads) {
-    const uint32_t nb = *M.n_broken < M.broken_cap ? *M.n_broken : M.broken_cap;
     if (M.cnt->overflow) return;
     const uint32_t lane = t % (uint32_t)REGROUP_LANES;
-    for (uint32_t g = t / (uint32_t)REGROUP_LANES; g < nb; g += n_threads / (uint32_t)REGROUP_LANES) {
+    list_for_each(M.n_broken, M.broken_cap, t / (uint32_t)REGROUP_LANES, n_threads / (uint32_t)REGROUP_LANES, [&](uint32_t g) {
         const RegroupPlan& P = plan[g];
         for (int r = 0; r < 8; ++r) {
             if (P.slot[r] == ID_NONE) continue;
@@ -1012,24 +1063,23 @@ __device__ __forceinline__ void inc_regroup_move_item(const MapRW& M, const Regr
                 }
             }
         }
-    }
+    });
 }
 __global__ void inc_regroup_move_kernel(MapRW M, const RegroupPlan* __restrict__ plan) {
     inc_regroup_move_item(M, plan, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
-// pass R3, one thread per (listed group, tile): the buckets point at their new runs
-__device__ __forceinline__ void inc_regroup_commit_item(const MapRW& M, const RegroupPlan* __restrict__ plan, uint32_t t) {
-    const uint32_t nb = *M.n_broken < M.broken_cap ? *M.n_broken : M.broken_cap;
-    if (t / 8u >= nb || M.cnt->overflow) return;
-    const RegroupPlan& P = plan[t / 8u];
-    const int r = (int)(t % 8u);
-    if (P.slot[r] != ID_NONE) {
+// pass R3, one thread per listed group: its buckets point at their new runs
+__device__ __forceinline__ void inc_regroup_commit_item(const MapRW& M, const RegroupPlan* __restrict__ plan, uint32_t g) {
+    if (M.cnt->overflow) return;
+    const RegroupPlan& P = plan[g];
+    for (int r = 0; r < 8; ++r) {
+        if (P.slot[r] == ID_NONE) continue;
         M.lv[0].table[P.slot[r]].z = P.to[r];
         M.lv[0].aux[P.slot[r]].cap = P.cap[r];
     }
 }
 __global__ void inc_regroup_commit_kernel(MapRW M, const RegroupPlan* __restrict__ plan) {
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < M.broken_cap * 8u; t += gridDim.x * blockDim.x) inc_regroup_commit_item(M, plan, t);
+    list_for_each(M.n_broken, M.broken_cap, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, [&](uint32_t g) { inc_regroup_commit_item(M, plan, g); });
 }
 
 // ---- eviction --------------------------------------------------------------------------------------------------

@@ -70,12 +70,12 @@ struct Emu {
     std::vector<uint4> gtable;          // tile groups: level-1 voxel -> {start, extent} of its runs' region
     std::vector<uint32_t> broken;       // groups the batch in flight broke up
     std::vector<RegroupPlan> plans;
-    uint32_t n_broken = 0;
+    uint32_t n_broken[LIST_SHARDS] = {};
     uint64_t regrouped = 0, compacted = 0;
     std::vector<uint4> comp;            // runs compacted in place by the batch in flight + their staging area
     std::vector<float4> cstage;
     std::vector<uint32_t> cnew;
-    uint32_t n_comp[2] = {0, 0};
+    uint32_t n_comp[2 * LIST_SHARDS] = {};
     std::vector<uint32_t> cellpos;      // [id]
     std::vector<float4> cell4;
     uint32_t pool_cap[INC_LEVELS] = {};
@@ -329,16 +329,16 @@ struct Emu {
         reset_batch();
         if (downsample) ensure_boxes();
         MapRW M = rw();
-        broken.assign((size_t)k * 27 + 64, 0xDEADBEEFu);
+        broken.assign(((size_t)k * 27 + 64) * LIST_SHARDS, 0xDEADBEEFu);   // (every shard can take the whole batch: the spread over the shards is the hash's)
         plans.assign(broken.size(), RegroupPlan{});
-        n_broken = 0;
+        for (auto& v : n_broken) v = 0;
         M.broken = broken.data();
         M.broken_cap = (uint32_t)broken.size();
-        M.n_broken = &n_broken;
-        comp.assign((size_t)k * 27 + 64, uint4{0, 0, 0, 0});
-        cstage.assign(1u << 18, float4{0, 0, 0, 0});
-        cnew.assign(1u << 18, 0xDEADBEEFu);
-        n_comp[0] = n_comp[1] = 0;
+        M.n_broken = n_broken;
+        comp.assign(((size_t)k * 27 + 64) * LIST_SHARDS, uint4{0, 0, 0, 0});
+        cstage.assign((size_t)(1u << 14) * LIST_SHARDS, float4{0, 0, 0, 0});
+        cnew.assign(cstage.size(), 0xDEADBEEFu);
+        for (auto& v : n_comp) v = 0;
         M.comp = comp.data();
         M.comp_cap = (uint32_t)comp.size();
         M.n_comp = n_comp;
@@ -372,7 +372,7 @@ struct Emu {
         std::vector<uint4> gtab[REPL_LEVELS];
         std::vector<uint32_t> gbase[REPL_LEVELS], gslot[REPL_LEVELS];
         std::vector<uint4> gdst[REPL_LEVELS];
-        std::vector<uint32_t> prank((size_t)k * REPL_LEVELS, 0u), pslot((size_t)k * REPL_LEVELS, 0u), gcnt(4, 0u);
+        std::vector<uint32_t> prank((size_t)k * REPL_LEVELS, 0u), pslot((size_t)k * REPL_LEVELS, 0u), gcnt(LIST_SHARDS, 0u);
         GroupRW G{};
         for (int l = 0; l < REPL_LEVELS; ++l) {
             gtab[l].assign(gsize, uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
@@ -401,7 +401,7 @@ struct Emu {
         const uint64_t kk = listed ? (uint64_t)(cnt.n_new ? cnt.n_new : 1u) : (uint64_t)k;
         launch(inc_group_kernel, (uint64_t)k * REPL_LEVELS, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), k);
         std::vector<uint32_t> rank((size_t)k * 27 * SORTED_LEVELS, 0u);
-        std::vector<uint4> reloc((size_t)k * 27 + 64);
+        std::vector<uint4> reloc(((size_t)k * 27 + 64) * LIST_SHARDS);
         const uint64_t t_grp = kk * REPL_LEVELS * GROUP_TARGETS;
         const uint64_t t_all = kk * INC_SLOTS_PER_POINT, t_rep = kk * 27 * SORTED_LEVELS;
         launch(inc_register_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
@@ -412,7 +412,7 @@ struct Emu {
         launch(inc_relocate_kernel, (uint64_t)16 * RELOC_LANES, M, (const uint4*)reloc.data(), (uint32_t)reloc.size(), (const uint32_t*)gcnt.data());
         launch(inc_resolve_kernel, t_grp, M, G, (const uint32_t*)alive.data(), k);
         launch(inc_compact_scatter_kernel, (uint64_t)8 * COMPACT_LANES, M);
-        compacted += n_comp[0];
+        compacted += list_count(n_comp, M.comp_cap);
         launch(inc_fill_kernel, t_all, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids);
         launch(inc_rank_kernel, t_rep, M, G, (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids, rank.data());
         launch(inc_place_kernel, t_rep, M, G, (const float4*)newp.data(), (const uint32_t*)alive.data(), (const uint32_t*)apos.data(), k, n_ids,
@@ -422,8 +422,8 @@ struct Emu {
         launch(inc_regroup_plan_kernel, 512, M, plans.data());
         launch(inc_regroup_move_kernel, 1024, M, (const RegroupPlan*)plans.data());
         launch(inc_regroup_commit_kernel, 512, M, (const RegroupPlan*)plans.data());
-        regrouped += n_broken;
-        relocations += gcnt[0];
+        regrouped += list_count(n_broken, M.broken_cap);
+        relocations += list_count(gcnt.data(), (uint32_t)reloc.size());
         n_ids += cnt.n_new;
         m += cnt.n_new;
         m -= n_dead;

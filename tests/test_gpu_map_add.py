@@ -331,3 +331,39 @@ def test_rebuild_gives_memory_back_after_the_map_shrank(lv):
         xb, Pb, pb, trb, sb = ctx.update(sc["x_init"], sc["P0"])
     assert pa == pb and np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
     assert [s["n_valid"] for s in sa] == [s["n_valid"] for s in sb]
+
+
+def test_reobserved_ground_is_compacted_in_place_and_stays_exact(capi, oracle, scene_small):
+    """The same ground scanned again and again (a sensor at rest; bench.py's cycle): every scan's points compete with the occupants of
+    their 0.2 m boxes, the losers stay behind as tombstones, buckets outgrow their room by their DEAD entries and are compacted
+    where they lie (lv_mapinc.hpp inc_compact_* — the device takes the ballot form of the gather, the host emulation of
+    tests/test_mapinc_emulation.py the loop form).  After every scan: the map equals the oracle's point for point, in order; the
+    5-NN of a probe scan — level 0, and level 1 over the tile groups' regions from a perturbed pose — equal brute force; and the
+    bucket pool has not grown (no run moved, no group was laid out again, no re-linearisation)."""
+    sc = scene_small
+    rng = np.random.default_rng(5)
+    ref = sc["map_xyz"].copy()
+    scan = (sc["map_xyz"][rng.integers(0, len(ref), 12_000)] + rng.normal(0, 0.02, (12_000, 3))).astype(np.float32)
+    probe = sc["scan_xyz"][:800]
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        used0 = None
+        for step in range(12):
+            batch = (scan + rng.normal(0, 0.004, scan.shape)).astype(np.float32)
+            ctx.map_add(batch, downsample=True)
+            ref = oracle.map_add(ref, batch, downsample=True)
+            assert ctx.map_size() == len(ref)
+            if step % 3 == 2 or step == 11:
+                assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref)), f"step {step}"
+                ctx.scan_set(probe)
+                for state in (sc["x_true"], sc["x_init"]):
+                    ctx.iterate(state)
+                    idx, d2 = ctx.fetch_knn()
+                    oi, od, _, _ = oracle.knn_brute(ref, oracle.transform_scan(state, probe))
+                    assert np.array_equal(idx, oi) and np.array_equal(_bits(d2), _bits(od)), f"step {step}"
+            st = ctx.map_stats()
+            if step == 3:
+                used0 = st["pool_used"][0]
+        assert st["relinearisations"] == 0
+        assert st["tombstones"] > 0
+        assert st["pool_used"][0] <= used0 * 1.02, (used0, st["pool_used"][0])   # (the churn of the later scans did not cost pool space)
