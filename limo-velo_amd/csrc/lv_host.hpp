@@ -175,6 +175,8 @@ struct MapStore {
     // background re-linearisation (lv_api.hip, round 5): while a compacted copy of this map is being rebuilt on another stream /
     // thread, the stop-the-world relinearise is deferred (only id-space exhaustion still forces it)
     bool defer_relinearise = false;
+    uint32_t last_new = 0;    // survivors of the previous insert batch: sizes the next batch's per-survivor launches (an estimate: add_staged)
+    bool have_last_new = false;
     bool pool_low = false;    // the last insert left less than a quarter of the bucket pool's free part (settle): a re-linearisation is wanted
     uint32_t slice_wgs = 0;   // != 0: the large grids of a (re)build go out in slices of that many workgroups (a store rebuilt in the background)
     bool wants_relinearise(size_t incoming) const;   // the trigger, whatever defer_relinearise says

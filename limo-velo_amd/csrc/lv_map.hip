@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(1024) void inc_small_front_kernel(MapRW M, BoxRW Bx
 __global__ __launch_bounds__(256) void inc_kill_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k,
                                                                 const float4* __restrict__ dead, uint32_t dead_cap, uint32_t g_kill) {
     if (blockIdx.x < g_kill) inc_kill_counted_item(M, dead, dead_cap, blockIdx.x * blockDim.x + threadIdx.x, g_kill * blockDim.x);
-    else inc_register_item(M, G, alive, k, inc_block_of(blockIdx.x - g_kill, gridDim.x - g_kill) * blockDim.x + threadIdx.x);
+    else LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, g_kill, gridDim.x - g_kill, inc_register_item(M, G, alive, k, t));
 }
 // (round 4: the listed runs move while every (group, target) notes where its target's batch tail lies — inc_resolve — and the new
 // entries go to the tails in a launch of their own behind it)
@@ -1209,13 +1209,13 @@ __global__ __launch_bounds__(256) void inc_relocate_resolve_kernel(MapRW M, Grou
                                                                    const uint4* __restrict__ reloc, uint32_t reloc_cap,
                                                                    const uint32_t* __restrict__ n_reloc, uint32_t g_rel) {
     if (blockIdx.x < g_rel) inc_relocate_item<LANES>(M, reloc, reloc_cap, n_reloc, blockIdx.x * blockDim.x + threadIdx.x, g_rel * blockDim.x);
-    else inc_resolve_item(M, G, alive, k, inc_block_of(blockIdx.x - g_rel, gridDim.x - g_rel) * blockDim.x + threadIdx.x);
+    else LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, g_rel, gridDim.x - g_rel, inc_resolve_item(M, G, alive, k, t));
 }
 __global__ __launch_bounds__(256) void inc_place_commit_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp,
                                                                const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
                                                                uint32_t id_base, const uint32_t* __restrict__ rank, uint32_t g_place) {
-    if (blockIdx.x < g_place) inc_place_item(M, G, newp, alive, apos, k, id_base, rank, inc_block_of(blockIdx.x, g_place) * blockDim.x + threadIdx.x);
-    else inc_commit_item(M, G, alive, k, inc_block_of(blockIdx.x - g_place, gridDim.x - g_place) * blockDim.x + threadIdx.x);
+    if (blockIdx.x < g_place) LV_INC_ITEMS(27 * SORTED_LEVELS, 0u, g_place, inc_place_item(M, G, newp, alive, apos, k, id_base, rank, t))
+    else LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, g_place, gridDim.x - g_place, inc_commit_item(M, G, alive, k, t))
 }
 
 // ---- lv_map_evict_box without a per-point search ---------------------------------------------------------------------------------
@@ -1500,7 +1500,10 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     hipLaunchKernelGGL(inc_group_kernel, dim3((uint32_t)(((uint64_t)k * REPL_LEVELS + B - 1) / B)), dim3(B), 0, stream, M, G, d_new,
                        d_nalive, k);
     }   // !fused_front
-    const bool counted_kill = downsample && k <= (uint32_t)SMALL_BATCH;
+    // (round 6: every batch leaves the length of its dead list on the device — the tombstone pass walks it in strides beside the
+    // registration pass — instead of fetching it in the middle of the insert: one host round trip and one launch less per insert;
+    // the append passes then cover every point of the batch, the ones that did not survive leaving at once)
+    const bool counted_kill = downsample != 0;
     if (!counted_kill && downsample) {
         // the counters of the front half (survivors, occupants that lost) size the launches that follow: fetched as a NOTE (a
         // one-thread kernel posts them into pinned memory, the host polls: lv_note.hpp) instead of a copy + stream synchronise,
@@ -1519,7 +1522,13 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     }
     // work items of the append passes: with a survivor list (and the counters just read) one per SURVIVOR and slot, else one per
     // point of the batch and slot (the dead leave at once)
-    const uint64_t kk = (listed && !counted_kill) ? (uint64_t)(h_cnt->n_new > 0 ? h_cnt->n_new : 1u) : (uint64_t)k;
+    // grids of the per-survivor passes: an ESTIMATE of the survivors — half again what the previous batch left — where the batch
+    // walks a survivor list (the kernels cover whatever lies beyond their grid in strides: LV_INC_ITEMS), else every point
+    uint64_t kk = (uint64_t)k;
+    if (listed && counted_kill && have_last_new) {
+        const uint64_t est = (uint64_t)last_new + (uint64_t)last_new / 2u + 2048u;
+        kk = est < (uint64_t)k ? est : (uint64_t)k;
+    }
     const uint64_t t_grp = kk * REPL_LEVELS * GROUP_TARGETS;
     const uint64_t t_all = kk * INC_SLOTS_PER_POINT, t_rep = kk * 27 * SORTED_LEVELS;
     const uint32_t g_grp = (uint32_t)((t_grp + B - 1) / B), g_all = (uint32_t)((t_all + B - 1) / B), g_rep = (uint32_t)((t_rep + B - 1) / B);
@@ -1530,7 +1539,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
     const uint32_t g_rel = ((uint32_t)(g_need < 2048 ? g_need : 2048) + 15u) & ~15u;   // (a multiple of 16 workgroups: 64 x n runs at a time, one per list shard)
     const uint32_t g_cmp = k <= (uint32_t)SMALL_BATCH ? 64u : 1024u;   // in-place compactions: how many is only known on the device (grid-stride)
     if (merged_back) {   // (see inc_kill_register_kernel)
-        const uint32_t g_kill = counted_kill ? 256u : 0u;   // the occupants that lost: how many is only known on the device
+        const uint32_t g_kill = counted_kill ? (k <= (uint32_t)SMALL_BATCH ? 256u : 2048u) : 0u;   // the occupants that lost: how many is only known on the device
         hipLaunchKernelGGL(inc_kill_register_kernel, dim3(g_kill + g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_dead, (uint32_t)dead_cap, g_kill);
         hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
         // runs that only their deleted entries made too long are compacted where they lie: staged here, written back below
@@ -1546,7 +1555,7 @@ int MapStore::add_staged(hipStream_t stream, uint32_t k, int downsample, float b
         hipLaunchKernelGGL(inc_rank_kernel, dim3(g_rep), dim3(B), 0, stream, M, G, d_nalive, d_napos, k, n_ids, d_rank);
         hipLaunchKernelGGL(inc_place_commit_kernel, dim3(g_rep + g_grp), dim3(B), 0, stream, M, G, d_new, d_nalive, d_napos, k, n_ids, d_rank, g_rep);
     } else {
-    if (counted_kill) hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(256), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
+    if (counted_kill) hipLaunchKernelGGL(inc_kill_counted_kernel, dim3(k <= (uint32_t)SMALL_BATCH ? 256 : 2048), dim3(B), 0, stream, M, d_dead, (uint32_t)dead_cap);
     hipLaunchKernelGGL(inc_register_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k);
     hipLaunchKernelGGL(inc_reserve_kernel, dim3(g_grp), dim3(B), 0, stream, M, G, d_nalive, k, d_reloc, (uint32_t)(t_rel / RELOC_LANES), d_gcnt);
     hipLaunchKernelGGL(inc_compact_gather_kernel, dim3(g_cmp), dim3(B), 0, stream, M);
@@ -1593,6 +1602,8 @@ int MapStore::settle(hipStream_t stream) {
     if (pending_counted_kill) n_dead = v[1] < dead_cap ? v[1] : (uint32_t)dead_cap;
     n_ids += v[0];
     m += v[0];
+    last_new = v[0];
+    have_last_new = true;
     m -= n_dead;
     tombstones += (uint64_t)n_dead * INC_SLOTS_PER_POINT;
     dropped_total += v[2];

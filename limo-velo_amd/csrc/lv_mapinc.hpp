@@ -121,6 +121,18 @@ __device__ __forceinline__ uint32_t inc_block_of(uint32_t b, uint32_t n) {
     return x * q + (x < r ? x : r) + b / 8u;
 }
 __device__ __forceinline__ uint32_t inc_thread_id() { return inc_block_of(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; }
+// The per-survivor passes of an insert are launched for an ESTIMATE of the batch's survivors (what the previous batch left: the
+// host no longer waits for the count in the middle of the insert) and walk any items beyond their grid in strides: `per` items
+// per surviving point, `first` / `stride` from the workgroups [b0, b0 + nb) that serve the stage.
+#define LV_INC_ITEMS(per, b0, nb, ...)                                                                                          \
+    {                                                                                                                          \
+        const uint64_t n_items_ = (uint64_t)(G.surv ? *G.n_live : k) * (uint64_t)(per);                                        \
+        const uint64_t stride_ = (uint64_t)(nb) * blockDim.x;                                                                  \
+        for (uint64_t t_ = (uint64_t)inc_block_of(blockIdx.x - (b0), (nb)) * blockDim.x + threadIdx.x; t_ < n_items_; t_ += stride_) { \
+            const uint32_t t = (uint32_t)t_;                                                                                   \
+            __VA_ARGS__;                                                                                                       \
+        }                                                                                                                      \
+    }
 
 __device__ __forceinline__ bool pt_alive(const float4& p) { return p.x < __uint_as_float(0x7F800000u) && p.x > -__uint_as_float(0x7F800000u); }
 __device__ __forceinline__ float pos_inf() { return __uint_as_float(0x7F800000u); }
@@ -669,7 +681,7 @@ __device__ __forceinline__ void inc_register_item(const MapRW& M, const GroupRW&
     G.gslot[l][r] = slot;
 }
 __global__ void inc_register_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    inc_register_item(M, G, alive, k, inc_thread_id());
+    LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, 0u, gridDim.x, inc_register_item(M, G, alive, k, t));
 }
 
 // pass 3: the group that took offset 0 of a target's tail makes room for the whole batch: a run that cannot take
@@ -737,7 +749,7 @@ __device__ __forceinline__ void inc_reserve_item(const MapRW& M, const GroupRW& 
 }
 __global__ void inc_reserve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k, uint4* __restrict__ reloc,
                                    uint32_t reloc_cap, uint32_t* __restrict__ n_reloc) {
-    inc_reserve_item(M, G, alive, k, reloc, reloc_cap, n_reloc, inc_thread_id());
+    LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, 0u, gridDim.x, inc_reserve_item(M, G, alive, k, reloc, reloc_cap, n_reloc, t));
 }
 
 // pass 3a: every (voxel group, target) notes where the target's batch tail starts in the pool and how long it is — table slot and
@@ -755,7 +767,7 @@ __device__ __forceinline__ void inc_resolve_item(const MapRW& M, const GroupRW& 
     G.gdst[l][r] = uint4{L.table[slot].z + a.tail0, a.pending, a.tail0, 0u};
 }
 __global__ void inc_resolve_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    inc_resolve_item(M, G, alive, k, inc_thread_id());
+    LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, 0u, gridDim.x, inc_resolve_item(M, G, alive, k, t));
 }
 
 // pass 3b: the listed runs move, one wavefront per run — a whole workgroup per run for small batches (LANES = 256: few runs, and
@@ -840,7 +852,7 @@ __device__ __forceinline__ void inc_fill_item(const MapRW& M, const GroupRW& G, 
 }
 __global__ void inc_fill_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                 const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base) {
-    inc_fill_item(M, G, newp, alive, apos, k, id_base, inc_thread_id());
+    LV_INC_ITEMS(INC_SLOTS_PER_POINT, 0u, gridDim.x, inc_fill_item(M, G, newp, alive, apos, k, id_base, t));
 }
 
 // pass 5: rank of every new bucket entry among the ids of its tail (levels 0, 1)
@@ -863,7 +875,7 @@ __device__ __forceinline__ void inc_rank_item(const MapRW& M, const GroupRW& G, 
 }
 __global__ void inc_rank_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ apos, uint32_t k,
                                 uint32_t id_base, uint32_t* __restrict__ rank) {
-    inc_rank_item(M, G, alive, apos, k, id_base, rank, inc_thread_id());
+    LV_INC_ITEMS(27 * SORTED_LEVELS, 0u, gridDim.x, inc_rank_item(M, G, alive, apos, k, id_base, rank, t));
 }
 
 // pass 6: every new bucket entry goes to its ranked place (all reads of pass 5 are done: kernel boundary)
@@ -890,7 +902,7 @@ __device__ __forceinline__ void inc_place_item(const MapRW& M, const GroupRW& G,
 }
 __global__ void inc_place_kernel(MapRW M, GroupRW G, const float4* __restrict__ newp, const uint32_t* __restrict__ alive,
                                  const uint32_t* __restrict__ apos, uint32_t k, uint32_t id_base, const uint32_t* __restrict__ rank) {
-    inc_place_item(M, G, newp, alive, apos, k, id_base, rank, inc_thread_id());
+    LV_INC_ITEMS(27 * SORTED_LEVELS, 0u, gridDim.x, inc_place_item(M, G, newp, alive, apos, k, id_base, rank, t));
 }
 
 // pass 7: the owner of every touched target takes the batch tail in
@@ -906,7 +918,7 @@ __device__ __forceinline__ void inc_commit_item(const MapRW& M, const GroupRW& G
     L.aux[slot].pending = 0u;
 }
 __global__ void inc_commit_kernel(MapRW M, GroupRW G, const uint32_t* __restrict__ alive, uint32_t k) {
-    inc_commit_item(M, G, alive, k, inc_thread_id());
+    LV_INC_ITEMS(REPL_LEVELS * GROUP_TARGETS, 0u, gridDim.x, inc_commit_item(M, G, alive, k, t));
 }
 
 // ---- runs compacted in place (see inc_reserve_item) -------------------------------------------------------------------------------
