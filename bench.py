@@ -265,8 +265,9 @@ def cpu_baseline(sc, passes_expected: int, budget_s: float = 20.0) -> dict:
         "unit": "KF-update iters/s",
         "cores": best_t,
         "kind": "port",
-        # the reference's OWN Localizator::correct (src/Modules/{Localizator,Mapper}.cpp, src/Objects/*.cpp, src/Utils/Utils.cpp
-        # compiled in place: oracle/_ref) on one core, where the prebuilt library travelled with the snapshot; `value` stays the
+        # the reference's Localizator::correct call chain (src/Modules/{Localizator,Mapper}.cpp, src/Objects/*.cpp, src/Utils/Utils.cpp
+        # compiled in place: oracle/_ref) over STAND-INS for its un-vendored dependencies (kNN = the oracle's kd-tree, not ikd-Tree;
+        # filter algebra = the oracle's, not IKFoM's: hence kind "reference_callers+standins") on one core, where the prebuilt library travelled with the snapshot; `value` stays the
         # faster multi-threaded port (the conservative comparison)
         "reference_build": ref_build,
         "sample": f"{reps} full updates ({passes} passes) of the same 64k-vs-1M workload on the oracle (pointer kd-tree, "
@@ -296,7 +297,7 @@ def reference_build_baseline(sc, max_updates: int = 2):
             reps += 1
         dt = time.perf_counter() - t0
         lvref.reset()
-        return {"value": passes / dt, "unit": "KF-update iters/s", "cores": 1, "kind": "reference",
+        return {"value": passes / dt, "unit": "KF-update iters/s", "cores": 1, "kind": "reference_callers+standins",
                 "sample": f"{reps} updates ({passes} passes) of the same workload through Localizator::correct of the reference's compiled "
                           "sources (first one includes the stand-in tree's build); stand-ins: kNN, esekf algebra"}
     except Exception as e:  # noqa: BLE001

@@ -156,8 +156,11 @@ int    lv_map_relinearise(lv_ctx* ctx);
  * the id space is dead and the map holds >= 200 000 points (lv_set_option "async_relinearise" 0: always the stop-the-world
  * form; "async_relinearise_min": the size threshold).  Returns at once. */
 int    lv_map_relinearise_async(lv_ctx* ctx);
-/* out = {state (0 idle, 1 rebuilding, 2 rebuilt and waiting to be adopted, 3 failed), rebuilds started, rebuilds adopted,
- * journaled operations not yet replayed}; wait != 0: block until a rebuild in flight has been adopted. */
+/* out = {state, rebuilds started, rebuilds adopted, journaled operations not yet replayed}; wait != 0: block until a rebuild in
+ * flight has been adopted.  States: 0 idle; 4 the worker is allocating the second store; 5 allocated, waiting for the snapshot the
+ * next map call enqueues; 1 rebuilding / replaying the journal; 2 rebuilt and waiting to be adopted; 3 failed (the next map call
+ * reports it on stderr, keeps the map as it is and switches this context to stop-the-world re-linearisations).  "In flight" is any
+ * state other than 0 and 3. */
 int    lv_map_rebuild_status(lv_ctx* ctx, int wait, uint64_t out[4]);
 /* KD_TREE<Point>::size()                          — src/Modules/Mapper.cpp:33,79 */
 size_t lv_map_size(lv_ctx* ctx);
@@ -300,7 +303,10 @@ int lv_filter_get(lv_ctx* ctx, lv_state* x, double* P);
 int lv_predict(lv_ctx* ctx, double dt, const double* Q, const double acc[3], const double gyro[3]);
 int lv_correct(lv_ctx* ctx, int* passes);
 /* Eigenvalues of the pose block (pos, rot) of H^T H of every pass of the last update run with degeneracy_mode >= 1:
- * eig receives n_passes x 6 doubles (capacity_passes rows available; Jacobi order, unsorted). */
+ * eig receives n_passes x 6 doubles (capacity_passes rows available; Jacobi order, unsorted).  A REPORT, not a filter input:
+ * updates that ran one launch per pass derive the values on the host from the logged sums, the three-kernel path derives them on
+ * the device (FMA-contracted), both by the same fixed 8 cyclic Jacobi sweeps; the two agree to rounding, not bit for bit —
+ * stated and tested tolerance 1e-9 relative to the largest eigenvalue (tests/test_gpu_configs.py, tests/test_gpu_parity.py). */
 int lv_get_degeneracy_values(lv_ctx* ctx, double* eig, int capacity_passes, int* n_passes);
 
 /* Split form of lv_update for multi-GPU runs (scan points sharded across ranks, map replicated):
@@ -414,7 +420,9 @@ int lv_set_fused_pass(lv_ctx* ctx, int enabled);
  * insert batches of up to 2048 points take their one-launch forms), "multi_overlap" (0: multi-round scans fit every round
  * between two barriers), "async_relinearise" / "async_relinearise_min" (the background map rebuild, lv_map_relinearise_async),
  * "async_relinearise_slice_wgs" (the worker's large grids go out in slices of that many workgroups; default 256, 0: whole grids;
- * round 5's opt-in "async_relinearise_paced_*" form was removed in round 6: LV_EINVAL like any unknown name).
+ * round 5's opt-in "async_relinearise_paced_*" form was removed in round 6: LV_EINVAL like any unknown name),
+ * "async_relinearise_journal_max" (default 4096: the number of map operations that may wait for the worker; a rebuild that falls
+ * further behind is cancelled, the map stays as it is, and this context re-linearises stop-the-world from then on).
  * None of those changes a result beyond the summation order of the workgroup partials.  ONE option does: "fast_fit" (default
  * 0) switches pass_kernel's plane fit to hardware reciprocal / square root + one Newton step — within a few f32 ulps of the
  * exact path, NOT bit-exact against the reference (tests/test_gpu_fast_fit.py states the flips and the state difference);

@@ -77,7 +77,10 @@ struct lv_ctx {
     bool relin_snap_side = false;         // the snapshot was enqueued on the side stream and the context's stream has not been ordered behind it yet (relin_order)
     bool relin_async = true;              // lv_set_option "async_relinearise" / LV_ASYNC_RELINEARISE=0: always stop-the-world
     size_t relin_async_min = 200000;      // smaller maps rebuild in ~2 ms: not worth a thread
-    uint64_t relin_started = 0, relin_swapped = 0, relin_replayed = 0;
+    uint64_t relin_started = 0, relin_swapped = 0;
+    std::atomic<uint64_t> relin_replayed{0};   // (written by the worker, read by lv_map_rebuild_status)
+    size_t relin_journal_max = 4096;       // journal entries beyond which a rebuild that cannot keep up is given up: the
+                                           // copy is cancelled and the active map takes the stop-the-world path when it needs one
     uint32_t relin_slice_wgs = 256;       // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids).  (Round 5's opt-in PACED form — the
                                           // grids as at most 32 looping 1024-thread workgroups — is gone: p99 0.5 instead of 0.6 ms, but two 4.6 ms cycles in 5 of
                                           // 17 replays that plain slices never showed, cause not found: profiles/experiments_r05/async_rebuild.txt §10-11)
@@ -1087,15 +1090,28 @@ int relin_journal_add(lv_ctx* c, uint32_t n, int downsample, float box, bool bui
         } else {
             LV_HIP(hipMalloc(&e.d_pts, (size_t)n * sizeof(float4)));
         }
-        LV_HIP(hipMemcpyAsync(e.d_pts, c->map.d_new, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-        LV_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
-        LV_HIP(hipEventRecord(e.ready, c->stream));
+        // (an error below must not leak the entry: ADVICE r05)
+        hipError_t je = hipMemcpyAsync(e.d_pts, c->map.d_new, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+        if (je == hipSuccess) je = hipEventCreateWithFlags(&e.ready, hipEventDisableTiming);
+        if (je == hipSuccess) je = hipEventRecord(e.ready, c->stream);
+        if (je != hipSuccess) {
+            relin_free_entry(e);
+            set_error("map rebuild journal: %s", hipGetErrorString(je));
+            return LV_EHIP;
+        }
         {
             std::lock_guard<std::mutex> g(c->relin_mu);
             st = c->relin_state;
-            if (st == 1) { c->relin_journal.push_back(e); return LV_OK; }
+            if (st == 1 && c->relin_journal.size() < c->relin_journal_max) { c->relin_journal.push_back(e); return LV_OK; }
         }
         relin_free_entry(e);
+        if (st == 1) {   // the worker does not drain the journal as fast as the caller fills it: give the copy up (bounded memory, bounded deferral)
+            fprintf(stderr, "[limovelo_hip] background map rebuild cannot keep up (%zu journaled operations): cancelled; re-linearisations of this context stop the world from here on\n",
+                    c->relin_journal_max);
+            relin_cancel(c);
+            c->relin_async = false;
+            return LV_OK;
+        }
     }
     if (st == 2) {
         // The worker caught up and reported "ready" after this call's relin_poll: the copy no longer takes journal entries, so
@@ -1121,8 +1137,9 @@ int relin_journal_evict(lv_ctx* c, int kind, const float* lo, const float* hi, i
     {
         std::lock_guard<std::mutex> g(c->relin_mu);
         st = c->relin_state;
-        if (st == 1) { c->relin_journal.push_back(e); return LV_OK; }
+        if (st == 1 && c->relin_journal.size() < c->relin_journal_max) { c->relin_journal.push_back(e); return LV_OK; }
     }
+    if (st == 1) { relin_cancel(c); c->relin_async = false; return LV_OK; }   // (journal full: see relin_journal_add)
     if (st == 2) return relin_poll(c);   // (ready since this call's poll: adopt the copy first, the caller's eviction then acts on it)
     return LV_OK;
 }
@@ -1231,8 +1248,8 @@ int lv_map_evict_box(lv_ctx* c, const float lo[3], const float hi[3], int keep_i
     uint32_t ne = 0;
     LV_SETTLE_MAP(c);
     LV_RELIN_POLL(c);
-    relin_journal_evict(c, 2, lo, hi, keep_inside, 0);
-    int rc = relin_order(c, c->stream);
+    int rc = relin_journal_evict(c, 2, lo, hi, keep_inside, 0);
+    if (!rc) rc = relin_order(c, c->stream);
     if (!rc) rc = c->map.evict_box(c->stream, lo, hi, keep_inside, &ne);
     if (n_evicted) *n_evicted = ne;
     return rc;
@@ -1243,8 +1260,8 @@ int lv_map_evict_oldest(lv_ctx* c, size_t n_oldest, size_t* n_evicted) {
     uint32_t ne = 0;
     LV_SETTLE_MAP(c);
     LV_RELIN_POLL(c);
-    relin_journal_evict(c, 3, nullptr, nullptr, 0, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest));
-    int rc = relin_order(c, c->stream);
+    int rc = relin_journal_evict(c, 3, nullptr, nullptr, 0, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest));
+    if (!rc) rc = relin_order(c, c->stream);
     if (!rc) rc = c->map.evict_oldest(c->stream, (uint32_t)(n_oldest > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : n_oldest), &ne);
     if (n_evicted) *n_evicted = ne;
     return rc;
@@ -1662,6 +1679,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
     else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
     else if (!std::strcmp(name, "async_relinearise_slice_wgs")) c->relin_slice_wgs = value > 0 ? (uint32_t)value : 0u;      // 0: whole grids
+    else if (!std::strcmp(name, "async_relinearise_journal_max")) c->relin_journal_max = value > 0 ? (size_t)value : 1;
     else if (!std::strcmp(name, "async_relinearise_test_delay_ms")) c->relin_test_delay_ms = value;
     else if (!std::strcmp(name, "async_relinearise_test_race")) c->relin_test_race = on;
     else if (!std::strcmp(name, "multi_overlap")) c->multi_overlap = on;

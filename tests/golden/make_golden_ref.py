@@ -2,6 +2,16 @@
 oracle/ref_build) run in this container on BASELINE configs[0] (2k-pt scan vs 50k-pt map, identity extrinsics and xaloc's with
 estimate_extrinsics).  The fixture travels where the reference cannot: tests/test_oracle.py / tests/test_gpu_golden.py compare the
 oracle and the HIP path with these arrays even on a box where neither /root/reference nor the prebuilt library exists.
+What "the reference's own code" covers — the library compiles the reference's callers, its un-vendored dependencies
+are stand-ins (oracle/ref_build: ikd-Tree's and IKFoM's interfaces over the oracle's kd-tree / update algebra, an Eigen stub for
+the QR), so the arrays fall in two classes:
+  PINNED to in-tree reference code: *_pose (State -> RotTransl), *_p_world_all (operator* on Points), *_H / *_h (the rows
+      Localizator::calculate_H writes), *_dist and the gates Mapper::match / Plane::is_plane / on_plane apply, *_update_passes and
+      *_update_n_valid (the loop and convergence rule as driven by the reference's call chain).
+  THROUGH STAND-INS (the oracle checking itself behind the reference's interfaces): *_src (which map points the 5-NN returns),
+      *_abcd (the QR solve), *_update_x / *_update_P / *_update_states (the IKFoM update algebra).  Those are pinned elsewhere:
+      tests/test_oracle_pins.py (published algorithms, brute force, numpy QR / solves).
+The npz carries the same lists under "pinned_fields" / "standin_fields".
 Run from the repo root:  python tests/golden/make_golden_ref.py"""
 import os
 import sys
@@ -38,6 +48,8 @@ for tag, extrinsics, est in (("id", "identity", 0), ("ext", "xaloc", 1)):
     out[tag + "_map_checksum"] = np.float64(sc["map_xyz"].astype(np.float64).sum())
 lr.set_config()
 lr.reset()
+out["pinned_fields"] = np.array(["pose", "p_world_all", "H", "h", "dist", "update_passes", "update_n_valid"])
+out["standin_fields"] = np.array(["src", "abcd", "update_x", "update_P", "update_states"])
 path = os.path.join(ROOT, "tests", "golden", "ref_cfg0.npz")
 np.savez_compressed(path, **out)
 print("saved", path, os.path.getsize(path), "bytes;", {k: v.shape for k, v in list(out.items())[:8]})

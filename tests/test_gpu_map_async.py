@@ -173,3 +173,29 @@ def test_insert_that_meets_a_copy_that_has_just_caught_up(capi, oracle, lv):
         ref = ref[~hole]
         s = ctx.map_rebuild_status(wait=True)
         assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+
+
+def test_rebuild_that_cannot_keep_up_is_given_up_and_the_map_stays_exact(capi, oracle, lv):
+    """The journal is bounded ("async_relinearise_journal_max"): a worker that falls further behind than that is cancelled — the
+    active map never depended on it — and the context's next re-linearisation is the stop-the-world one."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(300_000, 1500)
+    rng = np.random.default_rng(5)
+    ref = sc["map_xyz"]
+    with capi.Context() as ctx:
+        ctx.set_option("async_relinearise_journal_max", 3)
+        ctx.set_option("async_relinearise_test_delay_ms", 1500)
+        ctx.map_build(ref)
+        ctx.map_relinearise_async()
+        for step in range(8):
+            batch = (ref[rng.integers(0, len(ref), 800)] + rng.normal(0, 0.03, (800, 3))).astype(np.float32)
+            ctx.map_add(batch, downsample=True)
+            ref = oracle.map_add(ref, batch, downsample=True)
+            assert ctx.map_size() == len(ref), step
+        s = ctx.map_rebuild_status(wait=True)
+        assert s["state"] == 0 and s["adopted"] == 0 and s["journal"] == 0, s
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        ctx.map_relinearise()                                   # the stop-the-world form still works
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:800])
