@@ -156,6 +156,13 @@ int    lv_map_relinearise(lv_ctx* ctx);
  * the id space is dead and the map holds >= 200 000 points (lv_set_option "async_relinearise" 0: always the stop-the-world
  * form; "async_relinearise_min": the size threshold).  Returns at once. */
 int    lv_map_relinearise_async(lv_ctx* ctx);
+/* Set-up time (round 6): allocate — and touch — everything a background rebuild of the map as it stands needs (the second store's
+ * id buffers, pools and tables at the sizes a rebuild takes, the journal arena), by one synchronous rebuild of a snapshot that is
+ * then discarded.  Without it the FIRST background rebuild of a context spends its opening ~80 cycles of a 100 Hz stream in
+ * hipMalloc on the worker thread (a 10 M-point map: ~20 GB); later ones find the previous active store waiting either way.  The
+ * price is the second store's memory from the start instead of from the first rebuild.  Blocks; LV_ESTATE while a rebuild is in
+ * flight.  (The reference's counterpart: ikd-Tree's rebuild thread allocates its Rebuild_PCL_Storage on demand.) */
+int    lv_map_reserve_rebuild(lv_ctx* ctx);
 /* out = {state, rebuilds started, rebuilds adopted, journaled operations not yet replayed}; wait != 0: block until a rebuild in
  * flight has been adopted.  States: 0 idle; 4 the worker is allocating the second store; 5 allocated, waiting for the snapshot the
  * next map call enqueues; 1 rebuilding / replaying the journal; 2 rebuilt and waiting to be adopted; 3 failed (the next map call

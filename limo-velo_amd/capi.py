@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "lv_default_params", "lv_last_error", "lv_version", "lv_create", "lv_destroy", "lv_set_stream", "lv_get_stream",
     "lv_synchronize", "lv_map_build", "lv_map_add", "lv_map_add_scan", "lv_map_evict_box", "lv_map_evict_oldest", "lv_map_relinearise", "lv_map_get_stats",
     "lv_map_size", "lv_map_fetch", "lv_scan_set", "lv_scan_deskew", "lv_scan_downsample", "lv_scan_size", "lv_scan_fetch", "lv_iterate", "lv_pseudo_measurement",
-    "lv_map_relinearise_async", "lv_map_rebuild_status", "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
+    "lv_map_relinearise_async", "lv_map_reserve_rebuild", "lv_map_rebuild_status", "lv_update", "lv_filter_set", "lv_filter_get", "lv_predict", "lv_correct", "lv_get_degeneracy_values", "lv_update_begin", "lv_pass_reduce", "lv_sums_device_ptr", "lv_set_sums_buffer", "lv_pass_solve", "lv_update_end",
     "lv_set_capture", "lv_fetch_knn", "lv_fetch_matches", "lv_fetch_neighbors", "lv_set_record_dump", "lv_last_update_fused", "lv_last_passes", "lv_set_fused_pass", "lv_set_option", "lv_get_pass_clocks", "lv_pass_geometry", "lv_fetch_rows", "lv_calculate_H", "lv_get_timing", "lv_set_profiling", "lv_get_phase_clocks", "lv_get_solve_clocks", "lv_get_level_histogram",
     "lv_comm_unique_id", "lv_comm_init", "lv_comm_destroy", "lv_comm_world", "lv_comm_set_shard_max", "lv_set_comm_fused", "lv_comm_set_host_gather", "lv_comm_peer_export", "lv_comm_peer_init",
     "lv_cloud_format_preset", "lv_cloud_ingest", "lv_cloud_size", "lv_cloud_fetch", "lv_cloud_clear", "lv_cloud_reserve", "lv_reserve_stream", "lv_scan_deskew_window",
@@ -253,6 +253,10 @@ class Context:
 
     def map_relinearise_async(self):
         self._check(self.lib.lv_map_relinearise_async(self.h))
+
+    def map_reserve_rebuild(self):
+        """lv_map_reserve_rebuild: the second store of the background rebuild allocated (and touched) now, at set-up time."""
+        self._check(self.lib.lv_map_reserve_rebuild(self.h))
 
     def map_rebuild_status(self, wait=False) -> dict:
         out = (C.c_uint64 * 4)()

@@ -1283,6 +1283,40 @@ int lv_map_relinearise_async(lv_ctx* c) {
     return relin_start(c);
 }
 
+// Every allocation a background rebuild needs, made NOW (set-up time) instead of by the first rebuild's worker: the second store is
+// allocated for the map as it stands, filled from a snapshot and rebuilt once — synchronously, in whole grids — so that its id
+// buffers, pools and tables exist at the sizes a rebuild of this map takes, have been touched, and the journal arena is there.
+// The first background rebuild of the context then behaves like every later one (which find the previous active store waiting).
+int lv_map_reserve_rebuild(lv_ctx* c) {
+    LV_CHECK_CTX(c);
+    LV_SETTLE_MAP(c);
+    LV_RELIN_POLL(c);
+    if (c->relin_state != 0) { set_error("lv_map_reserve_rebuild: a background rebuild is in flight"); return LV_ESTATE; }
+    if (!c->map.built || c->map.m == 0) return LV_OK;
+    { int rs = relin_streams(c); if (rs) return rs; }
+    MapStore& S = c->relin_shadow;
+    S.n_ids = 0;
+    S.m = 0;
+    S.built = false;
+    S.slice_wgs = 0;
+    int rc = S.reserve((size_t)c->map.m + (size_t)c->map.m / 8 + 262144);
+    if (rc) return rc;
+    if (!c->relin_arena && hipMalloc(&c->relin_arena, c->relin_arena_bytes) != hipSuccess) { c->relin_arena = nullptr; (void)hipGetLastError(); }
+    LV_HIP(hipStreamSynchronize(c->stream));
+    if (c->side_stream) LV_HIP(hipStreamSynchronize(c->side_stream));
+    rc = c->map.snapshot_into(S, c->stream);
+    if (!rc) rc = S.rebuild(c->stream);
+    if (!rc && c->map.batch_cap) rc = S.reserve_batch(c->map.batch_cap);
+    if (!rc) rc = S.ensure_boxes(c->stream, 0.2f);   // (the 0.2 m box table a down-sampling replay builds: Mapper.cpp:65)
+    LV_HIP(hipStreamSynchronize(c->stream));
+    S.have_boxes = false;
+    // (the copy's contents are not kept: the next rebuild takes its own snapshot)
+    S.n_ids = 0;
+    S.m = 0;
+    S.built = false;
+    return rc;
+}
+
 int lv_map_rebuild_status(lv_ctx* c, int wait, uint64_t out[4]) {
     LV_CHECK_CTX(c);
     if (wait && c->relin_state != 0) {

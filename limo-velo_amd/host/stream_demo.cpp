@@ -76,6 +76,9 @@ int main(int argc, char** argv) {
                 // a window of delta seconds holds delta / FULL_ROTATION_TIME of a sweep (twice that for slack); scans after the voxel grid are smaller
                 const size_t win = (size_t)(2.0 * (double)max_n * std::max(delta, 0.01) / std::max(Config.full_rotation_time, 0.01)) + 4096;
                 lv_reserve_stream(HipRuntime::ctx(), on_device ? win : 0, 8192);
+                // ... and the second store of the background map rebuild (LV_DEMO_NO_REBUILD_RESERVE: left to the first rebuild's worker)
+                if (!getenv("LV_DEMO_NO_REBUILD_RESERVE") && lv_map_reserve_rebuild(HipRuntime::ctx()))
+                    throw std::runtime_error(std::string("lv_map_reserve_rebuild: ") + lv_last_error());
             }
         }
         // LV_DEMO_FORCE_REBUILD=K[:sync] — re-linearise the map after the K-th update (in the background; ":sync": stop-the-world)

@@ -199,3 +199,47 @@ def test_rebuild_that_cannot_keep_up_is_given_up_and_the_map_stays_exact(capi, o
         ctx.map_relinearise()                                   # the stop-the-world form still works
         assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
         _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:800])
+
+
+def test_reserved_second_store_serves_the_first_background_rebuild(capi, oracle, lv):
+    """lv_map_reserve_rebuild (round 6): the second store is allocated at set-up time, so the first background rebuild of a context
+    allocates nothing (device memory taken does not grow between the reservation and the adoption) and the map it hands over is
+    the stop-the-world path's, bit for bit."""
+    import torch
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(400_000, 3000)
+    rng = np.random.default_rng(5)
+    ref = sc["map_xyz"]
+    L = float(sc["L"])
+    with capi.Context() as ctx:
+        ctx.map_build(ref)
+        ctx.reserve_stream(0, 4096)
+        warm = (ref[:1500] + rng.normal(0, 0.03, (1500, 3))).astype(np.float32)   # (the active map's 0.2 m box table is built by its first down-sampling insert)
+        ctx.map_add(warm, downsample=True)
+        ref = oracle.map_add(ref, warm, downsample=True)
+        ctx.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        ctx.map_reserve_rebuild()
+        free_reserved = torch.cuda.mem_get_info()[0]
+        assert free_before - free_reserved > 100e6, "the second store takes memory NOW"
+        assert ctx.map_rebuild_status()["state"] == 0
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref)) and ctx.map_size() == len(ref)   # the active map is untouched
+        lo, hi = np.array([-0.5 * L, -2 * L, -5.0], np.float32), np.array([2 * L, 2 * L, 50.0], np.float32)
+        inside = np.all((ref >= lo) & (ref <= hi), axis=1)
+        assert ctx.map_evict_box(lo, hi, keep_inside=True) == int((~inside).sum())
+        ref = ref[inside]
+        st0 = ctx.map_rebuild_status()
+        ctx.map_relinearise_async()
+        for step in range(12):
+            c = np.array([0.1 * L + 0.02 * L * step, 0.1 * L, 0.0], np.float32)
+            near = ref[np.linalg.norm(ref - c, axis=1) < 15.0]
+            batch = (near[rng.integers(0, len(near), 1500)] + rng.normal(0, 0.03, (1500, 3))).astype(np.float32)
+            ctx.map_add(batch, downsample=True)
+            ref = oracle.map_add(ref, batch, downsample=True)
+        s = ctx.map_rebuild_status(wait=True)
+        assert s["state"] == 0 and s["adopted"] == st0["adopted"] + 1
+        free_after = torch.cuda.mem_get_info()[0]
+        assert free_reserved - free_after < 32e6, f"the first rebuild allocated {(free_reserved - free_after) / 1e6:.0f} MB more"
+        assert np.array_equal(_bits(ctx.map_fetch()), _bits(ref))
+        _knn_ok(ctx, oracle, ref, sc["x_init"], sc["scan_xyz"][:1500])
