@@ -1687,17 +1687,22 @@ __global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(Pass
 #define LV_COARSE_PROB 0.0005
 #endif
         if (__builtin_expect_with_probability(nq > 0, 1, LV_COARSE_PROB)) {   // (uniform) the open points, one per wavefront at a time: the level-2 / level-3 lists / every id
+            // (the lane index through an opaque move: everything this rare path derives from it — the lists' voxel offsets by lane, the
+            // record addresses — is loop-invariant, and hoisted out of the round loop it cost the kernel nine spilled registers,
+            // stored by every thread of every launch: 9.4 MB of scratch writes per launch, converged launches 24.1 -> 25.0 us)
+            int clane = lane;
+            asm volatile("" : "+v"(clane));
             for (int i = wave; i < nq; i += PK_THREADS / 64) {
                 const float4 e = s_queue[i];
                 const int p = __float_as_int(e.w);
                 const uint32_t q = s_queueq[i];
                 kkey kw[KNN];
-                knn_coarse<false>(a.map, kf, e.x, e.y, e.z, lane, kw, a.mp.max_dist_plane_sq, s_pref[wave], s_start[wave]);
+                knn_coarse<false>(a.map, kf, e.x, e.y, e.z, clane, kw, a.mp.max_dist_plane_sq, s_pref[wave], s_start[wave]);
                 int found = 0;
 #pragma unroll
                 for (int j = 0; j < KNN; ++j) found += key_real(kw[j]) ? 1 : 0;
-                if (lane < QREC_SLOTS && lane != 5) {   // (slot 5, the world point, is in the record already)
-                    const int slot = lane;
+                if (clane < QREC_SLOTS && clane != 5) {   // (slot 5, the world point, is in the record already)
+                    const int slot = clane;
                     float4 v;
                     if (slot < KNN) {
                         kkey kk = kw[0];
