@@ -497,7 +497,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // distance tie among their six nearest neighbours.
 template <int LANES, int K>
 __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const QGeom& geo, float qx, float qy, float qz, int tl,
-                                               kkey (&k)[K], uint32_t& bstart, long long* clk, Xyz* stage = nullptr) {
+                                               kkey (&k)[K], uint32_t& bstart, long long* clk, Xyz* stage = nullptr, uint32_t* bound = nullptr) {
+    // bound (optional): from a level that is NOT accepted although it saw K living candidates, the bits of the K-th smallest distance
+    // among them — K living points lie within it, so no point farther than that is among the query's K nearest (left alone otherwise)
     // stage (LDS, LANES * 8 entries of this team, or nullptr): the first chunk's candidates are kept there by
     // position, so that the caller can pick the winners up without another trip to memory
     const GridLevel g = bl == 0 ? map.bt[0] : map.gt;
@@ -593,6 +595,7 @@ __device__ __forceinline__ bool bucket_attempt(const MapView& map, int bl, const
         for (int j = 0; j + 1 < K; ++j) ok = ok && key_hi(k[j]) != key_hi(k[j + 1]);
     }
     if (ok) return true;
+    if (bound && key_real(k[K - 1])) *bound = min(*bound, key_hi(k[K - 1]));
 #pragma unroll
     for (int j = 0; j < K; ++j) k[j] = none_key();
     return false;
@@ -619,7 +622,10 @@ __device__ __forceinline__ float block_radius(const MapView& map, const QGeom& g
 }
 template <int K>
 __device__ __forceinline__ bool cells_attempt(const MapView& map, int bx, int by, int bz, int SIDE, float r, float qx, float qy, float qz, int lane,
-                                              kkey (&k)[K], uint32_t* s_pref, uint32_t* s_start) {
+                                              kkey (&k)[K], uint32_t* s_pref, uint32_t* s_start, const QGeom* geo = nullptr, uint32_t bound = 0x7FFFFFFFu) {
+    // geo + bound (optional; round 6): what the bucket levels proved on their way here — K living points lie within the distance
+    // whose bits are `bound` — so a list whose VOXEL is farther from the query than that holds none of the K nearest and is neither
+    // probed nor streamed: of the 27 voxels of a block a sphere of 1.2 .. 1.5 m touches about eight
     const int NC = SIDE * SIDE * SIDE;
     constexpr int U = 8;
     const GridLevel g = map.ct;
@@ -633,7 +639,19 @@ __device__ __forceinline__ bool cells_attempt(const MapView& map, int bx, int by
             const int dz = SIDE == 3 ? ci / 9 : (SIDE == 4 ? ci >> 4 : ci / 36), dy = SIDE == 3 ? (ci / 3) % 3 : (SIDE == 4 ? (ci >> 2) & 3 : (ci / 6) % 6),
                       dx = SIDE == 3 ? ci % 3 : (SIDE == 4 ? ci & 3 : ci % 6);
             const uint32_t nx = (uint32_t)(bx + dx), ny = (uint32_t)(by + dy), nz = (uint32_t)(bz + dz);
-            if (nx < (1u << 19) && ny < (1u << 19) && nz < (1u << 19)) {
+            bool wanted = nx < (1u << 19) && ny < (1u << 19) && nz < (1u << 19);
+            if (wanted && geo && bound < 0x7F800000u) {
+                // distance from the query to the voxel's box in level-0 voxel units, made smaller by the rounding of the voxel
+                // coordinates (as search_radius) and by 2e-3 relative before it is compared with the proven distance
+                const float err = 8.f * 1.1920928955078125e-07f * ((float)geo->amax + 8.f);
+                const float lx = (float)((int)(nx << 2) - CELL_OFFSET), ly = (float)((int)(ny << 2) - CELL_OFFSET), lz = (float)((int)(nz << 2) - CELL_OFFSET);
+                const float ex = fmaxf(fmaxf(lx - geo->tx, geo->tx - (lx + 4.f)) - err, 0.f);
+                const float ey = fmaxf(fmaxf(ly - geo->ty, geo->ty - (ly + 4.f)) - err, 0.f);
+                const float ez = fmaxf(fmaxf(lz - geo->tz, geo->tz - (lz + 4.f)) - err, 0.f);
+                const float d2 = (ex * ex + ey * ey + ez * ez) * (map.cell * map.cell) * 0.998f;
+                wanted = !(d2 > __uint_as_float(bound));
+            }
+            if (wanted) {
                 const uint64_t key = pack_cell(nx, ny, nz);
                 uint32_t slot = hash_cell(key, g.shift) & g.mask;
                 for (;;) {
@@ -737,7 +755,7 @@ __device__ __forceinline__ void brute_attempt(const MapView& map, float qx, floa
 #endif
 template <bool DBG, int K>
 __device__ LV_COARSE_INLINE int knn_coarse(const MapView& map, KfDev* __restrict__ kf, float wx, float wy, float wz, int lane, kkey (&kw)[K],
-                                          double max_dist_sq, uint32_t* s_pref, uint32_t* s_start) {
+                                          double max_dist_sq, uint32_t* s_pref, uint32_t* s_start, uint32_t bound = 0x7FFFFFFFu) {
 #ifdef LV_DIAG_NO_COARSE
     return 5;
 #endif
@@ -777,7 +795,7 @@ __device__ LV_COARSE_INLINE int knn_coarse(const MapView& map, KfDev* __restrict
                 r = block_radius(map, wgeo, 2, bx, by, bz, 4);
                 if (lane == 0) atomicAdd(&kf->fallback_queries, 1);
             }
-            done = cells_attempt(map, bx, by, bz, side, r, wx, wy, wz, lane, kw, s_pref, s_start);
+            done = cells_attempt(map, bx, by, bz, side, r, wx, wy, wz, lane, kw, s_pref, s_start, &wgeo, bound);
             if (done) wbin = side == 3 ? 2 : 3;
             stop = r > 0.f && (double)(r * r) >= max_dist_sq;
         }
@@ -806,7 +824,7 @@ template <int S, bool DBG, int K>
 __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict__ kf, float qx, float qy, float qz, int gl,
                                            kkey (&k)[K], uint32_t& bstart, int& src, long long* clk, bool hist,
                                            bool live, Xyz* stage0, double max_dist_sq, uint32_t* s_pref, uint32_t* s_start,
-                                           bool* undecided = nullptr) {
+                                           bool* undecided = nullptr, uint32_t* bound_out = nullptr) {
     // undecided != nullptr: stop after the bucket levels 0 / 1 and report whether the point is still open (the caller
     // then runs knn_coarse on it)
     if (undecided) *undecided = false;
@@ -818,6 +836,7 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
     // a match at Plane.cpp:42 whatever its tree search returned
     bool decided = !live || !finite;
     int hist_bin = -1;   // what decided (instrumentation): 0, 1 bucket level; 2, 3 voxel lists; 4 every id; 5 bounded stop
+    uint32_t bound = 0x7FFFFFFFu;   // what the bucket levels that were not accepted proved (bucket_attempt): prunes the list levels
     if (live && in_range) {
 #pragma unroll
 #ifndef LV_DIAG_LEVELS
@@ -826,13 +845,14 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
         for (int bl = 0; bl < LV_DIAG_LEVELS; ++bl) {   // level 0: the query's bucket; level 1: the region of its tile group (bucket_attempt)
             if (!decided) {
                 decided = bucket_attempt<S>(map, bl, geo, qx, qy, qz, gl, k, bstart, (DBG && bl == 0) ? clk : nullptr,
-                                            bl == 0 ? stage0 : nullptr);
+                                            bl == 0 ? stage0 : nullptr, bl == 1 ? &bound : nullptr);   // (level 1's bound: its region holds the level-0 bucket's neighbourhood and more)
                 if (decided) { src = bl; hist_bin = bl; }
             }
         }
     }
     if (undecided) {   // the caller shares the coarse levels out among the wavefronts of its workgroup (pass_kernel)
         *undecided = !decided;
+        if (bound_out) *bound_out = bound;
         return;
     }
     const int lane = (int)(threadIdx.x & 63u);
@@ -841,8 +861,9 @@ __device__ __forceinline__ void knn_search(const MapView& map, KfDev* __restrict
         const int L = __ffsll((long long)pending) - 1;   // leader lane of the scan point served now
         pending &= pending - 1;
         const float wx = __shfl(qx, L), wy = __shfl(qy, L), wz = __shfl(qz, L);
+        const uint32_t wbound = (uint32_t)__shfl((int)bound, L);
         kkey kw[K];
-        const int wbin = knn_coarse<DBG>(map, kf, wx, wy, wz, lane, kw, max_dist_sq, s_pref, s_start);
+        const int wbin = knn_coarse<DBG>(map, kf, wx, wy, wz, lane, kw, max_dist_sq, s_pref, s_start, wbound);
         if (lane / S == L / S) {   // (keys carry point ids: src stays -1)
 #pragma unroll
             for (int j = 0; j < K; ++j) k[j] = kw[j];
@@ -1328,7 +1349,8 @@ constexpr size_t PK_OFF_KEEP = PK_OFF_OUT + sizeof(double) * PK_FITW * 2 * SUMS_
 constexpr size_t PK_OFF_QN = PK_OFF_KEEP + ((sizeof(KeepLds) + 15) / 16) * 16;
 constexpr size_t PK_OFF_QUEUE = PK_OFF_QN + 32;                              // float4 [256] + uint32 [256]: points left to the coarse levels
 constexpr size_t PK_OFF_QUEUEQ = PK_OFF_QUEUE + sizeof(float4) * PK_RPTS_MAX;
-constexpr size_t PK_LDS_BYTES = PK_OFF_QUEUEQ + sizeof(uint32_t) * PK_RPTS_MAX;
+constexpr size_t PK_OFF_QUEUEB = PK_OFF_QUEUEQ + sizeof(uint32_t) * PK_RPTS_MAX;   // uint32 [256]: what the bucket levels proved about each queued point
+constexpr size_t PK_LDS_BYTES = PK_OFF_QUEUEB + sizeof(uint32_t) * PK_RPTS_MAX;
 constexpr size_t PK_OFF_BOOK = 32 * 1024;   // the books' scratch inside region 0: above the solve scratch and above the staged rows
 static_assert(sizeof(SolveLds) <= PK_OFF_BOOK && PK_OFF_BOOK + sizeof(BookLds) <= PK_REGION0, "solve / books scratch must fit under the stage");
 static_assert(sizeof(double) * PK_FITW * 64 * 14 <= PK_OFF_BOOK, "staged rows must stay below the books' scratch");
@@ -1443,6 +1465,7 @@ __global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(Pass
     int* s_qn = reinterpret_cast<int*>(smem + PK_OFF_QN);   // entries in the queue of points left to the coarse levels
     float4* s_queue = reinterpret_cast<float4*>(smem + PK_OFF_QUEUE);
     uint32_t* s_queueq = reinterpret_cast<uint32_t*>(smem + PK_OFF_QUEUEQ);
+    uint32_t* s_queueb = reinterpret_cast<uint32_t*>(smem + PK_OFF_QUEUEB);
     // [0] / [3] queue entries and [1] / [4] search-task counter of the even / odd rounds, [2] the books' sub-barrier, [5] fit
     // wavefronts that have taken their records out of the buffer (multi-round scans) — the prologue's barriers publish them
     if (threadIdx.x < 8) s_qn[threadIdx.x] = 0;
@@ -1628,12 +1651,14 @@ __global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(Pass
             // far tiles while it is off) goes to the workgroup's queue: the coarse levels take a whole wavefront per point,
             // and sixteen wavefronts share them out after the barrier instead of one wavefront serving its own in turn
             bool open_pt = false;
+            uint32_t open_bound = 0x7FFFFFFFu;
             knn_search<S, false>(a.map, kf, qx, qy, qz, gl, k, bstart, src, nullptr, false, live, s_stage[gq], a.mp.max_dist_plane_sq,
-                                 s_pref[wave], s_start[wave], &open_pt);
+                                 s_pref[wave], s_start[wave], &open_pt, &open_bound);
             if (open_pt && gl == 0) {
                 const int qi = atomicAdd(s_qcnt, 1);
                 s_queue[qi] = make_float4(qx, qy, qz, __int_as_float(step * PK_GROUPS + gqv));
                 s_queueq[qi] = q;
+                s_queueb[qi] = open_bound;
             }
             int found = 0;
 #pragma unroll
@@ -1697,7 +1722,7 @@ __global__ __launch_bounds__(PK_THREADS, PK_THREADS / 256) void pass_kernel(Pass
                 const int p = __float_as_int(e.w);
                 const uint32_t q = s_queueq[i];
                 kkey kw[KNN];
-                knn_coarse<false>(a.map, kf, e.x, e.y, e.z, clane, kw, a.mp.max_dist_plane_sq, s_pref[wave], s_start[wave]);
+                knn_coarse<false>(a.map, kf, e.x, e.y, e.z, clane, kw, a.mp.max_dist_plane_sq, s_pref[wave], s_start[wave], s_queueb[i]);
                 int found = 0;
 #pragma unroll
                 for (int j = 0; j < KNN; ++j) found += key_real(kw[j]) ? 1 : 0;
