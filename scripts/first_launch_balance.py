@@ -1,6 +1,8 @@
+"""Round 6: the first launch of the headline update, per workgroup (LV_PASS_CLK=1): when its search reaches the barrier, when it ends —
+which workgroups decide the launch's span and how much of their time lies behind the barrier (list levels + fits)."""
 import os, sys
 os.environ.setdefault("LV_PASS_CLK", "1")
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lvamd; lvamd.load()
 from limo_velo_amd import capi, synth

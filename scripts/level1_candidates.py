@@ -1,9 +1,14 @@
+"""CPU count (numpy / scipy, no GPU) of the candidates a level-1 point of the headline's first pass meets: how many scan points fail
+level 0 at the perturbed pose, the entries of the eight level-2 voxel lists around each of them, and what is left of those after
+pruning with the true 5th-neighbour distance / with the bound a failed level-0 attempt proves (profiles/experiments_r06/octant_level1_ab.txt)."""
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import lvamd; 
 from importlib import import_module
 import importlib.util, os
-spec = importlib.util.spec_from_file_location("synth", "/root/repo/limo-velo_amd/synth.py"); synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
+spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "limo-velo_amd", "synth.py")); synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
 from scipy.spatial import cKDTree
 sc = synth.make_scene(1_048_576, 65_536)
 M = sc["map_xyz"].astype(np.float32); S = sc["scan_xyz"].astype(np.float32)
