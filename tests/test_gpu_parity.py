@@ -508,3 +508,42 @@ def test_degeneracy_hook(capi, oracle, lv):
     assert np.abs(tr2 - tro).max() < 1e-8 and np.abs(x2 - xo).max() < 1e-8
     assert np.abs(P2 - Po).max() < 1e-8 * max(1.0, np.abs(Po).max())
     assert np.abs(x2[:2] - sc["x_init"][:2]).max() < 2e-3 < np.abs(x0[:2] - sc["x_init"][:2]).max()
+
+
+@pytest.mark.parametrize("scale", [3.0, 8.0])
+def test_list_levels_pruned_by_the_bucket_levels_bound_stay_exact(capi, oracle, lv, scale):
+    """Round 6: a point the bucket levels leave open carries the 5th-smallest distance its level-1 stream saw into the queue, and
+    the list levels neither probe nor stream a voxel list whose box lies beyond it (lv_match.hip cells_attempt).  With the pose off
+    by `scale` times the benchmark's perturbation thousands of points take that route: the hand-over records of the timed (pruning)
+    launch must still be the oracle's exact neighbours, bit for bit, wherever the reference's gate can accept them."""
+    from limo_velo_amd import synth
+
+    sc = synth.make_scene(300_000, 20_000)
+    x0 = np.array(sc["x_true"], np.float64).copy()
+    x0[:3] += scale * (np.array(sc["x_init"][:3]) - np.array(sc["x_true"][:3]))
+    # rotation: scale the quaternion's vector part of the perturbation about the true attitude
+    qt, qi = np.array(sc["x_true"][3:7]), np.array(sc["x_init"][3:7])
+    dq = qi - qt
+    q = qt + scale * dq
+    x0[3:7] = q / np.linalg.norm(q)
+    tree = oracle.KdTree(sc["map_xyz"])
+    with capi.Context(capi.default_params(MAX_NUM_ITERS=0)) as ctx:
+        ctx.map_build(sc["map_xyz"])
+        ctx.scan_set(sc["scan_xyz"])
+        ctx.iterate(x0)
+        hist = ctx.level_histogram()
+        ctx.set_record_dump(True)
+        ctx.update(x0, sc["P0"])
+        assert ctx.last_update_fused()
+        nbr, d2, pw, found = ctx.fetch_neighbors()
+    assert sum(hist[2:5]) > 200, hist   # (the route under test is taken by many points)
+    o = oracle.iterate(x0, sc["map_xyz"], sc["scan_xyz"], tree=tree)
+    max_d2 = float(capi.default_params().MAX_DIST_PLANE) ** 2
+    have = o["knn_idx"] != 0xFFFFFFFF
+    near = have.all(axis=1) & (o["knn_d2"][:, 4].astype(np.float64) < max_d2)
+    rejected = (found < 5) | ~(d2[:, 4].astype(np.float64) < max_d2)
+    assert rejected[~near].all()
+    exp = sc["map_xyz"][np.where(have, o["knn_idx"], 0)]
+    assert np.array_equal(_bits(nbr[near]), _bits(exp[near])), f"neighbour coordinates differ at {(nbr[near] != exp[near]).any(axis=(1, 2)).sum()} points"
+    assert np.array_equal(_bits(d2[near]), _bits(o["knn_d2"][near]))
+    print(f"\nlevel histogram at {scale} x the benchmark's perturbation: {hist[:6]}; {int(near.sum())} of {len(near)} points inside the gate")
