@@ -90,6 +90,7 @@ int main(int argc, char** argv) {
         int force_after2 = 0;   // LV_DEMO_FORCE_REBUILD2=K2: adopt the first rebuild (blocking, untimed), then force another one after update K2
         if (const char* e = getenv("LV_DEMO_FORCE_REBUILD2")) force_after2 = atoi(e);
         loop_times().on = getenv("LV_DEMO_TIMING") != nullptr;
+        FILE* passes_dump = getenv("LV_DEMO_PASSES_DUMP") ? fopen(getenv("LV_DEMO_PASSES_DUMP"), "w") : nullptr;   // one line per update: its measurement passes
         FILE* cycle_dump = getenv("LV_DEMO_CYCLE_DUMP") ? fopen(getenv("LV_DEMO_CYCLE_DUMP"), "w") : nullptr;   // "cycle ms rebuild-state adopted journal" per line
         double t_ingest = 0.0, t_imu = 0.0;
         constexpr size_t STEADY_AFTER = 30;   // the first three sweeps' worth of updates: first-touch allocations, buffers growing to size
@@ -161,6 +162,7 @@ int main(int argc, char** argv) {
                             loc.last_passes, accum.BUFFER_X.size());
                 out_t.push_back(clk.t2);
                 out_x.push_back(loc.get_x());
+                if (passes_dump) fprintf(passes_dump, "%d\n", loc.last_passes);   // (get_x() has pulled the update's results)
                 out_n.push_back((uint32_t)np);
                 if (out_t.size() == STEADY_AFTER) wall_steady0 = std::chrono::steady_clock::now();
             }
@@ -218,6 +220,7 @@ int main(int argc, char** argv) {
                                   "the cycle clock: cycle_ms does not contain it); read the cycle times, not the rate, for what a background rebuild costs"
                                 : "");
         if (cycle_dump) fclose(cycle_dump);
+        if (passes_dump) fclose(passes_dump);
         HipRuntime::shutdown();
         return 0;
     } catch (const std::exception& e) {

@@ -138,6 +138,10 @@ int main(int argc, char** argv) {
         const uint32_t np = i < npts.size() ? npts[i] : 0u;
         o.write(reinterpret_cast<const char*>(&np), 4);
     }
+    if (const char* pd = getenv("LV_DEMO_PASSES_DUMP")) {   // one line per update: the passes its iterated update took
+        std::ofstream po(pd);
+        for (uint32_t i = 0; i < n && i < kf->pass_log.size(); ++i) po << kf->pass_log[i] << "\n";
+    }
     std::cout << "ref_stream_demo: " << n << " updates (" << kf->update_log.size() << " filter updates, " << times.size() << " states), map "
               << Mapper::getInstance().size() << " points\n";
     return 0;

@@ -171,9 +171,11 @@ public:
         }
         lvref::from_oracle(x, x_);
         update_log.push_back(x);
+        pass_log.push_back(passes);
     }
 
     int passes = 0;
+    std::vector<int> pass_log;   // measurement passes of every update so far (ref_stream_main dumps it: LV_DEMO_PASSES_DUMP)
     std::vector<lvo_iter_out> sums_log;
     std::vector<lvo_state> trace_log;
 private:
