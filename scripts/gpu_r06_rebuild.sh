@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the background rebuild with its second store allocated at set-up time (lv_map_reserve_rebuild) against the round-5 form
 # (the first rebuild's worker allocates): the async tests, then REPS replays of configs[4] through the C++ host program with two
-# forced background rebuilds each, both ways in one box.
+# forced background rebuilds each, both ways in one box (AB="name=ENV=v,...;name2=..." replaces the two variants).
 set -u
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -9,7 +9,7 @@ O=gpurun_out/r06_rebuild
 mkdir -p $O
 make -s -C limo-velo_amd/host 2>&1 | tail -2
 timeout 900 python -m pytest tests/test_gpu_map_async.py -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
-LV_STREAM_ONLY_AB=1 LV_STREAM_AB="reserved=LV_DEMO_FORCE_REBUILD=80,LV_DEMO_FORCE_REBUILD2=160;worker_allocates=LV_DEMO_FORCE_REBUILD=80,LV_DEMO_FORCE_REBUILD2=160,LV_DEMO_NO_REBUILD_RESERVE=1" LV_STREAM_REPS=${REPS:-8} timeout 2400 python scripts/stream_bench_cpp.py 2>$O/stream_cpp.err | tail -1 > $O/rebuild_replays.json
+LV_STREAM_ONLY_AB=1 LV_STREAM_AB="${AB:-reserved=LV_DEMO_FORCE_REBUILD=80,LV_DEMO_FORCE_REBUILD2=160;worker_allocates=LV_DEMO_FORCE_REBUILD=80,LV_DEMO_FORCE_REBUILD2=160,LV_DEMO_NO_REBUILD_RESERVE=1}" LV_STREAM_REPS=${REPS:-8} timeout 2400 python scripts/stream_bench_cpp.py 2>$O/stream_cpp.err | tail -1 > $O/rebuild_replays.json
 python - <<PY
 import json
 d = json.load(open("$O/rebuild_replays.json"))
