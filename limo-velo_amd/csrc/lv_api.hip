@@ -81,6 +81,9 @@ struct lv_ctx {
     std::atomic<uint64_t> relin_replayed{0};   // (written by the worker, read by lv_map_rebuild_status)
     size_t relin_journal_max = 4096;       // journal entries beyond which a rebuild that cannot keep up is given up: the
                                            // copy is cancelled and the active map takes the stop-the-world path when it needs one
+    uint32_t relin_pause_us = 100;        // LV_RELIN_PAUSE_US / "async_relinearise_pause_us": the worker's slices are spaced by that long (lv_map.hip launch_sliced):
+                                          // a cycle beside the rebuild 0.25 instead of 0.29 ms, p99 0.53-0.57 instead of 0.62-0.68, the rebuild ~8 x longer in wall time
+                                          // (profiles/experiments_r06/rebuild_spaced_slices_ab.txt); 0: slices back to back
     uint32_t relin_slice_wgs = 256;       // LV_RELIN_SLICE_WGS: slice size of the worker's large launches (0: whole grids).  (Round 5's opt-in PACED form — the
                                           // grids as at most 32 looping 1024-thread workgroups — is gone: p99 0.5 instead of 0.6 ms, but two 4.6 ms cycles in 5 of
                                           // 17 replays that plain slices never showed, cause not found: profiles/experiments_r05/async_rebuild.txt §10-11)
@@ -701,6 +704,7 @@ int lv_create(const lv_params* params, int device, lv_ctx** out) {
     if (const char* e = getenv("LV_FUSED_MULTI")) c->fused_multi_round = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("LV_ASYNC_RELINEARISE")) c->relin_async = atoi(e) != 0;
     if (const char* e = getenv("LV_RELIN_SLICE_WGS")) c->relin_slice_wgs = (uint32_t)atol(e);
+    if (const char* e = getenv("LV_RELIN_PAUSE_US")) c->relin_pause_us = (uint32_t)atol(e);
     if (const char* e = getenv("LV_MULTI_OVERLAP")) c->multi_overlap = atoi(e) != 0;   // A/B: 0 = every round's fits between two barriers
     if (const char* e = getenv("LV_KEEPER_BY_COST")) c->keeper_by_cost = atoi(e) != 0;
     if (const char* e = getenv("LV_COMM_FUSED")) c->comm_fused = atoi(e) != 0;
@@ -907,6 +911,7 @@ void relin_worker_main(lv_ctx* c) {
     S.built = false;
     // the worker's big kernels leave the compute units every ~0.1 ms (launch_sliced, lv_map.hip)
     S.slice_wgs = c->relin_slice_wgs;
+    set_slice_pause_us(c->relin_pause_us);   // (this thread's launches only)
     if (S.reserve(c->relin_want) != LV_OK) { fail("reserve"); return; }
     if (!c->relin_arena) {
         if (hipMalloc(&c->relin_arena, c->relin_arena_bytes) != hipSuccess) { c->relin_arena = nullptr; (void)hipGetLastError(); }
@@ -1712,6 +1717,7 @@ int lv_set_option(lv_ctx* c, const char* name, int value) {
     else if (!std::strcmp(name, "fast_fit")) c->fast_fit = on;
     else if (!std::strcmp(name, "async_relinearise")) c->relin_async = on;
     else if (!std::strcmp(name, "async_relinearise_min")) c->relin_async_min = value > 0 ? (size_t)value : 0;
+    else if (!std::strcmp(name, "async_relinearise_pause_us")) c->relin_pause_us = value > 0 ? (uint32_t)value : 0u;
     else if (!std::strcmp(name, "async_relinearise_slice_wgs")) c->relin_slice_wgs = value > 0 ? (uint32_t)value : 0u;      // 0: whole grids
     else if (!std::strcmp(name, "async_relinearise_journal_max")) c->relin_journal_max = value > 0 ? (size_t)value : 1;
     else if (!std::strcmp(name, "async_relinearise_test_delay_ms")) c->relin_test_delay_ms = value;

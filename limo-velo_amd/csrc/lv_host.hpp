@@ -32,6 +32,7 @@ struct MapStats {   // == lv_map_stats (include/limovelo_hip.h)
     uint64_t bytes;
 };
 
+void set_slice_pause_us(uint32_t us);   // lv_map.hip: the calling THREAD's sliced launches are spaced by that many microseconds (0: back to back)
 struct MapStore {
     // ---- points by id (insertion order; deleted ids keep their slot with x = +inf)
     float4* d_orig = nullptr;

@@ -499,11 +499,22 @@ static inline int log2u(uint32_t size) {
 // (Round 5 also carried a PACED twin of every such kernel — at most 32 looping 1024-thread workgroups, so that half of the CUs
 // stay empty — which removed the waiting but showed two 4.6 ms cycles in 5 of 17 replays that plain slices never did; the cause
 // was not found and the form is gone: profiles/experiments_r05/async_rebuild.txt sections 7-11 keep its measurements.)
+// (round 6) ... and the slices can be SPACED: behind every slice one wavefront that sleeps for `pause` microseconds, so that the chip is
+// empty for that long and whatever the calling cycle launches meanwhile starts at once (set by the rebuild's worker thread for its own
+// launches only: slice_pause_us is thread-local; 0 = slices back to back)
+static thread_local uint32_t slice_pause_us = 0;
+void set_slice_pause_us(uint32_t us) { slice_pause_us = us; }
+__global__ void slice_pause_kernel(uint32_t us) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (long long)us * 100) __builtin_amdgcn_s_sleep(64);   // (100 MHz)
+}
 template <typename K, typename... A>
 static void launch_sliced(uint32_t slice, K kernel, uint32_t grid, uint32_t block, hipStream_t stream, A... args) {
     if (slice == 0 || grid <= slice) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args..., 0u); return; }
-    for (uint32_t b = 0; b < grid; b += slice)
+    for (uint32_t b = 0; b < grid; b += slice) {
         hipLaunchKernelGGL(kernel, dim3(grid - b < slice ? grid - b : slice), dim3(block), 0, stream, args..., b);
+        if (slice_pause_us) hipLaunchKernelGGL(slice_pause_kernel, dim3(1), dim3(64), 0, stream, slice_pause_us);
+    }
 }
 
 int MapStore::reserve(size_t cap) {
